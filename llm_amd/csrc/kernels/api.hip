@@ -1,0 +1,51 @@
+// api.hip -- introspection entry points of libmi355_kernels.so (include/mi355_kernels.h).
+#include "common.h"
+
+extern "C" {
+
+int mi355_abi_version(void) { return 1; }
+
+const char * mi355_error_string(int err) {
+    switch (err) {
+        case MI355_OK:            return "ok";
+        case MI355_E_TYPE:        return "unsupported block type";
+        case MI355_E_SHAPE:       return "bad shape (k not a multiple of the block size, negative dim, or ncols out of range)";
+        case MI355_E_ALIGN:       return "pointer or stride alignment not met";
+        case MI355_E_NULL:        return "required pointer is NULL";
+        case MI355_E_WORKSPACE:   return "workspace too small";
+        case MI355_E_UNSUPPORTED: return "variant not implemented";
+    }
+    if (err > 0) return hipGetErrorString((hipError_t)err);
+    return "unknown error";
+}
+
+int64_t mi355_blck_size(int type) {
+    switch (type) {
+        case MI355_TYPE_F32: case MI355_TYPE_F16: return 1;
+        case MI355_TYPE_Q4_0: case MI355_TYPE_Q8_0: case MI355_TYPE_Q8_1: return QK;
+        case MI355_TYPE_Q4_K: case MI355_TYPE_Q5_K: case MI355_TYPE_Q6_K: return QK_K;
+    }
+    return 0;
+}
+
+int64_t mi355_type_size(int type) {
+    switch (type) {
+        case MI355_TYPE_F32:  return 4;
+        case MI355_TYPE_F16:  return 2;
+        case MI355_TYPE_Q4_0: return 18;
+        case MI355_TYPE_Q8_0: return 34;
+        case MI355_TYPE_Q8_1: return 36;
+        case MI355_TYPE_Q4_K: return 144;
+        case MI355_TYPE_Q5_K: return 176;
+        case MI355_TYPE_Q6_K: return 210;
+    }
+    return 0;
+}
+
+int64_t mi355_row_size(int type, int64_t k) {
+    const int64_t bs = mi355_blck_size(type);
+    if (bs == 0 || k < 0 || k % bs != 0) return -1;
+    return k / bs * mi355_type_size(type);
+}
+
+} // extern "C"

@@ -1,0 +1,43 @@
+// common.h -- device helpers shared by the gfx950 kernels (wave64, v_dot4c_i32_i8, 128-bit loads).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+
+#include "mi355_kernels.h"
+
+#define QK   32
+#define QK_K 256
+
+typedef int   v4i __attribute__((ext_vector_type(4)));
+typedef int   v2i __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// 16-byte vectors at the 2-byte alignment GGUF blocks have (18 B q4_0, 34 B q8_0, 210 B q6_K);
+// gfx950 runs in unaligned-access mode, so these still compile to one global_load_dwordx4.
+struct __attribute__((packed, aligned(2))) v4i_a2 { v4i v; };
+struct __attribute__((packed, aligned(2))) v2i_a2 { v2i v; };
+
+static __device__ __forceinline__ float h2f(uint16_t h) { return __half2float(__ushort_as_half(h)); }
+
+// c + sum_i a.i8[i] * b.i8[i]  (v_dot4c_i32_i8)
+static __device__ __forceinline__ int dot4(int a, int b, int c) { return __builtin_amdgcn_sdot4(a, b, c, false); }
+
+// streamed-once loads: nt keeps weight lines from displacing the activations in L2
+static __device__ __forceinline__ v4i ld_nt16(const void * p) { return __builtin_nontemporal_load((const v4i *)p); }
+static __device__ __forceinline__ v4i ld_nt16_a2(const void * p) {
+    v4i r; __builtin_memcpy(&r, __builtin_assume_aligned(p, 2), 16); return r;
+}
+static __device__ __forceinline__ uint16_t ld_u16(const void * p) { return *(const uint16_t *)p; }
+
+static __device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// per-byte (x - c) for bytes x in [0,127], c in [0,127]: no borrow can cross a byte
+static __device__ __forceinline__ int sub_bytes(int x, int c4) { return ((x | 0x80808080) - c4) ^ 0x80808080; }
+
+#define MI355_CHECK_LAUNCH() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)

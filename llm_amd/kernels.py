@@ -1,0 +1,63 @@
+"""ctypes binding of lib/libmi355_kernels.so (C ABI: include/mi355_kernels.h).
+
+Product path: device pointers in, kernels launched on the caller's HIP stream.  There is NO
+fallback of any kind -- a missing or unloadable library raises ImportError here, and every non-zero
+return code raises Mi355Error.  torch is used by callers only for device memory and streams.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libmi355_kernels.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(f"{LIB_PATH} is not built: run `make -C llm_amd/csrc` (or __graft_entry__.build()); "
+                      "there is no CPU fallback for the MI355X kernels")
+lib = C.CDLL(LIB_PATH)
+
+_vp, _i64, _i32 = C.c_void_p, C.c_int64, C.c_int32
+
+EXPORTS = [
+    "mi355_abi_version", "mi355_error_string", "mi355_blck_size", "mi355_type_size", "mi355_row_size",
+    "mi355_quantize_row_q8_1", "mi355_act_q_bytes", "mi355_act_ds_bytes", "mi355_quantize_act",
+    "mi355_dequantize_row", "mi355_mul_mat_vec_q", "mi355_mul_mat_workspace_bytes", "mi355_mul_mat",
+]
+
+
+class MmvqArgs(C.Structure):
+    _fields_ = [
+        ("type", _i32), ("W", _vp), ("w_row_stride", _i64), ("w_ch_stride", _i64),
+        ("act_q", _vp), ("act_ds", _vp), ("act_ch_stride", _i64),
+        ("dst", _vp), ("dst_col_stride", _i64), ("dst_ch_stride", _i64),
+        ("m", _i64), ("k", _i64), ("ncols", _i32), ("nchannels", _i32), ("ch_ratio", _i32),
+        ("ids", _vp), ("ids_stride", _i32), ("ids_nused", _i32), ("act_ne1", _i32), ("n_expert", _i32),
+    ]
+
+
+lib.mi355_abi_version.restype = C.c_int
+lib.mi355_error_string.restype = C.c_char_p
+lib.mi355_error_string.argtypes = [C.c_int]
+for _n in ("mi355_blck_size", "mi355_type_size"):
+    getattr(lib, _n).restype = _i64
+    getattr(lib, _n).argtypes = [C.c_int]
+lib.mi355_row_size.restype = _i64
+lib.mi355_row_size.argtypes = [C.c_int, _i64]
+for _n in ("mi355_act_q_bytes", "mi355_act_ds_bytes", "mi355_mul_mat_workspace_bytes"):
+    getattr(lib, _n).restype = _i64
+    getattr(lib, _n).argtypes = [_i64, _i64]
+lib.mi355_quantize_row_q8_1.argtypes = [_vp, _vp] + [_i64] * 7 + [_vp]
+lib.mi355_quantize_act.argtypes = [_vp, _vp, _vp] + [_i64] * 7 + [_vp]
+lib.mi355_dequantize_row.argtypes = [C.c_int, _vp, _vp, _i64, _vp]
+lib.mi355_mul_mat_vec_q.argtypes = [C.POINTER(MmvqArgs), _vp]
+lib.mi355_mul_mat.argtypes = [C.c_int, _vp, _i64, _vp, _vp, _i64, _i64, _i64, _vp, _i64, _vp]
+
+
+class Mi355Error(RuntimeError):
+    def __init__(self, code, where):
+        self.code = code
+        super().__init__(f"{where}: {lib.mi355_error_string(code).decode()} ({code})")
+
+
+def check(code, where):
+    if code != 0:
+        raise Mi355Error(code, where)

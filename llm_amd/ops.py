@@ -1,0 +1,108 @@
+"""Host-side mirror of the reference's operator interface for the hot path, on torch device tensors.
+
+Same names and argument meaning as the ggml ops the backend serves (ggml/include/ggml.h):
+  mul_mat(a, b)            ggml_mul_mat      a = weights [M rows of K] (block-quantized bytes), b = [N, K] f32 -> [N, M] f32
+  mul_mat_id(as_, b, ids)  ggml_mul_mat_id
+plus the two contract-level primitives quantize_q8_1 / dequantize.  Everything runs through the C ABI
+of libmi355_kernels.so on the current torch stream; torch only owns the memory.
+"""
+import torch
+
+from . import blocks as B
+from . import kernels as K
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _u8(t):
+    assert t.is_cuda and t.dtype == torch.uint8 and t.is_contiguous()
+    return t
+
+
+def _dst_rows(dst):
+    return dst.stride(0) if dst.dim() > 1 else dst.numel()
+
+
+def quantize_q8_1(x):
+    """x: [..., K] f32 (last dim contiguous, up to 4-D) -> uint8 [rows, K/32*36] of block_q8_1."""
+    assert x.is_cuda and x.dtype == torch.float32 and x.stride(-1) == 1 and 1 <= x.dim() <= 4
+    k = x.shape[-1]
+    shp = [1] * (4 - x.dim()) + list(x.shape)
+    st = [0] * (4 - x.dim()) + list(x.stride())
+    ne3, ne2, ne1 = shp[0], shp[1], shp[2]
+    nb3, nb2, nb1 = (s * 4 for s in st[:3])
+    rows = ne1 * ne2 * ne3
+    y = torch.empty((rows, k // 32 * 36), dtype=torch.uint8, device=x.device)
+    K.check(K.lib.mi355_quantize_row_q8_1(x.data_ptr(), y.data_ptr(), k, ne1, ne2, ne3, nb1, nb2, nb3, _stream()),
+            "mi355_quantize_row_q8_1")
+    return y
+
+
+def quantize_act(x):
+    """x: [rows, K] f32 contiguous -> (act_q int8 [rows, K], act_ds f32 [rows, K/32, 2])."""
+    assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.is_contiguous()
+    rows, k = x.shape
+    aq = torch.empty((rows, k), dtype=torch.int8, device=x.device)
+    ads = torch.empty((rows, k // 32, 2), dtype=torch.float32, device=x.device)
+    K.check(K.lib.mi355_quantize_act(x.data_ptr(), aq.data_ptr(), ads.data_ptr(), k, rows, 1, 1, k * 4, 0, 0, _stream()),
+            "mi355_quantize_act")
+    return aq, ads
+
+
+def dequantize(t, blocks, n):
+    """blocks: uint8 device tensor holding n elements of type t -> f32 [n]."""
+    _u8(blocks)
+    assert blocks.numel() >= B.row_size(t, n)
+    y = torch.empty(n, dtype=torch.float32, device=blocks.device)
+    K.check(K.lib.mi355_dequantize_row(t, blocks.data_ptr(), y.data_ptr(), n, _stream()), "mi355_dequantize_row")
+    return y
+
+
+def mul_mat_vec_q(t, w, m, k, aq, ads, ncols, dst=None, w_row_stride=None):
+    """Decode mat-vec on pre-quantized activations (act rows 0..ncols-1)."""
+    _u8(w)
+    if dst is None:
+        dst = torch.empty((ncols, m), dtype=torch.float32, device=w.device)
+    a = K.MmvqArgs()
+    a.type, a.W, a.w_row_stride, a.w_ch_stride = t, w.data_ptr(), w_row_stride or B.row_size(t, k), 0
+    a.act_q, a.act_ds, a.act_ch_stride = aq.data_ptr(), ads.data_ptr(), 0
+    a.dst, a.dst_col_stride, a.dst_ch_stride = dst.data_ptr(), dst.stride(0), 0
+    a.m, a.k, a.ncols, a.nchannels, a.ch_ratio = m, k, ncols, 1, 1
+    K.check(K.lib.mi355_mul_mat_vec_q(a, _stream()), "mi355_mul_mat_vec_q")
+    return dst
+
+
+def mul_mat(t, w, b, m, workspace=None):
+    """ggml_mul_mat: w = [m rows] blocks of type t (uint8), b = [n, k] f32 -> [n, m] f32."""
+    _u8(w)
+    assert b.is_cuda and b.dtype == torch.float32 and b.dim() == 2 and b.is_contiguous()
+    n, k = b.shape
+    need = K.lib.mi355_mul_mat_workspace_bytes(k, n)
+    if workspace is None:
+        workspace = torch.empty(max(need, 256), dtype=torch.uint8, device=b.device)
+    dst = torch.empty((n, m), dtype=torch.float32, device=b.device)
+    K.check(K.lib.mi355_mul_mat(t, w.data_ptr(), B.row_size(t, k), b.data_ptr(), dst.data_ptr(), m, k, n,
+                                workspace.data_ptr(), workspace.numel(), _stream()), "mi355_mul_mat")
+    return dst
+
+
+def mul_mat_id(t, as_, b, ids, m, n_expert):
+    """ggml_mul_mat_id for decode-sized batches: as_ = [n_expert][m rows] blocks, b = [n_tokens, b_ne1, k] f32,
+    ids = [n_tokens, n_used] int32 (device) -> [n_tokens, n_used, m] f32."""
+    _u8(as_)
+    assert b.dim() == 3 and b.is_contiguous() and ids.dtype == torch.int32 and ids.dim() == 2
+    n_tok, b_ne1, k = b.shape
+    n_used = ids.shape[1]
+    aq, ads = quantize_act(b.reshape(n_tok * b_ne1, k))
+    dst = torch.empty((n_tok, n_used, m), dtype=torch.float32, device=b.device)
+    a = K.MmvqArgs()
+    rs = B.row_size(t, k)
+    a.type, a.W, a.w_row_stride, a.w_ch_stride = t, as_.data_ptr(), rs, rs * m
+    a.act_q, a.act_ds, a.act_ch_stride = aq.data_ptr(), ads.data_ptr(), b_ne1
+    a.dst, a.dst_col_stride, a.dst_ch_stride = dst.data_ptr(), m, m
+    a.m, a.k, a.ncols, a.nchannels, a.ch_ratio = m, k, 1, n_tok * n_used, 1
+    a.ids, a.ids_stride, a.ids_nused, a.act_ne1, a.n_expert = ids.data_ptr(), ids.stride(0), n_used, b_ne1, n_expert
+    K.check(K.lib.mi355_mul_mat_vec_q(a, _stream()), "mi355_mul_mat_vec_q(ids)")
+    return dst
