@@ -24,9 +24,11 @@ static __device__ __forceinline__ float h2f(uint16_t h) { return __half2float(__
 // c + sum_i a.i8[i] * b.i8[i]  (v_dot4c_i32_i8)
 static __device__ __forceinline__ int dot4(int a, int b, int c) { return __builtin_amdgcn_sdot4(a, b, c, false); }
 
-// streamed-once loads: nt keeps weight lines from displacing the activations in L2
+// nontemporal 16-byte load.  NOT used for GGUF weight blocks: a block's header shares its 128-B
+// line with the quants, and an nt line is dropped before the header load gets to it (measured
+// -12 % on the q4_K mat-vec, llm_amd/csrc/lab/q4k_lab.hip).
 static __device__ __forceinline__ v4i ld_nt16(const void * p) { return __builtin_nontemporal_load((const v4i *)p); }
-static __device__ __forceinline__ v4i ld_nt16_a2(const void * p) {
+static __device__ __forceinline__ v4i ld16_a2(const void * p) {
     v4i r; __builtin_memcpy(&r, __builtin_assume_aligned(p, 2), 16); return r;
 }
 static __device__ __forceinline__ uint16_t ld_u16(const void * p) { return *(const uint16_t *)p; }

@@ -6,21 +6,25 @@
 //
 // Roofline: HBM.  Algorithmic bytes per launch = M*(K/bs)*B + 4K + 4M.
 //
-// Shape of the kernel
-//   * a wavefront (64 lanes) owns RPW consecutive weight rows; a 256-thread workgroup = 4 waves.
-//   * the row is cut into "units" of 16..48 bytes of quant data; lane l takes units l, l+64, ...
-//     so one wave-load covers a contiguous 1 KiB (q4_K: 8 lanes x 16 B per 144 B block) of the
-//     row with 128-bit loads: weights go straight to VGPRs (streamed once: nontemporal), no LDS.
-//   * the nibbles / 6-bit fields are unpacked with a handful of bit ops per dword and fed to
-//     v_dot4c_i32_i8 against the q8_1 activations (internal SoA layout, see mi355_quantize_act);
-//     integer sums are exact, the per-32 scales are applied in f32.
+// Shape of the kernel (measured ablations: llm_amd/csrc/lab/q4k_lab.hip)
+//   * a wavefront (64 lanes) owns one weight row at a time; a 256-thread workgroup = 4 waves.
+//   * the q8_1 activations (internal SoA layout, see mi355_quantize_act) are staged once per
+//     workgroup in LDS; in the loop they come back with ds_read_b128, so the vector-memory pipe
+//     carries weights only (the TA/L1 path, not HBM, was the first bound of the naive version).
+//   * the row is cut into "units"; lane l takes units l, l+64, ...  A q4_K unit is one 64-value
+//     group = 32 B of nibbles (two 128-bit loads) + the block's 16 B header, so the 6-bit
+//     scale/min decode and the f32 epilogue are paid once per 64 weights.  Weights go straight
+//     to VGPRs (no LDS round trip), double-buffered in registers across loop iterations.
+//   * nibbles / 6-bit fields are unpacked with a few bit ops per dword and fed to
+//     v_dot4c_i32_i8; integer sums are exact, the per-32 scales are applied in f32.
 //   * wavefront-level xor-shuffle reduction, one f32 store per (row, column).
 //
-// Arithmetic contract (tests/test_mmvq.py): dst = sum over 32-blocks of
+// Arithmetic contract (tests/test_kernels_gpu.py): dst = sum over 32-blocks of
 //     d8 * ( dW_j * sum(qW*q8) - mW_j * sum(q8) )        (q4_K / q5_K)
 //     d8 * dW_j * sum((qW - off)*q8)                     (q4_0: off 8, q6_K: off 32, q8_0: off 0)
 // i.e. exactly dequant(W) . dequant_q8_1(x) up to f32 summation order.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -40,103 +44,112 @@ struct ActPtr {
 template <int TYPE> struct Unit;
 
 // ---- Q4_K: 144 B super-block = {half d, half dmin, u8 scales[12], u8 qs[128]} (ggml-common.h:285-295)
-// unit = 16 B of qs: chunk p (0..7) of block b.  Low nibbles are sub-block 2g, high nibbles 2g+1
-// (g = p/2), elements 16*(p&1) .. +15 of each (dequantize_row_q4_K, ggml-quants.c:1286-1293).
-struct K4Scales { float dsc0, dsc1, dm0, dm1; };
+// unit = group g (0..3) of block b: qs[32g .. 32g+31]; low nibbles are sub-block 2g, high nibbles
+// sub-block 2g+1, 32 values each (dequantize_row_q4_K, ggml-quants.c:1286-1293).
+struct K4Scales { int sc0, sc1; float fm0, fm1, d, dmin; };
 
 static __device__ __forceinline__ K4Scales k4_scales(const v4i hdr, int g) {
     // hdr.x = {d, dmin}; hdr.y/z/w = the 12 packed 6-bit scales/mins (get_scale_min_k4, ggml-quants.c:625-632)
     const uint32_t u0 = hdr.y, u1 = hdr.z, u2 = hdr.w;
-    const uint32_t sc_lo = u0 & 0x3f3f3f3fu;
-    const uint32_t m_lo  = u1 & 0x3f3f3f3fu;
-    const uint32_t sc_hi = (u2 & 0x0f0f0f0fu) | (((u0 >> 6) & 0x03030303u) << 4);
-    const uint32_t m_hi  = ((u2 >> 4) & 0x0f0f0f0fu) | (((u1 >> 6) & 0x03030303u) << 4);
     const int sh = (g & 1) * 16;
-    const uint32_t sc2 = ((g & 2) ? sc_hi : sc_lo) >> sh;
-    const uint32_t m2  = ((g & 2) ? m_hi : m_lo) >> sh;
-    const float d    = h2f((uint16_t)(hdr.x & 0xffff));
-    const float dmin = h2f((uint16_t)((uint32_t)hdr.x >> 16));
+    uint32_t sc2, m2;
+    if (g & 2) {
+        sc2 = ((u2 >> sh) & 0x0f0fu) | (((u0 >> (sh + 6)) & 0x0303u) << 4);
+        m2  = ((u2 >> (sh + 4)) & 0x0f0fu) | (((u1 >> (sh + 6)) & 0x0303u) << 4);
+    } else {
+        sc2 = (u0 >> sh) & 0x3f3fu;
+        m2  = (u1 >> sh) & 0x3f3fu;
+    }
     K4Scales s;
-    s.dsc0 = d * (float)(sc2 & 0xff);
-    s.dsc1 = d * (float)((sc2 >> 8) & 0xff);
-    s.dm0  = dmin * (float)(m2 & 0xff);
-    s.dm1  = dmin * (float)((m2 >> 8) & 0xff);
+    s.sc0 = (int)(sc2 & 0xff); s.sc1 = (int)(sc2 >> 8);
+    s.fm0 = (float)(m2 & 0xff); s.fm1 = (float)(m2 >> 8);
+    s.d    = h2f((uint16_t)(hdr.x & 0xffff));
+    s.dmin = h2f((uint16_t)((uint32_t)hdr.x >> 16));
     return s;
 }
 
-struct Act2x16 { v4i lo, hi; v4f ds; int slo, shi; }; // 2 x 16 int8, {d0, s0, d1, s1}, in-lane sums
+// activations of one 64-value group: 64 int8 + {d_lo, sum_lo, d_hi, sum_hi}
+struct Act64 { v4i q[4]; v4f ds; };
 
-static __device__ __forceinline__ Act2x16 load_act_k45(const ActPtr a, int u) {
-    const int b = u >> 3, p = u & 7, g = p >> 1;
-    const int e0 = b * QK_K + g * 64 + (p & 1) * 16;
-    Act2x16 r;
-    r.lo = *(const v4i *)(a.q + e0);
-    r.hi = *(const v4i *)(a.q + e0 + 32);
-    r.ds = *(const v4f *)(a.ds + (b * 8 + g * 2) * 2);
-    int s0 = 0, s1 = 0;
+template <class AP>
+static __device__ __forceinline__ Act64 load_act64(const AP a, int u) {
+    Act64 r;
 #pragma unroll
-    for (int i = 0; i < 4; i++) { s0 = dot4(0x01010101, r.lo[i], s0); s1 = dot4(0x01010101, r.hi[i], s1); }
-    r.slo = s0; r.shi = s1;
+    for (int i = 0; i < 4; i++) r.q[i] = *(const v4i *)(a.q + u * 64 + i * 16);
+    r.ds = *(const v4f *)(a.ds + u * 4);
     return r;
 }
 
-struct DecK45 { v4i lo, hi; K4Scales s; };
+struct DecK45 { v4i lo[2], hi[2]; K4Scales s; };
 
-static __device__ __forceinline__ float dot_k45(const DecK45 & w, const Act2x16 & a) {
+static __device__ __forceinline__ float dot_k45(const DecK45 & w, const Act64 & a) {
     int s0 = 0, s1 = 0;
 #pragma unroll
-    for (int i = 0; i < 4; i++) { s0 = dot4(w.lo[i], a.lo[i], s0); s1 = dot4(w.hi[i], a.hi[i], s1); }
-    return a.ds.x * (w.s.dsc0 * (float)s0 - w.s.dm0 * (float)a.slo) +
-           a.ds.z * (w.s.dsc1 * (float)s1 - w.s.dm1 * (float)a.shi);
+    for (int i = 0; i < 4; i++) {
+        s0 = dot4(w.lo[0][i], a.q[0][i], s0);
+        s0 = dot4(w.lo[1][i], a.q[1][i], s0);
+        s1 = dot4(w.hi[0][i], a.q[2][i], s1);
+        s1 = dot4(w.hi[1][i], a.q[3][i], s1);
+    }
+    // integer sub-block scale folded in before the single int->float conversion (|s*sc| < 2^24)
+    const float x = (float)(s0 * w.s.sc0) * a.ds.x + (float)(s1 * w.s.sc1) * a.ds.z;
+    const float y = w.s.fm0 * (a.ds.x * a.ds.y) + w.s.fm1 * (a.ds.z * a.ds.w);
+    return w.s.d * x - w.s.dmin * y;
 }
 
 template <> struct Unit<MI355_TYPE_Q4_K> {
-    static constexpr int ELEMS = 32;
-    struct Raw { v4i qs, hdr; };
+    static constexpr int ELEMS = 64;
+    struct Raw { v4i q0, q1, hdr; };
     typedef DecK45 Dec;
-    typedef Act2x16 Act;
+    typedef Act64 Act;
     static __device__ __forceinline__ Raw load(const uint8_t * row, int u) {
-        const uint8_t * blk = row + (int64_t)(u >> 3) * 144;
+        const uint8_t * blk = row + (int64_t)(u >> 2) * 144;
         Raw r;
-        r.qs  = ld_nt16(blk + 16 + (u & 7) * 16);
+        r.q0  = *(const v4i *)(blk + 16 + (u & 3) * 32);
+        r.q1  = *(const v4i *)(blk + 32 + (u & 3) * 32);
         r.hdr = *(const v4i *)blk;
         return r;
     }
     static __device__ __forceinline__ Dec decode(const Raw & r, int u) {
         Dec d;
-        d.lo = r.qs & 0x0f0f0f0f;
-        d.hi = (r.qs >> 4) & 0x0f0f0f0f;
-        d.s  = k4_scales(r.hdr, (u & 7) >> 1);
+        d.lo[0] = r.q0 & 0x0f0f0f0f;        d.lo[1] = r.q1 & 0x0f0f0f0f;
+        d.hi[0] = (r.q0 >> 4) & 0x0f0f0f0f; d.hi[1] = (r.q1 >> 4) & 0x0f0f0f0f;
+        d.s = k4_scales(r.hdr, u & 3);
         return d;
     }
-    static __device__ __forceinline__ Act load_act(const ActPtr a, int u) { return load_act_k45(a, u); }
+    template <class AP> static __device__ __forceinline__ Act load_act(const AP a, int u) { return load_act64(a, u); }
     static __device__ __forceinline__ float dot(const Dec & w, const Act & a) { return dot_k45(w, a); }
 };
 
 // ---- Q5_K: 176 B = {half d, half dmin, scales[12], qh[32], qs[128]} (ggml-common.h:302-313);
-// as q4_K plus bit (2g) / (2g+1) of qh[16*(p&1) + j] as the 5th bit (ggml-quants.c:1495-1496).
+// as q4_K plus bit (2g) / (2g+1) of qh[l] as the 5th bit of value l of the low / high sub-block
+// (dequantize_row_q5_K, ggml-quants.c:1495-1496).
 template <> struct Unit<MI355_TYPE_Q5_K> {
-    static constexpr int ELEMS = 32;
-    struct Raw { v4i qs, qh, hdr; };
+    static constexpr int ELEMS = 64;
+    struct Raw { v4i q0, q1, h0, h1, hdr; };
     typedef DecK45 Dec;
-    typedef Act2x16 Act;
+    typedef Act64 Act;
     static __device__ __forceinline__ Raw load(const uint8_t * row, int u) {
-        const uint8_t * blk = row + (int64_t)(u >> 3) * 176;
+        const uint8_t * blk = row + (int64_t)(u >> 2) * 176;
         Raw r;
-        r.qs  = ld_nt16(blk + 48 + (u & 7) * 16);
-        r.qh  = *(const v4i *)(blk + 16 + (u & 1) * 16);
+        r.q0  = *(const v4i *)(blk + 48 + (u & 3) * 32);
+        r.q1  = *(const v4i *)(blk + 64 + (u & 3) * 32);
+        r.h0  = *(const v4i *)(blk + 16);
+        r.h1  = *(const v4i *)(blk + 32);
         r.hdr = *(const v4i *)blk;
         return r;
     }
     static __device__ __forceinline__ Dec decode(const Raw & r, int u) {
-        const int g = (u & 7) >> 1;
+        const int g = u & 3;
         Dec d;
-        d.lo = (r.qs & 0x0f0f0f0f) | (((r.qh >> (2 * g)) & 0x01010101) << 4);
-        d.hi = ((r.qs >> 4) & 0x0f0f0f0f) | (((r.qh >> (2 * g + 1)) & 0x01010101) << 4);
-        d.s  = k4_scales(r.hdr, g);
+        d.lo[0] = (r.q0 & 0x0f0f0f0f) | (((r.h0 >> (2 * g)) & 0x01010101) << 4);
+        d.lo[1] = (r.q1 & 0x0f0f0f0f) | (((r.h1 >> (2 * g)) & 0x01010101) << 4);
+        d.hi[0] = ((r.q0 >> 4) & 0x0f0f0f0f) | (((r.h0 >> (2 * g + 1)) & 0x01010101) << 4);
+        d.hi[1] = ((r.q1 >> 4) & 0x0f0f0f0f) | (((r.h1 >> (2 * g + 1)) & 0x01010101) << 4);
+        d.s = k4_scales(r.hdr, g);
         return d;
     }
-    static __device__ __forceinline__ Act load_act(const ActPtr a, int u) { return load_act_k45(a, u); }
+    template <class AP> static __device__ __forceinline__ Act load_act(const AP a, int u) { return load_act64(a, u); }
     static __device__ __forceinline__ float dot(const Dec & w, const Act & a) { return dot_k45(w, a); }
 };
 
@@ -153,9 +166,9 @@ template <> struct Unit<MI355_TYPE_Q6_K> {
         const uint8_t * blk = row + (int64_t)(u >> 2) * 210;
         const int n = (u >> 1) & 1, h = u & 1;
         Raw r;
-        r.qla = ld_nt16_a2(blk + 64 * n + 16 * h);
-        r.qlb = ld_nt16_a2(blk + 64 * n + 32 + 16 * h);
-        r.qh  = ld_nt16_a2(blk + 128 + 32 * n + 16 * h);
+        r.qla = ld16_a2(blk + 64 * n + 16 * h);
+        r.qlb = ld16_a2(blk + 64 * n + 32 + 16 * h);
+        r.qh  = ld16_a2(blk + 128 + 32 * n + 16 * h);
         r.sc  = ((const v2i_a2 *)(blk + 192 + 8 * n))->v;
         r.d   = ld_u16(blk + 208);
         return r;
@@ -180,7 +193,7 @@ template <> struct Unit<MI355_TYPE_Q6_K> {
             for (int j = 0; j < 4; j++) d.q[i][j] = sub_bytes(d.q[i][j], 0x20202020);
         return d;
     }
-    static __device__ __forceinline__ Act load_act(const ActPtr a, int u) {
+    template <class AP> static __device__ __forceinline__ Act load_act(const AP a, int u) {
         const int b = u >> 2, n = (u >> 1) & 1, h = u & 1;
         const int e0 = b * QK_K + n * 128 + h * 16;
         Act r;
@@ -213,13 +226,13 @@ template <> struct Unit<MI355_TYPE_Q8_0> {
     static __device__ __forceinline__ Raw load(const uint8_t * row, int u) {
         const uint8_t * blk = row + (int64_t)u * 34;
         Raw r;
-        r.q0 = ld_nt16_a2(blk + 2);
-        r.q1 = ld_nt16_a2(blk + 18);
+        r.q0 = ld16_a2(blk + 2);
+        r.q1 = ld16_a2(blk + 18);
         r.d  = ld_u16(blk);
         return r;
     }
     static __device__ __forceinline__ Dec decode(const Raw & r, int) { Dec d; d.q0 = r.q0; d.q1 = r.q1; d.d = h2f(r.d); return d; }
-    static __device__ __forceinline__ Act load_act(const ActPtr a, int u) {
+    template <class AP> static __device__ __forceinline__ Act load_act(const AP a, int u) {
         Act r;
         r.q0 = *(const v4i *)(a.q + u * 32);
         r.q1 = *(const v4i *)(a.q + u * 32 + 16);
@@ -244,7 +257,7 @@ template <> struct Unit<MI355_TYPE_Q4_0> {
     static __device__ __forceinline__ Raw load(const uint8_t * row, int u) {
         const uint8_t * blk = row + (int64_t)u * 18;
         Raw r;
-        r.qs = ld_nt16_a2(blk + 2);
+        r.qs = ld16_a2(blk + 2);
         r.d  = ld_u16(blk);
         return r;
     }
@@ -258,7 +271,7 @@ template <> struct Unit<MI355_TYPE_Q4_0> {
         d.d = h2f(r.d);
         return d;
     }
-    static __device__ __forceinline__ Act load_act(const ActPtr a, int u) { return Unit<MI355_TYPE_Q8_0>::load_act(a, u); }
+    template <class AP> static __device__ __forceinline__ Act load_act(const AP a, int u) { return Unit<MI355_TYPE_Q8_0>::load_act(a, u); }
     static __device__ __forceinline__ float dot(const Dec & w, const Act & a) {
         int s = 0;
 #pragma unroll
@@ -276,10 +289,15 @@ struct KArgs {
     const int32_t * ids; int ids_stride, ids_nused, act_ne1, n_expert;
 };
 
-template <int TYPE, int NCOLS, int RPW>
+// LDS / global flavours of the activation pointers (address spaces stay static so the LDS build
+// reads with ds_read_b128, not flat loads)
+struct ActLds { const __attribute__((address_space(3))) int8_t * q; const __attribute__((address_space(3))) float * ds; };
+
+template <int TYPE, int NCOLS, bool LDSACT>
 __global__ void __launch_bounds__(256)
 mmvq_kernel(const KArgs a) {
     typedef Unit<TYPE> U;
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int ch   = blockIdx.y;
@@ -288,7 +306,7 @@ mmvq_kernel(const KArgs a) {
     if (a.ids) {
         const int tok = ch / a.ids_nused, slot = ch % a.ids_nused;
         const int ex = a.ids[(int64_t)tok * a.ids_stride + slot];
-        if (ex < 0 || ex >= a.n_expert) return; // out-of-range expert id: leave dst untouched
+        if (ex < 0 || ex >= a.n_expert) return; // out-of-range expert id (uniform per workgroup): dst untouched
         ch_w    = ex;
         act_row = (int64_t)tok * a.act_ch_stride + slot % a.act_ne1;
     } else {
@@ -296,81 +314,92 @@ mmvq_kernel(const KArgs a) {
         act_row = (int64_t)ch * a.act_ch_stride;
     }
 
-    const int row0 = (blockIdx.x * 4 + wave) * RPW;
-    if (row0 >= a.m) return;
+    const int row  = blockIdx.x * 4 + wave;
+    const int rowc = row < a.m ? row : a.m - 1;           // tail waves re-read the last row, never store
+    const uint8_t * wrow = a.W + ch_w * a.w_ch_stride + (int64_t)rowc * a.w_row_stride;
+    const int8_t * gq  = a.act_q + act_row * a.k;
+    const float  * gds = a.act_ds + act_row * (a.k / QK) * 2;
 
-    const uint8_t * wbase = a.W + ch_w * a.w_ch_stride;
-    const uint8_t * wrow[RPW];
-#pragma unroll
-    for (int r = 0; r < RPW; r++) {
-        const int row = row0 + r < a.m ? row0 + r : a.m - 1; // tail rows re-read the last row, never stored
-        wrow[r] = wbase + (int64_t)row * a.w_row_stride;
-    }
-    ActPtr act[NCOLS];
-#pragma unroll
-    for (int c = 0; c < NCOLS; c++) {
-        act[c].q  = a.act_q + (act_row + c) * a.k;
-        act[c].ds = a.act_ds + (act_row + c) * (a.k / QK) * 2;
-    }
-
-    float acc[RPW][NCOLS];
-#pragma unroll
-    for (int r = 0; r < RPW; r++)
-#pragma unroll
-        for (int c = 0; c < NCOLS; c++) acc[r][c] = 0.0f;
-
+    // Uniform trip count (lanes past the end re-read the last unit and contribute 0) so the loads
+    // are unconditional; the first weight loads are issued before the activation staging so their
+    // HBM latency overlaps it.
     const int nunits = a.k / U::ELEMS;
-#pragma unroll 2
-    for (int u = lane; u < nunits; u += 64) {
-        typename U::Raw raw[RPW];
+    const int niter  = (nunits + 63) >> 6;
+    typename U::Raw cur = U::load(wrow, lane < nunits ? lane : nunits - 1);
+
+    if (LDSACT) {
+        // activations -> LDS: [NCOLS][k] int8, then [NCOLS][k/32][2] f32 (columns are contiguous rows of act)
+        const int nq = NCOLS * a.k / 16, nds = NCOLS * (a.k / QK) * 2 / 4;
+        for (int i = threadIdx.x; i < nq; i += 256) ((v4i *)lds)[i] = ((const v4i *)gq)[i];
+        v4f * lds_ds = (v4f *)(lds + (size_t)NCOLS * a.k);
+        for (int i = threadIdx.x; i < nds; i += 256) lds_ds[i] = ((const v4f *)gds)[i];
+        __syncthreads();
+    }
+
+    float acc[NCOLS];
 #pragma unroll
-        for (int r = 0; r < RPW; r++) raw[r] = U::load(wrow[r], u);
+    for (int c = 0; c < NCOLS; c++) acc[c] = 0.0f;
+
+    // Register double buffer: the weights of iteration it+1 are requested before iteration it is
+    // consumed.  sched_barrier pins "all loads first": left alone the scheduler sinks each load
+    // next to its use and the loop degenerates into load / s_waitcnt vmcnt(0) pairs.
+    for (int it = 0; it < niter; it++) {
+        const int  u_raw = it * 64 + lane;
+        const bool valid = u_raw < nunits;
+        const int  u     = valid ? u_raw : nunits - 1;
+        typename U::Raw nxt;
+        if (it + 1 < niter) nxt = U::load(wrow, u_raw + 64 < nunits ? u_raw + 64 : nunits - 1);
         typename U::Act av[NCOLS];
+        if (LDSACT) {
+            const auto lq  = (const __attribute__((address_space(3))) int8_t *)lds;
+            const auto lds_ = (const __attribute__((address_space(3))) float *)(lds + (size_t)NCOLS * a.k);
 #pragma unroll
-        for (int c = 0; c < NCOLS; c++) av[c] = U::load_act(act[c], u);
+            for (int c = 0; c < NCOLS; c++) av[c] = U::load_act(ActLds{lq + c * a.k, lds_ + c * (a.k / QK) * 2}, u);
+        } else {
 #pragma unroll
-        for (int r = 0; r < RPW; r++) {
-            const typename U::Dec w = U::decode(raw[r], u);
-#pragma unroll
-            for (int c = 0; c < NCOLS; c++) acc[r][c] += U::dot(w, av[c]);
+            for (int c = 0; c < NCOLS; c++) av[c] = U::load_act(ActPtr{gq + (int64_t)c * a.k, gds + (int64_t)c * (a.k / QK) * 2}, u);
         }
+        __builtin_amdgcn_sched_barrier(0);
+        const typename U::Dec w = U::decode(cur, u);
+#pragma unroll
+        for (int c = 0; c < NCOLS; c++) {
+            const float v = U::dot(w, av[c]);
+            acc[c] += valid ? v : 0.0f;
+        }
+        if (it + 1 < niter) cur = nxt;
     }
 
     float * dch = a.dst + (int64_t)ch * a.dst_ch_stride;
 #pragma unroll
-    for (int r = 0; r < RPW; r++)
-#pragma unroll
-        for (int c = 0; c < NCOLS; c++) {
-            const float v = wave_sum(acc[r][c]);
-            if (lane == 0 && row0 + r < a.m) dch[(int64_t)c * a.dst_col_stride + row0 + r] = v;
-        }
+    for (int c = 0; c < NCOLS; c++) {
+        const float v = wave_sum(acc[c]);
+        if (lane == 0 && row < a.m) dch[(int64_t)c * a.dst_col_stride + row] = v;
+    }
 }
 
-template <int TYPE, int NCOLS, int RPW>
+static constexpr size_t LDS_ACT_LIMIT = 64 * 1024; // beyond this, activations are read through L1 instead
+
+template <int TYPE, int NCOLS>
 static int launch(const KArgs & a, int nchannels, hipStream_t stream) {
-    const dim3 grid((unsigned)((a.m + 4 * RPW - 1) / (4 * RPW)), (unsigned)nchannels);
-    mmvq_kernel<TYPE, NCOLS, RPW><<<grid, 256, 0, stream>>>(a);
+    const dim3 grid((unsigned)((a.m + 3) / 4), (unsigned)nchannels);
+    const size_t need = (size_t)NCOLS * ((size_t)a.k + (size_t)a.k / QK * 8);
+    if (need <= LDS_ACT_LIMIT) mmvq_kernel<TYPE, NCOLS, true><<<grid, 256, need, stream>>>(a);
+    else                       mmvq_kernel<TYPE, NCOLS, false><<<grid, 256, 0, stream>>>(a);
     MI355_CHECK_LAUNCH();
     return MI355_OK;
 }
 
 template <int TYPE>
 static int dispatch_cols(const KArgs & a, int ncols, int nchannels, hipStream_t s) {
-    // rows per wave: enough waves to fill 256 CUs x 8 waves first, then deepen per-wave work
-    const int64_t rows_total = (int64_t)a.m * nchannels;
-    constexpr int R2 = TYPE == MI355_TYPE_Q6_K ? 1 : 2; // q6_K units hold 3x the registers
     switch (ncols) {
-        case 1:
-            if (rows_total >= 16384) return launch<TYPE, 1, 4>(a, nchannels, s);
-            if (rows_total >= 4096)  return launch<TYPE, 1, 2>(a, nchannels, s);
-            return launch<TYPE, 1, 1>(a, nchannels, s);
-        case 2: return launch<TYPE, 2, R2>(a, nchannels, s);
-        case 3: return launch<TYPE, 3, R2>(a, nchannels, s);
-        case 4: return launch<TYPE, 4, R2>(a, nchannels, s);
-        case 5: return launch<TYPE, 5, 1>(a, nchannels, s);
-        case 6: return launch<TYPE, 6, 1>(a, nchannels, s);
-        case 7: return launch<TYPE, 7, 1>(a, nchannels, s);
-        case 8: return launch<TYPE, 8, 1>(a, nchannels, s);
+        case 1: return launch<TYPE, 1>(a, nchannels, s);
+        case 2: return launch<TYPE, 2>(a, nchannels, s);
+        case 3: return launch<TYPE, 3>(a, nchannels, s);
+        case 4: return launch<TYPE, 4>(a, nchannels, s);
+        case 5: return launch<TYPE, 5>(a, nchannels, s);
+        case 6: return launch<TYPE, 6>(a, nchannels, s);
+        case 7: return launch<TYPE, 7>(a, nchannels, s);
+        case 8: return launch<TYPE, 8>(a, nchannels, s);
     }
     return MI355_E_SHAPE;
 }
