@@ -1,0 +1,232 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X hot path.
+
+Metric (BASELINE.json): "Q4_K mat-vec GB/s (% HBM peak) ...".  One "step" = one decode token's
+worth of quantized mat-vecs of Llama-3-8B Q4_K_M: all 225 weight matrices (32 layers x
+{wq, wk, wv, wo, gate, up, down} + output; Q4_K with Q6_K where llama.cpp's Q4_K_M recipe uses it)
+streamed once from HBM in graph order, each preceded by the q8_1 quantization of the activation
+that feeds it (4 per layer).  Weights are random valid GGUF blocks resident in HBM (4.6 GB, so
+every launch is cold with respect to the 256 MiB Infinity Cache); activations are synthetic.
+value = algorithmic bytes of the whole step / step time (GB/s, whole job).
+
+  python bench.py --gpus N --steps K --warmup W     (N > 1: launched by torch.distributed.run)
+
+N > 1 is the reference's `-sm row`: every matrix is row-split across the ranks
+(llm_amd/split.py), each rank runs the mat-vec on its slice and the slices are combined with an
+RCCL all-gather; the total work is fixed, so "scaling" is "strong".
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s measured copy)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--model", default="llama3-8b")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
+    return ap.parse_args()
+
+
+def make_weights(torch, B, t, m, k, gen):
+    """random valid blocks of type t on the GPU: random quant bytes, finite fp16 scales."""
+    rs = B.row_size(t, k)
+    nb = k // B.BLCK_SIZE[t]
+    w = torch.randint(0, 256, (m * nb, B.TYPE_SIZE[t]), dtype=torch.uint8, device="cuda", generator=gen)
+    scale = {B.Q4_0: 0.05, B.Q8_0: 0.005, B.Q4_K: 0.003, B.Q5_K: 0.002, B.Q6_K: 0.0005}[t]
+    for off in B._HALF_FIELDS[t]:
+        d = ((torch.rand(m * nb, device="cuda", generator=gen) * 0.75 + 0.25) * scale).to(torch.float16)
+        w[:, off:off + 2] = d.view(torch.uint8).view(m * nb, 2)
+    return w.view(m, rs)
+
+
+def cpu_baseline(threads):
+    """ggml-cpu (the reference itself, oracle/_ref built from its sources) on the same mat-vec, host cores."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_bench")
+    if os.path.exists(exe):
+        try:
+            out = subprocess.run([exe, "q4_K", "14336", "4096", "1", str(threads), "10", "64"], capture_output=True,
+                                 text=True, timeout=120, check=True).stdout.strip().splitlines()[-1]
+            r = json.loads(out)
+            return {"value": round(r["gbps"], 2), "unit": "GB/s", "cores": threads, "kind": "reference",
+                    "sample": f"ggml-cpu MUL_MAT q4_K 14336x4096 n=1 rotating over 64 matrices (2.1 GB, cold), "
+                              f"{r['runs']} runs in ~10 s, {r['us_per_run']:.1f} us/run"}
+        except Exception as e:  # noqa: BLE001 -- fall through to the port, but say why
+            print(f"[bench] oracle/_ref/ref_bench failed ({e}); timing the oracle port instead", file=sys.stderr)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    import oracle_lib as O
+    import llm_amd.blocks as B
+    m, k = 512, 4096
+    w = B.random_blocks(B.Q4_K, m, k, seed=1)
+    x = np.random.default_rng(0).standard_normal((1, k)).astype(np.float32)
+    t0, runs = time.perf_counter(), 0
+    while time.perf_counter() - t0 < 10.0:
+        O.mul_mat(B.Q4_K, w, x, m, k, 1, "cpu")
+        runs += 1
+    us = (time.perf_counter() - t0) / runs * 1e6
+    return {"value": round(B.matvec_bytes(B.Q4_K, m, k) / us * 1e-3, 3), "unit": "GB/s", "cores": 1, "kind": "port",
+            "sample": f"oracle (scalar C) q4_K {m}x{k} n=1, {runs} runs in ~10 s"}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            print(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus}", file=sys.stderr)
+            sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import llm_amd.blocks as B
+    import llm_amd.kernels as K
+    import llm_amd.model_shapes as MS
+    import llm_amd.ops as ops
+    from llm_amd.split import all_gather_rows, row_split
+
+    dims = MS.MODELS[args.model]
+    mats = MS.decode_matrices(dims, "Q4_K_M")
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(1234 + rank)
+
+    # ---- resident state: weights (row slice of this rank), activations, outputs, act scratch
+    weights, rows = [], []
+    for mt in mats:
+        lo, hi = row_split(mt.m, world)[rank]
+        rows.append((lo, hi))
+        weights.append(make_weights(torch, B, mt.type, hi - lo, mt.k, gen))
+    xs = {k: torch.randn((1, k), device="cuda", generator=gen) for k in sorted({mt.k for mt in mats})}
+    acts = {k: (torch.empty((1, k), dtype=torch.int8, device="cuda"),
+                torch.empty((1, k // 32, 2), dtype=torch.float32, device="cuda")) for k in xs}
+    outs = [torch.empty((1, hi - lo), dtype=torch.float32, device="cuda") for lo, hi in rows]
+
+    def quantize(k, stream):
+        aq, ads = acts[k]
+        K.check(K.lib.mi355_quantize_act(xs[k].data_ptr(), aq.data_ptr(), ads.data_ptr(), k, 1, 1, 1, k * 4, 0, 0, stream),
+                "mi355_quantize_act")
+
+    mm_args = []
+    for mt, w, o in zip(mats, weights, outs):
+        a = K.MmvqArgs()
+        aq, ads = acts[mt.k]
+        a.type, a.W, a.w_row_stride, a.w_ch_stride = mt.type, w.data_ptr(), B.row_size(mt.type, mt.k), 0
+        a.act_q, a.act_ds, a.act_ch_stride = aq.data_ptr(), ads.data_ptr(), 0
+        a.dst, a.dst_col_stride, a.dst_ch_stride = o.data_ptr(), o.shape[1], 0
+        a.m, a.k, a.ncols, a.nchannels, a.ch_ratio = o.shape[1], mt.k, 1, 1, 1
+        mm_args.append(a)
+
+    def step(events=None):
+        """one decode token's mat-vecs on the current stream"""
+        stream = torch.cuda.current_stream().cuda_stream
+        last_src = None
+        for i, mt in enumerate(mats):
+            if mt.src != last_src:          # one q8_1 quantization per distinct activation, as in the graph
+                quantize(mt.k, stream)
+                last_src = mt.src
+            if events is not None and mt.type == B.Q4_K:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                K.check(K.lib.mi355_mul_mat_vec_q(mm_args[i], stream), "mi355_mul_mat_vec_q")
+                e1.record()
+                events.append((i, e0, e1))
+            else:
+                K.check(K.lib.mi355_mul_mat_vec_q(mm_args[i], stream), "mi355_mul_mat_vec_q")
+            if world > 1:
+                all_gather_rows(outs[i], mt.m, rank, world, dist)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    use_graph = world == 1 and not args.no_graph
+    run = step
+    if use_graph:
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            step()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            step()
+        run = g.replay
+
+    for _ in range(args.warmup):
+        run()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    alg_bytes = MS.decode_algorithmic_bytes(dims, "Q4_K_M")     # whole job (all ranks together)
+    ms_per_step = dt / args.steps * 1e3
+    value = alg_bytes / (dt / args.steps) * 1e-9
+
+    # ---- roofline of the dominant kernel: mmvq q4_K (n=1).  Duration = the dispatch's own start/stop
+    # events on the launch stream (hipExtLaunchKernelGGL, the library's timing mode), i.e. kernel
+    # execution time without launch gaps -- the same quantity rocprofv3 --kernel-trace reports.
+    K.lib.mi355_timing_reset()
+    K.lib.mi355_timing_enable(1)
+    nroof = max(1, min(args.steps, 5))
+    for _ in range(nroof):
+        step()
+    torch.cuda.synchronize()
+    K.lib.mi355_timing_enable(0)
+    n_launch, tot_us = K.timing_read("mmvq_q4_K_n1")
+    q4k_bytes = nroof * sum(B.matvec_bytes(mt.type, o.shape[1], mt.k) for mt, o in zip(mats, outs) if mt.type == B.Q4_K)
+    avg_us = tot_us / n_launch
+    achieved = q4k_bytes / tot_us * 1e-3
+    kernels = {tag: {"launches": n, "avg_us": round(us / n, 3)} for tag, (n, us) in K.timing_report().items() if n}
+    roofline = {"bound": "hbm", "kernel": "mmvq_kernel<q4_K, ncols=1>", "achieved": round(achieved, 1),
+                "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                "traffic": None, "launches": n_launch, "avg_launch_us": round(avg_us, 3),
+                "algorithmic_bytes_per_launch": round(q4k_bytes / n_launch), "all_kernels": kernels}
+
+    if rank == 0:
+        line = {
+            "metric": "Q4_K mat-vec GB/s", "value": round(value, 1), "unit": "GB/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "weak" if world == 1 else "strong", "vs_baseline": None,
+            "dtype": "int8", "data": "synthetic",
+            "config": {"workload": f"{dims.name} Q4_K_M decode mat-vec sweep: 225 weight matrices "
+                                   f"({MS.decode_weight_bytes(dims) / 1e9:.3f} GB, Q4_K + Q6_K per llama.cpp's recipe) streamed once per "
+                                   "step + q8_1 activation quantization, random-init GGUF blocks",
+                       "parallelism": "single GPU" if world == 1 else f"row split x{world} + RCCL all-gather",
+                       "launch": "hipGraph replay" if use_graph else "eager",
+                       "pct_hbm_peak": round(value / (HBM_PEAK_GBPS * world) * 100, 2),
+                       "decode_tokens_per_s_matvec_only": round(1e3 / ms_per_step, 1)},
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(min(16, os.cpu_count() or 1))
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -56,6 +56,18 @@ MI355_API int64_t     mi355_type_size(int type);        /* bytes per block, 0 if
 MI355_API int64_t     mi355_row_size(int type, int64_t k); /* bytes of a row of k elements, -1 if k % blck */
 
 /* ---------------------------------------------------------------------------------------------
+ * Per-launch kernel timing (the backend's per-op profiler; the reference only has the offline
+ * `test-backend-ops perf` mode, tests/test-backend-ops.cpp:598-749).  Off by default.  When on,
+ * every kernel launch carries a start/stop event pair on its own dispatch, so the time is the
+ * kernel's execution time (what rocprofv3 --kernel-trace reports), without launch gaps.
+ * Not graph-capture safe while enabled.  Tags: "mmvq_<type>_n<ncols>", "quantize_q8_1", "dequantize".
+ */
+MI355_API void    mi355_timing_enable(int on);
+MI355_API void    mi355_timing_reset(void);
+MI355_API int     mi355_timing_read(const char *tag, int64_t *launches, double *total_us);
+MI355_API int64_t mi355_timing_report(char *buf, int64_t cap);
+
+/* ---------------------------------------------------------------------------------------------
  * Activation quantization, f32 -> block_q8_1 {half d, half s, int8 qs[32]} (36 B / 32 values).
  * BIT-EXACT with quantize_row_q8_1_ref (ggml/src/ggml-quants.c:214-247):
  *   d = amax/127, id = d ? 1/d : 0, q = roundf(x*id), s = fp16(sum(q) * d).

@@ -5,6 +5,8 @@
 #include <stdint.h>
 
 #include "mi355_kernels.h"
+#include "timing.h"
+#include <string.h>
 
 #define QK   32
 #define QK_K 256

@@ -77,7 +77,7 @@ template <int TYPE>
 static int launch_deq(const void * blocks, float * y, int64_t n, hipStream_t stream) {
     const int64_t nb = (n + 255) / 256;
     const unsigned grid = (unsigned)(nb < 8192 ? nb : 8192);
-    dequantize_kernel<TYPE><<<grid, 256, 0, stream>>>((const uint8_t *)blocks, y, n);
+    MI355_LAUNCH("dequantize", (dequantize_kernel<TYPE>), dim3(grid), dim3(256), 0, stream, (const uint8_t *)blocks, y, n);
     MI355_CHECK_LAUNCH();
     return MI355_OK;
 }

@@ -25,6 +25,7 @@
 // i.e. exactly dequant(W) . dequant_q8_1(x) up to f32 summation order.
 #include "common.h"
 #include <stdlib.h>
+#include <string>
 
 namespace {
 
@@ -377,14 +378,23 @@ mmvq_kernel(const KArgs a) {
     }
 }
 
+static const char * type_name(int t) {
+    switch (t) {
+        case MI355_TYPE_Q4_0: return "q4_0"; case MI355_TYPE_Q8_0: return "q8_0"; case MI355_TYPE_Q4_K: return "q4_K";
+        case MI355_TYPE_Q5_K: return "q5_K"; case MI355_TYPE_Q6_K: return "q6_K";
+    }
+    return "?";
+}
+
 static constexpr size_t LDS_ACT_LIMIT = 64 * 1024; // beyond this, activations are read through L1 instead
 
 template <int TYPE, int NCOLS>
 static int launch(const KArgs & a, int nchannels, hipStream_t stream) {
     const dim3 grid((unsigned)((a.m + 3) / 4), (unsigned)nchannels);
     const size_t need = (size_t)NCOLS * ((size_t)a.k + (size_t)a.k / QK * 8);
-    if (need <= LDS_ACT_LIMIT) mmvq_kernel<TYPE, NCOLS, true><<<grid, 256, need, stream>>>(a);
-    else                       mmvq_kernel<TYPE, NCOLS, false><<<grid, 256, 0, stream>>>(a);
+    static const std::string tag = std::string("mmvq_") + type_name(TYPE) + "_n" + std::to_string(NCOLS);
+    if (need <= LDS_ACT_LIMIT) MI355_LAUNCH(tag.c_str(), (mmvq_kernel<TYPE, NCOLS, true>), grid, dim3(256), need, stream, a);
+    else                       MI355_LAUNCH(tag.c_str(), (mmvq_kernel<TYPE, NCOLS, false>), grid, dim3(256), 0, stream, a);
     MI355_CHECK_LAUNCH();
     return MI355_OK;
 }

@@ -87,11 +87,11 @@ static int launch_quantize(bool soa, const float * x, void * y, int8_t * aq, flo
     if (grid.y > 65535) return MI355_E_SHAPE;
     uint8_t * ya = (uint8_t *)y;
     if (soa) {
-        if (vec) quantize_q8_1_kernel<true, true><<<grid, block, 0, stream>>>(x, ya, aq, ads, k, ne1, ne2, nb1, nb2, nb3);
-        else     quantize_q8_1_kernel<true, false><<<grid, block, 0, stream>>>(x, ya, aq, ads, k, ne1, ne2, nb1, nb2, nb3);
+        if (vec) MI355_LAUNCH("quantize_q8_1", (quantize_q8_1_kernel<true, true>), grid, block, 0, stream, x, ya, aq, ads, k, ne1, ne2, nb1, nb2, nb3);
+        else     MI355_LAUNCH("quantize_q8_1", (quantize_q8_1_kernel<true, false>), grid, block, 0, stream, x, ya, aq, ads, k, ne1, ne2, nb1, nb2, nb3);
     } else {
-        if (vec) quantize_q8_1_kernel<false, true><<<grid, block, 0, stream>>>(x, ya, aq, ads, k, ne1, ne2, nb1, nb2, nb3);
-        else     quantize_q8_1_kernel<false, false><<<grid, block, 0, stream>>>(x, ya, aq, ads, k, ne1, ne2, nb1, nb2, nb3);
+        if (vec) MI355_LAUNCH("quantize_q8_1", (quantize_q8_1_kernel<false, true>), grid, block, 0, stream, x, ya, aq, ads, k, ne1, ne2, nb1, nb2, nb3);
+        else     MI355_LAUNCH("quantize_q8_1", (quantize_q8_1_kernel<false, false>), grid, block, 0, stream, x, ya, aq, ads, k, ne1, ne2, nb1, nb2, nb3);
     }
     MI355_CHECK_LAUNCH();
     return MI355_OK;

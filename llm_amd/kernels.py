@@ -20,6 +20,7 @@ _vp, _i64, _i32 = C.c_void_p, C.c_int64, C.c_int32
 EXPORTS = [
     "mi355_abi_version", "mi355_error_string", "mi355_blck_size", "mi355_type_size", "mi355_row_size",
     "mi355_quantize_row_q8_1", "mi355_act_q_bytes", "mi355_act_ds_bytes", "mi355_quantize_act",
+    "mi355_timing_enable", "mi355_timing_reset", "mi355_timing_read", "mi355_timing_report",
     "mi355_dequantize_row", "mi355_mul_mat_vec_q", "mi355_mul_mat_workspace_bytes", "mi355_mul_mat",
 ]
 
@@ -50,6 +51,32 @@ lib.mi355_quantize_act.argtypes = [_vp, _vp, _vp] + [_i64] * 7 + [_vp]
 lib.mi355_dequantize_row.argtypes = [C.c_int, _vp, _vp, _i64, _vp]
 lib.mi355_mul_mat_vec_q.argtypes = [C.POINTER(MmvqArgs), _vp]
 lib.mi355_mul_mat.argtypes = [C.c_int, _vp, _i64, _vp, _vp, _i64, _i64, _i64, _vp, _i64, _vp]
+
+
+lib.mi355_timing_enable.argtypes = [C.c_int]
+lib.mi355_timing_enable.restype = None
+lib.mi355_timing_reset.restype = None
+lib.mi355_timing_read.argtypes = [C.c_char_p, C.POINTER(_i64), C.POINTER(C.c_double)]
+lib.mi355_timing_report.argtypes = [C.c_char_p, _i64]
+lib.mi355_timing_report.restype = _i64
+
+
+def timing_read(tag):
+    """-> (launches, total_us) of the kernels launched under `tag` while timing was enabled."""
+    n, us = _i64(0), C.c_double(0.0)
+    check(lib.mi355_timing_read(tag.encode(), C.byref(n), C.byref(us)), "mi355_timing_read")
+    return n.value, us.value
+
+
+def timing_report():
+    need = lib.mi355_timing_report(None, 0)
+    buf = C.create_string_buffer(need + 64)
+    lib.mi355_timing_report(buf, need + 64)
+    out = {}
+    for line in buf.value.decode().splitlines():
+        tag, n, us = line.split()
+        out[tag] = (int(n), float(us))
+    return out
 
 
 class Mi355Error(RuntimeError):
