@@ -1,0 +1,732 @@
+// ggml-mi355.cpp -- ggml backend plugin for AMD Instinct MI355X (gfx950).
+//
+// Host side of the drop-in boundary: implements ggml's own plugin interface
+//   ggml_backend_reg_i / ggml_backend_device_i / ggml_backend_buffer_type_i / ggml_backend_buffer_i /
+//   ggml_backend_i            (reference: ggml/src/ggml-backend-impl.h:17-207)
+// and exports ggml_backend_init / ggml_backend_score (ggml-backend-impl.h:214-251) so that the
+// reference's unmodified llama-cli, llama-bench and test-backend-ops load it through
+// GGML_BACKEND_PATH (ggml/src/ggml-backend-reg.cpp:578-582).  The compute is in
+// libmi355_kernels.so (include/mi355_kernels.h); this file holds no kernels and no CPU fallback:
+// an op the kernels do not implement is reported by supports_op() == false and the scheduler keeps
+// it on another backend.
+//
+// Built against the reference's public headers (ggml.h, ggml-backend.h, ggml-backend-impl.h); the
+// ggml-base symbols it calls are resolved from the host executable at dlopen time.
+#include "ggml.h"
+#include "ggml-backend.h"
+#include "ggml-backend-impl.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "mi355_kernels.h"
+#include "mi355_ops.h"
+
+#define MI355_NAME "MI355"
+#define MI355_MAX_DEVICES 16
+
+// ggml's logger lives in ggml-base (ggml-impl.h is internal; the symbol is exported)
+extern "C" void ggml_log_internal(enum ggml_log_level level, const char * format, ...);
+#define MI_LOG_INFO(...)  ggml_log_internal(GGML_LOG_LEVEL_INFO, __VA_ARGS__)
+#define MI_LOG_WARN(...)  ggml_log_internal(GGML_LOG_LEVEL_WARN, __VA_ARGS__)
+#define MI_LOG_ERROR(...) ggml_log_internal(GGML_LOG_LEVEL_ERROR, __VA_ARGS__)
+#define MI_LOG_DEBUG(...) ggml_log_internal(GGML_LOG_LEVEL_DEBUG, __VA_ARGS__)
+
+// unrecoverable device errors abort with a message, as CUDA_CHECK does (ggml-cuda.cu:70-81)
+#define HIP_CHECK(expr)                                                                              \
+    do {                                                                                             \
+        hipError_t err_ = (expr);                                                                    \
+        if (err_ != hipSuccess) {                                                                    \
+            ggml_abort(__FILE__, __LINE__, "HIP error: %s\n  in %s", hipGetErrorString(err_), #expr); \
+        }                                                                                            \
+    } while (0)
+
+#define MI_CHECK(expr)                                                                               \
+    do {                                                                                             \
+        int rc_ = (expr);                                                                            \
+        if (rc_ != 0) {                                                                              \
+            ggml_abort(__FILE__, __LINE__, "mi355 kernel error: %s\n  in %s", mi355_error_string(rc_), #expr); \
+        }                                                                                            \
+    } while (0)
+
+static ggml_backend_reg_t ggml_backend_mi355_reg(void);
+
+// ------------------------------------------------------------------------------------------------
+// device info
+// ------------------------------------------------------------------------------------------------
+struct mi355_device_ctx {
+    int         device = 0;
+    std::string name;
+    std::string description;
+};
+
+static int mi355_device_count() {
+    static int count = [] {
+        int n = 0;
+        if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+        int ok = 0;
+        for (int i = 0; i < n && i < MI355_MAX_DEVICES; i++) {
+            hipDeviceProp_t p;
+            if (hipGetDeviceProperties(&p, i) != hipSuccess) break;
+            // the kernels are compiled for gfx950 only
+            if (strncmp(p.gcnArchName, "gfx950", 6) != 0) {
+                MI_LOG_WARN("%s: device %d is %s, not gfx950 -- ignored\n", MI355_NAME, i, p.gcnArchName);
+                break;
+            }
+            ok++;
+        }
+        return ok;
+    }();
+    return count;
+}
+
+static void mi355_set_device(int device) {
+    int cur = -1;
+    HIP_CHECK(hipGetDevice(&cur));
+    if (cur != device) HIP_CHECK(hipSetDevice(device));
+}
+
+// ------------------------------------------------------------------------------------------------
+// device buffer  (reference behaviour: ggml-cuda.cu:543-751)
+// ------------------------------------------------------------------------------------------------
+struct mi355_buffer_ctx {
+    int    device;
+    void * base;
+};
+
+struct mi355_buft_ctx {
+    int         device;
+    std::string name;
+};
+
+static bool buft_is_mi355(ggml_backend_buffer_type_t buft);
+
+static void mi355_buffer_free(ggml_backend_buffer_t buffer) {
+    mi355_buffer_ctx * ctx = (mi355_buffer_ctx *)buffer->context;
+    mi355_set_device(ctx->device);
+    HIP_CHECK(hipFree(ctx->base));
+    delete ctx;
+}
+
+static void * mi355_buffer_get_base(ggml_backend_buffer_t buffer) {
+    return ((mi355_buffer_ctx *)buffer->context)->base;
+}
+
+static enum ggml_status mi355_buffer_init_tensor(ggml_backend_buffer_t, ggml_tensor *) {
+    // rows are not padded (the kernels never read past a row), so there is nothing to initialise
+    return GGML_STATUS_SUCCESS;
+}
+
+static void mi355_buffer_memset_tensor(ggml_backend_buffer_t buffer, ggml_tensor * tensor, uint8_t value, size_t offset, size_t size) {
+    mi355_buffer_ctx * ctx = (mi355_buffer_ctx *)buffer->context;
+    mi355_set_device(ctx->device);
+    HIP_CHECK(hipMemset((char *)tensor->data + offset, value, size));
+    HIP_CHECK(hipDeviceSynchronize());
+}
+
+// set/get are synchronous host<->device copies (ggml-cuda.cu:604-618)
+static void mi355_buffer_set_tensor(ggml_backend_buffer_t buffer, ggml_tensor * tensor, const void * data, size_t offset, size_t size) {
+    mi355_buffer_ctx * ctx = (mi355_buffer_ctx *)buffer->context;
+    mi355_set_device(ctx->device);
+    HIP_CHECK(hipMemcpy((char *)tensor->data + offset, data, size, hipMemcpyHostToDevice));
+}
+
+static void mi355_buffer_get_tensor(ggml_backend_buffer_t buffer, const ggml_tensor * tensor, void * data, size_t offset, size_t size) {
+    mi355_buffer_ctx * ctx = (mi355_buffer_ctx *)buffer->context;
+    mi355_set_device(ctx->device);
+    HIP_CHECK(hipMemcpy(data, (const char *)tensor->data + offset, size, hipMemcpyDeviceToHost));
+}
+
+static bool mi355_buffer_cpy_tensor(ggml_backend_buffer_t buffer, const ggml_tensor * src, ggml_tensor * dst) {
+    ggml_backend_buffer_t sbuf = src->view_src ? src->view_src->buffer : src->buffer;
+    if (!sbuf || !buft_is_mi355(sbuf->buft)) return false; // foreign source: caller falls back to get/set
+    mi355_buffer_ctx * sctx = (mi355_buffer_ctx *)sbuf->context;
+    mi355_buffer_ctx * dctx = (mi355_buffer_ctx *)buffer->context;
+    mi355_set_device(dctx->device);
+    if (sctx->device == dctx->device) {
+        HIP_CHECK(hipMemcpy(dst->data, src->data, ggml_nbytes(src), hipMemcpyDeviceToDevice));
+    } else {
+        HIP_CHECK(hipMemcpyPeer(dst->data, dctx->device, src->data, sctx->device, ggml_nbytes(src)));
+    }
+    HIP_CHECK(hipDeviceSynchronize());
+    return true;
+}
+
+static void mi355_buffer_clear(ggml_backend_buffer_t buffer, uint8_t value) {
+    mi355_buffer_ctx * ctx = (mi355_buffer_ctx *)buffer->context;
+    mi355_set_device(ctx->device);
+    HIP_CHECK(hipMemset(ctx->base, value, buffer->size));
+    HIP_CHECK(hipDeviceSynchronize());
+}
+
+static const ggml_backend_buffer_i mi355_buffer_iface = {
+    /* .free_buffer   = */ mi355_buffer_free,
+    /* .get_base      = */ mi355_buffer_get_base,
+    /* .init_tensor   = */ mi355_buffer_init_tensor,
+    /* .memset_tensor = */ mi355_buffer_memset_tensor,
+    /* .set_tensor    = */ mi355_buffer_set_tensor,
+    /* .get_tensor    = */ mi355_buffer_get_tensor,
+    /* .cpy_tensor    = */ mi355_buffer_cpy_tensor,
+    /* .clear         = */ mi355_buffer_clear,
+    /* .reset         = */ NULL,
+};
+
+// buffer type
+static const char * mi355_buft_get_name(ggml_backend_buffer_type_t buft) {
+    return ((mi355_buft_ctx *)buft->context)->name.c_str();
+}
+
+static bool buft_is_mi355(ggml_backend_buffer_type_t buft) {
+    return buft->iface.get_name == mi355_buft_get_name; // identity by function pointer (ggml-cuda.cu:566-568)
+}
+
+static ggml_backend_buffer_t mi355_buft_alloc_buffer(ggml_backend_buffer_type_t buft, size_t size) {
+    mi355_buft_ctx * bctx = (mi355_buft_ctx *)buft->context;
+    mi355_set_device(bctx->device);
+    void * ptr = nullptr;
+    const size_t alloc = size > 0 ? size : 1;
+    hipError_t err = hipMalloc(&ptr, alloc);
+    if (err != hipSuccess) {
+        (void)hipGetLastError(); // allocation failure is the one soft error: NULL to the caller (ggml-cuda.cu:683-689)
+        MI_LOG_ERROR("%s: allocating %.2f MiB on device %d: hipMalloc failed: %s\n", __func__, size / 1024.0 / 1024.0,
+                     bctx->device, hipGetErrorString(err));
+        return nullptr;
+    }
+    mi355_buffer_ctx * ctx = new mi355_buffer_ctx{bctx->device, ptr};
+    return ggml_backend_buffer_init(buft, mi355_buffer_iface, ctx, size);
+}
+
+static size_t mi355_buft_get_alignment(ggml_backend_buffer_type_t) { return 128; }
+
+static ggml_backend_dev_t mi355_reg_get_device(ggml_backend_reg_t reg, size_t index);
+
+static ggml_backend_buffer_type_t mi355_buffer_type(int device) {
+    static std::mutex mu;
+    static ggml_backend_buffer_type bufts[MI355_MAX_DEVICES];
+    static bool inited = false;
+    std::lock_guard<std::mutex> lk(mu);
+    if (device < 0 || device >= mi355_device_count()) return nullptr;
+    if (!inited) {
+        for (int i = 0; i < mi355_device_count(); i++) {
+            bufts[i].iface = {
+                /* .get_name       = */ mi355_buft_get_name,
+                /* .alloc_buffer   = */ mi355_buft_alloc_buffer,
+                /* .get_alignment  = */ mi355_buft_get_alignment,
+                /* .get_max_size   = */ NULL,
+                /* .get_alloc_size = */ NULL,
+                /* .is_host        = */ NULL,
+            };
+            bufts[i].device  = mi355_reg_get_device(ggml_backend_mi355_reg(), i);
+            bufts[i].context = new mi355_buft_ctx{i, std::string(MI355_NAME) + std::to_string(i)};
+        }
+        inited = true;
+    }
+    return &bufts[device];
+}
+
+// ------------------------------------------------------------------------------------------------
+// pinned host buffer (ggml-cuda.cu:1086-1146)
+// ------------------------------------------------------------------------------------------------
+static const char * mi355_host_buft_name(ggml_backend_buffer_type_t) { return MI355_NAME "_Host"; }
+
+static void mi355_host_buffer_free(ggml_backend_buffer_t buffer) { HIP_CHECK(hipHostFree(buffer->context)); }
+
+static ggml_backend_buffer_t mi355_host_buft_alloc(ggml_backend_buffer_type_t buft, size_t size) {
+    void * ptr = nullptr;
+    if (getenv("GGML_MI355_NO_PINNED") == nullptr) {
+        hipError_t err = hipHostMalloc(&ptr, size > 0 ? size : 1, hipHostMallocDefault);
+        if (err != hipSuccess) { (void)hipGetLastError(); ptr = nullptr; }
+    }
+    if (!ptr) return ggml_backend_buft_alloc_buffer(ggml_backend_cpu_buffer_type(), size); // pageable fallback
+    ggml_backend_buffer_t buffer = ggml_backend_cpu_buffer_from_ptr(ptr, size);
+    buffer->buft = buft;
+    buffer->iface.free_buffer = mi355_host_buffer_free;
+    return buffer;
+}
+
+static ggml_backend_buffer_type_t mi355_host_buffer_type() {
+    static ggml_backend_buffer_type buft = {
+        /* .iface = */ {
+            /* .get_name       = */ mi355_host_buft_name,
+            /* .alloc_buffer   = */ mi355_host_buft_alloc,
+            /* .get_alignment  = */ ggml_backend_cpu_buffer_type()->iface.get_alignment,
+            /* .get_max_size   = */ NULL,
+            /* .get_alloc_size = */ ggml_backend_cpu_buffer_type()->iface.get_alloc_size,
+            /* .is_host        = */ ggml_backend_cpu_buffer_type()->iface.is_host,
+        },
+        /* .device  = */ mi355_reg_get_device(ggml_backend_mi355_reg(), 0),
+        /* .context = */ nullptr,
+    };
+    return &buft;
+}
+
+// ------------------------------------------------------------------------------------------------
+// backend (stream)
+// ------------------------------------------------------------------------------------------------
+struct mi355_backend_ctx {
+    int         device;
+    std::string name;
+    hipStream_t stream = nullptr;
+    // scratch for the q8_1 activations of the MUL_MAT in flight; grown on demand, reused across ops
+    void * scratch = nullptr;
+    size_t scratch_size = 0;
+
+    void * get_scratch(size_t need) {
+        if (need <= scratch_size) return scratch;
+        if (scratch) {
+            HIP_CHECK(hipStreamSynchronize(stream)); // earlier kernels may still read the old block
+            HIP_CHECK(hipFree(scratch));
+        }
+        scratch_size = (need + (8u << 20)) & ~((size_t)(1u << 20) - 1);
+        HIP_CHECK(hipMalloc(&scratch, scratch_size));
+        return scratch;
+    }
+};
+
+static ggml_guid_t mi355_guid() {
+    static ggml_guid guid = {0x4d, 0x49, 0x33, 0x35, 0x35, 0x58, 0x67, 0x66, 0x78, 0x39, 0x35, 0x30, 0x67, 0x67, 0x6d, 0x6c};
+    return &guid;
+}
+
+static const char * mi355_backend_get_name(ggml_backend_t backend) { return ((mi355_backend_ctx *)backend->context)->name.c_str(); }
+
+static void mi355_backend_free(ggml_backend_t backend) {
+    mi355_backend_ctx * ctx = (mi355_backend_ctx *)backend->context;
+    mi355_set_device(ctx->device);
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (ctx->scratch) HIP_CHECK(hipFree(ctx->scratch));
+    HIP_CHECK(hipStreamDestroy(ctx->stream));
+    delete ctx;
+    delete backend;
+}
+
+static bool tensor_on_device(const ggml_tensor * t, int device) {
+    ggml_backend_buffer_t buf = t->view_src ? t->view_src->buffer : t->buffer;
+    return buf && buft_is_mi355(buf->buft) && ((mi355_buffer_ctx *)buf->context)->device == device;
+}
+
+static void mi355_backend_set_tensor_async(ggml_backend_t backend, ggml_tensor * tensor, const void * data, size_t offset, size_t size) {
+    mi355_backend_ctx * ctx = (mi355_backend_ctx *)backend->context;
+    GGML_ASSERT(tensor_on_device(tensor, ctx->device) && "unsupported buffer type");
+    mi355_set_device(ctx->device);
+    HIP_CHECK(hipMemcpyAsync((char *)tensor->data + offset, data, size, hipMemcpyHostToDevice, ctx->stream));
+}
+
+static void mi355_backend_get_tensor_async(ggml_backend_t backend, const ggml_tensor * tensor, void * data, size_t offset, size_t size) {
+    mi355_backend_ctx * ctx = (mi355_backend_ctx *)backend->context;
+    GGML_ASSERT(tensor_on_device(tensor, ctx->device) && "unsupported buffer type");
+    mi355_set_device(ctx->device);
+    HIP_CHECK(hipMemcpyAsync(data, (const char *)tensor->data + offset, size, hipMemcpyDeviceToHost, ctx->stream));
+}
+
+static bool backend_is_mi355(ggml_backend_t backend) { return backend && ggml_guid_matches(backend->guid, mi355_guid()); }
+
+static bool mi355_backend_cpy_tensor_async(ggml_backend_t backend_src, ggml_backend_t backend_dst, const ggml_tensor * src, ggml_tensor * dst) {
+    if (!backend_is_mi355(backend_src) || !backend_is_mi355(backend_dst)) return false;
+    mi355_backend_ctx * sctx = (mi355_backend_ctx *)backend_src->context;
+    mi355_backend_ctx * dctx = (mi355_backend_ctx *)backend_dst->context;
+    if (!tensor_on_device(src, sctx->device) || !tensor_on_device(dst, dctx->device)) return false;
+    if (backend_src != backend_dst) {
+        // copy on the source stream, then make the destination stream wait for it (ggml-cuda.cu:2516-2569)
+        mi355_set_device(sctx->device);
+        if (sctx->device == dctx->device) {
+            HIP_CHECK(hipMemcpyAsync(dst->data, src->data, ggml_nbytes(dst), hipMemcpyDeviceToDevice, sctx->stream));
+        } else {
+            HIP_CHECK(hipMemcpyPeerAsync(dst->data, dctx->device, src->data, sctx->device, ggml_nbytes(dst), sctx->stream));
+        }
+        hipEvent_t ev;
+        HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        HIP_CHECK(hipEventRecord(ev, sctx->stream));
+        mi355_set_device(dctx->device);
+        HIP_CHECK(hipStreamWaitEvent(dctx->stream, ev, 0));
+        HIP_CHECK(hipEventDestroy(ev));
+    } else {
+        mi355_set_device(sctx->device);
+        HIP_CHECK(hipMemcpyAsync(dst->data, src->data, ggml_nbytes(dst), hipMemcpyDeviceToDevice, sctx->stream));
+    }
+    return true;
+}
+
+static void mi355_backend_synchronize(ggml_backend_t backend) {
+    mi355_backend_ctx * ctx = (mi355_backend_ctx *)backend->context;
+    mi355_set_device(ctx->device);
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+}
+
+// ------------------------------------------------------------------------------------------------
+// ops
+// ------------------------------------------------------------------------------------------------
+static bool is_weight_type(enum ggml_type t) {
+    return t == GGML_TYPE_Q4_0 || t == GGML_TYPE_Q8_0 || t == GGML_TYPE_Q4_K || t == GGML_TYPE_Q5_K || t == GGML_TYPE_Q6_K;
+}
+
+static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// MUL_MAT on block-quantized src0 (reference dispatch: ggml_cuda_mul_mat, ggml-cuda.cu:1988-2063;
+// contract ggml.c:2971-2986; oracle ggml_compute_forward_mul_mat, ggml-cpu.c:1196-1388)
+static void mi355_mul_mat(mi355_backend_ctx * ctx, ggml_tensor * dst) {
+    const ggml_tensor * src0 = dst->src[0];
+    const ggml_tensor * src1 = dst->src[1];
+    const int64_t K = src0->ne[0], M = src0->ne[1], ne02 = src0->ne[2], ne03 = src0->ne[3];
+    const int64_t N = src1->ne[1], ne12 = src1->ne[2], ne13 = src1->ne[3];
+    const int64_t rows = N * ne12 * ne13;
+    if (rows == 0 || M == 0) return;
+
+    // q8_1 activations for all of src1 (strided / permuted src1 is handled by the quantizer)
+    const size_t qb = align_up((size_t)mi355_act_q_bytes(K, rows), 256);
+    const size_t db = align_up((size_t)mi355_act_ds_bytes(K, rows), 256);
+    char * ws = (char *)ctx->get_scratch(qb + db);
+    int8_t * aq  = (int8_t *)ws;
+    float  * ads = (float *)(ws + qb);
+    MI_CHECK(mi355_quantize_act((const float *)src1->data, aq, ads, K, N, ne12, ne13, src1->nb[1], src1->nb[2], src1->nb[3], ctx->stream));
+
+    const int64_t r2 = ne12 / ne02, r3 = ne13 / ne03;
+    for (int64_t i13 = 0; i13 < ne13; i13++) {
+        for (int64_t c0 = 0; c0 < N; c0 += 8) {
+            mi355_mmvq_args a;
+            memset(&a, 0, sizeof(a));
+            a.type = (int32_t)src0->type;
+            a.W = (const char *)src0->data + (i13 / r3) * src0->nb[3];
+            a.w_row_stride = (int64_t)src0->nb[1];
+            a.w_ch_stride  = (int64_t)src0->nb[2];
+            a.act_q  = aq + (i13 * ne12 * N + c0) * K;
+            a.act_ds = ads + (i13 * ne12 * N + c0) * (K / 32) * 2;
+            a.act_ch_stride = N;
+            a.dst = (float *)((char *)dst->data + i13 * dst->nb[3]) + c0 * (dst->nb[1] / sizeof(float));
+            a.dst_col_stride = (int64_t)(dst->nb[1] / sizeof(float));
+            a.dst_ch_stride  = (int64_t)(dst->nb[2] / sizeof(float));
+            a.m = M; a.k = K;
+            a.ncols = (int32_t)(N - c0 < 8 ? N - c0 : 8);
+            a.nchannels = (int32_t)ne12;
+            a.ch_ratio  = (int32_t)r2;
+            MI_CHECK(mi355_mul_mat_vec_q(&a, ctx->stream));
+        }
+    }
+}
+
+// MUL_MAT_ID (contract ggml.c:3000-3036; reference ggml_cuda_mul_mat_id, ggml-cuda.cu:2065-2206;
+// oracle ggml_compute_forward_mul_mat_id, ggml-cpu.c:1470-1648).  Expert routing stays on the
+// device: the kernel reads ids itself, so there is no stream sync + host-side sort per call
+// (the reference does both, ggml-cuda/mmq.cu:157-158,188-189).
+static void mi355_mul_mat_id(mi355_backend_ctx * ctx, ggml_tensor * dst) {
+    const ggml_tensor * as  = dst->src[0];
+    const ggml_tensor * b   = dst->src[1];
+    const ggml_tensor * ids = dst->src[2];
+    const int64_t K = as->ne[0], M = as->ne[1], n_expert = as->ne[2];
+    const int64_t b_ne1 = b->ne[1], n_tokens = b->ne[2];
+    const int64_t n_used = ids->ne[0];
+    if (n_tokens == 0 || M == 0) return;
+    const int64_t rows = b_ne1 * n_tokens;
+    const size_t qb = align_up((size_t)mi355_act_q_bytes(K, rows), 256);
+    const size_t db = align_up((size_t)mi355_act_ds_bytes(K, rows), 256);
+    char * ws = (char *)ctx->get_scratch(qb + db);
+    int8_t * aq  = (int8_t *)ws;
+    float  * ads = (float *)(ws + qb);
+    MI_CHECK(mi355_quantize_act((const float *)b->data, aq, ads, K, b_ne1, n_tokens, 1, b->nb[1], b->nb[2], b->nb[3], ctx->stream));
+
+    // (token, slot) pairs are the launch's channels; at most 65535 per launch
+    const int64_t tok_per_launch = 65535 / n_used;
+    for (int64_t t0 = 0; t0 < n_tokens; t0 += tok_per_launch) {
+        const int64_t nt = n_tokens - t0 < tok_per_launch ? n_tokens - t0 : tok_per_launch;
+        mi355_mmvq_args a;
+        memset(&a, 0, sizeof(a));
+        a.type = (int32_t)as->type;
+        a.W = as->data;
+        a.w_row_stride = (int64_t)as->nb[1];
+        a.w_ch_stride  = (int64_t)as->nb[2];
+        a.act_q  = aq + t0 * b_ne1 * K;
+        a.act_ds = ads + t0 * b_ne1 * (K / 32) * 2;
+        a.act_ch_stride = b_ne1;
+        a.dst = (float *)((char *)dst->data + t0 * dst->nb[2]);
+        a.dst_col_stride = M;
+        a.dst_ch_stride  = (int64_t)(dst->nb[1] / sizeof(float));
+        a.m = M; a.k = K; a.ncols = 1;
+        a.nchannels = (int32_t)(nt * n_used);
+        a.ch_ratio = 1;
+        a.ids = (const int32_t *)((const char *)ids->data + t0 * ids->nb[1]);
+        a.ids_stride = (int32_t)(ids->nb[1] / sizeof(int32_t));
+        a.ids_nused  = (int32_t)n_used;
+        a.act_ne1    = (int32_t)b_ne1;
+        a.n_expert   = (int32_t)n_expert;
+        MI_CHECK(mi355_mul_mat_vec_q(&a, ctx->stream));
+    }
+}
+
+static bool mi355_compute_forward(mi355_backend_ctx * ctx, ggml_tensor * node) {
+    switch (node->op) {
+        case GGML_OP_MUL_MAT:    mi355_mul_mat(ctx, node);    return true;
+        case GGML_OP_MUL_MAT_ID: mi355_mul_mat_id(ctx, node); return true;
+        default: break;
+    }
+    return mi355_ops_forward(node, ctx->stream);
+}
+
+static enum ggml_status mi355_backend_graph_compute(ggml_backend_t backend, ggml_cgraph * cgraph) {
+    mi355_backend_ctx * ctx = (mi355_backend_ctx *)backend->context;
+    mi355_set_device(ctx->device);
+    const int n = ggml_graph_n_nodes(cgraph);
+    for (int i = 0; i < n; i++) {
+        ggml_tensor * node = ggml_graph_node(cgraph, i);
+        // empty tensors and pure view ops compute nothing (ggml-cuda.cu:2589)
+        if (ggml_is_empty(node) || node->op == GGML_OP_NONE || node->op == GGML_OP_RESHAPE || node->op == GGML_OP_VIEW ||
+            node->op == GGML_OP_PERMUTE || node->op == GGML_OP_TRANSPOSE) {
+            continue;
+        }
+        if (!mi355_compute_forward(ctx, node)) {
+            MI_LOG_ERROR("%s: op not supported %s (%s)\n", __func__, node->name, ggml_op_name(node->op));
+            return GGML_STATUS_FAILED;
+        }
+    }
+    return GGML_STATUS_SUCCESS;
+}
+
+static void mi355_backend_event_record(ggml_backend_t backend, ggml_backend_event_t event) {
+    mi355_backend_ctx * ctx = (mi355_backend_ctx *)backend->context;
+    mi355_set_device(ctx->device);
+    HIP_CHECK(hipEventRecord((hipEvent_t)event->context, ctx->stream));
+}
+
+static void mi355_backend_event_wait(ggml_backend_t backend, ggml_backend_event_t event) {
+    mi355_backend_ctx * ctx = (mi355_backend_ctx *)backend->context;
+    mi355_set_device(ctx->device);
+    HIP_CHECK(hipStreamWaitEvent(ctx->stream, (hipEvent_t)event->context, 0));
+}
+
+static const ggml_backend_i mi355_backend_iface = {
+    /* .get_name           = */ mi355_backend_get_name,
+    /* .free               = */ mi355_backend_free,
+    /* .set_tensor_async   = */ mi355_backend_set_tensor_async,
+    /* .get_tensor_async   = */ mi355_backend_get_tensor_async,
+    /* .cpy_tensor_async   = */ mi355_backend_cpy_tensor_async,
+    /* .synchronize        = */ mi355_backend_synchronize,
+    /* .graph_plan_create  = */ NULL,
+    /* .graph_plan_free    = */ NULL,
+    /* .graph_plan_update  = */ NULL,
+    /* .graph_plan_compute = */ NULL,
+    /* .graph_compute      = */ mi355_backend_graph_compute,
+    /* .event_record       = */ mi355_backend_event_record,
+    /* .event_wait         = */ mi355_backend_event_wait,
+};
+
+// ------------------------------------------------------------------------------------------------
+// device interface
+// ------------------------------------------------------------------------------------------------
+static const char * mi355_dev_get_name(ggml_backend_dev_t dev) { return ((mi355_device_ctx *)dev->context)->name.c_str(); }
+static const char * mi355_dev_get_description(ggml_backend_dev_t dev) { return ((mi355_device_ctx *)dev->context)->description.c_str(); }
+
+static void mi355_dev_get_memory(ggml_backend_dev_t dev, size_t * free, size_t * total) {
+    mi355_set_device(((mi355_device_ctx *)dev->context)->device);
+    HIP_CHECK(hipMemGetInfo(free, total));
+}
+
+static enum ggml_backend_dev_type mi355_dev_get_type(ggml_backend_dev_t) { return GGML_BACKEND_DEVICE_TYPE_GPU; }
+
+static void mi355_dev_get_props(ggml_backend_dev_t dev, ggml_backend_dev_props * props) {
+    props->name        = mi355_dev_get_name(dev);
+    props->description = mi355_dev_get_description(dev);
+    props->type        = mi355_dev_get_type(dev);
+    mi355_dev_get_memory(dev, &props->memory_free, &props->memory_total);
+    props->caps = {
+        /* .async                = */ true,
+        /* .host_buffer          = */ getenv("GGML_MI355_NO_PINNED") == nullptr,
+        /* .buffer_from_host_ptr = */ false,
+        /* .events               = */ true,
+    };
+}
+
+static ggml_backend_t mi355_dev_init_backend(ggml_backend_dev_t dev, const char *) {
+    mi355_device_ctx * dctx = (mi355_device_ctx *)dev->context;
+    mi355_set_device(dctx->device);
+    mi355_backend_ctx * ctx = new mi355_backend_ctx;
+    ctx->device = dctx->device;
+    ctx->name   = dctx->name;
+    HIP_CHECK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    ggml_backend_t backend = new ggml_backend{
+        /* .guid    = */ mi355_guid(),
+        /* .iface   = */ mi355_backend_iface,
+        /* .device  = */ dev,
+        /* .context = */ ctx,
+    };
+    return backend;
+}
+
+static ggml_backend_buffer_type_t mi355_dev_get_buffer_type(ggml_backend_dev_t dev) {
+    return mi355_buffer_type(((mi355_device_ctx *)dev->context)->device);
+}
+
+static ggml_backend_buffer_type_t mi355_dev_get_host_buffer_type(ggml_backend_dev_t) { return mi355_host_buffer_type(); }
+
+static bool mi355_dev_supports_op(ggml_backend_dev_t dev, const ggml_tensor * op) {
+    const int device = ((mi355_device_ctx *)dev->context)->device;
+    // every source must live on this device (ggml-cuda.cu:3088-3096); buffers may be absent while
+    // the scheduler is still assigning
+    for (int i = 0; i < GGML_MAX_SRC; i++) {
+        const ggml_tensor * s = op->src[i];
+        if (!s) continue;
+        ggml_backend_buffer_t buf = s->view_src ? s->view_src->buffer : s->buffer;
+        if (buf && buft_is_mi355(buf->buft) && ((mi355_buffer_ctx *)buf->context) &&
+            buf->size > 0 && ((mi355_buffer_ctx *)buf->context)->device != device) {
+            return false;
+        }
+    }
+    switch (op->op) {
+        case GGML_OP_NONE:
+        case GGML_OP_RESHAPE:
+        case GGML_OP_VIEW:
+        case GGML_OP_PERMUTE:
+        case GGML_OP_TRANSPOSE:
+            return true;
+        case GGML_OP_MUL_MAT: {
+            const ggml_tensor * a = op->src[0];
+            const ggml_tensor * b = op->src[1];
+            if (!is_weight_type(a->type) || b->type != GGML_TYPE_F32 || op->type != GGML_TYPE_F32) return false;
+            if (a->nb[0] != ggml_type_size(a->type) || b->nb[0] != sizeof(float)) return false; // rows contiguous
+            if (ggml_is_transposed(a) || !ggml_is_contiguous(op)) return false;
+            if (b->ne[2] % a->ne[2] != 0 || b->ne[3] % a->ne[3] != 0) return false;
+            if (b->ne[2] > 65535) return false;
+            // alignment the 128-bit loads rely on
+            if ((b->nb[1] | b->nb[2] | b->nb[3]) & 3) return false;
+            if ((a->type == GGML_TYPE_Q4_K || a->type == GGML_TYPE_Q5_K) && ((a->nb[1] | a->nb[2] | a->nb[3]) & 15)) return false;
+            return true;
+        }
+        case GGML_OP_MUL_MAT_ID: {
+            const ggml_tensor * a = op->src[0];
+            const ggml_tensor * b = op->src[1];
+            const ggml_tensor * ids = op->src[2];
+            if (!is_weight_type(a->type) || b->type != GGML_TYPE_F32 || op->type != GGML_TYPE_F32 || ids->type != GGML_TYPE_I32) return false;
+            if (a->nb[0] != ggml_type_size(a->type) || b->nb[0] != sizeof(float) || ids->nb[0] != sizeof(int32_t)) return false;
+            if (!ggml_is_contiguous(op) || a->ne[3] != 1 || b->ne[3] != 1) return false;
+            if (b->ne[1] != 1 && b->ne[1] != ids->ne[0]) return false;
+            if (ids->ne[0] > 65535) return false;
+            if ((a->type == GGML_TYPE_Q4_K || a->type == GGML_TYPE_Q5_K) && ((a->nb[1] | a->nb[2]) & 15)) return false;
+            return true;
+        }
+        default:
+            return mi355_ops_supported(op);
+    }
+}
+
+static bool mi355_dev_supports_buft(ggml_backend_dev_t dev, ggml_backend_buffer_type_t buft) {
+    if (!buft_is_mi355(buft)) return false;
+    return ((mi355_buft_ctx *)buft->context)->device == ((mi355_device_ctx *)dev->context)->device;
+}
+
+static int64_t op_batch_size(const ggml_tensor * op) {
+    switch (op->op) {
+        case GGML_OP_GET_ROWS:   return 0;
+        case GGML_OP_MUL_MAT:    return op->ne[1];
+        case GGML_OP_MUL_MAT_ID:
+        case GGML_OP_ROPE:       return op->ne[2];
+        default:                 return ggml_nrows(op);
+    }
+}
+
+// weights in host memory: worth copying to the GPU only for large batches (ggml-cuda.cu:3436-3457)
+static bool mi355_dev_offload_op(ggml_backend_dev_t, const ggml_tensor * op) { return op_batch_size(op) >= 32; }
+
+static ggml_backend_event_t mi355_dev_event_new(ggml_backend_dev_t dev) {
+    mi355_set_device(((mi355_device_ctx *)dev->context)->device);
+    hipEvent_t ev;
+    HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    return new ggml_backend_event{dev, ev};
+}
+
+static void mi355_dev_event_free(ggml_backend_dev_t, ggml_backend_event_t event) {
+    HIP_CHECK(hipEventDestroy((hipEvent_t)event->context));
+    delete event;
+}
+
+static void mi355_dev_event_synchronize(ggml_backend_dev_t, ggml_backend_event_t event) {
+    HIP_CHECK(hipEventSynchronize((hipEvent_t)event->context));
+}
+
+static const ggml_backend_device_i mi355_device_iface = {
+    /* .get_name             = */ mi355_dev_get_name,
+    /* .get_description      = */ mi355_dev_get_description,
+    /* .get_memory           = */ mi355_dev_get_memory,
+    /* .get_type             = */ mi355_dev_get_type,
+    /* .get_props            = */ mi355_dev_get_props,
+    /* .init_backend         = */ mi355_dev_init_backend,
+    /* .get_buffer_type      = */ mi355_dev_get_buffer_type,
+    /* .get_host_buffer_type = */ mi355_dev_get_host_buffer_type,
+    /* .buffer_from_host_ptr = */ NULL,
+    /* .supports_op          = */ mi355_dev_supports_op,
+    /* .supports_buft        = */ mi355_dev_supports_buft,
+    /* .offload_op           = */ mi355_dev_offload_op,
+    /* .event_new            = */ mi355_dev_event_new,
+    /* .event_free           = */ mi355_dev_event_free,
+    /* .event_synchronize    = */ mi355_dev_event_synchronize,
+};
+
+// ------------------------------------------------------------------------------------------------
+// registry
+// ------------------------------------------------------------------------------------------------
+struct mi355_reg_ctx {
+    std::vector<ggml_backend_dev_t> devices;
+};
+
+static const char * mi355_reg_get_name(ggml_backend_reg_t) { return MI355_NAME; }
+static size_t mi355_reg_get_device_count(ggml_backend_reg_t reg) { return ((mi355_reg_ctx *)reg->context)->devices.size(); }
+
+static ggml_backend_dev_t mi355_reg_get_device(ggml_backend_reg_t reg, size_t index) {
+    mi355_reg_ctx * ctx = (mi355_reg_ctx *)reg->context;
+    GGML_ASSERT(index < ctx->devices.size());
+    return ctx->devices[index];
+}
+
+static ggml_backend_feature * mi355_get_features(ggml_backend_reg_t) {
+    static ggml_backend_feature features[] = {
+        {"ARCH", "gfx950"}, {"WAVE", "64"}, {"DOT4_I8", "1"}, {"MFMA_I8", "1"}, {"NO_CUDA_COMPAT", "1"}, {nullptr, nullptr},
+    };
+    return features;
+}
+
+static void * mi355_reg_get_proc_address(ggml_backend_reg_t, const char * name) {
+    if (strcmp(name, "ggml_backend_get_features") == 0) return (void *)mi355_get_features;
+    // "ggml_backend_split_buffer_type", "ggml_backend_set_n_threads", host-buffer registration: not provided
+    return nullptr;
+}
+
+static const ggml_backend_reg_i mi355_reg_iface = {
+    /* .get_name         = */ mi355_reg_get_name,
+    /* .get_device_count = */ mi355_reg_get_device_count,
+    /* .get_device       = */ mi355_reg_get_device,
+    /* .get_proc_address = */ mi355_reg_get_proc_address,
+};
+
+static ggml_backend_reg_t ggml_backend_mi355_reg(void) {
+    static ggml_backend_reg reg;
+    static bool initialized = false;
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lk(mu);
+    if (!initialized) {
+        mi355_reg_ctx * ctx = new mi355_reg_ctx;
+        for (int i = 0; i < mi355_device_count(); i++) {
+            mi355_device_ctx * dctx = new mi355_device_ctx;
+            dctx->device = i;
+            dctx->name   = std::string(MI355_NAME) + std::to_string(i);
+            hipDeviceProp_t prop;
+            HIP_CHECK(hipGetDeviceProperties(&prop, i));
+            dctx->description = std::string(prop.name) + " (" + prop.gcnArchName + ")";
+            ctx->devices.push_back(new ggml_backend_device{mi355_device_iface, &reg, dctx});
+        }
+        reg.api_version = GGML_BACKEND_API_VERSION;
+        reg.iface       = mi355_reg_iface;
+        reg.context     = ctx;
+        initialized = true;
+    }
+    return &reg;
+}
+
+// exported entry points: what ggml_backend_load() looks up with dlsym (ggml-backend-reg.cpp:234-250)
+extern "C" {
+__attribute__((visibility("default"))) ggml_backend_reg_t ggml_backend_init(void) { return ggml_backend_mi355_reg(); }
+__attribute__((visibility("default"))) int ggml_backend_score(void) { return mi355_device_count() > 0 ? 100 : 0; }
+}
