@@ -146,6 +146,83 @@ MI355_API int mi355_mul_mat(int type, const void *W, int64_t w_row_stride, const
                             int64_t m, int64_t k, int64_t n, void *workspace, int64_t workspace_bytes,
                             void *stream);
 
+
+/* ---------------------------------------------------------------------------------------------
+ * The non-matmul ops of a Llama / Mixtral decode graph, so the reference's
+ * scheduler finds nothing to split back to the CPU.  Tensors are described ggml-style: 4 extents
+ * (ne[0] fastest) and 4 byte strides; types are ggml_type ids.
+ */
+typedef struct mi355_tensor {
+    void   *data;
+    int32_t type;
+    int64_t ne[4];
+    int64_t nb[4];
+} mi355_tensor;
+
+enum mi355_binary_op { MI355_ADD = 0, MI355_MUL = 1, MI355_SUB = 2, MI355_DIV = 3 };
+
+/* dst = a (op) b with ggml broadcasting of b (b.ne[i] divides dst.ne[i]); f32.
+ * Replaces ggml_cuda_op_add/mul/sub/div (ggml/src/ggml-cuda/binbcast.cu); oracle
+ * ggml_compute_forward_add etc. (ggml/src/ggml-cpu/binary-ops.cpp). */
+MI355_API int mi355_binary_f32(int op, const mi355_tensor *a, const mi355_tensor *b, const mi355_tensor *dst, void *stream);
+
+/* y = x * rsqrt(mean(x^2) + eps) per row of ne[0]; f32.  ggml_cuda_op_rms_norm (ggml-cuda/norm.cu);
+ * oracle ggml_compute_forward_rms_norm_f32 (ggml-cpu/ops.cpp). */
+MI355_API int mi355_rms_norm_f32(const mi355_tensor *x, const mi355_tensor *dst, float eps, void *stream);
+
+/* rotary embedding, modes NORMAL (0) and NEOX (2), optional freq_factors, YaRN parameters.
+ * ggml_cuda_op_rope (ggml-cuda/rope.cu); oracle ggml_compute_forward_rope_f32 (ggml-cpu/ops.cpp:5942-6110). */
+MI355_API int mi355_rope_f32(const mi355_tensor *x, const int32_t *pos, const float *freq_factors, const mi355_tensor *dst,
+                             int n_dims, int mode, int n_ctx_orig, float freq_base, float freq_scale, float ext_factor,
+                             float attn_factor, float beta_fast, float beta_slow, void *stream);
+
+/* gated linear unit, split or single-tensor form: dst = act(a) * b.  glu_op: 0 REGLU, 1 GEGLU, 2 SWIGLU
+ * (ggml.h:556-564); b may be NULL (then a holds both halves along ne[0]; `swapped` as in ggml).
+ * ggml_cuda_op_swiglu (ggml-cuda/unary.cu); oracle ggml_compute_forward_swiglu_f32 (ggml-cpu/ops.cpp:3476-3533). */
+MI355_API int mi355_glu_f32(int glu_op, const mi355_tensor *a, const mi355_tensor *b, const mi355_tensor *dst, int swapped, void *stream);
+
+/* copy / convert with arbitrary strides and equal element counts (ggml_cpy, ggml_cont, ggml_dup):
+ * f32 -> f32 | f16 | q8_0, f16 -> f16 | f32.  The q8_0 destination follows quantize_row_q8_0_ref
+ * (ggml-quants.c:188-211).  ggml_cuda_cpy (ggml-cuda/cpy.cu); oracle ggml_compute_forward_dup (ggml-cpu/ops.cpp). */
+MI355_API int mi355_cpy(const mi355_tensor *src, const mi355_tensor *dst, void *stream);
+
+/* dst[:, i, b2, b3] = dequant(src[:, ids[i, b2, b3], b2, b3]); src f32 | f16 | q4_0 | q8_0 | q4_K | q5_K | q6_K, ids i32.
+ * ggml_cuda_op_get_rows (ggml-cuda/getrows.cu); oracle ggml_compute_forward_get_rows (ggml-cpu/ops.cpp). */
+MI355_API int mi355_get_rows(const mi355_tensor *src, const mi355_tensor *ids, const mi355_tensor *dst, void *stream);
+
+/* dst = x * scale + bias (f32, contiguous).  ggml_cuda_op_scale (ggml-cuda/scale.cu). */
+MI355_API int mi355_scale_f32(const mi355_tensor *x, const mi355_tensor *dst, float scale, float bias, void *stream);
+
+/* row softmax with optional f16/f32 mask and ALiBi slope: dst = softmax(x*scale + slope*mask).
+ * ggml_cuda_op_soft_max (ggml-cuda/softmax.cu); oracle ggml_compute_forward_soft_max_f32 (ggml-cpu/ops.cpp). */
+MI355_API int mi355_soft_max_f32(const mi355_tensor *x, const mi355_tensor *mask, const mi355_tensor *dst,
+                                 float scale, float max_bias, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * FLASH_ATTN_EXT (ggml.h:2012-2033): dst = softmax(scale * Q K^T [softcap] + slope * mask) V with
+ * f16, q8_0 or q4_0 K/V (K and V of the same type), head size d in {64, 128, 256} (dk == dv).
+ * Replaces ggml_cuda_flash_attn_ext (ggml/src/ggml-cuda/fattn.cu:271-346); oracle
+ * ggml_compute_forward_flash_attn_ext_f16 (ggml/src/ggml-cpu/ops.cpp:7975-8192).
+ *   q    f32 [d, n_q, n_head, ne3]      byte strides q_nb1..3 (rows contiguous, 16-byte aligned)
+ *   k, v     [d, n_kv, n_head_kv, ne3]  byte strides *_nb1..3 (views of the KV cache)
+ *   mask f16 [n_kv, >= n_q, m_ne2, m_ne3] or NULL; -inf entries are skipped
+ *   dst  f32 [d, n_head, n_q, ne3]      byte strides d_nb1 (head), d_nb2 (token), d_nb3
+ * workspace (optional): lets long contexts split the KV range over several workgroups
+ * (mi355_flash_attn_ext_workspace_bytes gives the largest size the launcher can use).
+ */
+typedef struct mi355_fattn_args {
+    const float *q;    int64_t q_nb1, q_nb2, q_nb3;
+    const void  *k;    int32_t type_k; int64_t k_nb1, k_nb2, k_nb3;
+    const void  *v;    int32_t type_v; int64_t v_nb1, v_nb2, v_nb3;
+    const void  *mask; int64_t m_nb1, m_nb2, m_nb3, m_ne2, m_ne3;
+    float       *dst;  int64_t d_nb1, d_nb2, d_nb3;
+    int64_t d, n_q, n_kv, n_head, n_head_kv, ne3;
+    float scale, max_bias, logit_softcap;
+} mi355_fattn_args;
+
+MI355_API int64_t mi355_flash_attn_ext_workspace_bytes(const mi355_fattn_args *args);
+MI355_API int     mi355_flash_attn_ext(const mi355_fattn_args *args, void *workspace, int64_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

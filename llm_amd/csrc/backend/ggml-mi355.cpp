@@ -30,6 +30,7 @@
 #include "mi355_ops.h"
 
 #define MI355_NAME "MI355"
+#define MI355_DEV_PREFIX "MI355_"
 #define MI355_MAX_DEVICES 16
 
 // ggml's logger lives in ggml-base (ggml-impl.h is internal; the symbol is exported)
@@ -224,7 +225,7 @@ static ggml_backend_buffer_type_t mi355_buffer_type(int device) {
                 /* .is_host        = */ NULL,
             };
             bufts[i].device  = mi355_reg_get_device(ggml_backend_mi355_reg(), i);
-            bufts[i].context = new mi355_buft_ctx{i, std::string(MI355_NAME) + std::to_string(i)};
+            bufts[i].context = new mi355_buft_ctx{i, std::string(MI355_DEV_PREFIX) + std::to_string(i)};
         }
         inited = true;
     }
@@ -459,10 +460,56 @@ static void mi355_mul_mat_id(mi355_backend_ctx * ctx, ggml_tensor * dst) {
     }
 }
 
+// FLASH_ATTN_EXT (contract ggml.h:2012-2033; reference dispatch ggml-cuda/fattn.cu:271-346;
+// oracle ggml_compute_forward_flash_attn_ext_f16, ggml-cpu/ops.cpp:7975-8192)
+static void fattn_args_from(const ggml_tensor * dst, mi355_fattn_args * a) {
+    const ggml_tensor * q = dst->src[0], * k = dst->src[1], * v = dst->src[2], * mask = dst->src[3];
+    memset(a, 0, sizeof(*a));
+    a->q = (const float *)q->data; a->q_nb1 = q->nb[1]; a->q_nb2 = q->nb[2]; a->q_nb3 = q->nb[3];
+    a->k = k->data; a->type_k = (int32_t)k->type; a->k_nb1 = k->nb[1]; a->k_nb2 = k->nb[2]; a->k_nb3 = k->nb[3];
+    a->v = v->data; a->type_v = (int32_t)v->type; a->v_nb1 = v->nb[1]; a->v_nb2 = v->nb[2]; a->v_nb3 = v->nb[3];
+    if (mask) { a->mask = mask->data; a->m_nb1 = mask->nb[1]; a->m_nb2 = mask->nb[2]; a->m_nb3 = mask->nb[3]; a->m_ne2 = mask->ne[2]; a->m_ne3 = mask->ne[3]; }
+    a->dst = (float *)dst->data; a->d_nb1 = dst->nb[1]; a->d_nb2 = dst->nb[2]; a->d_nb3 = dst->nb[3];
+    a->d = q->ne[0]; a->n_q = q->ne[1]; a->n_head = q->ne[2]; a->ne3 = q->ne[3]; a->n_kv = k->ne[1]; a->n_head_kv = k->ne[2];
+    memcpy(&a->scale, (const float *)dst->op_params + 0, 4);
+    memcpy(&a->max_bias, (const float *)dst->op_params + 1, 4);
+    memcpy(&a->logit_softcap, (const float *)dst->op_params + 2, 4);
+}
+
+static bool mi355_flash_attn_supported(const ggml_tensor * op) {
+    const ggml_tensor * q = op->src[0], * k = op->src[1], * v = op->src[2], * mask = op->src[3];
+    if (q->type != GGML_TYPE_F32 || op->type != GGML_TYPE_F32) return false;
+    if (k->type != v->type || (k->type != GGML_TYPE_F16 && k->type != GGML_TYPE_Q8_0 && k->type != GGML_TYPE_Q4_0)) return false;
+    const int64_t d = q->ne[0];
+    if ((d != 64 && d != 128 && d != 256) || k->ne[0] != d || v->ne[0] != d) return false;
+    if (k->ne[3] != q->ne[3] || v->ne[3] != q->ne[3] || k->ne[2] != v->ne[2] || q->ne[2] % k->ne[2] != 0) return false;
+    if (q->nb[0] != sizeof(float) || k->nb[0] != ggml_type_size(k->type) || v->nb[0] != ggml_type_size(v->type)) return false;
+    if ((q->nb[1] | q->nb[2] | q->nb[3]) & 15) return false;
+    if (k->type == GGML_TYPE_F16 && ((k->nb[1] | k->nb[2] | k->nb[3] | v->nb[1] | v->nb[2] | v->nb[3]) & 15)) return false;
+    if (mask && (mask->type != GGML_TYPE_F16 || mask->nb[0] != sizeof(ggml_fp16_t))) return false;
+    if (!ggml_is_contiguous(op)) return false;
+    if (q->ne[1] > 65535 || q->ne[3] * 64 > 65535) return false;
+    return true;
+}
+
+static void mi355_flash_attn(mi355_backend_ctx * ctx, ggml_tensor * dst) {
+    mi355_fattn_args a;
+    fattn_args_from(dst, &a);
+    // a workspace lets long contexts split the KV range; only worth having for decode-sized batches
+    void * ws = nullptr;
+    int64_t ws_bytes = 0;
+    if (a.n_kv >= 1024 && a.n_head_kv * a.n_q * a.ne3 < 512) {
+        ws_bytes = mi355_flash_attn_ext_workspace_bytes(&a);
+        ws = ctx->get_scratch((size_t)ws_bytes);
+    }
+    MI_CHECK(mi355_flash_attn_ext(&a, ws, ws_bytes, ctx->stream));
+}
+
 static bool mi355_compute_forward(mi355_backend_ctx * ctx, ggml_tensor * node) {
     switch (node->op) {
-        case GGML_OP_MUL_MAT:    mi355_mul_mat(ctx, node);    return true;
-        case GGML_OP_MUL_MAT_ID: mi355_mul_mat_id(ctx, node); return true;
+        case GGML_OP_MUL_MAT:        mi355_mul_mat(ctx, node);    return true;
+        case GGML_OP_MUL_MAT_ID:     mi355_mul_mat_id(ctx, node); return true;
+        case GGML_OP_FLASH_ATTN_EXT: mi355_flash_attn(ctx, node); return true;
         default: break;
     }
     return mi355_ops_forward(node, ctx->stream);
@@ -608,6 +655,8 @@ static bool mi355_dev_supports_op(ggml_backend_dev_t dev, const ggml_tensor * op
             if ((a->type == GGML_TYPE_Q4_K || a->type == GGML_TYPE_Q5_K) && ((a->nb[1] | a->nb[2]) & 15)) return false;
             return true;
         }
+        case GGML_OP_FLASH_ATTN_EXT:
+            return mi355_flash_attn_supported(op);
         default:
             return mi355_ops_supported(op);
     }
@@ -711,7 +760,7 @@ static ggml_backend_reg_t ggml_backend_mi355_reg(void) {
         for (int i = 0; i < mi355_device_count(); i++) {
             mi355_device_ctx * dctx = new mi355_device_ctx;
             dctx->device = i;
-            dctx->name   = std::string(MI355_NAME) + std::to_string(i);
+            dctx->name   = std::string(MI355_DEV_PREFIX) + std::to_string(i);
             hipDeviceProp_t prop;
             HIP_CHECK(hipGetDeviceProperties(&prop, i));
             dctx->description = std::string(prop.name) + " (" + prop.gcnArchName + ")";

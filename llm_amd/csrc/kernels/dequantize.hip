@@ -6,65 +6,7 @@
 // Elementwise and HBM-bound: one lane per output element, consecutive lanes write consecutive
 // floats (coalesced 256 B per wave-store); block headers are re-read through L1.
 #include "common.h"
-
-static __device__ __forceinline__ void scale_min_k4(int j, const uint8_t * q, int & sc, int & m) {
-    // get_scale_min_k4, ggml-quants.c:625-632
-    if (j < 4) { sc = q[j] & 63; m = q[j + 4] & 63; }
-    else       { sc = (q[j + 4] & 0xF) | ((q[j - 4] >> 6) << 4); m = (q[j + 4] >> 4) | ((q[j] >> 6) << 4); }
-}
-
-template <int TYPE>
-static __device__ __forceinline__ float deq_elem(const uint8_t * __restrict__ base, int64_t i) {
-    if (TYPE == MI355_TYPE_Q4_0) {
-        const uint8_t * b = base + (i / QK) * 18;
-        const int j = i % QK;
-        const float d = h2f(*(const uint16_t *)b);
-        const int q = j < 16 ? (b[2 + j] & 0x0F) : (b[2 + j - 16] >> 4);
-        return __fmul_rn((float)(q - 8), d);
-    } else if (TYPE == MI355_TYPE_Q8_0) {
-        const uint8_t * b = base + (i / QK) * 34;
-        const float d = h2f(*(const uint16_t *)b);
-        return __fmul_rn((float)((const int8_t *)b)[2 + i % QK], d);
-    } else if (TYPE == MI355_TYPE_Q8_1) {
-        const uint8_t * b = base + (i / QK) * 36;
-        const float d = h2f(*(const uint16_t *)b);
-        return __fmul_rn((float)((const int8_t *)b)[4 + i % QK], d);
-    } else if (TYPE == MI355_TYPE_Q4_K || TYPE == MI355_TYPE_Q5_K) {
-        const int bsz = TYPE == MI355_TYPE_Q4_K ? 144 : 176;
-        const uint8_t * b = base + (i / QK_K) * bsz;
-        const int e  = i % QK_K;
-        const int j  = e / 32;           // sub-block 0..7
-        const int l  = e % 32;
-        const float d   = h2f(*(const uint16_t *)b);
-        const float min = h2f(*(const uint16_t *)(b + 2));
-        int sc, m;
-        scale_min_k4(j, b + 4, sc, m);
-        const float d1 = __fmul_rn(d, (float)sc);
-        const float m1 = __fmul_rn(min, (float)m);
-        const uint8_t * qs = b + (TYPE == MI355_TYPE_Q4_K ? 16 : 48) + (j / 2) * 32;
-        int q = (j & 1) ? (qs[l] >> 4) : (qs[l] & 0xF);
-        if (TYPE == MI355_TYPE_Q5_K) q += ((b[16 + l] >> j) & 1) ? 16 : 0;
-        return __fsub_rn(__fmul_rn(d1, (float)q), m1);
-    } else if (TYPE == MI355_TYPE_Q6_K) {
-        const uint8_t * b = base + (i / QK_K) * 210;
-        const int e  = i % QK_K;
-        const int n  = e / 128;          // half of the super-block
-        const int r  = e % 128;
-        const int g  = r / 32;           // which of q1..q4
-        const int l  = r % 32;
-        const uint8_t * ql = b + 64 * n;
-        const uint8_t * qh = b + 128 + 32 * n;
-        const int8_t  * sc = (const int8_t *)(b + 192 + 8 * n);
-        const float d = h2f(*(const uint16_t *)(b + 208));
-        const int lo = (g & 1) ? ql[l + 32] : ql[l];
-        const int nib = (g & 2) ? (lo >> 4) : (lo & 0xF);
-        const int q = (int)(int8_t)(nib | (((qh[l] >> (2 * g)) & 3) << 4)) - 32;
-        return __fmul_rn(__fmul_rn(d, (float)sc[l / 16 + 2 * g]), (float)q);
-    } else if (TYPE == MI355_TYPE_F16) {
-        return h2f(((const uint16_t *)base)[i]);
-    }
-    return 0.0f;
-}
+#include "deq_elem.h"
 
 template <int TYPE>
 __global__ void __launch_bounds__(256)

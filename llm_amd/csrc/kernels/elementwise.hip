@@ -1,0 +1,431 @@
+// elementwise.hip -- the non-matmul ops of a Llama / Mixtral decode graph.
+// All of them are HBM/launch-bound streaming passes: one lane per element (or per row for the
+// reductions), coalesced along ne[0], 128-bit accesses where the layout allows.
+// Behavioural spec = the reference's ggml-cpu implementations cited per entry point in
+// include/mi355_kernels.h; nothing here is derived from ggml-cuda.
+#include "common.h"
+#include "deq_elem.h"
+
+namespace {
+
+struct T4 {
+    char *  data;
+    int64_t ne[4];
+    int64_t nb[4];
+};
+
+static T4 t4(const mi355_tensor * t) {
+    T4 r;
+    r.data = (char *)t->data;
+    for (int i = 0; i < 4; i++) { r.ne[i] = t->ne[i]; r.nb[i] = t->nb[i]; }
+    return r;
+}
+
+static int64_t nelem(const mi355_tensor * t) { return t->ne[0] * t->ne[1] * t->ne[2] * t->ne[3]; }
+static int64_t nrows(const mi355_tensor * t) { return t->ne[1] * t->ne[2] * t->ne[3]; }
+static bool same_shape(const mi355_tensor * a, const mi355_tensor * b) {
+    return a->ne[0] == b->ne[0] && a->ne[1] == b->ne[1] && a->ne[2] == b->ne[2] && a->ne[3] == b->ne[3];
+}
+static unsigned grid_for(int64_t n, int block = 256) {
+    const int64_t g = (n + block - 1) / block;
+    return (unsigned)(g < 1 ? 1 : (g > 262144 ? 262144 : g));
+}
+
+static __device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// sum over the 256 threads of a block (4 waves)
+static __device__ __forceinline__ float block_sum(float v, float * sh) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sh[wave] = v;
+    __syncthreads();
+    return sh[0] + sh[1] + sh[2] + sh[3];
+}
+static __device__ __forceinline__ float block_max(float v, float * sh) {
+    v = wave_max(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sh[wave] = v;
+    __syncthreads();
+    return fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+}
+
+// ---------------------------------------------------------------- binary with broadcast
+template <int OP>
+__global__ void __launch_bounds__(256)
+binary_kernel(const T4 a, const T4 b, const T4 d, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int64_t i0 = i % d.ne[0], r = i / d.ne[0];
+        const int64_t i1 = r % d.ne[1], r2 = r / d.ne[1];
+        const int64_t i2 = r2 % d.ne[2], i3 = r2 / d.ne[2];
+        const float x = *(const float *)(a.data + i0 * a.nb[0] + i1 * a.nb[1] + i2 * a.nb[2] + i3 * a.nb[3]);
+        const float y = *(const float *)(b.data + (i0 % b.ne[0]) * b.nb[0] + (i1 % b.ne[1]) * b.nb[1] +
+                                         (i2 % b.ne[2]) * b.nb[2] + (i3 % b.ne[3]) * b.nb[3]);
+        float v;
+        if (OP == MI355_ADD) v = x + y; else if (OP == MI355_MUL) v = x * y; else if (OP == MI355_SUB) v = x - y; else v = x / y;
+        *(float *)(d.data + i0 * d.nb[0] + i1 * d.nb[1] + i2 * d.nb[2] + i3 * d.nb[3]) = v;
+    }
+}
+
+// ---------------------------------------------------------------- rms norm (one block per row)
+__global__ void __launch_bounds__(256)
+rms_norm_kernel(const T4 x, const T4 d, float eps) {
+    __shared__ float sh[4];
+    const int64_t row = blockIdx.x;
+    const int64_t i1 = row % x.ne[1], i2 = (row / x.ne[1]) % x.ne[2], i3 = row / (x.ne[1] * x.ne[2]);
+    const float * xr = (const float *)(x.data + i1 * x.nb[1] + i2 * x.nb[2] + i3 * x.nb[3]);
+    float * dr = (float *)(d.data + i1 * d.nb[1] + i2 * d.nb[2] + i3 * d.nb[3]);
+    const int n = (int)x.ne[0];
+    float s = 0.0f;
+    for (int i = threadIdx.x; i < n; i += 256) { const float v = xr[i]; s += v * v; }
+    s = block_sum(s, sh);
+    const float scale = 1.0f / sqrtf(s / (float)n + eps);
+    for (int i = threadIdx.x; i < n; i += 256) dr[i] = xr[i] * scale;
+}
+
+// ---------------------------------------------------------------- rope
+struct RopeP {
+    int n_dims, mode, ne0;
+    float theta_scale, freq_scale, ext_factor, attn_factor, corr0, corr1;
+};
+
+static __device__ __forceinline__ void rope_yarn(float theta_extrap, const RopeP & p, int i0, float & c, float & s) {
+    // rope_yarn, ggml-cpu/ops.cpp:5862-5877
+    float theta_interp = p.freq_scale * theta_extrap;
+    float theta = theta_interp;
+    float mscale = p.attn_factor;
+    if (p.ext_factor != 0.0f) {
+        const float y = (i0 / 2 - p.corr0) / fmaxf(0.001f, p.corr1 - p.corr0);
+        const float ramp_mix = (1.0f - fminf(1.0f, fmaxf(0.0f, y))) * p.ext_factor;
+        theta = theta_interp * (1 - ramp_mix) + theta_extrap * ramp_mix;
+        mscale *= 1.0f + 0.1f * logf(1.0f / p.freq_scale);
+    }
+    c = cosf(theta) * mscale;
+    s = sinf(theta) * mscale;
+}
+
+// one lane per rotated pair; rows = (head i1, token i2, batch i3)
+__global__ void __launch_bounds__(256)
+rope_kernel(const T4 x, const int32_t * __restrict__ pos, const float * __restrict__ ff, const T4 d, const RopeP p, int64_t npairs) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int half = p.ne0 / 2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < npairs; i += stride) {
+        const int ic = (int)(i % half);          // pair index inside the row
+        const int64_t r = i / half;
+        const int64_t i1 = r % x.ne[1], r2 = r / x.ne[1];
+        const int64_t i2 = r2 % x.ne[2], i3 = r2 / x.ne[2];
+        const char * xs = x.data + i1 * x.nb[1] + i2 * x.nb[2] + i3 * x.nb[3];
+        char * ds = d.data + i1 * d.nb[1] + i2 * d.nb[2] + i3 * d.nb[3];
+        const int i0 = 2 * ic;
+        if (i0 >= p.n_dims) { // dims beyond n_dims are copied through (ops.cpp: tail loops)
+            ((float *)ds)[i0]     = ((const float *)xs)[i0];
+            ((float *)ds)[i0 + 1] = ((const float *)xs)[i0 + 1];
+            continue;
+        }
+        // theta = pos * theta_scale^(i0/2) (the CPU builds it by repeated multiplication; powf agrees to ~1 ulp
+        // of the angle, inside the op's 1e-7 NMSE budget for the positions llama.cpp uses)
+        const float theta_base = (float)pos[i2] * powf(p.theta_scale, (float)ic);
+        float c, s;
+        rope_yarn(theta_base / (ff ? ff[ic] : 1.0f), p, i0, c, s);
+        if (p.mode & 2) { // NEOX: pairs (ic, ic + n_dims/2)
+            const float x0 = ((const float *)xs)[ic], x1 = ((const float *)xs)[ic + p.n_dims / 2];
+            ((float *)ds)[ic]                = x0 * c - x1 * s;
+            ((float *)ds)[ic + p.n_dims / 2] = x0 * s + x1 * c;
+        } else {          // NORMAL: adjacent pairs
+            const float x0 = ((const float *)xs)[i0], x1 = ((const float *)xs)[i0 + 1];
+            ((float *)ds)[i0]     = x0 * c - x1 * s;
+            ((float *)ds)[i0 + 1] = x0 * s + x1 * c;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- glu
+static __device__ __forceinline__ float act_glu(int op, float x) {
+    switch (op) {
+        case 0: return x > 0.0f ? x : 0.0f;                                  // REGLU
+        case 1: { const float c = 0.044715f, s = 0.79788456080286535587989211986876f; // GEGLU (tanh gelu, ggml_gelu_f32)
+                  return 0.5f * x * (1.0f + tanhf(s * x * (1.0f + c * x * x))); }
+        default: return x / (1.0f + expf(-x));                               // SWIGLU (ggml_silu_f32, vec.h:637-639)
+    }
+}
+
+__global__ void __launch_bounds__(256)
+glu_kernel(int op, const char * a, const char * b, int64_t a_row, int64_t b_row, char * d, int64_t d_row, int nc, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int64_t r = i / nc; const int c = (int)(i % nc);
+        const float x = ((const float *)(a + r * a_row))[c];
+        const float g = ((const float *)(b + r * b_row))[c];
+        ((float *)(d + r * d_row))[c] = act_glu(op, x) * g;
+    }
+}
+
+// ---------------------------------------------------------------- cpy
+template <class TS, class TD> static __device__ __forceinline__ TD cvt(TS v);
+template <> __device__ __forceinline__ float  cvt<float, float>(float v) { return v; }
+template <> __device__ __forceinline__ __half cvt<float, __half>(float v) { return __float2half_rn(v); }
+template <> __device__ __forceinline__ __half cvt<__half, __half>(__half v) { return v; }
+template <> __device__ __forceinline__ float  cvt<__half, float>(__half v) { return __half2float(v); }
+
+static __device__ __forceinline__ int64_t off4(const T4 & t, int64_t i, int64_t blk, int64_t step0 = 0) {
+    // linear index in units of blk elements along ne[0] -> byte offset; step0 = bytes per unit along ne[0]
+    // (defaults to nb[0]: right for blk == 1 and for block-quantized tensors, whose nb[0] is the block size)
+    const int64_t n0 = t.ne[0] / blk;
+    const int64_t i0 = i % n0, r = i / n0;
+    const int64_t i1 = r % t.ne[1], r2 = r / t.ne[1];
+    const int64_t i2 = r2 % t.ne[2], i3 = r2 / t.ne[2];
+    return i0 * (step0 ? step0 : t.nb[0]) + i1 * t.nb[1] + i2 * t.nb[2] + i3 * t.nb[3];
+}
+
+template <class TS, class TD>
+__global__ void __launch_bounds__(256)
+cpy_kernel(const T4 s, const T4 d, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        *(TD *)(d.data + off4(d, i, 1)) = cvt<TS, TD>(*(const TS *)(s.data + off4(s, i, 1)));
+}
+
+// f32 -> q8_0: one lane per 32-value block (quantize_row_q8_0_ref, ggml-quants.c:188-211)
+__global__ void __launch_bounds__(256)
+cpy_f32_q8_0_kernel(const T4 s, const T4 d, int64_t nblocks) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t ib = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; ib < nblocks; ib += stride) {
+        // the 32 source values are consecutive along the source's ne[0] (ne[0] % 32 == 0, nb[0] == 4)
+        const float * xs = (const float *)(s.data + off4(s, ib, 32, 32 * sizeof(float)));
+        uint8_t * blk = (uint8_t *)(d.data + off4(d, ib, 32));
+        float v[32], amax = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 32; j++) { v[j] = xs[j]; amax = fmaxf(amax, fabsf(v[j])); }
+        const float dd = __fdiv_rn(amax, 127.0f);
+        const float id = dd != 0.0f ? __fdiv_rn(1.0f, dd) : 0.0f;
+        *(uint16_t *)blk = __half_as_ushort(__float2half_rn(dd));
+#pragma unroll
+        for (int j = 0; j < 32; j++) {
+            const float r = roundf(__fmul_rn(v[j], id));
+            ((int8_t *)blk)[2 + j] = fabsf(r) < 2147483648.0f ? (int8_t)(int)r : 0;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- get_rows
+template <int TYPE>
+__global__ void __launch_bounds__(256)
+get_rows_kernel(const T4 s, const T4 ids, const T4 d, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int64_t i0 = i % d.ne[0], r = i / d.ne[0];
+        const int64_t i10 = r % d.ne[1], r2 = r / d.ne[1];
+        const int64_t i11 = r2 % d.ne[2], i12 = r2 / d.ne[2];
+        const int32_t row = *(const int32_t *)(ids.data + i10 * ids.nb[0] + i11 * ids.nb[1] + i12 * ids.nb[2]);
+        const uint8_t * src_row = (const uint8_t *)(s.data + (int64_t)row * s.nb[1] + i11 * s.nb[2] + i12 * s.nb[3]);
+        *(float *)(d.data + i0 * d.nb[0] + i10 * d.nb[1] + i11 * d.nb[2] + i12 * d.nb[3]) = deq_elem<TYPE>(src_row, i0);
+    }
+}
+
+// ---------------------------------------------------------------- scale
+__global__ void __launch_bounds__(256)
+scale_kernel(const float * x, float * d, float scale, float bias, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) d[i] = x[i] * scale + bias;
+}
+
+// ---------------------------------------------------------------- soft_max (one block per row)
+template <bool MASK_F16>
+__global__ void __launch_bounds__(256)
+soft_max_kernel(const T4 x, const T4 m, bool has_mask, const T4 d, float scale, float max_bias, float m0, float m1, uint32_t n_head_log2) {
+    __shared__ float sh[4];
+    const int64_t row = blockIdx.x;
+    const int64_t i1 = row % x.ne[1], i2 = (row / x.ne[1]) % x.ne[2], i3 = row / (x.ne[1] * x.ne[2]);
+    const float * xr = (const float *)(x.data + i1 * x.nb[1] + i2 * x.nb[2] + i3 * x.nb[3]);
+    float * dr = (float *)(d.data + i1 * d.nb[1] + i2 * d.nb[2] + i3 * d.nb[3]);
+    const char * mr = has_mask ? m.data + i1 * m.nb[1] + (i2 % m.ne[2]) * m.nb[2] + (i3 % m.ne[3]) * m.nb[3] : nullptr;
+    const uint32_t h = (uint32_t)i2;
+    const float slope = max_bias > 0.0f ? (h < n_head_log2 ? powf(m0, h + 1) : powf(m1, 2 * (h - n_head_log2) + 1)) : 1.0f;
+    const int n = (int)x.ne[0];
+    float mx = -INFINITY;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        float v = xr[i] * scale;
+        if (mr) v += slope * (MASK_F16 ? __half2float(((const __half *)mr)[i]) : ((const float *)mr)[i]);
+        dr[i] = v;
+        mx = fmaxf(mx, v);
+    }
+    mx = block_max(mx, sh);
+    float sum = 0.0f;
+    for (int i = threadIdx.x; i < n; i += 256) { const float e = expf(dr[i] - mx); dr[i] = e; sum += e; }
+    sum = block_sum(sum, sh);
+    const float inv = 1.0f / sum;
+    for (int i = threadIdx.x; i < n; i += 256) dr[i] *= inv;
+}
+
+} // namespace
+
+#define CHECK_T(t) do { if (!(t) || !(t)->data) return MI355_E_NULL; } while (0)
+
+extern "C" {
+
+int mi355_binary_f32(int op, const mi355_tensor * a, const mi355_tensor * b, const mi355_tensor * dst, void * stream) {
+    CHECK_T(a); CHECK_T(b); CHECK_T(dst);
+    if (a->type != MI355_TYPE_F32 || b->type != MI355_TYPE_F32 || dst->type != MI355_TYPE_F32) return MI355_E_TYPE;
+    if (!same_shape(a, dst)) return MI355_E_SHAPE;
+    for (int i = 0; i < 4; i++) if (b->ne[i] <= 0 || dst->ne[i] % b->ne[i] != 0) return nelem(dst) == 0 ? MI355_OK : MI355_E_SHAPE;
+    const int64_t n = nelem(dst);
+    if (n == 0) return MI355_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid(grid_for(n)), block(256);
+    switch (op) {
+        case MI355_ADD: MI355_LAUNCH("binary", (binary_kernel<MI355_ADD>), grid, block, 0, s, t4(a), t4(b), t4(dst), n); break;
+        case MI355_MUL: MI355_LAUNCH("binary", (binary_kernel<MI355_MUL>), grid, block, 0, s, t4(a), t4(b), t4(dst), n); break;
+        case MI355_SUB: MI355_LAUNCH("binary", (binary_kernel<MI355_SUB>), grid, block, 0, s, t4(a), t4(b), t4(dst), n); break;
+        case MI355_DIV: MI355_LAUNCH("binary", (binary_kernel<MI355_DIV>), grid, block, 0, s, t4(a), t4(b), t4(dst), n); break;
+        default: return MI355_E_UNSUPPORTED;
+    }
+    MI355_CHECK_LAUNCH();
+    return MI355_OK;
+}
+
+int mi355_rms_norm_f32(const mi355_tensor * x, const mi355_tensor * dst, float eps, void * stream) {
+    CHECK_T(x); CHECK_T(dst);
+    if (x->type != MI355_TYPE_F32 || dst->type != MI355_TYPE_F32) return MI355_E_TYPE;
+    if (!same_shape(x, dst) || x->nb[0] != 4 || dst->nb[0] != 4) return MI355_E_SHAPE;
+    const int64_t rows = nrows(x);
+    if (rows == 0 || x->ne[0] == 0) return MI355_OK;
+    if (rows > 0x7fffffff) return MI355_E_SHAPE;
+    MI355_LAUNCH("rms_norm", rms_norm_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, t4(x), t4(dst), eps);
+    MI355_CHECK_LAUNCH();
+    return MI355_OK;
+}
+
+int mi355_rope_f32(const mi355_tensor * x, const int32_t * pos, const float * freq_factors, const mi355_tensor * dst,
+                   int n_dims, int mode, int n_ctx_orig, float freq_base, float freq_scale, float ext_factor,
+                   float attn_factor, float beta_fast, float beta_slow, void * stream) {
+    CHECK_T(x); CHECK_T(dst);
+    if (!pos) return MI355_E_NULL;
+    if (x->type != MI355_TYPE_F32 || dst->type != MI355_TYPE_F32) return MI355_E_TYPE;
+    if (!same_shape(x, dst) || x->nb[0] != 4 || dst->nb[0] != 4 || n_dims > x->ne[0] || (n_dims & 1) || (x->ne[0] & 1)) return MI355_E_SHAPE;
+    if (mode != 0 && mode != 2) return MI355_E_UNSUPPORTED; // mrope / vision are not on this path
+    RopeP p;
+    p.n_dims = n_dims; p.mode = mode; p.ne0 = (int)x->ne[0];
+    p.theta_scale = powf(freq_base, -2.0f / n_dims);
+    p.freq_scale = freq_scale; p.ext_factor = ext_factor; p.attn_factor = attn_factor;
+    // ggml_rope_yarn_corr_dims, ggml.c:4002-4014
+    auto corr_dim = [&](float n_rot) { return n_dims * logf(n_ctx_orig / (n_rot * 2 * 3.14159265358979323846f)) / (2 * logf(freq_base)); };
+    const float start = floorf(corr_dim(beta_fast)), end = ceilf(corr_dim(beta_slow));
+    p.corr0 = start > 0 ? start : 0; p.corr1 = end < n_dims - 1 ? end : n_dims - 1;
+    const int64_t npairs = nelem(x) / 2;
+    if (npairs == 0) return MI355_OK;
+    MI355_LAUNCH("rope", rope_kernel, dim3(grid_for(npairs)), dim3(256), 0, (hipStream_t)stream, t4(x), pos, freq_factors, t4(dst), p, npairs);
+    MI355_CHECK_LAUNCH();
+    return MI355_OK;
+}
+
+int mi355_glu_f32(int glu_op, const mi355_tensor * a, const mi355_tensor * b, const mi355_tensor * dst, int swapped, void * stream) {
+    CHECK_T(a); CHECK_T(dst);
+    if (b && !b->data) return MI355_E_NULL;
+    if (a->type != MI355_TYPE_F32 || dst->type != MI355_TYPE_F32 || (b && b->type != MI355_TYPE_F32)) return MI355_E_TYPE;
+    if (glu_op < 0 || glu_op > 2) return MI355_E_UNSUPPORTED;
+    const int64_t nc = b ? a->ne[0] : a->ne[0] / 2;
+    if (dst->ne[0] != nc || nrows(dst) != nrows(a) || (b && !same_shape(a, b))) return MI355_E_SHAPE;
+    // rows contiguous ("contiguous_1"): row r lives at data + r*nb[1]
+    auto rows_dense = [](const mi355_tensor * t) { return t->nb[0] == 4 && t->nb[2] == t->nb[1] * t->ne[1] && t->nb[3] == t->nb[2] * t->ne[2]; };
+    if (!rows_dense(a) || !rows_dense(dst) || (b && !rows_dense(b))) return MI355_E_UNSUPPORTED;
+    const int64_t n = nc * nrows(dst);
+    if (n == 0) return MI355_OK;
+    const char * ap = (const char *)a->data, * bp = b ? (const char *)b->data : (const char *)a->data;
+    if (!b) { ap += swapped ? nc * 4 : 0; bp += swapped ? 0 : nc * 4; }
+    MI355_LAUNCH("glu", glu_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, glu_op, ap, bp, a->nb[1],
+                 b ? b->nb[1] : a->nb[1], (char *)dst->data, dst->nb[1], (int)nc, n);
+    MI355_CHECK_LAUNCH();
+    return MI355_OK;
+}
+
+int mi355_cpy(const mi355_tensor * src, const mi355_tensor * dst, void * stream) {
+    CHECK_T(src); CHECK_T(dst);
+    const int64_t n = nelem(src);
+    if (n != nelem(dst)) return MI355_E_SHAPE;
+    if (n == 0) return MI355_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 block(256);
+    const int st = src->type, dt = dst->type;
+    if (st == MI355_TYPE_F32 && dt == MI355_TYPE_Q8_0) {
+        if (src->ne[0] % 32 || dst->ne[0] % 32 || src->nb[0] != 4 || dst->nb[0] != 34) return MI355_E_SHAPE;
+        const int64_t nblk = n / 32;
+        MI355_LAUNCH("cpy", cpy_f32_q8_0_kernel, dim3(grid_for(nblk)), block, 0, s, t4(src), t4(dst), nblk);
+    } else if (st == MI355_TYPE_F32 && dt == MI355_TYPE_F32) {
+        MI355_LAUNCH("cpy", (cpy_kernel<float, float>), dim3(grid_for(n)), block, 0, s, t4(src), t4(dst), n);
+    } else if (st == MI355_TYPE_F32 && dt == MI355_TYPE_F16) {
+        MI355_LAUNCH("cpy", (cpy_kernel<float, __half>), dim3(grid_for(n)), block, 0, s, t4(src), t4(dst), n);
+    } else if (st == MI355_TYPE_F16 && dt == MI355_TYPE_F16) {
+        MI355_LAUNCH("cpy", (cpy_kernel<__half, __half>), dim3(grid_for(n)), block, 0, s, t4(src), t4(dst), n);
+    } else if (st == MI355_TYPE_F16 && dt == MI355_TYPE_F32) {
+        MI355_LAUNCH("cpy", (cpy_kernel<__half, float>), dim3(grid_for(n)), block, 0, s, t4(src), t4(dst), n);
+    } else {
+        return MI355_E_TYPE;
+    }
+    MI355_CHECK_LAUNCH();
+    return MI355_OK;
+}
+
+int mi355_get_rows(const mi355_tensor * src, const mi355_tensor * ids, const mi355_tensor * dst, void * stream) {
+    CHECK_T(src); CHECK_T(ids); CHECK_T(dst);
+    if (dst->type != MI355_TYPE_F32) return MI355_E_TYPE;
+    if (dst->ne[0] != src->ne[0] || dst->ne[1] != ids->ne[0] || dst->ne[2] != ids->ne[1] || dst->ne[3] != ids->ne[2]) return MI355_E_SHAPE;
+    const int64_t n = nelem(dst);
+    if (n == 0) return MI355_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid(grid_for(n)), block(256);
+#define GR(T) MI355_LAUNCH("get_rows", (get_rows_kernel<T>), grid, block, 0, s, t4(src), t4(ids), t4(dst), n); break
+    switch (src->type) {
+        case MI355_TYPE_F32:  GR(MI355_TYPE_F32);
+        case MI355_TYPE_F16:  GR(MI355_TYPE_F16);
+        case MI355_TYPE_Q4_0: GR(MI355_TYPE_Q4_0);
+        case MI355_TYPE_Q8_0: GR(MI355_TYPE_Q8_0);
+        case MI355_TYPE_Q4_K: GR(MI355_TYPE_Q4_K);
+        case MI355_TYPE_Q5_K: GR(MI355_TYPE_Q5_K);
+        case MI355_TYPE_Q6_K: GR(MI355_TYPE_Q6_K);
+        default: return MI355_E_TYPE;
+    }
+#undef GR
+    MI355_CHECK_LAUNCH();
+    return MI355_OK;
+}
+
+int mi355_scale_f32(const mi355_tensor * x, const mi355_tensor * dst, float scale, float bias, void * stream) {
+    CHECK_T(x); CHECK_T(dst);
+    if (x->type != MI355_TYPE_F32 || dst->type != MI355_TYPE_F32) return MI355_E_TYPE;
+    if (!same_shape(x, dst)) return MI355_E_SHAPE;
+    const int64_t n = nelem(x);
+    if (n == 0) return MI355_OK;
+    MI355_LAUNCH("scale", scale_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const float *)x->data, (float *)dst->data, scale, bias, n);
+    MI355_CHECK_LAUNCH();
+    return MI355_OK;
+}
+
+int mi355_soft_max_f32(const mi355_tensor * x, const mi355_tensor * mask, const mi355_tensor * dst, float scale, float max_bias, void * stream) {
+    CHECK_T(x); CHECK_T(dst);
+    if (mask && !mask->data) return MI355_E_NULL;
+    if (x->type != MI355_TYPE_F32 || dst->type != MI355_TYPE_F32) return MI355_E_TYPE;
+    if (mask && mask->type != MI355_TYPE_F16 && mask->type != MI355_TYPE_F32) return MI355_E_TYPE;
+    if (!same_shape(x, dst) || x->nb[0] != 4 || dst->nb[0] != 4) return MI355_E_SHAPE;
+    const int64_t rows = nrows(x);
+    if (rows == 0 || x->ne[0] == 0) return MI355_OK;
+    if (rows > 0x7fffffff) return MI355_E_SHAPE;
+    const uint32_t n_head = (uint32_t)x->ne[2];
+    const uint32_t n_head_log2 = 1u << (uint32_t)floorf(log2f((float)n_head));
+    const float m0 = powf(2.0f, -(max_bias) / n_head_log2), m1 = powf(2.0f, -(max_bias / 2.0f) / n_head_log2);
+    T4 m = mask ? t4(mask) : t4(x);
+    hipStream_t s = (hipStream_t)stream;
+    if (mask && mask->type == MI355_TYPE_F16)
+        MI355_LAUNCH("soft_max", (soft_max_kernel<true>), dim3((unsigned)rows), dim3(256), 0, s, t4(x), m, true, t4(dst), scale, max_bias, m0, m1, n_head_log2);
+    else
+        MI355_LAUNCH("soft_max", (soft_max_kernel<false>), dim3((unsigned)rows), dim3(256), 0, s, t4(x), m, mask != nullptr, t4(dst), scale, max_bias, m0, m1, n_head_log2);
+    MI355_CHECK_LAUNCH();
+    return MI355_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,285 @@
+// fattn.hip -- FLASH_ATTN_EXT with f16 / q8_0 / q4_0 KV cache for gfx950.
+//
+// Contract: ggml.h:2012-2033, ggml.c:4733-4786; oracle ggml_compute_forward_flash_attn_ext_f16
+// (ggml/src/ggml-cpu/ops.cpp:7975-8192).  Replaces ggml_cuda_flash_attn_ext (ggml-cuda/fattn.cu:271-346,
+// vec kernels fattn-vec-f32.cuh) -- not derived from them.
+//
+// Decode-shaped kernel (HBM-bound: K and V rows are streamed once):
+//   * one 256-thread workgroup per (kv head, query token, batch) and a slice of the KV range;
+//     all `R` query heads that share the kv head (GQA) are processed together, so K/V are read once.
+//   * LPR = D/8 lanes cooperate on one KV row (each lane owns 8 consecutive features: one 128-bit
+//     load of f16, or 8 bytes of q8_0), so a wave-load covers 64/LPR complete, contiguous rows.
+//   * every lane group runs its own online softmax (running max / sum / 8-wide f32 accumulator per
+//     query head) over rows g, g+G, ...; the G groups are merged through LDS at the end.
+//   * long contexts: the KV range is split over `nsplit` workgroups that write (m, l, acc) partials
+//     to a workspace; a second kernel merges them (same rescaling rule).
+// All accumulation is f32 (the CPU oracle accumulates f16 V in fp16; NMSE budget 5e-4).
+#include "common.h"
+
+namespace {
+
+struct FArgs {
+    const char * q; int64_t q_nb1, q_nb2, q_nb3;
+    const char * k; int64_t k_nb1, k_nb2, k_nb3;
+    const char * v; int64_t v_nb1, v_nb2, v_nb3;
+    const char * mask; int64_t m_nb1, m_nb2, m_nb3, m_ne2, m_ne3;
+    char * dst; int64_t d_nb1, d_nb2, d_nb3;
+    int n_q, n_kv, n_head, n_head_kv, ne3;
+    float scale, max_bias, logit_softcap, m0, m1;
+    uint32_t n_head_log2;
+    int nsplit;
+    float * part; // [ne3][n_q][n_head][nsplit][D + 2] when nsplit > 1
+};
+
+// 8 consecutive features of a K/V row as f32
+template <int TYPE>
+static __device__ __forceinline__ void load8(const char * row, int j, float * out) {
+    if (TYPE == MI355_TYPE_F16) {
+        const v4i raw = *(const v4i *)(row + j * 16);
+        const __half2 * h = (const __half2 *)&raw;
+#pragma unroll
+        for (int i = 0; i < 4; i++) { const float2 f = __half22float2(h[i]); out[2 * i] = f.x; out[2 * i + 1] = f.y; }
+    } else if (TYPE == MI355_TYPE_Q8_0) {
+        const char * blk = row + (j >> 2) * 34;
+        const float d = h2f(*(const uint16_t *)blk);
+        const int8_t * qs = (const int8_t *)(blk + 2 + (j & 3) * 8);
+        int w0, w1;
+        __builtin_memcpy(&w0, qs, 4); __builtin_memcpy(&w1, qs + 4, 4);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            out[i]     = __fmul_rn((float)(int8_t)(w0 >> (8 * i)), d);
+            out[4 + i] = __fmul_rn((float)(int8_t)(w1 >> (8 * i)), d);
+        }
+    } else { // Q4_0: 18 B blocks; element e of the block: e < 16 -> low nibble of qs[e], else high nibble of qs[e-16]
+        const char * blk = row + (j >> 2) * 18;
+        const float d = h2f(*(const uint16_t *)blk);
+        const int e0 = (j & 3) * 8;             // 0, 8, 16, 24
+        const uint8_t * qs = (const uint8_t *)(blk + 2 + (e0 & 15));
+        const int sh = e0 >= 16 ? 4 : 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) out[i] = __fmul_rn((float)(((qs[i] >> sh) & 0xF) - 8), d);
+    }
+}
+
+static __device__ __forceinline__ float alibi_slope(const FArgs & a, uint32_t h) {
+    if (!(a.max_bias > 0.0f)) return 1.0f;
+    return h < a.n_head_log2 ? powf(a.m0, h + 1) : powf(a.m1, 2 * (h - a.n_head_log2) + 1);
+}
+
+template <int D, int R, int TK, int TV>
+__global__ void __launch_bounds__(256)
+fattn_vec_kernel(const FArgs a) {
+    constexpr int LPR = D / 8;        // lanes per KV row
+    constexpr int G   = 256 / LPR;    // row groups per workgroup
+    extern __shared__ __attribute__((aligned(16))) float sm[]; // [R][G][D + 2]
+    const int tid = threadIdx.x;
+    const int j = tid % LPR, g = tid / LPR;
+    const int ratio = a.n_head / a.n_head_kv;
+    const int hgroups = (ratio + R - 1) / R;      // workgroups per kv head
+    const int hk = blockIdx.x / hgroups;          // kv head
+    const int h0 = hk * ratio + (blockIdx.x % hgroups) * R;
+    const int iq = blockIdx.y;
+    const int i3 = blockIdx.z / a.nsplit, split = blockIdx.z % a.nsplit;
+
+    // this lane's 8 query features for each of the R heads
+    float qf[R][8];
+    float slope[R];
+    const char * mrow[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const int h = h0 + r < hk * ratio + ratio ? h0 + r : hk * ratio + ratio - 1; // clamp (ratio % R != 0)
+        const float * qp = (const float *)(a.q + iq * a.q_nb1 + h * a.q_nb2 + i3 * a.q_nb3) + j * 8;
+        const v4f q0 = *(const v4f *)qp, q1 = *(const v4f *)(qp + 4);
+        qf[r][0] = q0.x; qf[r][1] = q0.y; qf[r][2] = q0.z; qf[r][3] = q0.w;
+        qf[r][4] = q1.x; qf[r][5] = q1.y; qf[r][6] = q1.z; qf[r][7] = q1.w;
+        slope[r] = alibi_slope(a, (uint32_t)h);
+        mrow[r] = a.mask ? a.mask + iq * a.m_nb1 + (h % a.m_ne2) * a.m_nb2 + (i3 % a.m_ne3) * a.m_nb3 : nullptr;
+    }
+    float m[R], l[R], acc[R][8];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        m[r] = -INFINITY; l[r] = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 8; i++) acc[r][i] = 0.0f;
+    }
+
+    const char * kbase = a.k + hk * a.k_nb2 + i3 * a.k_nb3;
+    const char * vbase = a.v + hk * a.v_nb2 + i3 * a.v_nb3;
+    // KV slice of this workgroup
+    const int per = (a.n_kv + a.nsplit - 1) / a.nsplit;
+    const int kv0 = split * per, kv1 = kv0 + per < a.n_kv ? kv0 + per : a.n_kv;
+    const float scale = a.logit_softcap != 0.0f ? a.scale / a.logit_softcap : a.scale;
+
+    for (int ic = kv0 + g; ic < kv1; ic += G) {
+        float kf[8], vf[8];
+        load8<TK>(kbase + (int64_t)ic * a.k_nb1, j, kf);
+        load8<TV>(vbase + (int64_t)ic * a.v_nb1, j, vf);
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            float s = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 8; i++) s += qf[r][i] * kf[i];
+#pragma unroll
+            for (int o = 1; o < LPR; o <<= 1) s += __shfl_xor(s, o, 64);
+            s *= scale;
+            if (a.logit_softcap != 0.0f) s = a.logit_softcap * tanhf(s);
+            const float mv = mrow[r] ? slope[r] * __half2float(((const __half *)mrow[r])[ic]) : 0.0f;
+            if (mv == -INFINITY) continue;      // masked out (ops.cpp:8105-8108); uniform inside the lane group
+            s += mv;
+            const float mn = fmaxf(m[r], s);
+            const float corr = expf(m[r] - mn), p = expf(s - mn);
+            m[r] = mn;
+            l[r] = l[r] * corr + p;
+#pragma unroll
+            for (int i = 0; i < 8; i++) acc[r][i] = acc[r][i] * corr + p * vf[i];
+        }
+    }
+
+    // merge the G lane groups through LDS
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        float * slot = sm + ((size_t)r * G + g) * (D + 2);
+#pragma unroll
+        for (int i = 0; i < 8; i++) slot[j * 8 + i] = acc[r][i];
+        if (j == 0) { slot[D] = m[r]; slot[D + 1] = l[r]; }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < R * D; idx += 256) {
+        const int r = idx / D, d = idx % D;
+        const int h = h0 + r;
+        if (h >= hk * ratio + ratio) continue;
+        const float * base = sm + (size_t)r * G * (D + 2);
+        float M = -INFINITY;
+        for (int gg = 0; gg < G; gg++) M = fmaxf(M, base[gg * (D + 2) + D]);
+        float L = 0.0f, O = 0.0f;
+        for (int gg = 0; gg < G; gg++) {
+            const float mg = base[gg * (D + 2) + D];
+            const float w = mg == -INFINITY ? 0.0f : expf(mg - M);
+            L += base[gg * (D + 2) + D + 1] * w;
+            O += base[gg * (D + 2) + d] * w;
+        }
+        if (a.nsplit == 1) {
+            float * o = (float *)(a.dst + h * a.d_nb1 + iq * a.d_nb2 + i3 * a.d_nb3);
+            o[d] = O / L;
+        } else {
+            float * p = a.part + ((((size_t)i3 * a.n_q + iq) * a.n_head + h) * a.nsplit + split) * (D + 2);
+            p[d] = O;
+            if (d == 0) { p[D] = M; p[D + 1] = L; }
+        }
+    }
+}
+
+template <int D>
+__global__ void __launch_bounds__(D)
+fattn_combine_kernel(const FArgs a) {
+    const int h = blockIdx.x, iq = blockIdx.y, i3 = blockIdx.z, d = threadIdx.x;
+    const float * p = a.part + (((size_t)i3 * a.n_q + iq) * a.n_head + h) * a.nsplit * (D + 2);
+    float M = -INFINITY;
+    for (int s = 0; s < a.nsplit; s++) M = fmaxf(M, p[s * (D + 2) + D]);
+    float L = 0.0f, O = 0.0f;
+    for (int s = 0; s < a.nsplit; s++) {
+        const float ms = p[s * (D + 2) + D];
+        const float w = ms == -INFINITY ? 0.0f : expf(ms - M);
+        L += p[s * (D + 2) + D + 1] * w;
+        O += p[s * (D + 2) + d] * w;
+    }
+    float * o = (float *)(a.dst + h * a.d_nb1 + iq * a.d_nb2 + i3 * a.d_nb3);
+    o[d] = O / L;
+}
+
+template <int D, int R, int TK, int TV>
+static int launch_vec(const FArgs & a, hipStream_t s) {
+    constexpr int G = 256 / (D / 8);
+    const int ratio = a.n_head / a.n_head_kv;
+    const int hgroups = (ratio + R - 1) / R;
+    const dim3 grid((unsigned)(a.n_head_kv * hgroups), (unsigned)a.n_q, (unsigned)(a.ne3 * a.nsplit));
+    const size_t sh = (size_t)R * G * (D + 2) * sizeof(float);
+    if (sh > 48 * 1024) { // raise the dynamic-LDS cap once per instantiation
+        static const hipError_t attr = hipFuncSetAttribute((const void *)fattn_vec_kernel<D, R, TK, TV>,
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        if (attr != hipSuccess) return (int)attr;
+    }
+    MI355_LAUNCH("fattn_vec", (fattn_vec_kernel<D, R, TK, TV>), grid, dim3(256), sh, s, a);
+    MI355_CHECK_LAUNCH();
+    if (a.nsplit > 1) {
+        MI355_LAUNCH("fattn_combine", (fattn_combine_kernel<D>), dim3((unsigned)a.n_head, (unsigned)a.n_q, (unsigned)a.ne3), dim3(D), 0, s, a);
+        MI355_CHECK_LAUNCH();
+    }
+    return MI355_OK;
+}
+
+template <int D, int TK, int TV>
+static int dispatch_r(const FArgs & a, hipStream_t s) {
+    const int ratio = a.n_head / a.n_head_kv;
+    if (ratio >= 8 && D <= 128) return launch_vec<D, 8, TK, TV>(a, s);
+    if (ratio >= 4) return launch_vec<D, 4, TK, TV>(a, s);
+    if (ratio >= 2) return launch_vec<D, 2, TK, TV>(a, s);
+    return launch_vec<D, 1, TK, TV>(a, s);
+}
+
+template <int D>
+static int dispatch_types(const FArgs & a, int tk, int tv, hipStream_t s) {
+    if (tk == MI355_TYPE_F16 && tv == MI355_TYPE_F16)   return dispatch_r<D, MI355_TYPE_F16, MI355_TYPE_F16>(a, s);
+    if (tk == MI355_TYPE_Q8_0 && tv == MI355_TYPE_Q8_0) return dispatch_r<D, MI355_TYPE_Q8_0, MI355_TYPE_Q8_0>(a, s);
+    if (tk == MI355_TYPE_Q4_0 && tv == MI355_TYPE_Q4_0) return dispatch_r<D, MI355_TYPE_Q4_0, MI355_TYPE_Q4_0>(a, s);
+    return MI355_E_TYPE;
+}
+
+} // namespace
+
+extern "C" {
+
+int64_t mi355_flash_attn_ext_workspace_bytes(const mi355_fattn_args * p) {
+    if (!p) return -1;
+    // partials for the largest split the launcher may choose
+    return (int64_t)p->ne3 * p->n_q * p->n_head * 64 * (p->d + 2) * (int64_t)sizeof(float);
+}
+
+int mi355_flash_attn_ext(const mi355_fattn_args * p, void * workspace, int64_t workspace_bytes, void * stream) {
+    if (!p || !p->q || !p->k || !p->v || !p->dst) return MI355_E_NULL;
+    if (p->d != 64 && p->d != 128 && p->d != 256) return MI355_E_UNSUPPORTED;
+    if (p->n_head_kv < 1 || p->n_head % p->n_head_kv != 0 || p->n_q < 0 || p->n_kv < 0 || p->ne3 < 1) return MI355_E_SHAPE;
+    if (p->n_q > 65535 || p->ne3 * 64 > 65535) return MI355_E_SHAPE;
+    if (p->mask && (p->m_ne2 < 1 || p->m_ne3 < 1)) return MI355_E_SHAPE;
+    if (((uintptr_t)p->q | (uintptr_t)p->q_nb1 | (uintptr_t)p->q_nb2 | (uintptr_t)p->q_nb3) & 15) return MI355_E_ALIGN;
+    if (p->type_k == MI355_TYPE_F16 && (((uintptr_t)p->k | (uintptr_t)p->k_nb1 | (uintptr_t)p->k_nb2 | (uintptr_t)p->k_nb3) & 15)) return MI355_E_ALIGN;
+    if (p->type_v == MI355_TYPE_F16 && (((uintptr_t)p->v | (uintptr_t)p->v_nb1 | (uintptr_t)p->v_nb2 | (uintptr_t)p->v_nb3) & 15)) return MI355_E_ALIGN;
+    if (p->n_q == 0 || p->n_head == 0) return MI355_OK;
+
+    FArgs a;
+    a.q = (const char *)p->q; a.q_nb1 = p->q_nb1; a.q_nb2 = p->q_nb2; a.q_nb3 = p->q_nb3;
+    a.k = (const char *)p->k; a.k_nb1 = p->k_nb1; a.k_nb2 = p->k_nb2; a.k_nb3 = p->k_nb3;
+    a.v = (const char *)p->v; a.v_nb1 = p->v_nb1; a.v_nb2 = p->v_nb2; a.v_nb3 = p->v_nb3;
+    a.mask = (const char *)p->mask; a.m_nb1 = p->m_nb1; a.m_nb2 = p->m_nb2; a.m_nb3 = p->m_nb3; a.m_ne2 = p->m_ne2; a.m_ne3 = p->m_ne3;
+    a.dst = (char *)p->dst; a.d_nb1 = p->d_nb1; a.d_nb2 = p->d_nb2; a.d_nb3 = p->d_nb3;
+    a.n_q = (int)p->n_q; a.n_kv = (int)p->n_kv; a.n_head = (int)p->n_head; a.n_head_kv = (int)p->n_head_kv; a.ne3 = (int)p->ne3;
+    a.scale = p->scale; a.max_bias = p->max_bias; a.logit_softcap = p->logit_softcap;
+    a.n_head_log2 = 1u << (uint32_t)floorf(log2f((float)p->n_head));
+    a.m0 = powf(2.0f, -(p->max_bias) / a.n_head_log2);
+    a.m1 = powf(2.0f, -(p->max_bias / 2.0f) / a.n_head_log2);
+
+    // KV split: enough workgroups to fill 256 CUs when the (head, token) grid alone cannot,
+    // at least 256 KV rows per slice, bounded by the workspace
+    int nsplit = 1;
+    const int64_t base_wgs = (int64_t)p->n_head_kv * p->n_q * p->ne3;
+    if (workspace && base_wgs < 512 && p->n_kv >= 1024) {
+        int64_t want = 1024 / (base_wgs > 0 ? base_wgs : 1);
+        const int64_t max_by_len = p->n_kv / 256;
+        if (want > max_by_len) want = max_by_len;
+        if (want > 64) want = 64;
+        const int64_t per = (int64_t)p->ne3 * p->n_q * p->n_head * (p->d + 2) * (int64_t)sizeof(float);
+        if (per > 0 && want * per > workspace_bytes) want = workspace_bytes / per;
+        if (want > 1) nsplit = (int)want;
+    }
+    a.nsplit = nsplit;
+    a.part = (float *)workspace;
+    hipStream_t s = (hipStream_t)stream;
+    switch (p->d) {
+        case 64:  return dispatch_types<64>(a, p->type_k, p->type_v, s);
+        case 128: return dispatch_types<128>(a, p->type_k, p->type_v, s);
+        case 256: return dispatch_types<256>(a, p->type_k, p->type_v, s);
+    }
+    return MI355_E_UNSUPPORTED;
+}
+
+} // extern "C"
