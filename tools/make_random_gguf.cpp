@@ -1,0 +1,127 @@
+// make_random_gguf -- writes a random-init llama-architecture GGUF with the tensor types of
+// llama.cpp's Q4_K_M (or pure Q8_0 / Q4_0) recipe, for end-to-end benchmarks without any download.
+// Uses the reference's public gguf.h / ggml.h API (writer: ggml/src/gguf.cpp); metadata keys as read by
+// src/llama-model.cpp:447-596; type map per src/llama-quant.cpp:178-404; tokenizer "no_vocab"
+// (src/llama-vocab.cpp:1383-1403).  Weights are random *valid* blocks (random quants, finite fp16
+// scales), norms are 1.0.
+//   make-random-gguf <out.gguf> <8b|70b|tiny> [Q4_K_M|Q8_0|Q4_0]
+#include "ggml.h"
+#include "gguf.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+struct Dims { int n_embd, n_layer, n_head, n_head_kv, n_ff, n_vocab; bool is_70b; };
+
+static uint64_t rng_state = 0x9E3779B97F4A7C15ull;
+static inline uint64_t rnd() { rng_state ^= rng_state << 13; rng_state ^= rng_state >> 7; rng_state ^= rng_state << 17; return rng_state; }
+
+static bool use_more_bits(int i, int n) { return i < n / 8 || i >= 7 * n / 8 || (i - n / 8) % 3 == 2; } // llama-quant.cpp:185-187
+
+static void fill_blocks(ggml_tensor * t) {
+    const size_t nbytes = ggml_nbytes(t);
+    uint64_t * p = (uint64_t *)t->data;
+    for (size_t i = 0; i < nbytes / 8; i++) p[i] = rnd();
+    for (size_t i = nbytes / 8 * 8; i < nbytes; i++) ((uint8_t *)t->data)[i] = (uint8_t)rnd();
+    const size_t ts = ggml_type_size(t->type), nb = nbytes / ts;
+    auto put_half = [&](uint8_t * at, float lo, float hi, bool sign) {
+        float f = lo + (hi - lo) * (float)(rnd() >> 40) * (1.0f / 16777216.0f);
+        if (sign && (rnd() & 1)) f = -f;
+        const ggml_fp16_t h = ggml_fp32_to_fp16(f);
+        memcpy(at, &h, 2);
+    };
+    for (size_t b = 0; b < nb; b++) {
+        uint8_t * blk = (uint8_t *)t->data + b * ts;
+        switch (t->type) {
+            case GGML_TYPE_Q4_0: put_half(blk, 0.01f, 0.05f, true); break;
+            case GGML_TYPE_Q8_0: put_half(blk, 0.001f, 0.005f, true); break;
+            case GGML_TYPE_Q4_K: case GGML_TYPE_Q5_K:
+                put_half(blk, 0.0002f, 0.0008f, false); put_half(blk + 2, 0.0002f, 0.0008f, false); break;
+            case GGML_TYPE_Q6_K: put_half(blk + 208, 0.00002f, 0.0001f, true); break;
+            default: break;
+        }
+    }
+}
+
+int main(int argc, char ** argv) {
+    if (argc < 3) { fprintf(stderr, "usage: %s out.gguf 8b|70b|tiny [Q4_K_M|Q8_0|Q4_0]\n", argv[0]); return 2; }
+    const std::string out = argv[1], model = argv[2], ftype = argc > 3 ? argv[3] : "Q4_K_M";
+    Dims d;
+    if (model == "8b")        d = {4096, 32, 32, 8, 14336, 128256, false};
+    else if (model == "70b")  d = {8192, 80, 64, 8, 28672, 128256, true};
+    else if (model == "tiny") d = {1024, 4, 8, 2, 2816, 32000, false};
+    else { fprintf(stderr, "unknown model %s\n", model.c_str()); return 2; }
+    const ggml_type base = ftype == "Q8_0" ? GGML_TYPE_Q8_0 : ftype == "Q4_0" ? GGML_TYPE_Q4_0 : GGML_TYPE_Q4_K;
+    const bool km = ftype == "Q4_K_M";
+    const int head_dim = d.n_embd / d.n_head, kv_dim = head_dim * d.n_head_kv;
+
+    // size the context: every tensor lives in it until the file is written
+    size_t total = 0;
+    auto rs = [&](ggml_type t, int64_t k, int64_t m) { return ggml_row_size(t, k) * m + 256; };
+    total += rs(GGML_TYPE_Q6_K, d.n_embd, d.n_vocab) * 2;
+    for (int i = 0; i < d.n_layer; i++)
+        total += rs(GGML_TYPE_Q8_0, d.n_embd, d.n_embd) * 2 + rs(GGML_TYPE_Q8_0, d.n_embd, kv_dim) * 2 + rs(GGML_TYPE_Q8_0, d.n_embd, d.n_ff) * 2 +
+                 rs(GGML_TYPE_Q8_0, d.n_ff, d.n_embd) + 3 * (d.n_embd * 4 + 256);
+    ggml_init_params ip = {total + (64u << 20), nullptr, false};
+    ggml_context * ctx = ggml_init(ip);
+    if (!ctx) { fprintf(stderr, "ggml_init failed (%zu bytes)\n", total); return 1; }
+    gguf_context * g = gguf_init_empty();
+
+    gguf_set_val_str(g, "general.architecture", "llama");
+    gguf_set_val_str(g, "general.name", ("random-llama-" + model + "-" + ftype).c_str());
+    gguf_set_val_u32(g, "llama.context_length", 8192);
+    gguf_set_val_u32(g, "llama.embedding_length", d.n_embd);
+    gguf_set_val_u32(g, "llama.block_count", d.n_layer);
+    gguf_set_val_u32(g, "llama.feed_forward_length", d.n_ff);
+    gguf_set_val_u32(g, "llama.attention.head_count", d.n_head);
+    gguf_set_val_u32(g, "llama.attention.head_count_kv", d.n_head_kv);
+    gguf_set_val_f32(g, "llama.attention.layer_norm_rms_epsilon", 1e-5f);
+    gguf_set_val_u32(g, "llama.rope.dimension_count", head_dim);
+    gguf_set_val_f32(g, "llama.rope.freq_base", 500000.0f);
+    gguf_set_val_u32(g, "llama.vocab_size", d.n_vocab);
+    gguf_set_val_u32(g, "general.file_type", km ? 15 : (base == GGML_TYPE_Q8_0 ? 7 : 2));
+    gguf_set_val_str(g, "tokenizer.ggml.model", "no_vocab");
+
+    auto add_w = [&](const std::string & name, ggml_type t, int64_t k, int64_t m) {
+        ggml_tensor * x = ggml_new_tensor_2d(ctx, t, k, m);
+        ggml_set_name(x, name.c_str());
+        fill_blocks(x);
+        gguf_add_tensor(g, x);
+    };
+    auto add_norm = [&](const std::string & name) {
+        ggml_tensor * x = ggml_new_tensor_1d(ctx, GGML_TYPE_F32, d.n_embd);
+        ggml_set_name(x, name.c_str());
+        for (int i = 0; i < d.n_embd; i++) ((float *)x->data)[i] = 1.0f;
+        gguf_add_tensor(g, x);
+    };
+    add_w("token_embd.weight", base, d.n_embd, d.n_vocab);
+    for (int il = 0; il < d.n_layer; il++) {
+        ggml_type t_v = base, t_down = base;
+        if (km) {
+            const bool more = use_more_bits(il, d.n_layer);
+            t_v = more ? GGML_TYPE_Q6_K : (d.is_70b ? GGML_TYPE_Q5_K : GGML_TYPE_Q4_K); // llama-quant.cpp:291-299
+            t_down = more ? GGML_TYPE_Q6_K : GGML_TYPE_Q4_K;                           // llama-quant.cpp:347-353
+        }
+        const std::string p = "blk." + std::to_string(il) + ".";
+        add_norm(p + "attn_norm.weight");
+        add_w(p + "attn_q.weight", base, d.n_embd, d.n_embd);
+        add_w(p + "attn_k.weight", base, d.n_embd, kv_dim);
+        add_w(p + "attn_v.weight", t_v, d.n_embd, kv_dim);
+        add_w(p + "attn_output.weight", base, d.n_embd, d.n_embd);
+        add_norm(p + "ffn_norm.weight");
+        add_w(p + "ffn_gate.weight", base, d.n_embd, d.n_ff);
+        add_w(p + "ffn_up.weight", base, d.n_embd, d.n_ff);
+        add_w(p + "ffn_down.weight", t_down, d.n_ff, d.n_embd);
+    }
+    add_norm("output_norm.weight");
+    add_w("output.weight", km ? GGML_TYPE_Q6_K : base, d.n_embd, d.n_vocab);
+
+    if (!gguf_write_to_file(g, out.c_str(), false)) { fprintf(stderr, "write failed\n"); return 1; }
+    printf("wrote %s (%s %s, %.2f GB)\n", out.c_str(), model.c_str(), ftype.c_str(), ggml_used_mem(ctx) / 1e9);
+    gguf_free(g);
+    ggml_free(ctx);
+    return 0;
+}
