@@ -138,6 +138,13 @@ typedef struct mi355_mmvq_args {
 
 MI355_API int mi355_mul_mat_vec_q(const mi355_mmvq_args *args, void *stream);
 
+/* Prefill tile kernel (int8 MFMA): dst[c][r] = sum_k W[r][k] * act[c][k] for any n (meant for n > 8).
+ * Same operands as the mat-vec (one channel).  Returns MI355_E_UNSUPPORTED when k % 128 != 0 (callers
+ * then use the mat-vec kernel over column groups).  Replaces ggml_cuda_mul_mat_q / mul_mat_q
+ * (ggml/src/ggml-cuda/mmq.cu:68-224, mmq.cuh:2606-2841). */
+MI355_API int mi355_mul_mat_q(int type, const void *W, int64_t w_row_stride, const int8_t *act_q, const float *act_ds,
+                              float *dst, int64_t dst_col_stride, int64_t m, int64_t k, int64_t n, void *stream);
+
 /* Convenience for the common case (2-D contiguous W, contiguous f32 x[n][k], dst[n][m]):
  * quantizes x into `workspace` (>= mi355_mul_mat_workspace_bytes(k, n)) and runs the mat-vec
  * (n <= 8) or the MFMA tile kernel (n > 8).  Two launches on `stream`. */

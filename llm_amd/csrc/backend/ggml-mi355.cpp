@@ -389,6 +389,19 @@ static void mi355_mul_mat(mi355_backend_ctx * ctx, ggml_tensor * dst) {
     MI_CHECK(mi355_quantize_act((const float *)src1->data, aq, ads, K, N, ne12, ne13, src1->nb[1], src1->nb[2], src1->nb[3], ctx->stream));
 
     const int64_t r2 = ne12 / ne02, r3 = ne13 / ne03;
+    if (N > 8 && K % 128 == 0) {
+        // prefill: int8-MFMA tile kernel, one launch per broadcast channel
+        for (int64_t i13 = 0; i13 < ne13; i13++) {
+            for (int64_t i12 = 0; i12 < ne12; i12++) {
+                const char * W = (const char *)src0->data + (i13 / r3) * src0->nb[3] + (i12 / r2) * src0->nb[2];
+                const int64_t arow = (i13 * ne12 + i12) * N;
+                float * d = (float *)((char *)dst->data + i13 * dst->nb[3] + i12 * dst->nb[2]);
+                MI_CHECK(mi355_mul_mat_q((int)src0->type, W, (int64_t)src0->nb[1], aq + arow * K, ads + arow * (K / 32) * 2, d,
+                                         (int64_t)(dst->nb[1] / sizeof(float)), M, K, N, ctx->stream));
+            }
+        }
+        return;
+    }
     for (int64_t i13 = 0; i13 < ne13; i13++) {
         for (int64_t c0 = 0; c0 < N; c0 += 8) {
             mi355_mmvq_args a;

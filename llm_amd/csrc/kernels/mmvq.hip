@@ -330,10 +330,10 @@ mmvq_kernel(const KArgs a) {
 
     if (LDSACT) {
         // activations -> LDS: [NCOLS][k] int8, then [NCOLS][k/32][2] f32 (columns are contiguous rows of act)
-        const int nq = NCOLS * a.k / 16, nds = NCOLS * (a.k / QK) * 2 / 4;
+        const int nq = NCOLS * a.k / 16, nds = NCOLS * (a.k / QK); // 16-byte chunks of q, {d, sum} pairs
         for (int i = threadIdx.x; i < nq; i += 256) ((v4i *)lds)[i] = ((const v4i *)gq)[i];
-        v4f * lds_ds = (v4f *)(lds + (size_t)NCOLS * a.k);
-        for (int i = threadIdx.x; i < nds; i += 256) lds_ds[i] = ((const v4f *)gds)[i];
+        v2f * lds_ds = (v2f *)(lds + (size_t)NCOLS * a.k);
+        for (int i = threadIdx.x; i < nds; i += 256) lds_ds[i] = ((const v2f *)gds)[i];
         __syncthreads();
     }
 
@@ -425,7 +425,8 @@ extern "C" int mi355_mul_mat_vec_q(const mi355_mmvq_args * p, void * stream) {
     if (p->ids && (p->ids_nused < 1 || p->act_ne1 < 1 || p->n_expert < 1)) return MI355_E_SHAPE;
     // alignment the loads rely on: activations 16 B; q4_K/q5_K blocks 16 B; the 2-byte-aligned
     // types (q4_0, q8_0, q6_K) only need their natural 2 B
-    if (((uintptr_t)p->act_q & 15) || ((uintptr_t)p->act_ds & 15) || ((uintptr_t)p->dst & 3)) return MI355_E_ALIGN;
+    if (((uintptr_t)p->act_q & 15) || ((uintptr_t)p->act_ds & 7) || ((uintptr_t)p->dst & 3)) return MI355_E_ALIGN;
+    if (p->k % QK_K == 0 && ((uintptr_t)p->act_ds & 15)) return MI355_E_ALIGN;
     const bool a16 = p->type == MI355_TYPE_Q4_K || p->type == MI355_TYPE_Q5_K;
     const uintptr_t wal = (uintptr_t)p->W | (uintptr_t)p->w_row_stride | (uintptr_t)p->w_ch_stride;
     if (wal & (a16 ? 15 : 1)) return MI355_E_ALIGN;

@@ -3,10 +3,6 @@
 // columns -> mat-vec kernel (HBM-bound), larger batches -> tile kernel.
 #include "common.h"
 
-extern "C" int mi355_mul_mat_q_tiles(int type, const void * W, int64_t w_row_stride, const int8_t * act_q,
-                                     const float * act_ds, float * dst, int64_t dst_col_stride,
-                                     int64_t m, int64_t k, int64_t n, void * stream);
-
 static int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 
 extern "C" int64_t mi355_mul_mat_workspace_bytes(int64_t k, int64_t n) {
@@ -28,7 +24,7 @@ extern "C" int mi355_mul_mat(int type, const void * W, int64_t w_row_stride, con
     int rc = mi355_quantize_act(x, aq, ads, k, n, 1, 1, k * 4, k * n * 4, k * n * 4, stream);
     if (rc) return rc;
     if (n > 8) {
-        rc = mi355_mul_mat_q_tiles(type, W, w_row_stride, aq, ads, dst, m, m, k, n, stream);
+        rc = mi355_mul_mat_q(type, W, w_row_stride, aq, ads, dst, m, m, k, n, stream);
         if (rc != MI355_E_UNSUPPORTED) return rc;
     }
     // mat-vec kernel over groups of up to 8 columns

@@ -23,7 +23,7 @@ EXPORTS = [
     "mi355_timing_enable", "mi355_timing_reset", "mi355_timing_read", "mi355_timing_report",
     "mi355_binary_f32", "mi355_rms_norm_f32", "mi355_rope_f32", "mi355_glu_f32", "mi355_cpy", "mi355_get_rows",
     "mi355_scale_f32", "mi355_soft_max_f32", "mi355_flash_attn_ext_workspace_bytes", "mi355_flash_attn_ext",
-    "mi355_dequantize_row", "mi355_mul_mat_vec_q", "mi355_mul_mat_workspace_bytes", "mi355_mul_mat",
+    "mi355_dequantize_row", "mi355_mul_mat_vec_q", "mi355_mul_mat_q", "mi355_mul_mat_workspace_bytes", "mi355_mul_mat",
 ]
 
 
@@ -52,6 +52,7 @@ lib.mi355_quantize_row_q8_1.argtypes = [_vp, _vp] + [_i64] * 7 + [_vp]
 lib.mi355_quantize_act.argtypes = [_vp, _vp, _vp] + [_i64] * 7 + [_vp]
 lib.mi355_dequantize_row.argtypes = [C.c_int, _vp, _vp, _i64, _vp]
 lib.mi355_mul_mat_vec_q.argtypes = [C.POINTER(MmvqArgs), _vp]
+lib.mi355_mul_mat_q.argtypes = [C.c_int, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp]
 lib.mi355_mul_mat.argtypes = [C.c_int, _vp, _i64, _vp, _vp, _i64, _i64, _i64, _vp, _i64, _vp]
 
 

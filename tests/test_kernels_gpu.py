@@ -141,8 +141,33 @@ def test_mmvq_model_shapes_linearity(ops, t, m, k):
     assert O.nmse(want, y1[:, rows]) <= 1e-10
 
 
+@pytest.mark.parametrize("t", B.WEIGHT_TYPES)
+@pytest.mark.parametrize("m,k,n", [(128, 256, 128), (130, 1024, 33), (64, 512, 9), (300, 2048, 200), (257, 256, 129)])
+def test_mmq_int8_mfma_vs_oracle_contract(ops, t, m, k, n):
+    # n > 8 and k % 128 == 0 -> the int8-MFMA tile kernel (mi355_mul_mat_q); same q8_1 contract as the mat-vec
+    rng = np.random.default_rng(m + k + n)
+    w = B.random_blocks(t, m, k, seed=m * 7 + k + n + t)
+    x = rng.standard_normal((n, k)).astype(np.float32)
+    got = ops.mul_mat(t, dev(w), dev(x), m).cpu().numpy()
+    want = O.mul_mat(t, w, x, m, k, n, "q8_1")
+    assert O.nmse(want, got) <= 1e-10
+    assert O.nmse(O.mul_mat(t, w, x, m, k, n, "cpu"), got) <= 5e-4
+
+
+def test_mmq_matches_matvec_path_at_model_shape(ops):
+    # pp512-shaped launch vs the decode kernel on the same data (first 8 columns)
+    t, m, k, n = B.Q4_K, 1024, 4096, 512
+    rng = np.random.default_rng(3)
+    w = B.random_blocks(t, m, k, seed=11)
+    x = rng.standard_normal((n, k)).astype(np.float32)
+    wd, xd = dev(w), dev(x)
+    big = ops.mul_mat(t, wd, xd, m).cpu().numpy()
+    small = ops.mul_mat(t, wd, xd[:8].contiguous(), m).cpu().numpy()
+    assert O.nmse(small, big[:8]) <= 1e-10
+
+
 def test_mul_mat_large_batch_falls_back_to_column_groups(ops):
-    t, m, k, n = B.Q4_K, 96, 512, 19
+    t, m, k, n = B.Q4_0, 96, 96, 19   # k % 128 != 0: no tile kernel
     rng = np.random.default_rng(9)
     w = B.random_blocks(t, m, k, seed=9)
     x = rng.standard_normal((n, k)).astype(np.float32)
