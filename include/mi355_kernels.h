@@ -176,6 +176,9 @@ MI355_API int mi355_binary_f32(int op, const mi355_tensor *a, const mi355_tensor
 /* y = x * rsqrt(mean(x^2) + eps) per row of ne[0]; f32.  ggml_cuda_op_rms_norm (ggml-cuda/norm.cu);
  * oracle ggml_compute_forward_rms_norm_f32 (ggml-cpu/ops.cpp). */
 MI355_API int mi355_rms_norm_f32(const mi355_tensor *x, const mi355_tensor *dst, float eps, void *stream);
+/* fused RMS_NORM followed by MUL with a per-feature weight vector w[ne0] (the norm weight of every
+ * llama layer): dst = (x * rsqrt(mean(x^2) + eps)) * w, same f32 op order as the two separate nodes. */
+MI355_API int mi355_rms_norm_mul_f32(const mi355_tensor *x, const float *w, const mi355_tensor *dst, float eps, void *stream);
 
 /* rotary embedding, modes NORMAL (0) and NEOX (2), optional freq_factors, YaRN parameters.
  * ggml_cuda_op_rope (ggml-cuda/rope.cu); oracle ggml_compute_forward_rope_f32 (ggml-cpu/ops.cpp:5942-6110). */

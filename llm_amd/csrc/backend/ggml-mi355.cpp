@@ -275,19 +275,47 @@ struct mi355_backend_ctx {
     int         device;
     std::string name;
     hipStream_t stream = nullptr;
-    // scratch for the q8_1 activations of the MUL_MAT in flight; grown on demand, reused across ops
-    void * scratch = nullptr;
-    size_t scratch_size = 0;
+    // device scratch, grown on demand and reused across ops:
+    //   [0] q8_1 activations of the MUL_MAT / MUL_MAT_ID in flight   [1] split-KV partials of FLASH_ATTN_EXT
+    void * scratch[2] = {nullptr, nullptr};
+    size_t scratch_size[2] = {0, 0};
 
-    void * get_scratch(size_t need) {
-        if (need <= scratch_size) return scratch;
-        if (scratch) {
+    // the activation tensor whose q8_1 form currently sits in scratch[0]: consecutive MUL_MATs that read
+    // the same src1 (wq/wk/wv, gate/up) quantize it once.  Dropped as soon as any node writes into it.
+    struct {
+        bool valid = false;
+        const void * data = nullptr;
+        size_t span = 0;
+        int64_t ne[4] = {0, 0, 0, 0};
+        size_t nb[4] = {0, 0, 0, 0};
+    } act_cache;
+
+    void * get_scratch(int which, size_t need) {
+        if (need <= scratch_size[which]) return scratch[which];
+        if (scratch[which]) {
             HIP_CHECK(hipStreamSynchronize(stream)); // earlier kernels may still read the old block
-            HIP_CHECK(hipFree(scratch));
+            HIP_CHECK(hipFree(scratch[which]));
         }
-        scratch_size = (need + (8u << 20)) & ~((size_t)(1u << 20) - 1);
-        HIP_CHECK(hipMalloc(&scratch, scratch_size));
-        return scratch;
+        if (which == 0) act_cache.valid = false;
+        scratch_size[which] = (need + (8u << 20)) & ~((size_t)(1u << 20) - 1);
+        HIP_CHECK(hipMalloc(&scratch[which], scratch_size[which]));
+        return scratch[which];
+    }
+
+    bool act_cached(const ggml_tensor * t) const {
+        if (!act_cache.valid || act_cache.data != t->data) return false;
+        for (int i = 0; i < 4; i++) if (act_cache.ne[i] != t->ne[i] || act_cache.nb[i] != t->nb[i]) return false;
+        return true;
+    }
+    void act_remember(const ggml_tensor * t) {
+        act_cache.valid = true; act_cache.data = t->data; act_cache.span = ggml_nbytes(t);
+        for (int i = 0; i < 4; i++) { act_cache.ne[i] = t->ne[i]; act_cache.nb[i] = t->nb[i]; }
+    }
+    void act_invalidate_if_written(const ggml_tensor * node) {
+        if (!act_cache.valid) return;
+        const char * w0 = (const char *)node->data, * w1 = w0 + ggml_nbytes(node);
+        const char * c0 = (const char *)act_cache.data, * c1 = c0 + act_cache.span;
+        if (w0 < c1 && c0 < w1) act_cache.valid = false;
     }
 };
 
@@ -302,7 +330,7 @@ static void mi355_backend_free(ggml_backend_t backend) {
     mi355_backend_ctx * ctx = (mi355_backend_ctx *)backend->context;
     mi355_set_device(ctx->device);
     HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    if (ctx->scratch) HIP_CHECK(hipFree(ctx->scratch));
+    for (int i = 0; i < 2; i++) if (ctx->scratch[i]) HIP_CHECK(hipFree(ctx->scratch[i]));
     HIP_CHECK(hipStreamDestroy(ctx->stream));
     delete ctx;
     delete backend;
@@ -383,10 +411,13 @@ static void mi355_mul_mat(mi355_backend_ctx * ctx, ggml_tensor * dst) {
     // q8_1 activations for all of src1 (strided / permuted src1 is handled by the quantizer)
     const size_t qb = align_up((size_t)mi355_act_q_bytes(K, rows), 256);
     const size_t db = align_up((size_t)mi355_act_ds_bytes(K, rows), 256);
-    char * ws = (char *)ctx->get_scratch(qb + db);
+    char * ws = (char *)ctx->get_scratch(0, qb + db);
     int8_t * aq  = (int8_t *)ws;
     float  * ads = (float *)(ws + qb);
-    MI_CHECK(mi355_quantize_act((const float *)src1->data, aq, ads, K, N, ne12, ne13, src1->nb[1], src1->nb[2], src1->nb[3], ctx->stream));
+    if (!ctx->act_cached(src1)) {
+        MI_CHECK(mi355_quantize_act((const float *)src1->data, aq, ads, K, N, ne12, ne13, src1->nb[1], src1->nb[2], src1->nb[3], ctx->stream));
+        ctx->act_remember(src1);
+    }
 
     const int64_t r2 = ne12 / ne02, r3 = ne13 / ne03;
     if (N > 8 && K % 128 == 0) {
@@ -440,10 +471,13 @@ static void mi355_mul_mat_id(mi355_backend_ctx * ctx, ggml_tensor * dst) {
     const int64_t rows = b_ne1 * n_tokens;
     const size_t qb = align_up((size_t)mi355_act_q_bytes(K, rows), 256);
     const size_t db = align_up((size_t)mi355_act_ds_bytes(K, rows), 256);
-    char * ws = (char *)ctx->get_scratch(qb + db);
+    char * ws = (char *)ctx->get_scratch(0, qb + db);
     int8_t * aq  = (int8_t *)ws;
     float  * ads = (float *)(ws + qb);
-    MI_CHECK(mi355_quantize_act((const float *)b->data, aq, ads, K, b_ne1, n_tokens, 1, b->nb[1], b->nb[2], b->nb[3], ctx->stream));
+    if (!ctx->act_cached(b)) {   // gate / up experts read the same b
+        MI_CHECK(mi355_quantize_act((const float *)b->data, aq, ads, K, b_ne1, n_tokens, 1, b->nb[1], b->nb[2], b->nb[3], ctx->stream));
+        ctx->act_remember(b);
+    }
 
     // (token, slot) pairs are the launch's channels; at most 65535 per launch
     const int64_t tok_per_launch = 65535 / n_used;
@@ -513,7 +547,7 @@ static void mi355_flash_attn(mi355_backend_ctx * ctx, ggml_tensor * dst) {
     int64_t ws_bytes = 0;
     if (a.n_kv >= 1024 && a.n_head_kv * a.n_q * a.ne3 < 512) {
         ws_bytes = mi355_flash_attn_ext_workspace_bytes(&a);
-        ws = ctx->get_scratch((size_t)ws_bytes);
+        ws = ctx->get_scratch(1, (size_t)ws_bytes);
     }
     MI_CHECK(mi355_flash_attn_ext(&a, ws, ws_bytes, ctx->stream));
 }
@@ -528,15 +562,50 @@ static bool mi355_compute_forward(mi355_backend_ctx * ctx, ggml_tensor * node) {
     return mi355_ops_forward(node, ctx->stream);
 }
 
+static bool mi355_try_fuse_rms_norm_mul(mi355_backend_ctx * ctx, ggml_cgraph * cgraph, int i) {
+    ggml_tensor * norm = ggml_graph_node(cgraph, i);
+    ggml_tensor * mul  = ggml_graph_node(cgraph, i + 1);
+    if (mul->op != GGML_OP_MUL || getenv("GGML_MI355_NO_FUSE")) return false;
+    const ggml_tensor * w = mul->src[0] == norm ? mul->src[1] : (mul->src[1] == norm ? mul->src[0] : nullptr);
+    if (!w || w == norm) return false;
+    if (w->type != GGML_TYPE_F32 || mul->type != GGML_TYPE_F32 || norm->type != GGML_TYPE_F32) return false;
+    if (w->ne[0] != norm->ne[0] || ggml_nrows(w) != 1 || w->nb[0] != sizeof(float)) return false;
+    if (!ggml_are_same_shape(norm, mul) || norm->nb[0] != sizeof(float) || mul->nb[0] != sizeof(float)) return false;
+    if (norm->src[0]->nb[0] != sizeof(float)) return false;
+    if (norm->flags & GGML_TENSOR_FLAG_OUTPUT) return false;
+    const int n = ggml_graph_n_nodes(cgraph);
+    for (int j = i + 2; j < n; j++) {           // any other reader of the un-multiplied norm?
+        const ggml_tensor * t = ggml_graph_node(cgraph, j);
+        for (int s = 0; s < GGML_MAX_SRC; s++) if (t->src[s] == norm || (t->src[s] && t->src[s]->view_src == norm)) return false;
+    }
+    ctx->act_invalidate_if_written(mul);
+    float eps;
+    memcpy(&eps, norm->op_params, sizeof(float));
+    mi355_tensor tx, td;
+    const ggml_tensor * x = norm->src[0];
+    tx.data = x->data; tx.type = (int32_t)x->type; td.data = mul->data; td.type = (int32_t)mul->type;
+    for (int d = 0; d < 4; d++) { tx.ne[d] = x->ne[d]; tx.nb[d] = (int64_t)x->nb[d]; td.ne[d] = mul->ne[d]; td.nb[d] = (int64_t)mul->nb[d]; }
+    MI_CHECK(mi355_rms_norm_mul_f32(&tx, (const float *)w->data, &td, eps, ctx->stream));
+    return true;
+}
+
 static enum ggml_status mi355_backend_graph_compute(ggml_backend_t backend, ggml_cgraph * cgraph) {
     mi355_backend_ctx * ctx = (mi355_backend_ctx *)backend->context;
     mi355_set_device(ctx->device);
+    ctx->act_cache.valid = false; // tensors may have been rewritten through set_tensor / copies between calls
     const int n = ggml_graph_n_nodes(cgraph);
     for (int i = 0; i < n; i++) {
         ggml_tensor * node = ggml_graph_node(cgraph, i);
         // empty tensors and pure view ops compute nothing (ggml-cuda.cu:2589)
         if (ggml_is_empty(node) || node->op == GGML_OP_NONE || node->op == GGML_OP_RESHAPE || node->op == GGML_OP_VIEW ||
             node->op == GGML_OP_PERMUTE || node->op == GGML_OP_TRANSPOSE) {
+            continue;
+        }
+        ctx->act_invalidate_if_written(node);
+        // fusion: RMS_NORM followed by MUL with the per-feature norm weight (every llama layer), when the
+        // norm result has no other reader in this graph
+        if (node->op == GGML_OP_RMS_NORM && i + 1 < n && mi355_try_fuse_rms_norm_mul(ctx, cgraph, i)) {
+            i++;
             continue;
         }
         if (!mi355_compute_forward(ctx, node)) {

@@ -74,19 +74,45 @@ binary_kernel(const T4 a, const T4 b, const T4 d, int64_t n) {
 }
 
 // ---------------------------------------------------------------- rms norm (one block per row)
+// y = x * rsqrt(mean(x^2) + eps) [* w]: the row is read once with 128-bit loads and kept in registers
+// (rows up to 8192 floats); rows that are longer or not 16-byte aligned take the two-pass path.
+template <bool HAS_W>
 __global__ void __launch_bounds__(256)
-rms_norm_kernel(const T4 x, const T4 d, float eps) {
+rms_norm_kernel(const T4 x, const float * __restrict__ w, const T4 d, float eps, bool vec) {
     __shared__ float sh[4];
     const int64_t row = blockIdx.x;
     const int64_t i1 = row % x.ne[1], i2 = (row / x.ne[1]) % x.ne[2], i3 = row / (x.ne[1] * x.ne[2]);
     const float * xr = (const float *)(x.data + i1 * x.nb[1] + i2 * x.nb[2] + i3 * x.nb[3]);
     float * dr = (float *)(d.data + i1 * d.nb[1] + i2 * d.nb[2] + i3 * d.nb[3]);
     const int n = (int)x.ne[0];
+    if (vec) {
+        constexpr int MAXV = 8;
+        const int n4 = n >> 2;
+        v4f v[MAXV];
+        float s = 0.0f;
+#pragma unroll
+        for (int j = 0; j < MAXV; j++) {
+            const int i = threadIdx.x + j * 256;
+            if (i < n4) { v[j] = ((const v4f *)xr)[i]; s += v[j].x * v[j].x + v[j].y * v[j].y + v[j].z * v[j].z + v[j].w * v[j].w; }
+        }
+        s = block_sum(s, sh);
+        const float scale = 1.0f / sqrtf(s / (float)n + eps);
+#pragma unroll
+        for (int j = 0; j < MAXV; j++) {
+            const int i = threadIdx.x + j * 256;
+            if (i < n4) {
+                v4f o = v[j] * scale;            // (x * scale) then * w: the op order of the unfused graph
+                if (HAS_W) o = o * ((const v4f *)w)[i];
+                ((v4f *)dr)[i] = o;
+            }
+        }
+        return;
+    }
     float s = 0.0f;
-    for (int i = threadIdx.x; i < n; i += 256) { const float v = xr[i]; s += v * v; }
+    for (int i = threadIdx.x; i < n; i += 256) { const float t = xr[i]; s += t * t; }
     s = block_sum(s, sh);
     const float scale = 1.0f / sqrtf(s / (float)n + eps);
-    for (int i = threadIdx.x; i < n; i += 256) dr[i] = xr[i] * scale;
+    for (int i = threadIdx.x; i < n; i += 256) { float o = xr[i] * scale; if (HAS_W) o *= w[i]; dr[i] = o; }
 }
 
 // ---------------------------------------------------------------- rope
@@ -289,16 +315,29 @@ int mi355_binary_f32(int op, const mi355_tensor * a, const mi355_tensor * b, con
     return MI355_OK;
 }
 
-int mi355_rms_norm_f32(const mi355_tensor * x, const mi355_tensor * dst, float eps, void * stream) {
+static int launch_rms_norm(const mi355_tensor * x, const float * w, const mi355_tensor * dst, float eps, void * stream) {
     CHECK_T(x); CHECK_T(dst);
     if (x->type != MI355_TYPE_F32 || dst->type != MI355_TYPE_F32) return MI355_E_TYPE;
     if (!same_shape(x, dst) || x->nb[0] != 4 || dst->nb[0] != 4) return MI355_E_SHAPE;
     const int64_t rows = nrows(x);
     if (rows == 0 || x->ne[0] == 0) return MI355_OK;
     if (rows > 0x7fffffff) return MI355_E_SHAPE;
-    MI355_LAUNCH("rms_norm", rms_norm_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, t4(x), t4(dst), eps);
+    uintptr_t al = (uintptr_t)x->data | (uintptr_t)dst->data | (uintptr_t)w;
+    for (int i = 1; i < 4; i++) al |= (uintptr_t)x->nb[i] | (uintptr_t)dst->nb[i];
+    const bool vec = (al & 15) == 0 && x->ne[0] % 4 == 0 && x->ne[0] <= 8192;
+    if (w) MI355_LAUNCH("rms_norm_mul", (rms_norm_kernel<true>), dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, t4(x), w, t4(dst), eps, vec);
+    else   MI355_LAUNCH("rms_norm", (rms_norm_kernel<false>), dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, t4(x), w, t4(dst), eps, vec);
     MI355_CHECK_LAUNCH();
     return MI355_OK;
+}
+
+int mi355_rms_norm_f32(const mi355_tensor * x, const mi355_tensor * dst, float eps, void * stream) {
+    return launch_rms_norm(x, nullptr, dst, eps, stream);
+}
+
+int mi355_rms_norm_mul_f32(const mi355_tensor * x, const float * w, const mi355_tensor * dst, float eps, void * stream) {
+    if (!w) return MI355_E_NULL;
+    return launch_rms_norm(x, w, dst, eps, stream);
 }
 
 int mi355_rope_f32(const mi355_tensor * x, const int32_t * pos, const float * freq_factors, const mi355_tensor * dst,
