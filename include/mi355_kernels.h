@@ -179,6 +179,11 @@ MI355_API int mi355_rms_norm_f32(const mi355_tensor *x, const mi355_tensor *dst,
 /* fused RMS_NORM followed by MUL with a per-feature weight vector w[ne0] (the norm weight of every
  * llama layer): dst = (x * rsqrt(mean(x^2) + eps)) * w, same f32 op order as the two separate nodes. */
 MI355_API int mi355_rms_norm_mul_f32(const mi355_tensor *x, const float *w, const mi355_tensor *dst, float eps, void *stream);
+/* ... and additionally the q8_1 form of dst in the internal activation layout (mi355_quantize_act), so the
+ * MUL_MATs that consume dst need no separate quantization launch.  Rows up to 8192 floats, ne0 % 32 == 0,
+ * 16-byte aligned; otherwise MI355_E_UNSUPPORTED.  Row r of dst is activation row r. */
+MI355_API int mi355_rms_norm_mul_quant_f32(const mi355_tensor *x, const float *w, const mi355_tensor *dst, float eps,
+                                           int8_t *act_q, float *act_ds, void *stream);
 
 /* rotary embedding, modes NORMAL (0) and NEOX (2), optional freq_factors, YaRN parameters.
  * ggml_cuda_op_rope (ggml-cuda/rope.cu); oracle ggml_compute_forward_rope_f32 (ggml-cpu/ops.cpp:5942-6110). */
@@ -190,6 +195,9 @@ MI355_API int mi355_rope_f32(const mi355_tensor *x, const int32_t *pos, const fl
  * (ggml.h:556-564); b may be NULL (then a holds both halves along ne[0]; `swapped` as in ggml).
  * ggml_cuda_op_swiglu (ggml-cuda/unary.cu); oracle ggml_compute_forward_swiglu_f32 (ggml-cpu/ops.cpp:3476-3533). */
 MI355_API int mi355_glu_f32(int glu_op, const mi355_tensor *a, const mi355_tensor *b, const mi355_tensor *dst, int swapped, void *stream);
+/* same, plus the q8_1 form of dst (see mi355_rms_norm_mul_quant_f32); nc % 32 == 0, 16-byte aligned rows */
+MI355_API int mi355_glu_quant_f32(int glu_op, const mi355_tensor *a, const mi355_tensor *b, const mi355_tensor *dst, int swapped,
+                                  int8_t *act_q, float *act_ds, void *stream);
 
 /* copy / convert with arbitrary strides and equal element counts (ggml_cpy, ggml_cont, ggml_dup):
  * f32 -> f32 | f16 | q8_0, f16 -> f16 | f32.  The q8_0 destination follows quantize_row_q8_0_ref

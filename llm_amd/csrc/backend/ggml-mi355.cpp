@@ -414,7 +414,7 @@ static void mi355_mul_mat(mi355_backend_ctx * ctx, ggml_tensor * dst) {
     char * ws = (char *)ctx->get_scratch(0, qb + db);
     int8_t * aq  = (int8_t *)ws;
     float  * ads = (float *)(ws + qb);
-    if (!ctx->act_cached(src1)) {
+    if (!ctx->act_cached(src1) || getenv("GGML_MI355_NO_FUSE")) {
         MI_CHECK(mi355_quantize_act((const float *)src1->data, aq, ads, K, N, ne12, ne13, src1->nb[1], src1->nb[2], src1->nb[3], ctx->stream));
         ctx->act_remember(src1);
     }
@@ -552,11 +552,14 @@ static void mi355_flash_attn(mi355_backend_ctx * ctx, ggml_tensor * dst) {
     MI_CHECK(mi355_flash_attn_ext(&a, ws, ws_bytes, ctx->stream));
 }
 
+static bool mi355_glu_with_quant(mi355_backend_ctx * ctx, ggml_tensor * node);
+
 static bool mi355_compute_forward(mi355_backend_ctx * ctx, ggml_tensor * node) {
     switch (node->op) {
         case GGML_OP_MUL_MAT:        mi355_mul_mat(ctx, node);    return true;
         case GGML_OP_MUL_MAT_ID:     mi355_mul_mat_id(ctx, node); return true;
         case GGML_OP_FLASH_ATTN_EXT: mi355_flash_attn(ctx, node); return true;
+        case GGML_OP_GLU:            if (mi355_glu_with_quant(ctx, node)) return true; break;
         default: break;
     }
     return mi355_ops_forward(node, ctx->stream);
@@ -585,7 +588,35 @@ static bool mi355_try_fuse_rms_norm_mul(mi355_backend_ctx * ctx, ggml_cgraph * c
     const ggml_tensor * x = norm->src[0];
     tx.data = x->data; tx.type = (int32_t)x->type; td.data = mul->data; td.type = (int32_t)mul->type;
     for (int d = 0; d < 4; d++) { tx.ne[d] = x->ne[d]; tx.nb[d] = (int64_t)x->nb[d]; td.ne[d] = mul->ne[d]; td.nb[d] = (int64_t)mul->nb[d]; }
+    // decode-sized rows: also emit the q8_1 form for the MUL_MATs that read the result
+    const int64_t rows = ggml_nrows(mul), K = mul->ne[0];
+    if (rows <= 8 && K % 32 == 0 && K <= 8192 && ggml_is_contiguous(mul)) {
+        const size_t qb = align_up((size_t)mi355_act_q_bytes(K, rows), 256), db = align_up((size_t)mi355_act_ds_bytes(K, rows), 256);
+        char * ws = (char *)ctx->get_scratch(0, qb + db);
+        const int rc = mi355_rms_norm_mul_quant_f32(&tx, (const float *)w->data, &td, eps, (int8_t *)ws, (float *)(ws + qb), ctx->stream);
+        if (rc == MI355_OK) { ctx->act_remember(mul); return true; }
+        if (rc != MI355_E_UNSUPPORTED) MI_CHECK(rc);
+    }
     MI_CHECK(mi355_rms_norm_mul_f32(&tx, (const float *)w->data, &td, eps, ctx->stream));
+    return true;
+}
+
+// GLU whose result feeds ffn_down at decode: fused q8_1 quantization of the output
+static bool mi355_glu_with_quant(mi355_backend_ctx * ctx, ggml_tensor * node) {
+    const ggml_tensor * a = node->src[0], * b = node->src[1];
+    const int64_t rows = ggml_nrows(node), K = node->ne[0];
+    if (rows > 8 || K % 32 != 0 || !ggml_is_contiguous(node) || getenv("GGML_MI355_NO_FUSE")) return false;
+    auto T = [](const ggml_tensor * t) { mi355_tensor r; r.data = t->data; r.type = (int32_t)t->type;
+                                         for (int d = 0; d < 4; d++) { r.ne[d] = t->ne[d]; r.nb[d] = (int64_t)t->nb[d]; } return r; };
+    mi355_tensor ta = T(a), tb, td = T(node);
+    if (b) tb = T(b);
+    const size_t qb = align_up((size_t)mi355_act_q_bytes(K, rows), 256), db = align_up((size_t)mi355_act_ds_bytes(K, rows), 256);
+    char * ws = (char *)ctx->get_scratch(0, qb + db);
+    const int rc = mi355_glu_quant_f32((int)ggml_get_glu_op(node), &ta, b ? &tb : nullptr, &td, ((const int32_t *)node->op_params)[1],
+                                       (int8_t *)ws, (float *)(ws + qb), ctx->stream);
+    if (rc == MI355_E_UNSUPPORTED) return false;
+    MI_CHECK(rc);
+    ctx->act_remember(node);
     return true;
 }
 

@@ -44,4 +44,26 @@ static __device__ __forceinline__ float wave_sum(float v) {
 // per-byte (x - c) for bytes x in [0,127], c in [0,127]: no borrow can cross a byte
 static __device__ __forceinline__ int sub_bytes(int x, int c4) { return ((x | 0x80808080) - c4) ^ 0x80808080; }
 
+// q8_1 quantization of 4 consecutive values per lane, 8 consecutive lanes = one 32-block
+// (quantize_row_q8_1_ref semantics, see quantize.hip).  Writes the 4 int8 and, from the block's
+// first lane, {float(fp16(d)), float(sum q)} of the internal SoA layout.  All 8 lanes must be active.
+static __device__ __forceinline__ void quant4_soa(const float v[4], int8_t * q_dst, float * ds_dst, bool leader) {
+    float amax = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+    const float d  = __fdiv_rn(amax, 127.0f);
+    const float id = d != 0.0f ? __fdiv_rn(1.0f, d) : 0.0f;
+    int q[4], sum = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const float r = roundf(__fmul_rn(v[j], id));
+        q[j] = fabsf(r) < 2147483648.0f ? (int)(int8_t)(int)r : 0;
+        sum += q[j];
+    }
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) sum += __shfl_xor(sum, o, 64);
+    *(uint32_t *)q_dst = (uint32_t)(q[0] & 0xff) | ((uint32_t)(q[1] & 0xff) << 8) | ((uint32_t)(q[2] & 0xff) << 16) | ((uint32_t)(q[3] & 0xff) << 24);
+    if (leader) { v2f ds; ds.x = __half2float(__float2half_rn(d)); ds.y = (float)sum; *(v2f *)ds_dst = ds; }
+}
+
 #define MI355_CHECK_LAUNCH() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)

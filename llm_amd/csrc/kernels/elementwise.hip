@@ -78,7 +78,7 @@ binary_kernel(const T4 a, const T4 b, const T4 d, int64_t n) {
 // (rows up to 8192 floats); rows that are longer or not 16-byte aligned take the two-pass path.
 template <bool HAS_W>
 __global__ void __launch_bounds__(256)
-rms_norm_kernel(const T4 x, const float * __restrict__ w, const T4 d, float eps, bool vec) {
+rms_norm_kernel(const T4 x, const float * __restrict__ w, const T4 d, float eps, bool vec, int8_t * __restrict__ aq, float * __restrict__ ads) {
     __shared__ float sh[4];
     const int64_t row = blockIdx.x;
     const int64_t i1 = row % x.ne[1], i2 = (row / x.ne[1]) % x.ne[2], i3 = row / (x.ne[1] * x.ne[2]);
@@ -104,6 +104,10 @@ rms_norm_kernel(const T4 x, const float * __restrict__ w, const T4 d, float eps,
                 v4f o = v[j] * scale;            // (x * scale) then * w: the op order of the unfused graph
                 if (HAS_W) o = o * ((const v4f *)w)[i];
                 ((v4f *)dr)[i] = o;
+                if (aq) { // fused q8_1 quantization of the row for the MUL_MATs that consume it
+                    const float ov[4] = {o.x, o.y, o.z, o.w};
+                    quant4_soa(ov, aq + row * n + 4 * i, ads + (row * (n / QK) + (i >> 3)) * 2, (i & 7) == 0);
+                }
             }
         }
         return;
@@ -190,6 +194,20 @@ glu_kernel(int op, const char * a, const char * b, int64_t a_row, int64_t b_row,
         const float g = ((const float *)(b + r * b_row))[c];
         ((float *)(d + r * d_row))[c] = act_glu(op, x) * g;
     }
+}
+
+// vectorized split-GLU with fused q8_1 quantization of the result (decode: the result feeds ffn_down)
+__global__ void __launch_bounds__(256)
+glu_quant_kernel(int op, const char * a, const char * b, int64_t a_row, int64_t b_row, char * d, int64_t d_row, int nc,
+                 int8_t * __restrict__ aq, float * __restrict__ ads) {
+    const int i = blockIdx.y * 256 + threadIdx.x;    // float4 index inside the row
+    if (i * 4 >= nc) return;                         // nc % 32 == 0: whole 8-lane groups leave together
+    const int64_t r = blockIdx.x;
+    const v4f x = ((const v4f *)(a + r * a_row))[i], g = ((const v4f *)(b + r * b_row))[i];
+    float o[4] = {act_glu(op, x.x) * g.x, act_glu(op, x.y) * g.y, act_glu(op, x.z) * g.z, act_glu(op, x.w) * g.w};
+    v4f ov = {o[0], o[1], o[2], o[3]};
+    ((v4f *)(d + r * d_row))[i] = ov;
+    quant4_soa(o, aq + r * nc + 4 * i, ads + (r * (nc / QK) + (i >> 3)) * 2, (i & 7) == 0);
 }
 
 // ---------------------------------------------------------------- cpy
@@ -315,7 +333,7 @@ int mi355_binary_f32(int op, const mi355_tensor * a, const mi355_tensor * b, con
     return MI355_OK;
 }
 
-static int launch_rms_norm(const mi355_tensor * x, const float * w, const mi355_tensor * dst, float eps, void * stream) {
+static int launch_rms_norm(const mi355_tensor * x, const float * w, const mi355_tensor * dst, float eps, int8_t * aq, float * ads, void * stream) {
     CHECK_T(x); CHECK_T(dst);
     if (x->type != MI355_TYPE_F32 || dst->type != MI355_TYPE_F32) return MI355_E_TYPE;
     if (!same_shape(x, dst) || x->nb[0] != 4 || dst->nb[0] != 4) return MI355_E_SHAPE;
@@ -325,19 +343,26 @@ static int launch_rms_norm(const mi355_tensor * x, const float * w, const mi355_
     uintptr_t al = (uintptr_t)x->data | (uintptr_t)dst->data | (uintptr_t)w;
     for (int i = 1; i < 4; i++) al |= (uintptr_t)x->nb[i] | (uintptr_t)dst->nb[i];
     const bool vec = (al & 15) == 0 && x->ne[0] % 4 == 0 && x->ne[0] <= 8192;
-    if (w) MI355_LAUNCH("rms_norm_mul", (rms_norm_kernel<true>), dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, t4(x), w, t4(dst), eps, vec);
-    else   MI355_LAUNCH("rms_norm", (rms_norm_kernel<false>), dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, t4(x), w, t4(dst), eps, vec);
+    if (aq && (!vec || x->ne[0] % QK != 0 || !ads)) return MI355_E_UNSUPPORTED;
+    if (w) MI355_LAUNCH("rms_norm_mul", (rms_norm_kernel<true>), dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, t4(x), w, t4(dst), eps, vec, aq, ads);
+    else   MI355_LAUNCH("rms_norm", (rms_norm_kernel<false>), dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, t4(x), w, t4(dst), eps, vec, aq, ads);
     MI355_CHECK_LAUNCH();
     return MI355_OK;
 }
 
 int mi355_rms_norm_f32(const mi355_tensor * x, const mi355_tensor * dst, float eps, void * stream) {
-    return launch_rms_norm(x, nullptr, dst, eps, stream);
+    return launch_rms_norm(x, nullptr, dst, eps, nullptr, nullptr, stream);
 }
 
 int mi355_rms_norm_mul_f32(const mi355_tensor * x, const float * w, const mi355_tensor * dst, float eps, void * stream) {
     if (!w) return MI355_E_NULL;
-    return launch_rms_norm(x, w, dst, eps, stream);
+    return launch_rms_norm(x, w, dst, eps, nullptr, nullptr, stream);
+}
+
+int mi355_rms_norm_mul_quant_f32(const mi355_tensor * x, const float * w, const mi355_tensor * dst, float eps,
+                                 int8_t * act_q, float * act_ds, void * stream) {
+    if (!w || !act_q || !act_ds) return MI355_E_NULL;
+    return launch_rms_norm(x, w, dst, eps, act_q, act_ds, stream);
 }
 
 int mi355_rope_f32(const mi355_tensor * x, const int32_t * pos, const float * freq_factors, const mi355_tensor * dst,
@@ -363,7 +388,21 @@ int mi355_rope_f32(const mi355_tensor * x, const int32_t * pos, const float * fr
     return MI355_OK;
 }
 
+static int launch_glu(int glu_op, const mi355_tensor * a, const mi355_tensor * b, const mi355_tensor * dst, int swapped,
+                      int8_t * aq, float * ads, void * stream);
+
 int mi355_glu_f32(int glu_op, const mi355_tensor * a, const mi355_tensor * b, const mi355_tensor * dst, int swapped, void * stream) {
+    return launch_glu(glu_op, a, b, dst, swapped, nullptr, nullptr, stream);
+}
+
+int mi355_glu_quant_f32(int glu_op, const mi355_tensor * a, const mi355_tensor * b, const mi355_tensor * dst, int swapped,
+                        int8_t * act_q, float * act_ds, void * stream) {
+    if (!act_q || !act_ds) return MI355_E_NULL;
+    return launch_glu(glu_op, a, b, dst, swapped, act_q, act_ds, stream);
+}
+
+static int launch_glu(int glu_op, const mi355_tensor * a, const mi355_tensor * b, const mi355_tensor * dst, int swapped,
+                      int8_t * aq, float * ads, void * stream) {
     CHECK_T(a); CHECK_T(dst);
     if (b && !b->data) return MI355_E_NULL;
     if (a->type != MI355_TYPE_F32 || dst->type != MI355_TYPE_F32 || (b && b->type != MI355_TYPE_F32)) return MI355_E_TYPE;
@@ -377,6 +416,15 @@ int mi355_glu_f32(int glu_op, const mi355_tensor * a, const mi355_tensor * b, co
     if (n == 0) return MI355_OK;
     const char * ap = (const char *)a->data, * bp = b ? (const char *)b->data : (const char *)a->data;
     if (!b) { ap += swapped ? nc * 4 : 0; bp += swapped ? 0 : nc * 4; }
+    if (aq) {
+        const uintptr_t al = (uintptr_t)ap | (uintptr_t)bp | (uintptr_t)dst->data | (uintptr_t)a->nb[1] | (uintptr_t)(b ? b->nb[1] : a->nb[1]) | (uintptr_t)dst->nb[1];
+        if ((al & 15) || nc % QK != 0 || nrows(dst) > 0x7fffffff) return MI355_E_UNSUPPORTED;
+        const dim3 grid((unsigned)nrows(dst), (unsigned)((nc / 4 + 255) / 256));
+        MI355_LAUNCH("glu_quant", glu_quant_kernel, grid, dim3(256), 0, (hipStream_t)stream, glu_op, ap, bp, a->nb[1],
+                     b ? b->nb[1] : a->nb[1], (char *)dst->data, dst->nb[1], (int)nc, aq, ads);
+        MI355_CHECK_LAUNCH();
+        return MI355_OK;
+    }
     MI355_LAUNCH("glu", glu_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, glu_op, ap, bp, a->nb[1],
                  b ? b->nb[1] : a->nb[1], (char *)dst->data, dst->nb[1], (int)nc, n);
     MI355_CHECK_LAUNCH();

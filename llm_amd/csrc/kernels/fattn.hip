@@ -5,7 +5,7 @@
 // vec kernels fattn-vec-f32.cuh) -- not derived from them.
 //
 // Decode-shaped kernel (HBM-bound: K and V rows are streamed once):
-//   * one 256-thread workgroup per (kv head, query token, batch) and a slice of the KV range;
+//   * one 512-thread workgroup per (kv head, query token, batch) and a slice of the KV range;
 //     all `R` query heads that share the kv head (GQA) are processed together, so K/V are read once.
 //   * LPR = D/8 lanes cooperate on one KV row (each lane owns 8 consecutive features: one 128-bit
 //     load of f16, or 8 bytes of q8_0), so a wave-load covers 64/LPR complete, contiguous rows.
@@ -66,12 +66,16 @@ static __device__ __forceinline__ float alibi_slope(const FArgs & a, uint32_t h)
     return h < a.n_head_log2 ? powf(a.m0, h + 1) : powf(a.m1, 2 * (h - a.n_head_log2) + 1);
 }
 
+constexpr int FA_THREADS = 512; // 8 waves: the KV loop is a chain of dependent loads, so rows are spread wide
+                                 // (1024 threads would cap the kernel at 128 VGPRs and spill for R >= 4)
+
 template <int D, int R, int TK, int TV>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(FA_THREADS)
 fattn_vec_kernel(const FArgs a) {
-    constexpr int LPR = D / 8;        // lanes per KV row
-    constexpr int G   = 256 / LPR;    // row groups per workgroup
-    extern __shared__ __attribute__((aligned(16))) float sm[]; // [R][G][D + 2]
+    constexpr int LPR = D / 8;               // lanes per KV row
+    constexpr int G   = FA_THREADS / LPR;    // row groups per workgroup
+    constexpr int NW  = FA_THREADS / 64;     // waves
+    extern __shared__ __attribute__((aligned(16))) float sm[]; // [R][NW][D + 2]
     const int tid = threadIdx.x;
     const int j = tid % LPR, g = tid / LPR;
     const int ratio = a.n_head / a.n_head_kv;
@@ -110,8 +114,7 @@ fattn_vec_kernel(const FArgs a) {
     const int kv0 = split * per, kv1 = kv0 + per < a.n_kv ? kv0 + per : a.n_kv;
     const float scale = a.logit_softcap != 0.0f ? a.scale / a.logit_softcap : a.scale;
 
-    // software pipeline: the K/V rows of step i+1 are requested before step i is consumed, so the loop
-    // is not a chain of dependent HBM round trips (39 us -> a few us at n_kv = 256)
+    // software pipeline: the K/V rows of step i+1 are requested before step i is consumed
     float kf[8], vf[8], kn[8], vn[8];
     int ic = kv0 + g;
     if (ic < kv1) {
@@ -119,7 +122,7 @@ fattn_vec_kernel(const FArgs a) {
         load8<TV>(vbase + (int64_t)ic * a.v_nb1, j, vf);
     }
     for (; ic < kv1; ic += G) {
-        const int in = ic + G < kv1 ? ic + G : ic;   // last step re-reads its own row (already in cache)
+        const int in = ic + G < kv1 ? ic + G : ic;   // the last step re-reads its own row
         load8<TK>(kbase + (int64_t)in * a.k_nb1, j, kn);
         load8<TV>(vbase + (int64_t)in * a.v_nb1, j, vn);
         float mv[R];
@@ -147,24 +150,38 @@ fattn_vec_kernel(const FArgs a) {
         for (int i = 0; i < 8; i++) { kf[i] = kn[i]; vf[i] = vn[i]; }
     }
 
-    // merge the G lane groups through LDS
+    // merge: first the lane groups of each wave (xor-shuffles), then the waves through LDS
+    const int wave = tid >> 6;
 #pragma unroll
     for (int r = 0; r < R; r++) {
-        float * slot = sm + ((size_t)r * G + g) * (D + 2);
 #pragma unroll
-        for (int i = 0; i < 8; i++) slot[j * 8 + i] = acc[r][i];
-        if (j == 0) { slot[D] = m[r]; slot[D + 1] = l[r]; }
+        for (int o = LPR; o < 64; o <<= 1) {
+            const float mo = __shfl_xor(m[r], o, 64), lo = __shfl_xor(l[r], o, 64);
+            const float mn = fmaxf(m[r], mo);
+            const float w0 = m[r] == -INFINITY ? 0.0f : expf(m[r] - mn);
+            const float w1 = mo == -INFINITY ? 0.0f : expf(mo - mn);
+            l[r] = l[r] * w0 + lo * w1;
+#pragma unroll
+            for (int i = 0; i < 8; i++) acc[r][i] = acc[r][i] * w0 + __shfl_xor(acc[r][i], o, 64) * w1;
+            m[r] = mn;
+        }
+        if ((tid & 63) < LPR) {
+            float * slot = sm + ((size_t)r * NW + wave) * (D + 2);
+#pragma unroll
+            for (int i = 0; i < 8; i++) slot[j * 8 + i] = acc[r][i];
+            if (j == 0) { slot[D] = m[r]; slot[D + 1] = l[r]; }
+        }
     }
     __syncthreads();
-    for (int idx = tid; idx < R * D; idx += 256) {
+    for (int idx = tid; idx < R * D; idx += FA_THREADS) {
         const int r = idx / D, d = idx % D;
         const int h = h0 + r;
         if (h >= hk * ratio + ratio) continue;
-        const float * base = sm + (size_t)r * G * (D + 2);
+        const float * base = sm + (size_t)r * NW * (D + 2);
         float M = -INFINITY;
-        for (int gg = 0; gg < G; gg++) M = fmaxf(M, base[gg * (D + 2) + D]);
+        for (int gg = 0; gg < NW; gg++) M = fmaxf(M, base[gg * (D + 2) + D]);
         float L = 0.0f, O = 0.0f;
-        for (int gg = 0; gg < G; gg++) {
+        for (int gg = 0; gg < NW; gg++) {
             const float mg = base[gg * (D + 2) + D];
             const float w = mg == -INFINITY ? 0.0f : expf(mg - M);
             L += base[gg * (D + 2) + D + 1] * w;
@@ -201,17 +218,17 @@ fattn_combine_kernel(const FArgs a) {
 
 template <int D, int R, int TK, int TV>
 static int launch_vec(const FArgs & a, hipStream_t s) {
-    constexpr int G = 256 / (D / 8);
+    constexpr int NW = FA_THREADS / 64;
     const int ratio = a.n_head / a.n_head_kv;
     const int hgroups = (ratio + R - 1) / R;
     const dim3 grid((unsigned)(a.n_head_kv * hgroups), (unsigned)a.n_q, (unsigned)(a.ne3 * a.nsplit));
-    const size_t sh = (size_t)R * G * (D + 2) * sizeof(float);
+    const size_t sh = (size_t)R * NW * (D + 2) * sizeof(float);
     if (sh > 48 * 1024) { // raise the dynamic-LDS cap once per instantiation
         static const hipError_t attr = hipFuncSetAttribute((const void *)fattn_vec_kernel<D, R, TK, TV>,
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
         if (attr != hipSuccess) return (int)attr;
     }
-    MI355_LAUNCH("fattn_vec", (fattn_vec_kernel<D, R, TK, TV>), grid, dim3(256), sh, s, a);
+    MI355_LAUNCH("fattn_vec", (fattn_vec_kernel<D, R, TK, TV>), grid, dim3(FA_THREADS), sh, s, a);
     MI355_CHECK_LAUNCH();
     if (a.nsplit > 1) {
         MI355_LAUNCH("fattn_combine", (fattn_combine_kernel<D>), dim3((unsigned)a.n_head, (unsigned)a.n_q, (unsigned)a.ne3), dim3(D), 0, s, a);

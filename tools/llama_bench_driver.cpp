@@ -52,7 +52,7 @@ static bool test_gen(llama_context * ctx, int n_gen, int n_vocab) {
 }
 
 int main(int argc, char ** argv) {
-    std::string model_path, ctk = "f16", ctv = "f16";
+    std::string model_path, ctk = "f16", ctv = "f16", dump_path;
     int n_prompt = 512, n_gen = 128, reps = 3, ngl = 99, fa = 1, threads = 8, n_batch = 2048, n_ubatch = 512;
     for (int i = 1; i < argc; i++) {
         const std::string a = argv[i];
@@ -60,6 +60,7 @@ int main(int argc, char ** argv) {
         if (a == "-m") model_path = next(); else if (a == "-p") n_prompt = atoi(next().c_str()); else if (a == "-n") n_gen = atoi(next().c_str());
         else if (a == "-r") reps = atoi(next().c_str()); else if (a == "-ngl") ngl = atoi(next().c_str()); else if (a == "-fa") fa = atoi(next().c_str());
         else if (a == "-ctk") ctk = next(); else if (a == "-ctv") ctv = next(); else if (a == "-t") threads = atoi(next().c_str());
+        else if (a == "--dump-logits") dump_path = next();
         else if (a == "-b") n_batch = atoi(next().c_str()); else if (a == "-ub") n_ubatch = atoi(next().c_str());
         else { fprintf(stderr, "unknown arg %s\n", a.c_str()); return 2; }
     }
@@ -90,6 +91,25 @@ int main(int argc, char ** argv) {
     if (!ctx) { fprintf(stderr, "failed to create context\n"); return 1; }
 
     srand(1234);
+    if (!dump_path.empty()) {
+        // parity mode: a fixed 48-token prompt in one batch, then 6 single-token decodes fed with fixed tokens;
+        // the logits of the last prompt token and of every decode step are written as raw f32
+        std::vector<llama_token> prompt(48);
+        for (size_t i = 0; i < prompt.size(); i++) prompt[i] = (llama_token)((i * 7919 + 13) % n_vocab);
+        FILE * f = fopen(dump_path.c_str(), "wb");
+        if (!f) { perror(dump_path.c_str()); return 1; }
+        if (llama_decode(ctx, llama_batch_get_one(prompt.data(), (int)prompt.size())) != 0) return 1;
+        fwrite(llama_get_logits_ith(ctx, -1), sizeof(float), n_vocab, f);
+        for (int s = 0; s < 6; s++) {
+            llama_token tok = (llama_token)((s * 104729 + 71) % n_vocab);
+            if (llama_decode(ctx, llama_batch_get_one(&tok, 1)) != 0) return 1;
+            fwrite(llama_get_logits_ith(ctx, -1), sizeof(float), n_vocab, f);
+        }
+        fclose(f);
+        printf("{\"dumped\": \"%s\", \"n_vocab\": %d, \"rows\": 7, \"devices\": \"%s\"}\n", dump_path.c_str(), n_vocab, devs.c_str());
+        llama_free(ctx); llama_model_free(model); llama_backend_free();
+        return 0;
+    }
     std::vector<double> pp_ts, tg_ts;
     // warm-up (llama-bench.cpp:1925-1946)
     if (n_prompt > 0) test_prompt(ctx, n_prompt, n_batch, n_vocab);
