@@ -1,0 +1,53 @@
+/*
+ * ggml_mi355.h -- the drop-in boundary of libggml-mi355.so, the MI355X (gfx950 / CDNA4) ggml backend
+ * plugin.  These are the ONLY symbols the reference binds: ggml's loader looks them up with dlsym
+ * after dlopen (ggml/src/ggml-backend-reg.cpp:234-250; declared by GGML_BACKEND_DL_IMPL /
+ * GGML_BACKEND_DL_SCORE_IMPL in ggml/src/ggml-backend-impl.h:214-251).  Everything else is reached
+ * through the function tables of the object ggml_backend_init() returns:
+ *
+ *   ggml_backend_reg_i          ggml-backend-impl.h:181-207   name "MI355", devices "MI355_<i>"
+ *   ggml_backend_device_i       ggml-backend-impl.h:137-179   type GPU, caps {async, host_buffer, events}
+ *   ggml_backend_buffer_type_i  ggml-backend-impl.h:17-29     hipMalloc buffers (alignment 128), pinned host
+ *   ggml_backend_buffer_i       ggml-backend-impl.h:41-58     synchronous set/get/memset/cpy/clear
+ *   ggml_backend_i              ggml-backend-impl.h:87-117    one in-order HIP stream; async graph_compute
+ *
+ * It replaces the reference's ggml-cuda plugin entry (ggml_backend_cuda_reg,
+ * ggml/src/ggml-cuda/ggml-cuda.cu:3660-3715, GGML_BACKEND_DL_IMPL at :3748) for the ops of the hot
+ * path: MUL_MAT / MUL_MAT_ID on Q4_0, Q8_0, Q4_K, Q5_K, Q6_K weights, FLASH_ATTN_EXT with f16 /
+ * q8_0 / q4_0 KV, and the small ops of a Llama / Mixtral graph so the scheduler has no CPU split.
+ *
+ * Loading (no change to the reference):  GGML_BACKEND_PATH=/path/libggml-mi355.so llama-bench ...
+ * (ggml_backend_load_all_from_path, ggml-backend-reg.cpp:578-582), or ggml_backend_load(path).
+ * The plugin leaves the ggml-base symbols undefined and resolves them against the host executable's
+ * libggml-base.so, so the reference must be built with shared libraries.
+ *
+ * Proc addresses served by reg->iface.get_proc_address:
+ *   "ggml_backend_get_features"        ggml_backend_feature * (*)(ggml_backend_reg_t)
+ *   "ggml_backend_split_buffer_type"   ggml_backend_buffer_type_t (*)(int main_device, const float * tensor_split)
+ *                                      (ggml/include/ggml-backend.h:188; row split, ggml-cuda.cu:1044-1084)
+ *
+ * Environment switches (diagnostics, read by the plugin):
+ *   GGML_MI355_NO_FUSE=1     run every graph node with its own kernel, no activation-quantization cache
+ *   GGML_MI355_NO_PINNED=1   do not offer the pinned host buffer type
+ */
+#ifndef GGML_MI355_H
+#define GGML_MI355_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+struct ggml_backend_reg;   /* ggml/src/ggml-backend-impl.h:191-207 */
+
+#define GGML_MI355_API __attribute__((visibility("default")))
+
+/* The registry object (static lifetime, api_version == GGML_BACKEND_API_VERSION).  Required. */
+GGML_MI355_API struct ggml_backend_reg * ggml_backend_init(void);
+
+/* 0 when no gfx950 device is visible (the loader then skips the plugin), 100 otherwise.  Optional. */
+GGML_MI355_API int ggml_backend_score(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GGML_MI355_H */

@@ -48,8 +48,10 @@ def all_gather_rows(local_out, nrows, rank, world_size, dist, pad_rows=None):
     send = torch.zeros((ncols, pad), dtype=local_out.dtype, device=local_out.device)
     lo, hi = splits[rank]
     send[:, : hi - lo] = local_out
-    recv = torch.empty((world_size, ncols, pad), dtype=local_out.dtype, device=local_out.device)
-    dist.all_gather_into_tensor(recv, send)
+    # flat buffers: the concatenating form both RCCL and gloo accept
+    recv = torch.empty(world_size * ncols * pad, dtype=local_out.dtype, device=local_out.device)
+    dist.all_gather_into_tensor(recv, send.view(-1))
+    recv = recv.view(world_size, ncols, pad)
     full = torch.empty((ncols, nrows), dtype=local_out.dtype, device=local_out.device)
     for r, (l, h) in enumerate(splits):
         full[:, l:h] = recv[r, :, : h - l]

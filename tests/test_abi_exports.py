@@ -47,3 +47,20 @@ def test_argument_errors_need_no_gpu():
     assert K.lib.mi355_quantize_row_q8_1(16, 16, 33, 1, 1, 1, 132, 132, 132, None) == -2  # k % 32
     assert K.lib.mi355_dequantize_row(77, 16, 16, 256, None) == -1
     assert b"alignment" in K.lib.mi355_error_string(-3)
+
+
+def test_plugin_exports_the_loader_symbols():
+    """include/ggml_mi355.h: the two symbols ggml's loader dlsym()s (ggml-backend-reg.cpp:234-250).
+    The plugin cannot be dlopen()ed without libggml-base, so read its dynamic symbol table."""
+    import subprocess
+    src = open(os.path.join(ROOT, "include", "ggml_mi355.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = re.findall(r"GGML_MI355_API\s+[\w\s\*]+?\b(ggml_backend_\w+)\s*\(", src)
+    assert sorted(names) == ["ggml_backend_init", "ggml_backend_score"]
+    so = os.path.join(ROOT, "llm_amd", "lib", "libggml-mi355.so")
+    assert os.path.exists(so), "build the plugin: make -C llm_amd/csrc plugin"
+    out = subprocess.run(["nm", "-D", "--defined-only", so], capture_output=True, text=True, check=True).stdout
+    defined = {ln.split()[-1] for ln in out.splitlines() if " T " in ln}
+    assert set(names) <= defined, defined
+    # nothing else leaks: the plugin's only defined text symbols are the loader's two
+    assert defined == set(names), defined
