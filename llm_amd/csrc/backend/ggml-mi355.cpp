@@ -68,7 +68,10 @@ struct mi355_device_ctx {
     std::string description;
 };
 
-static int mi355_device_count() {
+// Physical gfx950 devices.  GGML_MI355_VIRTUAL_DEVICES=n (diagnostics / tests) presents n ggml devices
+// that all map round-robin onto the physical ones, so the multi-device code paths (row split, peer
+// copies, cross-device events) can be exercised on a single-GPU machine.
+static int mi355_physical_count() {
     static int count = [] {
         int n = 0;
         if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
@@ -88,10 +91,31 @@ static int mi355_device_count() {
     return count;
 }
 
+static int mi355_device_count() {
+    static int count = [] {
+        const int phys = mi355_physical_count();
+        const char * v = getenv("GGML_MI355_VIRTUAL_DEVICES");
+        if (phys > 0 && v && atoi(v) > 0) return atoi(v) < MI355_MAX_DEVICES ? atoi(v) : MI355_MAX_DEVICES;
+        return phys;
+    }();
+    return count;
+}
+
+static int mi355_phys(int device) { return device % mi355_physical_count(); }
+
 static void mi355_set_device(int device) {
     int cur = -1;
     HIP_CHECK(hipGetDevice(&cur));
-    if (cur != device) HIP_CHECK(hipSetDevice(device));
+    if (cur != mi355_phys(device)) HIP_CHECK(hipSetDevice(mi355_phys(device)));
+}
+
+// device-to-device copy between two ggml devices (which may share a physical GPU)
+static void mi355_copy_d2d_async(void * dst, int dst_dev, const void * src, int src_dev, size_t n, hipStream_t stream) {
+    if (mi355_phys(dst_dev) == mi355_phys(src_dev)) {
+        HIP_CHECK(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToDevice, stream));
+    } else {
+        HIP_CHECK(hipMemcpyPeerAsync(dst, mi355_phys(dst_dev), src, mi355_phys(src_dev), n, stream));
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -151,11 +175,7 @@ static bool mi355_buffer_cpy_tensor(ggml_backend_buffer_t buffer, const ggml_ten
     mi355_buffer_ctx * sctx = (mi355_buffer_ctx *)sbuf->context;
     mi355_buffer_ctx * dctx = (mi355_buffer_ctx *)buffer->context;
     mi355_set_device(dctx->device);
-    if (sctx->device == dctx->device) {
-        HIP_CHECK(hipMemcpy(dst->data, src->data, ggml_nbytes(src), hipMemcpyDeviceToDevice));
-    } else {
-        HIP_CHECK(hipMemcpyPeer(dst->data, dctx->device, src->data, sctx->device, ggml_nbytes(src)));
-    }
+    mi355_copy_d2d_async(dst->data, dctx->device, src->data, sctx->device, ggml_nbytes(src), nullptr);
     HIP_CHECK(hipDeviceSynchronize());
     return true;
 }
@@ -269,6 +289,198 @@ static ggml_backend_buffer_type_t mi355_host_buffer_type() {
 }
 
 // ------------------------------------------------------------------------------------------------
+// row-split buffer type: llama.cpp's `-sm row` (reference: ggml_backend_cuda_split_buffer_type and its
+// buffer, ggml-cuda.cu:753-1084).  A 2-D weight matrix is cut by rows across all devices; device d
+// holds rows [row_low, row_high) contiguously in its own allocation, made per tensor in init_tensor
+// (tensor->extra keeps the per-device pointers); tensor->data is a dummy address that is never
+// dereferenced.  Only MUL_MAT may read such a tensor (supports_op), and set/get move whole tensors.
+// ------------------------------------------------------------------------------------------------
+#define MI355_ROW_ROUNDING 128   // rows per MMQ tile (mmq.hip BM); the reference uses mmq_y = 128 on AMD (mmq.cuh:126-129)
+
+struct mi355_split_buft_ctx {
+    int         main_device;
+    float       split[MI355_MAX_DEVICES];   // cumulative, normalised: device d starts at nrows * split[d]
+    std::string name;
+};
+
+struct mi355_split_extra {
+    void *  data[MI355_MAX_DEVICES]     = {};
+    int64_t row_low[MI355_MAX_DEVICES]  = {};
+    int64_t row_high[MI355_MAX_DEVICES] = {};
+};
+
+struct mi355_split_buffer_ctx {
+    std::vector<mi355_split_extra *> extras;
+    ~mi355_split_buffer_ctx() {
+        for (mi355_split_extra * e : extras) {
+            for (int d = 0; d < MI355_MAX_DEVICES; d++) {
+                if (e->data[d]) { mi355_set_device(d); HIP_CHECK(hipFree(e->data[d])); }
+            }
+            delete e;
+        }
+    }
+};
+
+// boundaries exactly as get_row_split (ggml-cuda.cu:768-781): float product truncated, rounded down to the
+// tile height, the last device takes the remainder
+static void mi355_row_split(const float * split, int64_t nrows, int d, int64_t * lo, int64_t * hi) {
+    const int n = mi355_device_count();
+    *lo = d == 0 ? 0 : (int64_t)(nrows * split[d]);
+    *lo -= *lo % MI355_ROW_ROUNDING;
+    if (d == n - 1) {
+        *hi = nrows;
+    } else {
+        *hi = (int64_t)(nrows * split[d + 1]);
+        *hi -= *hi % MI355_ROW_ROUNDING;
+    }
+}
+
+static const char * mi355_split_buft_get_name(ggml_backend_buffer_type_t buft) {
+    return ((mi355_split_buft_ctx *)buft->context)->name.c_str();
+}
+
+static bool buft_is_mi355_split(ggml_backend_buffer_type_t buft) {
+    return buft->iface.get_name == mi355_split_buft_get_name;
+}
+
+static bool tensor_is_split(const ggml_tensor * t) { return t && t->buffer && buft_is_mi355_split(t->buffer->buft); }
+
+static void mi355_split_buffer_free(ggml_backend_buffer_t buffer) { delete (mi355_split_buffer_ctx *)buffer->context; }
+
+static void * mi355_split_buffer_get_base(ggml_backend_buffer_t) { return (void *)0x1000; }
+
+static enum ggml_status mi355_split_buffer_init_tensor(ggml_backend_buffer_t buffer, ggml_tensor * tensor) {
+    GGML_ASSERT(tensor->view_src == nullptr && "views of split tensors are not supported");
+    GGML_ASSERT(ggml_is_contiguous(tensor) && "split buffers only hold contiguous tensors");
+    mi355_split_buffer_ctx * ctx  = (mi355_split_buffer_ctx *)buffer->context;
+    mi355_split_buft_ctx *   bctx = (mi355_split_buft_ctx *)buffer->buft->context;
+    mi355_split_extra * extra = new mi355_split_extra;
+    ctx->extras.push_back(extra);
+    const size_t row_bytes = ggml_row_size(tensor->type, tensor->ne[0]);
+    for (int d = 0; d < mi355_device_count(); d++) {
+        mi355_row_split(bctx->split, ggml_nrows(tensor), d, &extra->row_low[d], &extra->row_high[d]);
+        const int64_t rows = extra->row_high[d] - extra->row_low[d];
+        if (rows == 0) continue;
+        mi355_set_device(d);
+        hipError_t err = hipMalloc(&extra->data[d], rows * row_bytes);
+        if (err != hipSuccess) {
+            (void)hipGetLastError();
+            MI_LOG_ERROR("%s: allocating %.2f MiB of %s on device %d failed: %s\n", __func__, rows * row_bytes / 1048576.0,
+                         tensor->name, d, hipGetErrorString(err));
+            return GGML_STATUS_ALLOC_FAILED;
+        }
+    }
+    tensor->extra = extra;
+    return GGML_STATUS_SUCCESS;
+}
+
+// split tensors are written and read whole (ggml-cuda.cu:878-954)
+static void mi355_split_buffer_set_tensor(ggml_backend_buffer_t, ggml_tensor * tensor, const void * data, size_t offset, size_t size) {
+    GGML_ASSERT(offset == 0 && size == ggml_nbytes(tensor));
+    mi355_split_extra * extra = (mi355_split_extra *)tensor->extra;
+    const size_t row_bytes = tensor->nb[1];
+    for (int d = 0; d < mi355_device_count(); d++) {
+        if (!extra->data[d]) continue;
+        mi355_set_device(d);
+        HIP_CHECK(hipMemcpy(extra->data[d], (const char *)data + extra->row_low[d] * row_bytes,
+                            (extra->row_high[d] - extra->row_low[d]) * row_bytes, hipMemcpyHostToDevice));
+    }
+}
+
+static void mi355_split_buffer_get_tensor(ggml_backend_buffer_t, const ggml_tensor * tensor, void * data, size_t offset, size_t size) {
+    GGML_ASSERT(offset == 0 && size == ggml_nbytes(tensor));
+    const mi355_split_extra * extra = (const mi355_split_extra *)tensor->extra;
+    const size_t row_bytes = tensor->nb[1];
+    for (int d = 0; d < mi355_device_count(); d++) {
+        if (!extra->data[d]) continue;
+        mi355_set_device(d);
+        HIP_CHECK(hipMemcpy((char *)data + extra->row_low[d] * row_bytes, extra->data[d],
+                            (extra->row_high[d] - extra->row_low[d]) * row_bytes, hipMemcpyDeviceToHost));
+    }
+}
+
+static void mi355_split_buffer_clear(ggml_backend_buffer_t, uint8_t) {}
+
+static const ggml_backend_buffer_i mi355_split_buffer_iface = {
+    /* .free_buffer   = */ mi355_split_buffer_free,
+    /* .get_base      = */ mi355_split_buffer_get_base,
+    /* .init_tensor   = */ mi355_split_buffer_init_tensor,
+    /* .memset_tensor = */ NULL,
+    /* .set_tensor    = */ mi355_split_buffer_set_tensor,
+    /* .get_tensor    = */ mi355_split_buffer_get_tensor,
+    /* .cpy_tensor    = */ NULL,
+    /* .clear         = */ mi355_split_buffer_clear,
+    /* .reset         = */ NULL,
+};
+
+static ggml_backend_buffer_t mi355_split_buft_alloc_buffer(ggml_backend_buffer_type_t buft, size_t size) {
+    // device memory is allocated per tensor in init_tensor; `size` is the cap ggml-alloc enforces
+    return ggml_backend_buffer_init(buft, mi355_split_buffer_iface, new mi355_split_buffer_ctx, size);
+}
+
+static size_t mi355_split_buft_get_alloc_size(ggml_backend_buffer_type_t buft, const ggml_tensor * tensor) {
+    GGML_ASSERT(ggml_is_contiguous(tensor) && "split buffers only hold contiguous tensors");
+    mi355_split_buft_ctx * bctx = (mi355_split_buft_ctx *)buft->context;
+    size_t total = 0;
+    for (int d = 0; d < mi355_device_count(); d++) {
+        int64_t lo, hi;
+        mi355_row_split(bctx->split, ggml_nrows(tensor), d, &lo, &hi);
+        total += (hi - lo) * ggml_row_size(tensor->type, tensor->ne[0]);
+    }
+    return total;
+}
+
+static bool mi355_split_buft_is_host(ggml_backend_buffer_type_t) { return false; }
+
+// exported through get_proc_address("ggml_backend_split_buffer_type") -- ggml-backend.h:188, caller
+// src/llama-model.cpp:351-363.  tensor_split has one weight per device (all zero / NULL: split by memory).
+static ggml_backend_buffer_type_t mi355_split_buffer_type(int main_device, const float * tensor_split) {
+    static std::mutex mu;
+    static std::vector<ggml_backend_buffer_type *> made;   // never freed: buffer types have static lifetime
+    std::lock_guard<std::mutex> lk(mu);
+    const int n = mi355_device_count();
+    if (main_device < 0 || main_device >= n) return nullptr;
+    float w[MI355_MAX_DEVICES] = {};
+    bool all_zero = true;
+    for (int d = 0; d < n && tensor_split; d++) if (tensor_split[d] != 0.0f) all_zero = false;
+    for (int d = 0; d < n; d++) {
+        if (all_zero) {
+            size_t free_b, total_b;
+            mi355_set_device(d);
+            HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
+            w[d] = (float)total_b;
+        } else {
+            w[d] = tensor_split[d];
+        }
+    }
+    float cum[MI355_MAX_DEVICES] = {}, sum = 0.0f;
+    for (int d = 0; d < n; d++) { cum[d] = sum; sum += w[d]; }
+    for (int d = 0; d < n; d++) cum[d] /= sum;
+    for (ggml_backend_buffer_type * b : made) {
+        mi355_split_buft_ctx * c = (mi355_split_buft_ctx *)b->context;
+        if (c->main_device == main_device && memcmp(c->split, cum, sizeof(cum)) == 0) return b;
+    }
+    mi355_split_buft_ctx * c = new mi355_split_buft_ctx;
+    c->main_device = main_device;
+    memcpy(c->split, cum, sizeof(cum));
+    c->name = std::string(MI355_DEV_PREFIX) + std::to_string(main_device) + "_Split";
+    ggml_backend_buffer_type * b = new ggml_backend_buffer_type{
+        /* .iface = */ {
+            /* .get_name       = */ mi355_split_buft_get_name,
+            /* .alloc_buffer   = */ mi355_split_buft_alloc_buffer,
+            /* .get_alignment  = */ mi355_buft_get_alignment,
+            /* .get_max_size   = */ NULL,
+            /* .get_alloc_size = */ mi355_split_buft_get_alloc_size,
+            /* .is_host        = */ mi355_split_buft_is_host,
+        },
+        /* .device  = */ mi355_reg_get_device(ggml_backend_mi355_reg(), main_device),
+        /* .context = */ c,
+    };
+    made.push_back(b);
+    return b;
+}
+
+// ------------------------------------------------------------------------------------------------
 // backend (stream)
 // ------------------------------------------------------------------------------------------------
 struct mi355_backend_ctx {
@@ -290,6 +502,34 @@ struct mi355_backend_ctx {
         size_t nb[4] = {0, 0, 0, 0};
     } act_cache;
 
+    // row split: this stream is the "main" one of a split MUL_MAT; every other device that owns rows gets a
+    // helper stream, a copy of the quantized activations and an event the main stream waits on
+    struct peer_t {
+        hipStream_t stream = nullptr;
+        hipEvent_t  done = nullptr;
+        void *      act = nullptr;
+        size_t      act_size = 0;
+        uint64_t    act_version = 0;
+    } peers[MI355_MAX_DEVICES];
+    hipEvent_t ev_ready = nullptr;
+    uint64_t   act_version = 0;     // bumped whenever scratch[0] receives new activations
+
+    peer_t & peer(int d) {
+        peer_t & p = peers[d];
+        if (!p.stream) {
+            mi355_set_device(d);
+            HIP_CHECK(hipStreamCreateWithFlags(&p.stream, hipStreamNonBlocking));
+            HIP_CHECK(hipEventCreateWithFlags(&p.done, hipEventDisableTiming));
+            if (mi355_phys(d) != mi355_phys(device)) {   // the helper writes its rows straight into our dst over xGMI
+                hipError_t err = hipDeviceEnablePeerAccess(mi355_phys(device), 0);
+                if (err != hipSuccess && err != hipErrorPeerAccessAlreadyEnabled) HIP_CHECK(err);
+                (void)hipGetLastError();
+            }
+            mi355_set_device(device);
+        }
+        return p;
+    }
+
     void * get_scratch(int which, size_t need) {
         if (need <= scratch_size[which]) return scratch[which];
         if (scratch[which]) {
@@ -308,6 +548,7 @@ struct mi355_backend_ctx {
         return true;
     }
     void act_remember(const ggml_tensor * t) {
+        act_version++;
         act_cache.valid = true; act_cache.data = t->data; act_cache.span = ggml_nbytes(t);
         for (int i = 0; i < 4; i++) { act_cache.ne[i] = t->ne[i]; act_cache.nb[i] = t->nb[i]; }
     }
@@ -331,6 +572,17 @@ static void mi355_backend_free(ggml_backend_t backend) {
     mi355_set_device(ctx->device);
     HIP_CHECK(hipStreamSynchronize(ctx->stream));
     for (int i = 0; i < 2; i++) if (ctx->scratch[i]) HIP_CHECK(hipFree(ctx->scratch[i]));
+    if (ctx->ev_ready) HIP_CHECK(hipEventDestroy(ctx->ev_ready));
+    for (int d = 0; d < MI355_MAX_DEVICES; d++) {
+        mi355_backend_ctx::peer_t & p = ctx->peers[d];
+        if (!p.stream) continue;
+        mi355_set_device(d);
+        HIP_CHECK(hipStreamSynchronize(p.stream));
+        if (p.act) HIP_CHECK(hipFree(p.act));
+        HIP_CHECK(hipEventDestroy(p.done));
+        HIP_CHECK(hipStreamDestroy(p.stream));
+    }
+    mi355_set_device(ctx->device);
     HIP_CHECK(hipStreamDestroy(ctx->stream));
     delete ctx;
     delete backend;
@@ -365,11 +617,7 @@ static bool mi355_backend_cpy_tensor_async(ggml_backend_t backend_src, ggml_back
     if (backend_src != backend_dst) {
         // copy on the source stream, then make the destination stream wait for it (ggml-cuda.cu:2516-2569)
         mi355_set_device(sctx->device);
-        if (sctx->device == dctx->device) {
-            HIP_CHECK(hipMemcpyAsync(dst->data, src->data, ggml_nbytes(dst), hipMemcpyDeviceToDevice, sctx->stream));
-        } else {
-            HIP_CHECK(hipMemcpyPeerAsync(dst->data, dctx->device, src->data, sctx->device, ggml_nbytes(dst), sctx->stream));
-        }
+        mi355_copy_d2d_async(dst->data, dctx->device, src->data, sctx->device, ggml_nbytes(dst), sctx->stream);
         hipEvent_t ev;
         HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
         HIP_CHECK(hipEventRecord(ev, sctx->stream));
@@ -400,10 +648,56 @@ static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 // MUL_MAT on block-quantized src0 (reference dispatch: ggml_cuda_mul_mat, ggml-cuda.cu:1988-2063;
 // contract ggml.c:2971-2986; oracle ggml_compute_forward_mul_mat, ggml-cpu.c:1196-1388)
+// the launches of one MUL_MAT over rows [row_low, row_low + M) of the weight matrix whose first owned row is at
+// W: int8-MFMA tile kernel for prefill-sized N, mat-vec kernel in groups of 8 columns otherwise
+static void mi355_mul_mat_launch(const ggml_tensor * dst, const char * W, int64_t row_low, int64_t M,
+                                 const int8_t * aq, const float * ads, hipStream_t stream) {
+    const ggml_tensor * src0 = dst->src[0];
+    const ggml_tensor * src1 = dst->src[1];
+    const int64_t K = src0->ne[0], ne02 = src0->ne[2], ne03 = src0->ne[3];
+    const int64_t N = src1->ne[1], ne12 = src1->ne[2], ne13 = src1->ne[3];
+    const int64_t r2 = ne12 / ne02, r3 = ne13 / ne03;
+    char * dbase = (char *)dst->data + row_low * sizeof(float);
+    if (N > 8 && K % 128 == 0) {
+        // prefill: int8-MFMA tile kernel, one launch per broadcast channel
+        for (int64_t i13 = 0; i13 < ne13; i13++) {
+            for (int64_t i12 = 0; i12 < ne12; i12++) {
+                const char * Wc = W + (i13 / r3) * src0->nb[3] + (i12 / r2) * src0->nb[2];
+                const int64_t arow = (i13 * ne12 + i12) * N;
+                float * d = (float *)(dbase + i13 * dst->nb[3] + i12 * dst->nb[2]);
+                MI_CHECK(mi355_mul_mat_q((int)src0->type, Wc, (int64_t)src0->nb[1], aq + arow * K, ads + arow * (K / 32) * 2, d,
+                                         (int64_t)(dst->nb[1] / sizeof(float)), M, K, N, stream));
+            }
+        }
+        return;
+    }
+    for (int64_t i13 = 0; i13 < ne13; i13++) {
+        for (int64_t c0 = 0; c0 < N; c0 += 8) {
+            mi355_mmvq_args a;
+            memset(&a, 0, sizeof(a));
+            a.type = (int32_t)src0->type;
+            a.W = W + (i13 / r3) * src0->nb[3];
+            a.w_row_stride = (int64_t)src0->nb[1];
+            a.w_ch_stride  = (int64_t)src0->nb[2];
+            a.act_q  = aq + (i13 * ne12 * N + c0) * K;
+            a.act_ds = ads + (i13 * ne12 * N + c0) * (K / 32) * 2;
+            a.act_ch_stride = N;
+            a.dst = (float *)(dbase + i13 * dst->nb[3]) + c0 * (dst->nb[1] / sizeof(float));
+            a.dst_col_stride = (int64_t)(dst->nb[1] / sizeof(float));
+            a.dst_ch_stride  = (int64_t)(dst->nb[2] / sizeof(float));
+            a.m = M; a.k = K;
+            a.ncols = (int32_t)(N - c0 < 8 ? N - c0 : 8);
+            a.nchannels = (int32_t)ne12;
+            a.ch_ratio  = (int32_t)r2;
+            MI_CHECK(mi355_mul_mat_vec_q(&a, stream));
+        }
+    }
+}
+
 static void mi355_mul_mat(mi355_backend_ctx * ctx, ggml_tensor * dst) {
     const ggml_tensor * src0 = dst->src[0];
     const ggml_tensor * src1 = dst->src[1];
-    const int64_t K = src0->ne[0], M = src0->ne[1], ne02 = src0->ne[2], ne03 = src0->ne[3];
+    const int64_t K = src0->ne[0], M = src0->ne[1];
     const int64_t N = src1->ne[1], ne12 = src1->ne[2], ne13 = src1->ne[3];
     const int64_t rows = N * ne12 * ne13;
     if (rows == 0 || M == 0) return;
@@ -419,40 +713,49 @@ static void mi355_mul_mat(mi355_backend_ctx * ctx, ggml_tensor * dst) {
         ctx->act_remember(src1);
     }
 
-    const int64_t r2 = ne12 / ne02, r3 = ne13 / ne03;
-    if (N > 8 && K % 128 == 0) {
-        // prefill: int8-MFMA tile kernel, one launch per broadcast channel
-        for (int64_t i13 = 0; i13 < ne13; i13++) {
-            for (int64_t i12 = 0; i12 < ne12; i12++) {
-                const char * W = (const char *)src0->data + (i13 / r3) * src0->nb[3] + (i12 / r2) * src0->nb[2];
-                const int64_t arow = (i13 * ne12 + i12) * N;
-                float * d = (float *)((char *)dst->data + i13 * dst->nb[3] + i12 * dst->nb[2]);
-                MI_CHECK(mi355_mul_mat_q((int)src0->type, W, (int64_t)src0->nb[1], aq + arow * K, ads + arow * (K / 32) * 2, d,
-                                         (int64_t)(dst->nb[1] / sizeof(float)), M, K, N, ctx->stream));
-            }
-        }
+    if (!tensor_is_split(src0)) {
+        mi355_mul_mat_launch(dst, (const char *)src0->data, 0, M, aq, ads, ctx->stream);
         return;
     }
-    for (int64_t i13 = 0; i13 < ne13; i13++) {
-        for (int64_t c0 = 0; c0 < N; c0 += 8) {
-            mi355_mmvq_args a;
-            memset(&a, 0, sizeof(a));
-            a.type = (int32_t)src0->type;
-            a.W = (const char *)src0->data + (i13 / r3) * src0->nb[3];
-            a.w_row_stride = (int64_t)src0->nb[1];
-            a.w_ch_stride  = (int64_t)src0->nb[2];
-            a.act_q  = aq + (i13 * ne12 * N + c0) * K;
-            a.act_ds = ads + (i13 * ne12 * N + c0) * (K / 32) * 2;
-            a.act_ch_stride = N;
-            a.dst = (float *)((char *)dst->data + i13 * dst->nb[3]) + c0 * (dst->nb[1] / sizeof(float));
-            a.dst_col_stride = (int64_t)(dst->nb[1] / sizeof(float));
-            a.dst_ch_stride  = (int64_t)(dst->nb[2] / sizeof(float));
-            a.m = M; a.k = K;
-            a.ncols = (int32_t)(N - c0 < 8 ? N - c0 : 8);
-            a.nchannels = (int32_t)ne12;
-            a.ch_ratio  = (int32_t)r2;
-            MI_CHECK(mi355_mul_mat_vec_q(&a, ctx->stream));
+
+    // Row split (reference: ggml_cuda_op_mul_mat, ggml-cuda.cu:1431-1749).  This stream's device is the main
+    // one: it quantized src1 and owns dst.  Every other device with rows gets the quantized activations by one
+    // peer copy (skipped when it already holds this version), runs the same kernels on its row slice and
+    // stores its rows *directly into dst on the main device* (peer stores over xGMI) -- no staging buffer and
+    // no gather copy.  One event forks the helpers off the main stream, one per helper joins them.
+    const mi355_split_extra * extra = (const mi355_split_extra *)src0->extra;
+    GGML_ASSERT(extra && src0->ne[2] == 1 && src0->ne[3] == 1);
+    if (!ctx->ev_ready) HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_ready, hipEventDisableTiming));
+    HIP_CHECK(hipEventRecord(ctx->ev_ready, ctx->stream));
+    const int ndev = mi355_device_count();
+    for (int d = 0; d < ndev; d++) {
+        if (d == ctx->device || !extra->data[d]) continue;
+        mi355_backend_ctx::peer_t & p = ctx->peer(d);
+        mi355_set_device(d);
+        HIP_CHECK(hipStreamWaitEvent(p.stream, ctx->ev_ready, 0));
+        if (p.act_size < qb + db) {
+            HIP_CHECK(hipStreamSynchronize(p.stream));
+            if (p.act) HIP_CHECK(hipFree(p.act));
+            p.act_size = (qb + db + (1u << 20)) & ~((size_t)(1u << 20) - 1);
+            HIP_CHECK(hipMalloc(&p.act, p.act_size));
+            p.act_version = 0;
         }
+        if (p.act_version != ctx->act_version) {
+            mi355_copy_d2d_async(p.act, d, ws, ctx->device, qb + db, p.stream);
+            p.act_version = ctx->act_version;
+        }
+        mi355_mul_mat_launch(dst, (const char *)extra->data[d], extra->row_low[d], extra->row_high[d] - extra->row_low[d],
+                             (const int8_t *)p.act, (const float *)((const char *)p.act + qb), p.stream);
+        HIP_CHECK(hipEventRecord(p.done, p.stream));
+    }
+    mi355_set_device(ctx->device);
+    if (extra->data[ctx->device]) {
+        mi355_mul_mat_launch(dst, (const char *)extra->data[ctx->device], extra->row_low[ctx->device],
+                             extra->row_high[ctx->device] - extra->row_low[ctx->device], aq, ads, ctx->stream);
+    }
+    for (int d = 0; d < ndev; d++) {
+        if (d == ctx->device || !extra->data[d]) continue;
+        HIP_CHECK(hipStreamWaitEvent(ctx->stream, ctx->peers[d].done, 0));
     }
 }
 
@@ -736,6 +1039,10 @@ static bool mi355_dev_supports_op(ggml_backend_dev_t dev, const ggml_tensor * op
             return false;
         }
     }
+    // a row-split tensor can only be the weight of a MUL_MAT (ggml-cuda.cu:3079-3086)
+    for (int i = 0; i < GGML_MAX_SRC; i++) {
+        if (tensor_is_split(op->src[i]) && !(op->op == GGML_OP_MUL_MAT && i == 0)) return false;
+    }
     switch (op->op) {
         case GGML_OP_NONE:
         case GGML_OP_RESHAPE:
@@ -746,6 +1053,13 @@ static bool mi355_dev_supports_op(ggml_backend_dev_t dev, const ggml_tensor * op
         case GGML_OP_MUL_MAT: {
             const ggml_tensor * a = op->src[0];
             const ggml_tensor * b = op->src[1];
+            if (tensor_is_split(a)) {
+                // 2-D weights only, and this device must own rows (ggml-cuda.cu:3137-3150)
+                if (a->ne[2] > 1 || a->ne[3] > 1) return false;
+                int64_t lo, hi;
+                mi355_row_split(((mi355_split_buft_ctx *)a->buffer->buft->context)->split, ggml_nrows(a), device, &lo, &hi);
+                if (lo == hi) return false;
+            }
             if (!is_weight_type(a->type) || b->type != GGML_TYPE_F32 || op->type != GGML_TYPE_F32) return false;
             if (a->nb[0] != ggml_type_size(a->type) || b->nb[0] != sizeof(float)) return false; // rows contiguous
             if (ggml_is_transposed(a) || !ggml_is_contiguous(op)) return false;
@@ -776,6 +1090,7 @@ static bool mi355_dev_supports_op(ggml_backend_dev_t dev, const ggml_tensor * op
 }
 
 static bool mi355_dev_supports_buft(ggml_backend_dev_t dev, ggml_backend_buffer_type_t buft) {
+    if (buft_is_mi355_split(buft)) return buft->device == dev;   // ggml-cuda.cu:3433
     if (!buft_is_mi355(buft)) return false;
     return ((mi355_buft_ctx *)buft->context)->device == ((mi355_device_ctx *)dev->context)->device;
 }
@@ -852,7 +1167,8 @@ static ggml_backend_feature * mi355_get_features(ggml_backend_reg_t) {
 
 static void * mi355_reg_get_proc_address(ggml_backend_reg_t, const char * name) {
     if (strcmp(name, "ggml_backend_get_features") == 0) return (void *)mi355_get_features;
-    // "ggml_backend_split_buffer_type", "ggml_backend_set_n_threads", host-buffer registration: not provided
+    if (strcmp(name, "ggml_backend_split_buffer_type") == 0) return (void *)mi355_split_buffer_type;
+    // "ggml_backend_set_n_threads", host-buffer registration: not provided
     return nullptr;
 }
 
@@ -875,7 +1191,7 @@ static ggml_backend_reg_t ggml_backend_mi355_reg(void) {
             dctx->device = i;
             dctx->name   = std::string(MI355_DEV_PREFIX) + std::to_string(i);
             hipDeviceProp_t prop;
-            HIP_CHECK(hipGetDeviceProperties(&prop, i));
+            HIP_CHECK(hipGetDeviceProperties(&prop, mi355_phys(i)));
             dctx->description = std::string(prop.name) + " (" + prop.gcnArchName + ")";
             ctx->devices.push_back(new ggml_backend_device{mi355_device_iface, &reg, dctx});
         }

@@ -84,3 +84,37 @@ def test_fusions_are_bit_exact(tmp_path):
         assert r.returncode == 0, r.stderr[-3000:]
         outs.append(np.fromfile(path, dtype=np.uint32))
     assert np.array_equal(outs[0], outs[1])
+
+
+def test_row_split_mul_mat_bit_exact_on_virtual_devices():
+    """the plugin's split buffer type (`-sm row`).  Two ggml devices mapped onto the one GPU
+    (GGML_MI355_VIRTUAL_DEVICES=2) exercise helper streams, the activation copy, cross-stream events and row
+    offsets; MUL_MAT on a split weight must equal MUL_MAT on the unsplit weight bit for bit, for all five
+    weight types, mat-vec and tile kernel, skewed splits, either device as main (tools/test_split_mul_mat.cpp)."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "test-split-mul-mat")
+    assert os.path.exists(exe), "oracle/_ref/test-split-mul-mat is not built (make -C oracle drivers)"
+    env = dict(os.environ, GGML_BACKEND_PATH=PLUGIN, GGML_MI355_VIRTUAL_DEVICES="2")
+    r = subprocess.run([exe], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-2000:]
+    assert "0 failed" in r.stdout
+
+
+def test_llama_row_split_logits_equal_single_device(tmp_path):
+    """Whole model with `-sm row -ts 1,1` over two virtual devices (layers 0-1 main on MI355_0, 2-3 on MI355_1,
+    every weight matrix row-split over both) gives the same logits as the single-device run, to the bit."""
+    import numpy as np
+    tool = os.path.join(ROOT, "tools", "run_llama_bench.sh")
+    outs = []
+    for split in (False, True):
+        path = str(tmp_path / f"logits_{int(split)}.bin")
+        env = dict(os.environ)
+        args = [tool, "tiny", "Q4_K_M", "--dump-logits", path]
+        if split:
+            env["GGML_MI355_VIRTUAL_DEVICES"] = "2"
+            args += ["-sm", "row", "-ts", "1,1"]
+        r = subprocess.run(args, capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stderr[-3000:]
+        if split:
+            assert "MI355_0_Split" in r.stderr + r.stdout, (r.stderr + r.stdout)[-3000:]
+        outs.append(np.fromfile(path, dtype=np.uint32))
+    assert np.array_equal(outs[0], outs[1])

@@ -4,7 +4,7 @@
 // llama_synchronize; warm-up run first; reps timed with a monotonic clock).  llama-bench itself needs
 // the generated build-info of the reference's cmake build, so this small driver stands in for it; the
 // backend under test is picked up the same way (ggml_backend_load_all + GGML_BACKEND_PATH).
-//   mi355-llama-bench -m model.gguf [-p 512] [-n 128] [-r 3] [-ngl 99] [-fa 1] [-ctk f16] [-ctv f16] [-t threads] [-b 2048] [-ub 512]
+//   mi355-llama-bench -m model.gguf [-p 512] [-n 128] [-r 3] [-ngl 99] [-fa 1] [-ctk f16] [-ctv f16] [-t threads] [-b 2048] [-ub 512] [-sm none|layer|row] [-mg 0] [-ts 1,1]
 #include "ggml.h"
 #include "ggml-backend.h"
 #include "llama.h"
@@ -52,7 +52,8 @@ static bool test_gen(llama_context * ctx, int n_gen, int n_vocab) {
 }
 
 int main(int argc, char ** argv) {
-    std::string model_path, ctk = "f16", ctv = "f16", dump_path;
+    std::string model_path, ctk = "f16", ctv = "f16", dump_path, sm = "layer", ts_arg;
+    int main_gpu = 0;
     int n_prompt = 512, n_gen = 128, reps = 3, ngl = 99, fa = 1, threads = 8, n_batch = 2048, n_ubatch = 512;
     for (int i = 1; i < argc; i++) {
         const std::string a = argv[i];
@@ -61,6 +62,7 @@ int main(int argc, char ** argv) {
         else if (a == "-r") reps = atoi(next().c_str()); else if (a == "-ngl") ngl = atoi(next().c_str()); else if (a == "-fa") fa = atoi(next().c_str());
         else if (a == "-ctk") ctk = next(); else if (a == "-ctv") ctv = next(); else if (a == "-t") threads = atoi(next().c_str());
         else if (a == "--dump-logits") dump_path = next();
+        else if (a == "-sm") sm = next(); else if (a == "-mg") main_gpu = atoi(next().c_str()); else if (a == "-ts") ts_arg = next();
         else if (a == "-b") n_batch = atoi(next().c_str()); else if (a == "-ub") n_ubatch = atoi(next().c_str());
         else { fprintf(stderr, "unknown arg %s\n", a.c_str()); return 2; }
     }
@@ -76,6 +78,20 @@ int main(int argc, char ** argv) {
     llama_model_params mp = llama_model_default_params();
     mp.n_gpu_layers = ngl;
     mp.use_mmap = true;
+    // -sm none|layer|row, -mg main gpu, -ts a,b,... (llama-bench.cpp:1018-1035 has the same switches)
+    mp.split_mode = sm == "none" ? LLAMA_SPLIT_MODE_NONE : sm == "row" ? LLAMA_SPLIT_MODE_ROW : LLAMA_SPLIT_MODE_LAYER;
+    mp.main_gpu = main_gpu;
+    static float tensor_split[128] = {0};
+    if (!ts_arg.empty()) {
+        size_t pos = 0; int n = 0;
+        while (pos <= ts_arg.size() && n < 128) {
+            size_t e = ts_arg.find(',', pos);
+            if (e == std::string::npos) e = ts_arg.size();
+            tensor_split[n++] = (float)atof(ts_arg.substr(pos, e - pos).c_str());
+            pos = e + 1;
+        }
+        mp.tensor_split = tensor_split;
+    }
     llama_model * model = llama_model_load_from_file(model_path.c_str(), mp);
     if (!model) { fprintf(stderr, "failed to load %s\n", model_path.c_str()); return 1; }
     const int n_vocab = llama_vocab_n_tokens(llama_model_get_vocab(model));

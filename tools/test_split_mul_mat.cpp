@@ -1,0 +1,133 @@
+// test_split_mul_mat -- row-split (`-sm row`) MUL_MAT through the public ggml API.
+//
+// For every weight type and a set of shapes: the same quantized matrix is stored once in the plugin's
+// split buffer type (get_proc_address "ggml_backend_split_buffer_type", ggml-backend.h:188) and once in
+// the ordinary device buffer; MUL_MAT(W_split, x) and MUL_MAT(W_plain, x) run on the main device's
+// backend and must agree BIT FOR BIT (each output row is computed by the same kernel code either way),
+// and get_tensor of the split tensor must return the bytes that were set.  Needs >= 2 MI355 devices:
+// on a single-GPU box run with GGML_MI355_VIRTUAL_DEVICES=2 (both ggml devices map to the one GPU, so
+// helper streams, the activation copy, cross-stream events and the row offsets are all exercised).
+//   GGML_BACKEND_PATH=.../libggml-mi355.so GGML_MI355_VIRTUAL_DEVICES=2 test-split-mul-mat
+#include "ggml.h"
+#include "ggml-alloc.h"
+#include "ggml-backend.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <string>
+#include <vector>
+
+typedef ggml_backend_buffer_type_t (*split_buft_fn)(int main_device, const float * tensor_split);
+
+static int n_fail = 0, n_ok = 0;
+
+static void check(bool ok, const std::string & what) {
+    if (ok) { n_ok++; } else { n_fail++; printf("FAIL: %s\n", what.c_str()); }
+}
+
+static bool run_case(ggml_backend_reg_t reg, split_buft_fn split_buft, int main_dev, const float * ts, ggml_type type,
+                     int64_t M, int64_t K, int64_t N, int64_t ne2) {
+    char tag[256];
+    snprintf(tag, sizeof(tag), "%s M=%lld K=%lld N=%lld ne2=%lld main=%d ts=%g,%g", ggml_type_name(type), (long long)M, (long long)K,
+             (long long)N, (long long)ne2, main_dev, ts ? ts[0] : 0.0f, ts ? ts[1] : 0.0f);
+    ggml_backend_dev_t dev = ggml_backend_reg_dev_get(reg, main_dev);
+    ggml_backend_t backend = ggml_backend_dev_init(dev, nullptr);
+    ggml_backend_buffer_type_t sbuft = split_buft(main_dev, ts);
+    if (!backend || !sbuft) { check(false, std::string(tag) + ": no backend / split buffer type"); return false; }
+
+    // weights: one context per buffer type
+    ggml_init_params ip = { ggml_tensor_overhead() * 8, nullptr, true };
+    ggml_context * cs = ggml_init(ip);
+    ggml_context * cp = ggml_init(ip);
+    ggml_tensor * Ws = ggml_new_tensor_2d(cs, type, K, M);
+    ggml_tensor * Wp = ggml_new_tensor_2d(cp, type, K, M);
+    ggml_backend_buffer_t bs = ggml_backend_alloc_ctx_tensors_from_buft(cs, sbuft);
+    ggml_backend_buffer_t bp = ggml_backend_alloc_ctx_tensors_from_buft(cp, ggml_backend_dev_buffer_type(dev));
+    if (!bs || !bp) { check(false, std::string(tag) + ": weight allocation"); return false; }
+
+    std::mt19937 rng(1234 + (unsigned)(M * 31 + K * 7 + N));
+    std::uniform_real_distribution<float> U(-1.0f, 1.0f);
+    std::vector<float> wf(M * K);
+    for (float & v : wf) v = U(rng);
+    std::vector<uint8_t> wq(ggml_nbytes(Ws));
+    ggml_quantize_chunk(type, wf.data(), wq.data(), 0, M, K, nullptr);
+    ggml_backend_tensor_set(Ws, wq.data(), 0, wq.size());
+    ggml_backend_tensor_set(Wp, wq.data(), 0, wq.size());
+    std::vector<uint8_t> back(wq.size(), 0xee);
+    ggml_backend_tensor_get(Ws, back.data(), 0, back.size());
+    check(memcmp(back.data(), wq.data(), wq.size()) == 0, std::string(tag) + ": set/get round trip of the split tensor");
+
+    // graph on the main device
+    ggml_init_params ig = { ggml_tensor_overhead() * 16 + ggml_graph_overhead(), nullptr, true };
+    ggml_context * cg = ggml_init(ig);
+    ggml_tensor * x  = ggml_new_tensor_3d(cg, GGML_TYPE_F32, K, N, ne2);
+    ggml_tensor * ys = ggml_mul_mat(cg, Ws, x);
+    ggml_tensor * yp = ggml_mul_mat(cg, Wp, x);
+    const bool sup = ggml_backend_dev_supports_op(dev, ys);
+    if (!sup) {   // a main device that owns no rows must refuse the op (ggml-cuda.cu:3141-3149)
+        printf("  %-60s not supported on MI355_%d (main device owns no rows)\n", tag, main_dev);
+        ggml_free(cg); ggml_backend_buffer_free(bs); ggml_backend_buffer_free(bp); ggml_free(cs); ggml_free(cp); ggml_backend_free(backend);
+        return false;
+    }
+    ggml_cgraph * gf = ggml_new_graph(cg);
+    ggml_build_forward_expand(gf, ys);
+    ggml_build_forward_expand(gf, yp);
+    ggml_backend_buffer_t bg = ggml_backend_alloc_ctx_tensors(cg, backend);
+    std::vector<float> xf(K * N * ne2);
+    for (float & v : xf) v = U(rng);
+    ggml_backend_tensor_set(x, xf.data(), 0, xf.size() * sizeof(float));
+    std::vector<float> poison(M * N * ne2, -12345.0f);
+    ggml_backend_tensor_set(ys, poison.data(), 0, poison.size() * sizeof(float));
+    bool ok = true;
+    for (int rep = 0; rep < 2 && ok; rep++) {     // twice: the second run finds the activation copy already on the helper
+        ok = ggml_backend_graph_compute(backend, gf) == GGML_STATUS_SUCCESS;
+    }
+    check(ok, std::string(tag) + ": graph_compute");
+    std::vector<float> a(M * N * ne2), b(M * N * ne2);
+    ggml_backend_tensor_get(ys, a.data(), 0, a.size() * sizeof(float));
+    ggml_backend_tensor_get(yp, b.data(), 0, b.size() * sizeof(float));
+    const bool same = memcmp(a.data(), b.data(), a.size() * sizeof(float)) == 0;
+    double ref2 = 0;
+    for (float v : b) ref2 += (double)v * v;
+    check(same && ref2 > 0, std::string(tag) + ": split result == unsplit result (bitwise)");
+    printf("  %-60s %s\n", tag, same ? "OK" : "MISMATCH");
+
+    ggml_backend_buffer_free(bg); ggml_free(cg);
+    ggml_backend_buffer_free(bs); ggml_backend_buffer_free(bp);
+    ggml_free(cs); ggml_free(cp);
+    ggml_backend_free(backend);
+    return same;
+}
+
+int main() {
+    ggml_backend_load_all();
+    ggml_backend_reg_t reg = ggml_backend_reg_by_name("MI355");
+    if (!reg) { printf("MI355 backend not loaded (GGML_BACKEND_PATH?)\n"); return 2; }
+    const int ndev = (int)ggml_backend_reg_dev_count(reg);
+    if (ndev < 2) { printf("need >= 2 MI355 devices (GGML_MI355_VIRTUAL_DEVICES=2), have %d\n", ndev); return 2; }
+    split_buft_fn split_buft = (split_buft_fn)ggml_backend_reg_get_proc_address(reg, "ggml_backend_split_buffer_type");
+    if (!split_buft) { printf("no ggml_backend_split_buffer_type\n"); return 1; }
+    // the same (main_device, tensor_split) must give the same object (buffer types are compared by pointer)
+    const float even[16] = {1, 1}, skew[16] = {3, 1};
+    check(split_buft(0, even) == split_buft(0, even), "split buffer type is a singleton per (main, split)");
+    check(split_buft(0, even) != split_buft(1, even), "distinct main devices give distinct buffer types");
+    check(split_buft(0, even) != split_buft(0, skew), "distinct splits give distinct buffer types");
+
+    const ggml_type types[] = { GGML_TYPE_Q4_0, GGML_TYPE_Q8_0, GGML_TYPE_Q4_K, GGML_TYPE_Q5_K, GGML_TYPE_Q6_K };
+    int ran = 0;
+    for (ggml_type t : types) {
+        ran += run_case(reg, split_buft, 0, even, t, 512, 256, 1, 1);      // equal slices, decode
+        ran += run_case(reg, split_buft, 0, even, t, 384, 512, 3, 1);      // 128 / 256 rows
+        ran += run_case(reg, split_buft, 1, even, t, 1024, 256, 8, 1);     // the other device is the main one
+        ran += run_case(reg, split_buft, 0, skew, t, 1024, 512, 5, 2);     // 768 / 256, broadcast over ne2
+        ran += run_case(reg, split_buft, 0, even, t, 512, 512, 33, 1);     // prefill tile kernel on both halves
+        ran += run_case(reg, split_buft, 1, skew, t, 640, 256, 64, 1);     // 384 / 256, tile kernel, main = 1
+    }
+    // fewer rows than the rounding: device 0 owns nothing and must refuse, device 1 owns all and must run
+    check(!run_case(reg, split_buft, 0, even, GGML_TYPE_Q4_K, 100, 256, 1, 1), "main device without rows refuses the op");
+    check(run_case(reg, split_buft, 1, even, GGML_TYPE_Q4_K, 100, 256, 1, 1), "device that owns all rows runs it");
+    printf("%d checks ok, %d failed, %d cases ran\n", n_ok, n_fail, ran);
+    return n_fail == 0 && ran >= 30 ? 0 : 1;
+}
