@@ -185,6 +185,13 @@ MI355_API int mi355_rms_norm_mul_f32(const mi355_tensor *x, const float *w, cons
 MI355_API int mi355_rms_norm_mul_quant_f32(const mi355_tensor *x, const float *w, const mi355_tensor *dst, float eps,
                                            int8_t *act_q, float *act_ds, void *stream);
 
+/* residual ADD feeding the next block's norm, in one launch: sum = a + b (stored, same shape, no broadcast), then
+ * dst = (sum * rsqrt(mean(sum^2) + eps)) * w, optionally also its q8_1 form (act_q / act_ds both NULL or both set).
+ * Same f32 op order as the three separate graph nodes ADD, RMS_NORM, MUL.  Rows up to 8192 floats, 16-byte aligned,
+ * otherwise MI355_E_UNSUPPORTED (callers then run the nodes one by one). */
+MI355_API int mi355_add_rms_norm_mul_f32(const mi355_tensor *a, const mi355_tensor *b, const mi355_tensor *sum, const float *w,
+                                         const mi355_tensor *dst, float eps, int8_t *act_q, float *act_ds, void *stream);
+
 /* rotary embedding, modes NORMAL (0) and NEOX (2), optional freq_factors, YaRN parameters.
  * ggml_cuda_op_rope (ggml-cuda/rope.cu); oracle ggml_compute_forward_rope_f32 (ggml-cpu/ops.cpp:5942-6110). */
 MI355_API int mi355_rope_f32(const mi355_tensor *x, const int32_t *pos, const float *freq_factors, const mi355_tensor *dst,

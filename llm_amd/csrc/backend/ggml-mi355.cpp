@@ -848,7 +848,7 @@ static void mi355_flash_attn(mi355_backend_ctx * ctx, ggml_tensor * dst) {
     // a workspace lets long contexts split the KV range; only worth having for decode-sized batches
     void * ws = nullptr;
     int64_t ws_bytes = 0;
-    if (a.n_kv >= 1024 && a.n_head_kv * a.n_q * a.ne3 < 512) {
+    if (a.n_kv >= 128 && a.n_head_kv * a.n_q * a.ne3 < 512) {
         ws_bytes = mi355_flash_attn_ext_workspace_bytes(&a);
         ws = ctx->get_scratch(1, (size_t)ws_bytes);
     }
@@ -868,7 +868,28 @@ static bool mi355_compute_forward(mi355_backend_ctx * ctx, ggml_tensor * node) {
     return mi355_ops_forward(node, ctx->stream);
 }
 
-static bool mi355_try_fuse_rms_norm_mul(mi355_backend_ctx * ctx, ggml_cgraph * cgraph, int i) {
+// A fused kernel reads and writes per element index, so an output may share memory with an input only when the
+// two coincide exactly (in-place); a shifted overlap (ggml-alloc reusing part of a freed block) would let one row's
+// store land on another row's not-yet-read input.
+static bool alias_safe(const ggml_tensor * out, const ggml_tensor * in) {
+    const char * o0 = (const char *)out->data, * o1 = o0 + ggml_nbytes(out);
+    const char * i0 = (const char *)in->data,  * i1 = i0 + ggml_nbytes(in);
+    if (o1 <= i0 || i1 <= o0) return true;
+    if (o0 != i0) return false;
+    for (int d = 0; d < 4; d++) if (out->nb[d] != in->nb[d] || out->ne[d] != in->ne[d]) return false;
+    return true;
+}
+
+static mi355_tensor to_mi355_tensor(const ggml_tensor * t) {
+    mi355_tensor r;
+    r.data = t->data; r.type = (int32_t)t->type;
+    for (int d = 0; d < 4; d++) { r.ne[d] = t->ne[d]; r.nb[d] = (int64_t)t->nb[d]; }
+    return r;
+}
+
+// RMS_NORM at node i followed by MUL with the per-feature norm weight; when `add` is given it is the ADD at node
+// i-1 whose result the norm reads (residual add), and all three nodes run as one kernel.
+static bool mi355_try_fuse_rms_norm_mul(mi355_backend_ctx * ctx, ggml_cgraph * cgraph, int i, ggml_tensor * add = nullptr) {
     ggml_tensor * norm = ggml_graph_node(cgraph, i);
     ggml_tensor * mul  = ggml_graph_node(cgraph, i + 1);
     if (mul->op != GGML_OP_MUL || getenv("GGML_MI355_NO_FUSE")) return false;
@@ -884,19 +905,46 @@ static bool mi355_try_fuse_rms_norm_mul(mi355_backend_ctx * ctx, ggml_cgraph * c
         const ggml_tensor * t = ggml_graph_node(cgraph, j);
         for (int s = 0; s < GGML_MAX_SRC; s++) if (t->src[s] == norm || (t->src[s] && t->src[s]->view_src == norm)) return false;
     }
-    ctx->act_invalidate_if_written(mul);
+    const ggml_tensor * x = norm->src[0];
+    if (!alias_safe(mul, x) || !alias_safe(mul, w)) return false;
+    if (add) {
+        const ggml_tensor * a = add->src[0], * b = add->src[1];
+        if (x != add || add->type != GGML_TYPE_F32 || a->type != GGML_TYPE_F32 || b->type != GGML_TYPE_F32) return false;
+        if (!ggml_are_same_shape(a, add) || !ggml_are_same_shape(b, add)) return false;
+        if (a->nb[0] != sizeof(float) || b->nb[0] != sizeof(float) || add->nb[0] != sizeof(float)) return false;
+        if (!alias_safe(add, a) || !alias_safe(add, b) || !alias_safe(mul, a) || !alias_safe(mul, b)) return false;
+        const char * m0 = (const char *)mul->data, * s0 = (const char *)add->data;
+        if (m0 < s0 + ggml_nbytes(add) && s0 < m0 + ggml_nbytes(mul)) return false;   // the two outputs must be disjoint
+    }
     float eps;
     memcpy(&eps, norm->op_params, sizeof(float));
-    mi355_tensor tx, td;
-    const ggml_tensor * x = norm->src[0];
-    tx.data = x->data; tx.type = (int32_t)x->type; td.data = mul->data; td.type = (int32_t)mul->type;
-    for (int d = 0; d < 4; d++) { tx.ne[d] = x->ne[d]; tx.nb[d] = (int64_t)x->nb[d]; td.ne[d] = mul->ne[d]; td.nb[d] = (int64_t)mul->nb[d]; }
+    mi355_tensor tx = to_mi355_tensor(x), td = to_mi355_tensor(mul);
     // decode-sized rows: also emit the q8_1 form for the MUL_MATs that read the result
     const int64_t rows = ggml_nrows(mul), K = mul->ne[0];
-    if (rows <= 8 && K % 32 == 0 && K <= 8192 && ggml_is_contiguous(mul)) {
+    const bool quant = rows <= 8 && K % 32 == 0 && K <= 8192 && ggml_is_contiguous(mul);
+    int8_t * aq = nullptr; float * ads = nullptr;
+    if (quant) {
         const size_t qb = align_up((size_t)mi355_act_q_bytes(K, rows), 256), db = align_up((size_t)mi355_act_ds_bytes(K, rows), 256);
         char * ws = (char *)ctx->get_scratch(0, qb + db);
-        const int rc = mi355_rms_norm_mul_quant_f32(&tx, (const float *)w->data, &td, eps, (int8_t *)ws, (float *)(ws + qb), ctx->stream);
+        aq = (int8_t *)ws; ads = (float *)(ws + qb);
+    }
+    if (add) {
+        mi355_tensor ta = to_mi355_tensor(add->src[0]), tb = to_mi355_tensor(add->src[1]), ts = to_mi355_tensor(add);
+        int rc = mi355_add_rms_norm_mul_f32(&ta, &tb, &ts, (const float *)w->data, &td, eps, aq, ads, ctx->stream);
+        if (rc == MI355_E_UNSUPPORTED && quant) {
+            aq = nullptr; ads = nullptr;
+            rc = mi355_add_rms_norm_mul_f32(&ta, &tb, &ts, (const float *)w->data, &td, eps, nullptr, nullptr, ctx->stream);
+        }
+        if (rc == MI355_E_UNSUPPORTED) return false;
+        MI_CHECK(rc);
+        ctx->act_invalidate_if_written(add);
+        ctx->act_invalidate_if_written(mul);
+        if (aq) ctx->act_remember(mul);
+        return true;
+    }
+    ctx->act_invalidate_if_written(mul);
+    if (quant) {
+        const int rc = mi355_rms_norm_mul_quant_f32(&tx, (const float *)w->data, &td, eps, aq, ads, ctx->stream);
         if (rc == MI355_OK) { ctx->act_remember(mul); return true; }
         if (rc != MI355_E_UNSUPPORTED) MI_CHECK(rc);
     }
@@ -933,6 +981,12 @@ static enum ggml_status mi355_backend_graph_compute(ggml_backend_t backend, ggml
         // empty tensors and pure view ops compute nothing (ggml-cuda.cu:2589)
         if (ggml_is_empty(node) || node->op == GGML_OP_NONE || node->op == GGML_OP_RESHAPE || node->op == GGML_OP_VIEW ||
             node->op == GGML_OP_PERMUTE || node->op == GGML_OP_TRANSPOSE) {
+            continue;
+        }
+        // fusion: residual ADD -> RMS_NORM -> MUL(weight) in one launch (the add result stays a graph tensor)
+        if (node->op == GGML_OP_ADD && i + 2 < n && ggml_graph_node(cgraph, i + 1)->op == GGML_OP_RMS_NORM &&
+            ggml_graph_node(cgraph, i + 1)->src[0] == node && mi355_try_fuse_rms_norm_mul(ctx, cgraph, i + 1, node)) {
+            i += 2;
             continue;
         }
         ctx->act_invalidate_if_written(node);

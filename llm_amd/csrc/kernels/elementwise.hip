@@ -76,24 +76,37 @@ binary_kernel(const T4 a, const T4 b, const T4 d, int64_t n) {
 // ---------------------------------------------------------------- rms norm (one block per row)
 // y = x * rsqrt(mean(x^2) + eps) [* w]: the row is read once with 128-bit loads and kept in registers
 // (rows up to 8192 floats); rows that are longer or not 16-byte aligned take the two-pass path.
-template <bool HAS_W>
+// HAS_ADD: the row is first formed as x + y and that sum is also stored (residual add feeding the next norm).
+template <bool HAS_W, bool HAS_ADD>
 __global__ void __launch_bounds__(256)
-rms_norm_kernel(const T4 x, const float * __restrict__ w, const T4 d, float eps, bool vec, int8_t * __restrict__ aq, float * __restrict__ ads) {
+rms_norm_kernel(const T4 x, const T4 y, const T4 sum, const float * __restrict__ w, const T4 d, float eps, bool vec,
+                int8_t * __restrict__ aq, float * __restrict__ ads) {
     __shared__ float sh[4];
-    const int64_t row = blockIdx.x;
-    const int64_t i1 = row % x.ne[1], i2 = (row / x.ne[1]) % x.ne[2], i3 = row / (x.ne[1] * x.ne[2]);
+    const int row = blockIdx.x;
+    const int ne1 = (int)x.ne[1], ne2 = (int)x.ne[2];
+    const int i1 = row % ne1, i2 = (row / ne1) % ne2, i3 = row / (ne1 * ne2);
     const float * xr = (const float *)(x.data + i1 * x.nb[1] + i2 * x.nb[2] + i3 * x.nb[3]);
     float * dr = (float *)(d.data + i1 * d.nb[1] + i2 * d.nb[2] + i3 * d.nb[3]);
     const int n = (int)x.ne[0];
     if (vec) {
         constexpr int MAXV = 8;
         const int n4 = n >> 2;
-        v4f v[MAXV];
+        v4f v[MAXV], wv[MAXV];
         float s = 0.0f;
 #pragma unroll
         for (int j = 0; j < MAXV; j++) {
             const int i = threadIdx.x + j * 256;
-            if (i < n4) { v[j] = ((const v4f *)xr)[i]; s += v[j].x * v[j].x + v[j].y * v[j].y + v[j].z * v[j].z + v[j].w * v[j].w; }
+            if (i < n4) {
+                v[j] = ((const v4f *)xr)[i];
+                if (HAS_W) wv[j] = ((const v4f *)w)[i];   // requested now so its latency hides behind the reduction
+                if (HAS_ADD) {
+                    const float * yr = (const float *)(y.data + i1 * y.nb[1] + i2 * y.nb[2] + i3 * y.nb[3]);
+                    v[j] = v[j] + ((const v4f *)yr)[i];
+                    float * sr = (float *)(sum.data + i1 * sum.nb[1] + i2 * sum.nb[2] + i3 * sum.nb[3]);
+                    ((v4f *)sr)[i] = v[j];
+                }
+                s += v[j].x * v[j].x + v[j].y * v[j].y + v[j].z * v[j].z + v[j].w * v[j].w;
+            }
         }
         s = block_sum(s, sh);
         const float scale = 1.0f / sqrtf(s / (float)n + eps);
@@ -102,11 +115,11 @@ rms_norm_kernel(const T4 x, const float * __restrict__ w, const T4 d, float eps,
             const int i = threadIdx.x + j * 256;
             if (i < n4) {
                 v4f o = v[j] * scale;            // (x * scale) then * w: the op order of the unfused graph
-                if (HAS_W) o = o * ((const v4f *)w)[i];
+                if (HAS_W) o = o * wv[j];
                 ((v4f *)dr)[i] = o;
                 if (aq) { // fused q8_1 quantization of the row for the MUL_MATs that consume it
                     const float ov[4] = {o.x, o.y, o.z, o.w};
-                    quant4_soa(ov, aq + row * n + 4 * i, ads + (row * (n / QK) + (i >> 3)) * 2, (i & 7) == 0);
+                    quant4_soa(ov, aq + (int64_t)row * n + 4 * i, ads + ((int64_t)row * (n / QK) + (i >> 3)) * 2, (i & 7) == 0);
                 }
             }
         }
@@ -333,7 +346,8 @@ int mi355_binary_f32(int op, const mi355_tensor * a, const mi355_tensor * b, con
     return MI355_OK;
 }
 
-static int launch_rms_norm(const mi355_tensor * x, const float * w, const mi355_tensor * dst, float eps, int8_t * aq, float * ads, void * stream) {
+static int launch_rms_norm(const mi355_tensor * x, const mi355_tensor * y, const mi355_tensor * sum, const float * w,
+                           const mi355_tensor * dst, float eps, int8_t * aq, float * ads, void * stream) {
     CHECK_T(x); CHECK_T(dst);
     if (x->type != MI355_TYPE_F32 || dst->type != MI355_TYPE_F32) return MI355_E_TYPE;
     if (!same_shape(x, dst) || x->nb[0] != 4 || dst->nb[0] != 4) return MI355_E_SHAPE;
@@ -342,27 +356,45 @@ static int launch_rms_norm(const mi355_tensor * x, const float * w, const mi355_
     if (rows > 0x7fffffff) return MI355_E_SHAPE;
     uintptr_t al = (uintptr_t)x->data | (uintptr_t)dst->data | (uintptr_t)w;
     for (int i = 1; i < 4; i++) al |= (uintptr_t)x->nb[i] | (uintptr_t)dst->nb[i];
+    if (y) {
+        CHECK_T(y); CHECK_T(sum);
+        if (y->type != MI355_TYPE_F32 || sum->type != MI355_TYPE_F32) return MI355_E_TYPE;
+        if (!same_shape(x, y) || !same_shape(x, sum) || y->nb[0] != 4 || sum->nb[0] != 4) return MI355_E_SHAPE;
+        al |= (uintptr_t)y->data | (uintptr_t)sum->data;
+        for (int i = 1; i < 4; i++) al |= (uintptr_t)y->nb[i] | (uintptr_t)sum->nb[i];
+    }
     const bool vec = (al & 15) == 0 && x->ne[0] % 4 == 0 && x->ne[0] <= 8192;
     if (aq && (!vec || x->ne[0] % QK != 0 || !ads)) return MI355_E_UNSUPPORTED;
-    if (w) MI355_LAUNCH("rms_norm_mul", (rms_norm_kernel<true>), dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, t4(x), w, t4(dst), eps, vec, aq, ads);
-    else   MI355_LAUNCH("rms_norm", (rms_norm_kernel<false>), dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, t4(x), w, t4(dst), eps, vec, aq, ads);
+    if (y && (!vec || !w)) return MI355_E_UNSUPPORTED;
+    const dim3 grid((unsigned)rows), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (y)      MI355_LAUNCH("add_rms_norm_mul", (rms_norm_kernel<true, true>), grid, block, 0, s, t4(x), t4(y), t4(sum), w, t4(dst), eps, vec, aq, ads);
+    else if (w) MI355_LAUNCH("rms_norm_mul", (rms_norm_kernel<true, false>), grid, block, 0, s, t4(x), t4(x), t4(x), w, t4(dst), eps, vec, aq, ads);
+    else        MI355_LAUNCH("rms_norm", (rms_norm_kernel<false, false>), grid, block, 0, s, t4(x), t4(x), t4(x), w, t4(dst), eps, vec, aq, ads);
     MI355_CHECK_LAUNCH();
     return MI355_OK;
 }
 
 int mi355_rms_norm_f32(const mi355_tensor * x, const mi355_tensor * dst, float eps, void * stream) {
-    return launch_rms_norm(x, nullptr, dst, eps, nullptr, nullptr, stream);
+    return launch_rms_norm(x, nullptr, nullptr, nullptr, dst, eps, nullptr, nullptr, stream);
 }
 
 int mi355_rms_norm_mul_f32(const mi355_tensor * x, const float * w, const mi355_tensor * dst, float eps, void * stream) {
     if (!w) return MI355_E_NULL;
-    return launch_rms_norm(x, w, dst, eps, nullptr, nullptr, stream);
+    return launch_rms_norm(x, nullptr, nullptr, w, dst, eps, nullptr, nullptr, stream);
 }
 
 int mi355_rms_norm_mul_quant_f32(const mi355_tensor * x, const float * w, const mi355_tensor * dst, float eps,
                                  int8_t * act_q, float * act_ds, void * stream) {
     if (!w || !act_q || !act_ds) return MI355_E_NULL;
-    return launch_rms_norm(x, w, dst, eps, act_q, act_ds, stream);
+    return launch_rms_norm(x, nullptr, nullptr, w, dst, eps, act_q, act_ds, stream);
+}
+
+int mi355_add_rms_norm_mul_f32(const mi355_tensor * a, const mi355_tensor * b, const mi355_tensor * sum, const float * w,
+                               const mi355_tensor * dst, float eps, int8_t * act_q, float * act_ds, void * stream) {
+    if (!w || !b || !sum) return MI355_E_NULL;
+    if ((act_q == nullptr) != (act_ds == nullptr)) return MI355_E_NULL;
+    return launch_rms_norm(a, b, sum, w, dst, eps, act_q, act_ds, stream);
 }
 
 int mi355_rope_f32(const mi355_tensor * x, const int32_t * pos, const float * freq_factors, const mi355_tensor * dst,

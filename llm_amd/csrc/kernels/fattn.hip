@@ -287,14 +287,17 @@ int mi355_flash_attn_ext(const mi355_fattn_args * p, void * workspace, int64_t w
     a.m0 = powf(2.0f, -(p->max_bias) / a.n_head_log2);
     a.m1 = powf(2.0f, -(p->max_bias / 2.0f) / a.n_head_log2);
 
-    // KV split: enough workgroups to fill 256 CUs when the (head, token) grid alone cannot,
-    // at least 256 KV rows per slice, bounded by the workspace
+    // KV split.  The KV loop is a chain of memory round trips (one per G = 512/(d/8) rows), so for decode-sized
+    // grids the range is cut until every workgroup has about one round trip of rows -- all loads of the op are
+    // then in flight at once -- up to 64 slices, bounded by the workspace; the partials are merged by
+    // fattn_combine_kernel.
     int nsplit = 1;
     const int64_t base_wgs = (int64_t)p->n_head_kv * p->n_q * p->ne3;
-    if (workspace && base_wgs < 512 && p->n_kv >= 1024) {
-        int64_t want = 1024 / (base_wgs > 0 ? base_wgs : 1);
-        const int64_t max_by_len = p->n_kv / 256;
-        if (want > max_by_len) want = max_by_len;
+    const int64_t G = FA_THREADS / (p->d / 8);
+    if (workspace && base_wgs < 512 && p->n_kv >= 4 * G) {
+        int64_t want = (p->n_kv + G - 1) / G;
+        const int64_t fill = 2048 / (base_wgs > 0 ? base_wgs : 1);   // no point beyond ~8 workgroups per CU
+        if (want > fill) want = fill;
         if (want > 64) want = 64;
         const int64_t per = (int64_t)p->ne3 * p->n_q * p->n_head * (p->d + 2) * (int64_t)sizeof(float);
         if (per > 0 && want * per > workspace_bytes) want = workspace_bytes / per;
