@@ -35,6 +35,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--model", default="llama3-8b")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-group", action="store_true", help="one launch per matrix instead of grouped QKV / gate+up launches")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
     return ap.parse_args()
 
@@ -123,34 +124,42 @@ def main():
         K.check(K.lib.mi355_quantize_act(xs[k].data_ptr(), aq.data_ptr(), ads.data_ptr(), k, 1, 1, 1, k * 4, 0, 0, stream),
                 "mi355_quantize_act")
 
-    mm_args = []
-    for mt, w, o in zip(mats, weights, outs):
+    # Launch plan: matrices that read the same activation and have the same block type (wq/wk[/wv], gate/up)
+    # share ONE grouped launch (mi355_mul_mat_vec_q_group); --no-group launches every matrix on its own.
+    def mm_arg(mt, w, o):
         a = K.MmvqArgs()
         aq, ads = acts[mt.k]
         a.type, a.W, a.w_row_stride, a.w_ch_stride = mt.type, w.data_ptr(), B.row_size(mt.type, mt.k), 0
         a.act_q, a.act_ds, a.act_ch_stride = aq.data_ptr(), ads.data_ptr(), 0
         a.dst, a.dst_col_stride, a.dst_ch_stride = o.data_ptr(), o.shape[1], 0
         a.m, a.k, a.ncols, a.nchannels, a.ch_ratio = o.shape[1], mt.k, 1, 1, 1
-        mm_args.append(a)
+        return a
 
-    def step(events=None):
+    plan = []      # (quantize_k or None, ctypes array of MmvqArgs, n, [matrix indices])
+    last_src = None
+    for i, mt in enumerate(mats):
+        need_q = mt.k if mt.src != last_src else None   # one q8_1 quantization per distinct activation, as in the graph
+        last_src = mt.src
+        prev = plan[-1] if plan else None
+        if (not args.no_group and need_q is None and prev and len(prev[3]) < 4 and mats[prev[3][0]].type == mt.type
+                and mats[prev[3][0]].k == mt.k and mats[prev[3][0]].src == mt.src):
+            prev[3].append(i)
+        else:
+            plan.append([need_q, None, 0, [i]])
+    for p in plan:
+        arr = (K.MmvqArgs * len(p[3]))(*[mm_arg(mats[i], weights[i], outs[i]) for i in p[3]])
+        p[1], p[2] = arr, len(p[3])
+
+    def step():
         """one decode token's mat-vecs on the current stream"""
         stream = torch.cuda.current_stream().cuda_stream
-        last_src = None
-        for i, mt in enumerate(mats):
-            if mt.src != last_src:          # one q8_1 quantization per distinct activation, as in the graph
-                quantize(mt.k, stream)
-                last_src = mt.src
-            if events is not None and mt.type == B.Q4_K:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                K.check(K.lib.mi355_mul_mat_vec_q(mm_args[i], stream), "mi355_mul_mat_vec_q")
-                e1.record()
-                events.append((i, e0, e1))
-            else:
-                K.check(K.lib.mi355_mul_mat_vec_q(mm_args[i], stream), "mi355_mul_mat_vec_q")
+        for need_q, arr, n, idx in plan:
+            if need_q is not None:
+                quantize(need_q, stream)
+            K.check(K.lib.mi355_mul_mat_vec_q_group(arr, n, stream), "mi355_mul_mat_vec_q_group")
             if world > 1:
-                all_gather_rows(outs[i], mt.m, rank, world, dist)
+                for i in idx:
+                    all_gather_rows(outs[i], mats[i].m, rank, world, dist)
 
     def barrier():
         if world > 1:
@@ -205,6 +214,7 @@ def main():
                 "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
                 "traffic": None, "launches": n_launch, "avg_launch_us": round(avg_us, 3),
                 "algorithmic_bytes_per_launch": round(q4k_bytes / n_launch), "all_kernels": kernels}
+    n_launches = sum(1 for p in plan) + sum(1 for p in plan if p[0] is not None)
 
     if rank == 0:
         line = {
@@ -217,6 +227,7 @@ def main():
                                    "step + q8_1 activation quantization, random-init GGUF blocks",
                        "parallelism": "single GPU" if world == 1 else f"row split x{world} + RCCL all-gather",
                        "launch": "hipGraph replay" if use_graph else "eager",
+                       "launches_per_step": n_launches, "grouped": not args.no_group,
                        "pct_hbm_peak": round(value / (HBM_PEAK_GBPS * world) * 100, 2),
                        "decode_tokens_per_s_matvec_only": round(1e3 / ms_per_step, 1)},
             "roofline": roofline,

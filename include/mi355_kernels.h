@@ -138,12 +138,33 @@ typedef struct mi355_mmvq_args {
 
 MI355_API int mi355_mul_mat_vec_q(const mi355_mmvq_args *args, void *stream);
 
+/* Grouped mat-vec: n_mats (1..MI355_MMVQ_MAX_GROUP) matrices of the same type and k that read the SAME quantized
+ * activations (same act_q / act_ds / ncols; nchannels == 1, no ids) computed by ONE launch -- wq/wk/wv or ffn
+ * gate/up at decode.  The reference launches one mul_mat_vec_q per matrix (ggml-cuda/mmvq.cu:491-561); on MI355X
+ * the ~3 us floor of a launch is a large part of a 9 MB mat-vec, so the matrices share a grid instead.  Results are
+ * bit-identical to separate mi355_mul_mat_vec_q calls. */
+#define MI355_MMVQ_MAX_GROUP 4
+MI355_API int mi355_mul_mat_vec_q_group(const mi355_mmvq_args *args, int n_mats, void *stream);
+
 /* Prefill tile kernel (int8 MFMA): dst[c][r] = sum_k W[r][k] * act[c][k] for any n (meant for n > 8).
  * Same operands as the mat-vec (one channel).  Returns MI355_E_UNSUPPORTED when k % 128 != 0 (callers
  * then use the mat-vec kernel over column groups).  Replaces ggml_cuda_mul_mat_q / mul_mat_q
  * (ggml/src/ggml-cuda/mmq.cu:68-224, mmq.cuh:2606-2841). */
 MI355_API int mi355_mul_mat_q(int type, const void *W, int64_t w_row_stride, const int8_t *act_q, const float *act_ds,
                               float *dst, int64_t dst_col_stride, int64_t m, int64_t k, int64_t n, void *stream);
+
+/* Prefill GEMM, second form: dequantize-in-LDS + bf16 MFMA (v_mfma_f32_32x32x16_bf16), f32 accumulation.
+ * The block scales are applied once per weight while a tile is staged instead of once per 32-block per output
+ * element, which is what bounds the int8 kernel above on CDNA4.  Activations are rounded
+ * to bf16 once per distinct src1 by mi355_act_bf16 (x: 4-D f32 with byte strides as in mi355_quantize_act; y: bf16
+ * [rows][k], 16-byte aligned, k % 8 == 0) -- there is no q8_1 pass on this path.  Same contract and error budget as
+ * mi355_mul_mat_q (NMSE <= 5e-4 vs ggml-cpu; measured ~3e-6).  MI355_E_UNSUPPORTED when k % 64 != 0.
+ * Replaces the reference's large-batch path (mul_mat_q, or dequantize + hipBLAS GEMM: ggml-cuda.cu:1223-1340).
+ *   act_bf16: n columns of k bf16, act_row_stride elements apart (multiple of 8) */
+MI355_API int mi355_act_bf16(const float *x, uint16_t *y, int64_t k, int64_t ne1, int64_t ne2, int64_t ne3,
+                             int64_t nb1, int64_t nb2, int64_t nb3, void *stream);
+MI355_API int mi355_mul_mat_dq(int type, const void *W, int64_t w_row_stride, const uint16_t *act_bf16, int64_t act_row_stride,
+                               float *dst, int64_t dst_col_stride, int64_t m, int64_t k, int64_t n, void *stream);
 
 /* Convenience for the common case (2-D contiguous W, contiguous f32 x[n][k], dst[n][m]):
  * quantizes x into `workspace` (>= mi355_mul_mat_workspace_bytes(k, n)) and runs the mat-vec

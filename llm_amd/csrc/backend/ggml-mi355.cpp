@@ -496,6 +496,7 @@ struct mi355_backend_ctx {
     // the same src1 (wq/wk/wv, gate/up) quantize it once.  Dropped as soon as any node writes into it.
     struct {
         bool valid = false;
+        int fmt = 0;                // 0: q8_1 SoA (mi355_quantize_act), 1: bf16 rows (mi355_act_bf16)
         const void * data = nullptr;
         size_t span = 0;
         int64_t ne[4] = {0, 0, 0, 0};
@@ -542,13 +543,14 @@ struct mi355_backend_ctx {
         return scratch[which];
     }
 
-    bool act_cached(const ggml_tensor * t) const {
-        if (!act_cache.valid || act_cache.data != t->data) return false;
+    bool act_cached(const ggml_tensor * t, int fmt = 0) const {
+        if (!act_cache.valid || act_cache.data != t->data || act_cache.fmt != fmt) return false;
         for (int i = 0; i < 4; i++) if (act_cache.ne[i] != t->ne[i] || act_cache.nb[i] != t->nb[i]) return false;
         return true;
     }
-    void act_remember(const ggml_tensor * t) {
+    void act_remember(const ggml_tensor * t, int fmt = 0) {
         act_version++;
+        act_cache.fmt = fmt;
         act_cache.valid = true; act_cache.data = t->data; act_cache.span = ggml_nbytes(t);
         for (int i = 0; i < 4; i++) { act_cache.ne[i] = t->ne[i]; act_cache.nb[i] = t->nb[i]; }
     }
@@ -651,13 +653,27 @@ static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 // the launches of one MUL_MAT over rows [row_low, row_low + M) of the weight matrix whose first owned row is at
 // W: int8-MFMA tile kernel for prefill-sized N, mat-vec kernel in groups of 8 columns otherwise
 static void mi355_mul_mat_launch(const ggml_tensor * dst, const char * W, int64_t row_low, int64_t M,
-                                 const int8_t * aq, const float * ads, hipStream_t stream) {
+                                 const int8_t * aq, const float * ads, hipStream_t stream, bool bf16 = false) {
     const ggml_tensor * src0 = dst->src[0];
     const ggml_tensor * src1 = dst->src[1];
     const int64_t K = src0->ne[0], ne02 = src0->ne[2], ne03 = src0->ne[3];
     const int64_t N = src1->ne[1], ne12 = src1->ne[2], ne13 = src1->ne[3];
     const int64_t r2 = ne12 / ne02, r3 = ne13 / ne03;
     char * dbase = (char *)dst->data + row_low * sizeof(float);
+    if (bf16) {
+        // prefill: dequantize-in-LDS bf16 MFMA GEMM on activations rounded to bf16 (aq holds them), one launch per channel
+        const uint16_t * ab = (const uint16_t *)aq;
+        for (int64_t i13 = 0; i13 < ne13; i13++) {
+            for (int64_t i12 = 0; i12 < ne12; i12++) {
+                const char * Wc = W + (i13 / r3) * src0->nb[3] + (i12 / r2) * src0->nb[2];
+                const int64_t arow = (i13 * ne12 + i12) * N;
+                float * d = (float *)(dbase + i13 * dst->nb[3] + i12 * dst->nb[2]);
+                MI_CHECK(mi355_mul_mat_dq((int)src0->type, Wc, (int64_t)src0->nb[1], ab + arow * K, K, d,
+                                          (int64_t)(dst->nb[1] / sizeof(float)), M, K, N, stream));
+            }
+        }
+        return;
+    }
     if (N > 8 && K % 128 == 0) {
         // prefill: int8-MFMA tile kernel, one launch per broadcast channel
         for (int64_t i13 = 0; i13 < ne13; i13++) {
@@ -702,19 +718,26 @@ static void mi355_mul_mat(mi355_backend_ctx * ctx, ggml_tensor * dst) {
     const int64_t rows = N * ne12 * ne13;
     if (rows == 0 || M == 0) return;
 
-    // q8_1 activations for all of src1 (strided / permuted src1 is handled by the quantizer)
-    const size_t qb = align_up((size_t)mi355_act_q_bytes(K, rows), 256);
-    const size_t db = align_up((size_t)mi355_act_ds_bytes(K, rows), 256);
+    // Activations for all of src1 (strided / permuted src1 is handled by the converters), once per distinct src1:
+    // prefill-sized N: rounded to bf16 for the dequantize-in-LDS MFMA GEMM; otherwise q8_1 for the mat-vec kernel
+    // (GGML_MI355_MMQ_INT8=1 keeps prefill on the int8 MFMA tile kernel, which consumes q8_1 as well).
+    static const bool int8_mmq = getenv("GGML_MI355_MMQ_INT8") != nullptr;
+    const bool bf16 = N > 8 && K % 64 == 0 && !int8_mmq &&
+                      ((((uintptr_t)src1->data | src1->nb[1] | src1->nb[2] | src1->nb[3]) & 15) == 0);
+    size_t qb, db;
+    if (bf16) { qb = align_up((size_t)rows * K * 2, 256); db = 0; }
+    else      { qb = align_up((size_t)mi355_act_q_bytes(K, rows), 256); db = align_up((size_t)mi355_act_ds_bytes(K, rows), 256); }
     char * ws = (char *)ctx->get_scratch(0, qb + db);
     int8_t * aq  = (int8_t *)ws;
     float  * ads = (float *)(ws + qb);
-    if (!ctx->act_cached(src1) || getenv("GGML_MI355_NO_FUSE")) {
-        MI_CHECK(mi355_quantize_act((const float *)src1->data, aq, ads, K, N, ne12, ne13, src1->nb[1], src1->nb[2], src1->nb[3], ctx->stream));
-        ctx->act_remember(src1);
+    if (!ctx->act_cached(src1, bf16) || getenv("GGML_MI355_NO_FUSE")) {
+        if (bf16) MI_CHECK(mi355_act_bf16((const float *)src1->data, (uint16_t *)ws, K, N, ne12, ne13, src1->nb[1], src1->nb[2], src1->nb[3], ctx->stream));
+        else      MI_CHECK(mi355_quantize_act((const float *)src1->data, aq, ads, K, N, ne12, ne13, src1->nb[1], src1->nb[2], src1->nb[3], ctx->stream));
+        ctx->act_remember(src1, bf16);
     }
 
     if (!tensor_is_split(src0)) {
-        mi355_mul_mat_launch(dst, (const char *)src0->data, 0, M, aq, ads, ctx->stream);
+        mi355_mul_mat_launch(dst, (const char *)src0->data, 0, M, aq, ads, ctx->stream, bf16);
         return;
     }
 
@@ -745,13 +768,13 @@ static void mi355_mul_mat(mi355_backend_ctx * ctx, ggml_tensor * dst) {
             p.act_version = ctx->act_version;
         }
         mi355_mul_mat_launch(dst, (const char *)extra->data[d], extra->row_low[d], extra->row_high[d] - extra->row_low[d],
-                             (const int8_t *)p.act, (const float *)((const char *)p.act + qb), p.stream);
+                             (const int8_t *)p.act, (const float *)((const char *)p.act + qb), p.stream, bf16);
         HIP_CHECK(hipEventRecord(p.done, p.stream));
     }
     mi355_set_device(ctx->device);
     if (extra->data[ctx->device]) {
         mi355_mul_mat_launch(dst, (const char *)extra->data[ctx->device], extra->row_low[ctx->device],
-                             extra->row_high[ctx->device] - extra->row_low[ctx->device], aq, ads, ctx->stream);
+                             extra->row_high[ctx->device] - extra->row_low[ctx->device], aq, ads, ctx->stream, bf16);
     }
     for (int d = 0; d < ndev; d++) {
         if (d == ctx->device || !extra->data[d]) continue;
@@ -971,13 +994,102 @@ static bool mi355_glu_with_quant(mi355_backend_ctx * ctx, ggml_tensor * node) {
     return true;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Grouped decode mat-vecs.  wq/wk/wv (and ffn gate/up) read the same activation; llama.cpp's graph has them a few
+// nodes apart (the rope of Q sits between wq and wk).  When MUL_MAT node i is a decode mat-vec, later MUL_MATs with
+// the same src1, weight type and shapes are HOISTED into its launch (mi355_mul_mat_vec_q_group) -- legal when
+// nothing between i and j reads or writes the bytes node j's result will occupy (ggml-alloc reuses freed blocks, so
+// this is checked on addresses) and nothing in between writes src1.  Hoisted nodes are marked done and skipped.
+// ------------------------------------------------------------------------------------------------
+static bool ranges_overlap(const void * a, size_t an, const void * b, size_t bn) {
+    const char * a0 = (const char *)a, * b0 = (const char *)b;
+    return a0 < b0 + bn && b0 < a0 + an;
+}
+
+static bool is_view_op(const ggml_tensor * t) {
+    return t->op == GGML_OP_NONE || t->op == GGML_OP_RESHAPE || t->op == GGML_OP_VIEW || t->op == GGML_OP_PERMUTE || t->op == GGML_OP_TRANSPOSE;
+}
+
+static bool matvec_groupable(const ggml_tensor * node) {
+    if (node->op != GGML_OP_MUL_MAT) return false;
+    const ggml_tensor * a = node->src[0], * b = node->src[1];
+    if (!is_weight_type(a->type) || tensor_is_split(a) || a->op != GGML_OP_NONE || a->view_src) return false;
+    if (a->ne[2] != 1 || a->ne[3] != 1 || b->ne[2] != 1 || b->ne[3] != 1 || b->ne[1] < 1 || b->ne[1] > 8) return false;
+    return ggml_is_contiguous(node) && a->ne[1] > 0;
+}
+
+static int mi355_collect_matvec_group(ggml_cgraph * cgraph, int i, const std::vector<char> & done, int * members) {
+    const int n = ggml_graph_n_nodes(cgraph);
+    const ggml_tensor * first = ggml_graph_node(cgraph, i);
+    const ggml_tensor * src1 = first->src[1];
+    int cnt = 0;
+    members[cnt++] = i;
+    const int horizon = i + 12 < n ? i + 12 : n;
+    for (int j = i + 1; j < horizon && cnt < MI355_MMVQ_MAX_GROUP; j++) {
+        const ggml_tensor * cand = ggml_graph_node(cgraph, j);
+        if (done[j] || !matvec_groupable(cand) || cand->src[1] != src1 || cand->src[0]->type != first->src[0]->type ||
+            cand->src[0]->ne[0] != first->src[0]->ne[0]) continue;
+        const size_t dn = ggml_nbytes(cand);
+        bool safe = !ranges_overlap(cand->data, dn, src1->data, ggml_nbytes(src1));
+        for (int m = 0; m < cnt && safe; m++) {
+            const ggml_tensor * g = ggml_graph_node(cgraph, members[m]);
+            if (ranges_overlap(cand->data, dn, g->data, ggml_nbytes(g))) safe = false;
+        }
+        for (int t = i + 1; t < j && safe; t++) {
+            const ggml_tensor * mid = ggml_graph_node(cgraph, t);
+            if (done[t] || ggml_is_empty(mid)) continue;
+            bool member = false;
+            for (int m = 0; m < cnt; m++) if (members[m] == t) member = true;
+            if (member) continue;
+            if (!is_view_op(mid)) {
+                if (ranges_overlap(cand->data, dn, mid->data, ggml_nbytes(mid))) safe = false;              // would clobber / be clobbered
+                if (ranges_overlap(src1->data, ggml_nbytes(src1), mid->data, ggml_nbytes(mid))) safe = false; // src1 rewritten before j
+            }
+            for (int sidx = 0; sidx < GGML_MAX_SRC && safe; sidx++) {
+                const ggml_tensor * ms = mid->src[sidx];
+                if (ms && ms->data && ranges_overlap(cand->data, dn, ms->data, ggml_nbytes(ms))) safe = false; // reads the old contents
+            }
+        }
+        if (safe) members[cnt++] = j;
+    }
+    return cnt;
+}
+
+static void mi355_mul_mat_group(mi355_backend_ctx * ctx, ggml_cgraph * cgraph, const int * members, int cnt) {
+    const ggml_tensor * first = ggml_graph_node(cgraph, members[0]);
+    const ggml_tensor * src1 = first->src[1];
+    const int64_t K = src1->ne[0], N = src1->ne[1];
+    const size_t qb = align_up((size_t)mi355_act_q_bytes(K, N), 256);
+    const size_t db = align_up((size_t)mi355_act_ds_bytes(K, N), 256);
+    char * ws = (char *)ctx->get_scratch(0, qb + db);
+    if (!ctx->act_cached(src1)) {
+        MI_CHECK(mi355_quantize_act((const float *)src1->data, (int8_t *)ws, (float *)(ws + qb), K, N, 1, 1, src1->nb[1], src1->nb[2], src1->nb[3], ctx->stream));
+        ctx->act_remember(src1);
+    }
+    mi355_mmvq_args a[MI355_MMVQ_MAX_GROUP];
+    memset(a, 0, sizeof(a));
+    for (int m = 0; m < cnt; m++) {
+        const ggml_tensor * node = ggml_graph_node(cgraph, members[m]);
+        const ggml_tensor * w = node->src[0];
+        a[m].type = (int32_t)w->type;
+        a[m].W = w->data; a[m].w_row_stride = (int64_t)w->nb[1];
+        a[m].act_q = (const int8_t *)ws; a[m].act_ds = (const float *)(ws + qb); a[m].act_ch_stride = N;
+        a[m].dst = (float *)node->data; a[m].dst_col_stride = (int64_t)(node->nb[1] / sizeof(float));
+        a[m].m = w->ne[1]; a[m].k = K; a[m].ncols = (int32_t)N; a[m].nchannels = 1; a[m].ch_ratio = 1;
+    }
+    MI_CHECK(mi355_mul_mat_vec_q_group(a, cnt, ctx->stream));
+}
+
 static enum ggml_status mi355_backend_graph_compute(ggml_backend_t backend, ggml_cgraph * cgraph) {
     mi355_backend_ctx * ctx = (mi355_backend_ctx *)backend->context;
     mi355_set_device(ctx->device);
     ctx->act_cache.valid = false; // tensors may have been rewritten through set_tensor / copies between calls
     const int n = ggml_graph_n_nodes(cgraph);
+    const bool fuse = getenv("GGML_MI355_NO_FUSE") == nullptr;
+    std::vector<char> done(n, 0);    // nodes already computed by a hoisting fusion
     for (int i = 0; i < n; i++) {
         ggml_tensor * node = ggml_graph_node(cgraph, i);
+        if (done[i]) continue;
         // empty tensors and pure view ops compute nothing (ggml-cuda.cu:2589)
         if (ggml_is_empty(node) || node->op == GGML_OP_NONE || node->op == GGML_OP_RESHAPE || node->op == GGML_OP_VIEW ||
             node->op == GGML_OP_PERMUTE || node->op == GGML_OP_TRANSPOSE) {
@@ -990,6 +1102,16 @@ static enum ggml_status mi355_backend_graph_compute(ggml_backend_t backend, ggml
             continue;
         }
         ctx->act_invalidate_if_written(node);
+        // fusion: decode mat-vecs that share their activation run as one grouped launch
+        if (fuse && matvec_groupable(node)) {
+            int members[MI355_MMVQ_MAX_GROUP];
+            const int cnt = mi355_collect_matvec_group(cgraph, i, done, members);
+            if (cnt > 1) {
+                mi355_mul_mat_group(ctx, cgraph, members, cnt);
+                for (int m = 1; m < cnt; m++) done[members[m]] = 1;
+                continue;
+            }
+        }
         // fusion: RMS_NORM followed by MUL with the per-feature norm weight (every llama layer), when the
         // norm result has no other reader in this graph
         if (node->op == GGML_OP_RMS_NORM && i + 1 < n && mi355_try_fuse_rms_norm_mul(ctx, cgraph, i)) {

@@ -1,0 +1,306 @@
+// mmdq.hip -- prefill MUL_MAT on block-quantized weights as a dequantize-in-LDS bf16 MFMA GEMM.
+//
+// Same contract as mul_mat_q (ggml/src/ggml-cuda/mmq.cu:68-224): dst[n][m] = sum_k W[m][k] * x[n][k], f32 out,
+// N > 8.  The int8 tile kernel (mmq.hip) follows the reference's MMQ arithmetic -- int8 x int8 -> i32 per
+// 32-block, f32 rescale per block -- and that rescale is its bound on CDNA4: ~50 VALU instructions per
+// 32x32 tile per 32-block against 32 cycles of MFMA, i.e. the matrix cores idle ~90 % of the time.
+// Here the per-block scales are applied ONCE per weight while the tile is staged (each weight of the
+// 128 x 64 tile is dequantized exactly as dequantize_row_* does, then rounded to bf16), the activations
+// are rounded f32 -> bf16 once per distinct src1 (mi355_act_bf16; no q8_1 pass at all), and the inner loop is nothing but
+// ds_read_b128 + v_mfma_f32_32x32x16_bf16 with f32 accumulation.  Error: two bf16 roundings per
+// product (2^-9 relative each) ~ 3e-6 NMSE, well inside the 5e-4 budget of test-backend-ops and
+// smaller than the q8 activation quantization of either reference backend.
+//
+// Roofline: bf16 MFMA (2.5 PFLOP/s dense).  flops = 2*M*N*K (tests/test-backend-ops.cpp:2262-2265).
+//
+// Tiling: workgroup = 256 threads = 4 waves, output tile 128 (weight rows) x 128 (activation columns),
+// K step 64.  Each wave owns 64 x 64 = 2 x 2 MFMA tiles.  LDS rows have a 144-byte pitch (128 B of
+// bf16 + 16) so the 16-byte operand reads of 32 consecutive rows spread over all banks.  Global loads
+// of stage s+1 are issued into registers before the MFMAs of stage s (single LDS buffer, register
+// prefetch).
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int PITCH = BK * 2 + 16;   // bytes per LDS row
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+struct DArgs {
+    const uint8_t * W; int64_t w_row_stride;
+    const uint16_t * x; int64_t x_row_stride;  // bf16 activations (mi355_act_bf16), elements between columns
+    float * dst; int64_t dst_col_stride;
+    int m, n, k;
+};
+
+// 32 consecutive weights of one row, raw, as loaded from global memory
+template <int TYPE> struct Raw;
+template <> struct Raw<MI355_TYPE_Q4_K> { v4i q0, q1, hdr; };
+template <> struct Raw<MI355_TYPE_Q5_K> { v4i q0, q1, h0, h1, hdr; };
+template <> struct Raw<MI355_TYPE_Q6_K> { v4i l0, l1, h0, h1; uint32_t sc; uint16_t d; };
+template <> struct Raw<MI355_TYPE_Q8_0> { v4i q0, q1; uint16_t d; };
+template <> struct Raw<MI355_TYPE_Q4_0> { v4i qs; uint16_t d; };
+
+template <int TYPE>
+static __device__ __forceinline__ Raw<TYPE> load_raw(const uint8_t * wrow, int k) {   // k % 32 == 0
+    Raw<TYPE> r;
+    if constexpr (TYPE == MI355_TYPE_Q4_K) {
+        const uint8_t * blk = wrow + (int64_t)(k >> 8) * 144;
+        const int j = (k >> 5) & 7;
+        r.q0 = *(const v4i *)(blk + 16 + (j >> 1) * 32);
+        r.q1 = *(const v4i *)(blk + 32 + (j >> 1) * 32);
+        r.hdr = *(const v4i *)blk;
+    } else if constexpr (TYPE == MI355_TYPE_Q5_K) {
+        const uint8_t * blk = wrow + (int64_t)(k >> 8) * 176;
+        const int j = (k >> 5) & 7;
+        r.q0 = *(const v4i *)(blk + 48 + (j >> 1) * 32);
+        r.q1 = *(const v4i *)(blk + 64 + (j >> 1) * 32);
+        r.h0 = *(const v4i *)(blk + 16);
+        r.h1 = *(const v4i *)(blk + 32);
+        r.hdr = *(const v4i *)blk;
+    } else if constexpr (TYPE == MI355_TYPE_Q6_K) {
+        // chunk = quarter i of half n: ql[64n + 32(i&1) + l] nibble (i>>1), qh[32n + l] >> 2i, sc[8n + 2i + l/16]
+        const uint8_t * blk = wrow + (int64_t)(k >> 8) * 210;
+        const int n = (k >> 7) & 1, i = (k >> 5) & 3;
+        r.l0 = ld16_a2(blk + 64 * n + 32 * (i & 1));
+        r.l1 = ld16_a2(blk + 64 * n + 32 * (i & 1) + 16);
+        r.h0 = ld16_a2(blk + 128 + 32 * n);
+        r.h1 = ld16_a2(blk + 128 + 32 * n + 16);
+        r.sc = ld_u16(blk + 192 + 8 * n + 2 * i);
+        r.d  = ld_u16(blk + 208);
+    } else if constexpr (TYPE == MI355_TYPE_Q8_0) {
+        const uint8_t * blk = wrow + (int64_t)(k >> 5) * 34;
+        r.q0 = ld16_a2(blk + 2);
+        r.q1 = ld16_a2(blk + 18);
+        r.d  = ld_u16(blk);
+    } else {
+        const uint8_t * blk = wrow + (int64_t)(k >> 5) * 18;
+        r.qs = ld16_a2(blk + 2);
+        r.d  = ld_u16(blk);
+    }
+    return r;
+}
+
+static __device__ __forceinline__ void k4_one(const v4i hdr, int j, float & dsc, float & dm) {
+    // get_scale_min_k4 (ggml-quants.c:625-632) for sub-block j, times d / dmin
+    const uint32_t u0 = hdr.y, u1 = hdr.z, u2 = hdr.w;
+    const int g = j >> 1, sh = (g & 1) * 16 + (j & 1) * 8;
+    uint32_t sc, m;
+    if (g & 2) {
+        sc = ((u2 >> sh) & 0x0fu) | (((u0 >> (sh + 6)) & 0x03u) << 4);
+        m  = ((u2 >> (sh + 4)) & 0x0fu) | (((u1 >> (sh + 6)) & 0x03u) << 4);
+    } else {
+        sc = (u0 >> sh) & 0x3fu;
+        m  = (u1 >> sh) & 0x3fu;
+    }
+    dsc = h2f((uint16_t)(hdr.x & 0xffff)) * (float)sc;
+    dm  = h2f((uint16_t)((uint32_t)hdr.x >> 16)) * (float)m;
+}
+
+static __device__ __forceinline__ float ubyte(int w, int i) { return (float)((w >> (8 * i)) & 0xff); }
+
+// dequantize the 32 weights to f32 (same formulas as dequantize_row_*, ggml-quants.c)
+template <int TYPE>
+static __device__ __forceinline__ void dequant32(const Raw<TYPE> & r, int k, float * f) {
+    if constexpr (TYPE == MI355_TYPE_Q4_K || TYPE == MI355_TYPE_Q5_K) {
+        const int j = (k >> 5) & 7, sh = (j & 1) * 4;
+        float dsc, dm;
+        k4_one(r.hdr, j, dsc, dm);
+#pragma unroll
+        for (int w = 0; w < 8; w++) {
+            int q = ((w < 4 ? r.q0[w] : r.q1[w - 4]) >> sh) & 0x0f0f0f0f;
+            if constexpr (TYPE == MI355_TYPE_Q5_K) q |= (((w < 4 ? r.h0[w] : r.h1[w - 4]) >> j) & 0x01010101) << 4;
+#pragma unroll
+            for (int i = 0; i < 4; i++) f[4 * w + i] = dsc * ubyte(q, i) - dm;
+        }
+    } else if constexpr (TYPE == MI355_TYPE_Q6_K) {
+        const int i2 = (k >> 5) & 3;
+        const float d = h2f(r.d);
+        const float s0 = d * (float)(int8_t)(r.sc & 0xff), s1 = d * (float)(int8_t)(r.sc >> 8);
+#pragma unroll
+        for (int w = 0; w < 8; w++) {
+            const int ql = ((w < 4 ? r.l0[w] : r.l1[w - 4]) >> (4 * (i2 >> 1))) & 0x0f0f0f0f;
+            const int qh = (((w < 4 ? r.h0[w] : r.h1[w - 4]) >> (2 * i2)) & 0x03030303) << 4;
+            const int q = ql | qh;
+#pragma unroll
+            for (int i = 0; i < 4; i++) f[4 * w + i] = (w < 4 ? s0 : s1) * (ubyte(q, i) - 32.0f);
+        }
+    } else if constexpr (TYPE == MI355_TYPE_Q8_0) {
+        const float d = h2f(r.d);
+#pragma unroll
+        for (int w = 0; w < 8; w++) {
+            const int q = w < 4 ? r.q0[w] : r.q1[w - 4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) f[4 * w + i] = d * (float)(int8_t)(q >> (8 * i));
+        }
+    } else {
+        const float d = h2f(r.d);
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                f[4 * w + i]      = d * (ubyte(r.qs[w] & 0x0f0f0f0f, i) - 8.0f);
+                f[16 + 4 * w + i] = d * (ubyte((r.qs[w] >> 4) & 0x0f0f0f0f, i) - 8.0f);
+            }
+        }
+    }
+}
+
+// 32 f32 -> 32 bf16 (round to nearest even), 64 bytes into LDS
+static __device__ __forceinline__ void store_bf16x32(uint8_t * dst, const float * f) {
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        bf16x8 v;
+#pragma unroll
+        for (int i = 0; i < 8; i++) v[i] = (__bf16)f[8 * c + i];
+        *(bf16x8 *)(dst + 16 * c) = v;
+    }
+}
+
+template <int TYPE>
+__global__ void __launch_bounds__(256)
+mmdq_kernel(const DArgs a) {
+    __shared__ __attribute__((aligned(16))) uint8_t Lw[BM * PITCH];
+    __shared__ __attribute__((aligned(16))) uint8_t La[BN * PITCH];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
+    const int wm_ = wave & 1, wn_ = wave >> 1;       // wave's 64 x 64 sub-tile
+    const int lr = lane & 31, lh = lane >> 5;
+
+    // staging role: row / column (tid >> 1), 32-value half (tid & 1)
+    const int sr = tid >> 1, hf = tid & 1;
+    const int wr = m0 + sr < a.m ? m0 + sr : a.m - 1;
+    const uint8_t * wrow = a.W + (int64_t)wr * a.w_row_stride;
+    const int col = n0 + sr;
+    const bool col_ok = col < a.n;
+    const uint16_t * xcol = a.x + (int64_t)(col_ok ? col : 0) * a.x_row_stride;
+
+    v16f acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
+
+    Raw<TYPE> wraw = load_raw<TYPE>(wrow, hf * 32);
+    v4i xraw[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) xraw[i] = ((const v4i *)(xcol + hf * 32))[i];
+
+    for (int k0 = 0; k0 < a.k; k0 += BK) {
+        // registers -> LDS (dequantized / rounded to bf16)
+        {
+            float f[32];
+            dequant32<TYPE>(wraw, k0 + hf * 32, f);
+            store_bf16x32(Lw + sr * PITCH + hf * 64, f);
+            const v4i z = {0, 0, 0, 0};
+#pragma unroll
+            for (int i = 0; i < 4; i++) *(v4i *)(La + sr * PITCH + hf * 64 + 16 * i) = col_ok ? xraw[i] : z;
+        }
+        __syncthreads();
+        // next stage's global loads fly during the MFMAs
+        if (k0 + BK < a.k) {
+            wraw = load_raw<TYPE>(wrow, k0 + BK + hf * 32);
+#pragma unroll
+            for (int i = 0; i < 4; i++) xraw[i] = ((const v4i *)(xcol + k0 + BK + hf * 32))[i];
+        }
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ks++) {
+            bf16x8 af[2], wf[2];
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                af[t] = *(const bf16x8 *)(La + (wn_ * 64 + t * 32 + lr) * PITCH + ks * 32 + lh * 16);
+                wf[t] = *(const bf16x8 *)(Lw + (wm_ * 64 + t * 32 + lr) * PITCH + ks * 32 + lh * 16);
+            }
+#pragma unroll
+            for (int tm = 0; tm < 2; tm++)
+#pragma unroll
+                for (int tn = 0; tn < 2; tn++)
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tn], wf[tm], acc[tm][tn], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // C register r of lane (lr, lh): activation column n = (r&3) + 8*(r>>2) + 4*lh, weight row m = lr
+#pragma unroll
+    for (int tm = 0; tm < 2; tm++) {
+        const int m = m0 + wm_ * 64 + tm * 32 + lr;
+#pragma unroll
+        for (int tn = 0; tn < 2; tn++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int n = n0 + wn_ * 64 + tn * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (m < a.m && n < a.n) a.dst[(int64_t)n * a.dst_col_stride + m] = acc[tm][tn][r];
+            }
+    }
+}
+
+// f32 (4-D, strided rows) -> bf16 [rows][k], round to nearest even; one lane per 8 values
+__global__ void __launch_bounds__(256)
+act_bf16_kernel(const char * x, uint16_t * y, int k, int ne1, int ne2, int64_t nb1, int64_t nb2, int64_t nb3) {
+    const int row = blockIdx.x;
+    const int i1 = row % ne1, i2 = (row / ne1) % ne2, i3 = row / (ne1 * ne2);
+    const float * xr = (const float *)(x + i1 * nb1 + i2 * nb2 + i3 * nb3);
+    for (int c = blockIdx.y * 256 + threadIdx.x; c * 8 < k; c += gridDim.y * 256) {
+        const v4f a = ((const v4f *)xr)[2 * c], b = ((const v4f *)xr)[2 * c + 1];
+        bf16x8 v;
+        v[0] = (__bf16)a.x; v[1] = (__bf16)a.y; v[2] = (__bf16)a.z; v[3] = (__bf16)a.w;
+        v[4] = (__bf16)b.x; v[5] = (__bf16)b.y; v[6] = (__bf16)b.z; v[7] = (__bf16)b.w;
+        *(bf16x8 *)(y + (int64_t)row * k + 8 * c) = v;
+    }
+}
+
+template <int TYPE>
+static int launch(const DArgs & a, hipStream_t s, const char * tag) {
+    const dim3 grid((unsigned)((a.n + BN - 1) / BN), (unsigned)((a.m + BM - 1) / BM));
+    MI355_LAUNCH(tag, (mmdq_kernel<TYPE>), grid, dim3(256), 0, s, a);
+    MI355_CHECK_LAUNCH();
+    return MI355_OK;
+}
+
+} // namespace
+
+extern "C" int mi355_act_bf16(const float * x, uint16_t * y, int64_t k, int64_t ne1, int64_t ne2, int64_t ne3,
+                              int64_t nb1, int64_t nb2, int64_t nb3, void * stream) {
+    if (!x || !y) return MI355_E_NULL;
+    if (k <= 0 || k % 8 != 0 || ne1 < 0 || ne2 < 0 || ne3 < 0 || k > 0x7fffffff) return MI355_E_SHAPE;
+    const int64_t rows = ne1 * ne2 * ne3;
+    if (rows > 0x7fffffff) return MI355_E_SHAPE;
+    if (((uintptr_t)x | (uintptr_t)y | (uintptr_t)nb1 | (uintptr_t)nb2 | (uintptr_t)nb3) & 15) return MI355_E_ALIGN;
+    if (rows == 0) return MI355_OK;
+    const unsigned gy = (unsigned)((k / 8 + 255) / 256);
+    MI355_LAUNCH("act_bf16", act_bf16_kernel, dim3((unsigned)rows, gy < 64 ? gy : 64), dim3(256), 0, (hipStream_t)stream,
+                 (const char *)x, y, (int)k, (int)ne1, (int)ne2, nb1, nb2, nb3);
+    MI355_CHECK_LAUNCH();
+    return MI355_OK;
+}
+
+extern "C" int mi355_mul_mat_dq(int type, const void * W, int64_t w_row_stride, const uint16_t * x, int64_t x_row_stride,
+                                float * dst, int64_t dst_col_stride, int64_t m, int64_t k, int64_t n, void * stream) {
+    if (!W || !x || !dst) return MI355_E_NULL;
+    const int64_t bs = mi355_blck_size(type);
+    if (bs == 0 || type == MI355_TYPE_F32 || type == MI355_TYPE_F16 || type == MI355_TYPE_Q8_1) return MI355_E_TYPE;
+    if (m < 0 || n < 0 || k <= 0 || k % bs != 0 || m > 0x7fffffff || n > 0x7fffffff || k > 0x7fffffff) return MI355_E_SHAPE;
+    if (k % BK != 0) return MI355_E_UNSUPPORTED;          // caller falls back to the mat-vec kernel
+    if ((n + BN - 1) / BN > 0x7fffffff / 2 || (m + BM - 1) / BM > 65535) return MI355_E_UNSUPPORTED;
+    if (((uintptr_t)x & 15) || (x_row_stride & 7) || ((uintptr_t)dst & 3) || x_row_stride < k) return MI355_E_ALIGN;
+    const bool a16 = type == MI355_TYPE_Q4_K || type == MI355_TYPE_Q5_K;
+    if (((uintptr_t)W | (uintptr_t)w_row_stride) & (a16 ? 15 : 1)) return MI355_E_ALIGN;
+    if (w_row_stride < mi355_row_size(type, k)) return MI355_E_SHAPE;
+    if (m == 0 || n == 0) return MI355_OK;
+    DArgs a;
+    a.W = (const uint8_t *)W; a.w_row_stride = w_row_stride; a.x = x; a.x_row_stride = x_row_stride;
+    a.dst = dst; a.dst_col_stride = dst_col_stride; a.m = (int)m; a.n = (int)n; a.k = (int)k;
+    hipStream_t s = (hipStream_t)stream;
+    switch (type) {
+        case MI355_TYPE_Q4_0: return launch<MI355_TYPE_Q4_0>(a, s, "mmdq_q4_0");
+        case MI355_TYPE_Q8_0: return launch<MI355_TYPE_Q8_0>(a, s, "mmdq_q8_0");
+        case MI355_TYPE_Q4_K: return launch<MI355_TYPE_Q4_K>(a, s, "mmdq_q4_K");
+        case MI355_TYPE_Q5_K: return launch<MI355_TYPE_Q5_K>(a, s, "mmdq_q5_K");
+        case MI355_TYPE_Q6_K: return launch<MI355_TYPE_Q6_K>(a, s, "mmdq_q6_K");
+    }
+    return MI355_E_TYPE;
+}

@@ -26,6 +26,7 @@
 #include "common.h"
 #include <stdlib.h>
 #include <string>
+#include <string.h>
 
 namespace {
 
@@ -294,45 +295,28 @@ struct KArgs {
 // reads with ds_read_b128, not flat loads)
 struct ActLds { const __attribute__((address_space(3))) int8_t * q; const __attribute__((address_space(3))) float * ds; };
 
+// One wave, one weight row: the body shared by the single-matrix and the grouped kernel.
+//   wmat: first row of the matrix; row: this wave's row (rows >= m compute on the last row and store nothing)
 template <int TYPE, int NCOLS, bool LDSACT>
-__global__ void __launch_bounds__(256)
-mmvq_kernel(const KArgs a) {
+static __device__ __forceinline__ void mmvq_row(const uint8_t * wmat, int64_t w_row_stride, int m, int row, const int8_t * gq,
+                                                const float * gds, int k, float * dch, int64_t dst_col_stride, uint8_t * lds) {
     typedef Unit<TYPE> U;
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const int ch   = blockIdx.y;
-
-    int64_t ch_w, act_row;
-    if (a.ids) {
-        const int tok = ch / a.ids_nused, slot = ch % a.ids_nused;
-        const int ex = a.ids[(int64_t)tok * a.ids_stride + slot];
-        if (ex < 0 || ex >= a.n_expert) return; // out-of-range expert id (uniform per workgroup): dst untouched
-        ch_w    = ex;
-        act_row = (int64_t)tok * a.act_ch_stride + slot % a.act_ne1;
-    } else {
-        ch_w    = ch / a.ch_ratio;
-        act_row = (int64_t)ch * a.act_ch_stride;
-    }
-
-    const int row  = blockIdx.x * 4 + wave;
-    const int rowc = row < a.m ? row : a.m - 1;           // tail waves re-read the last row, never store
-    const uint8_t * wrow = a.W + ch_w * a.w_ch_stride + (int64_t)rowc * a.w_row_stride;
-    const int8_t * gq  = a.act_q + act_row * a.k;
-    const float  * gds = a.act_ds + act_row * (a.k / QK) * 2;
+    const int rowc = row < m ? row : m - 1;           // tail waves re-read the last row, never store
+    const uint8_t * wrow = wmat + (int64_t)rowc * w_row_stride;
 
     // Uniform trip count (lanes past the end re-read the last unit and contribute 0) so the loads
     // are unconditional; the first weight loads are issued before the activation staging so their
     // HBM latency overlaps it.
-    const int nunits = a.k / U::ELEMS;
+    const int nunits = k / U::ELEMS;
     const int niter  = (nunits + 63) >> 6;
     typename U::Raw cur = U::load(wrow, lane < nunits ? lane : nunits - 1);
 
     if (LDSACT) {
         // activations -> LDS: [NCOLS][k] int8, then [NCOLS][k/32][2] f32 (columns are contiguous rows of act)
-        const int nq = NCOLS * a.k / 16, nds = NCOLS * (a.k / QK); // 16-byte chunks of q, {d, sum} pairs
+        const int nq = NCOLS * k / 16, nds = NCOLS * (k / QK); // 16-byte chunks of q, {d, sum} pairs
         for (int i = threadIdx.x; i < nq; i += 256) ((v4i *)lds)[i] = ((const v4i *)gq)[i];
-        v2f * lds_ds = (v2f *)(lds + (size_t)NCOLS * a.k);
+        v2f * lds_ds = (v2f *)(lds + (size_t)NCOLS * k);
         for (int i = threadIdx.x; i < nds; i += 256) lds_ds[i] = ((const v2f *)gds)[i];
         __syncthreads();
     }
@@ -353,12 +337,12 @@ mmvq_kernel(const KArgs a) {
         typename U::Act av[NCOLS];
         if (LDSACT) {
             const auto lq  = (const __attribute__((address_space(3))) int8_t *)lds;
-            const auto lds_ = (const __attribute__((address_space(3))) float *)(lds + (size_t)NCOLS * a.k);
+            const auto lds_ = (const __attribute__((address_space(3))) float *)(lds + (size_t)NCOLS * k);
 #pragma unroll
-            for (int c = 0; c < NCOLS; c++) av[c] = U::load_act(ActLds{lq + c * a.k, lds_ + c * (a.k / QK) * 2}, u);
+            for (int c = 0; c < NCOLS; c++) av[c] = U::load_act(ActLds{lq + c * k, lds_ + c * (k / QK) * 2}, u);
         } else {
 #pragma unroll
-            for (int c = 0; c < NCOLS; c++) av[c] = U::load_act(ActPtr{gq + (int64_t)c * a.k, gds + (int64_t)c * (a.k / QK) * 2}, u);
+            for (int c = 0; c < NCOLS; c++) av[c] = U::load_act(ActPtr{gq + (int64_t)c * k, gds + (int64_t)c * (k / QK) * 2}, u);
         }
         __builtin_amdgcn_sched_barrier(0);
         const typename U::Dec w = U::decode(cur, u);
@@ -370,12 +354,59 @@ mmvq_kernel(const KArgs a) {
         if (it + 1 < niter) cur = nxt;
     }
 
-    float * dch = a.dst + (int64_t)ch * a.dst_ch_stride;
 #pragma unroll
     for (int c = 0; c < NCOLS; c++) {
         const float v = wave_sum(acc[c]);
-        if (lane == 0 && row < a.m) dch[(int64_t)c * a.dst_col_stride + row] = v;
+        if (lane == 0 && row < m) dch[(int64_t)c * dst_col_stride + row] = v;
     }
+}
+
+template <int TYPE, int NCOLS, bool LDSACT>
+__global__ void __launch_bounds__(256)
+mmvq_kernel(const KArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const int wave = threadIdx.x >> 6;
+    const int ch   = blockIdx.y;
+
+    int64_t ch_w, act_row;
+    if (a.ids) {
+        const int tok = ch / a.ids_nused, slot = ch % a.ids_nused;
+        const int ex = a.ids[(int64_t)tok * a.ids_stride + slot];
+        if (ex < 0 || ex >= a.n_expert) return; // out-of-range expert id (uniform per workgroup): dst untouched
+        ch_w    = ex;
+        act_row = (int64_t)tok * a.act_ch_stride + slot % a.act_ne1;
+    } else {
+        ch_w    = ch / a.ch_ratio;
+        act_row = (int64_t)ch * a.act_ch_stride;
+    }
+    mmvq_row<TYPE, NCOLS, LDSACT>(a.W + ch_w * a.w_ch_stride, a.w_row_stride, a.m, blockIdx.x * 4 + wave,
+                                  a.act_q + act_row * a.k, a.act_ds + act_row * (a.k / QK) * 2, a.k,
+                                  a.dst + (int64_t)ch * a.dst_ch_stride, a.dst_col_stride, lds);
+}
+
+// Grouped launch: up to MI355_MMVQ_MAX_GROUP matrices of the same type and K that read the SAME activations
+// (wq/wk/wv, ffn gate/up) share one grid, so the per-launch floor (dispatch + cold-start latency + tail) is paid
+// once.  Workgroups [blk_end[i-1], blk_end[i]) belong to matrix i.
+struct KGroup {
+    const uint8_t * W[MI355_MMVQ_MAX_GROUP]; int64_t w_row_stride[MI355_MMVQ_MAX_GROUP];
+    float * dst[MI355_MMVQ_MAX_GROUP]; int64_t dst_col_stride[MI355_MMVQ_MAX_GROUP];
+    int m[MI355_MMVQ_MAX_GROUP], blk_end[MI355_MMVQ_MAX_GROUP];
+    const int8_t * act_q; const float * act_ds;
+    int k, n;
+};
+
+template <int TYPE, int NCOLS, bool LDSACT>
+__global__ void __launch_bounds__(256)
+mmvq_group_kernel(const KGroup a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const int wave = threadIdx.x >> 6;
+    int mi = 0, blk0 = 0;
+#pragma unroll
+    for (int i = 0; i + 1 < MI355_MMVQ_MAX_GROUP; i++) {
+        if (i + 1 < a.n && (int)blockIdx.x >= a.blk_end[i]) { mi = i + 1; blk0 = a.blk_end[i]; }
+    }
+    mmvq_row<TYPE, NCOLS, LDSACT>(a.W[mi], a.w_row_stride[mi], a.m[mi], ((int)blockIdx.x - blk0) * 4 + wave, a.act_q, a.act_ds,
+                                  a.k, a.dst[mi], a.dst_col_stride[mi], lds);
 }
 
 static const char * type_name(int t) {
@@ -399,6 +430,32 @@ static int launch(const KArgs & a, int nchannels, hipStream_t stream) {
     return MI355_OK;
 }
 
+template <int TYPE, int NCOLS>
+static int launch_group(const KGroup & a, hipStream_t stream) {
+    const dim3 grid((unsigned)a.blk_end[a.n - 1]);
+    const size_t need = (size_t)NCOLS * ((size_t)a.k + (size_t)a.k / QK * 8);
+    static const std::string tag = std::string("mmvq_") + type_name(TYPE) + "_n" + std::to_string(NCOLS);
+    if (need <= LDS_ACT_LIMIT) MI355_LAUNCH(tag.c_str(), (mmvq_group_kernel<TYPE, NCOLS, true>), grid, dim3(256), need, stream, a);
+    else                       MI355_LAUNCH(tag.c_str(), (mmvq_group_kernel<TYPE, NCOLS, false>), grid, dim3(256), 0, stream, a);
+    MI355_CHECK_LAUNCH();
+    return MI355_OK;
+}
+
+template <int TYPE>
+static int dispatch_group_cols(const KGroup & a, int ncols, hipStream_t s) {
+    switch (ncols) {
+        case 1: return launch_group<TYPE, 1>(a, s);
+        case 2: return launch_group<TYPE, 2>(a, s);
+        case 3: return launch_group<TYPE, 3>(a, s);
+        case 4: return launch_group<TYPE, 4>(a, s);
+        case 5: return launch_group<TYPE, 5>(a, s);
+        case 6: return launch_group<TYPE, 6>(a, s);
+        case 7: return launch_group<TYPE, 7>(a, s);
+        case 8: return launch_group<TYPE, 8>(a, s);
+    }
+    return MI355_E_SHAPE;
+}
+
 template <int TYPE>
 static int dispatch_cols(const KArgs & a, int ncols, int nchannels, hipStream_t s) {
     switch (ncols) {
@@ -416,7 +473,7 @@ static int dispatch_cols(const KArgs & a, int ncols, int nchannels, hipStream_t 
 
 } // namespace
 
-extern "C" int mi355_mul_mat_vec_q(const mi355_mmvq_args * p, void * stream) {
+static int validate(const mi355_mmvq_args * p) {
     if (!p || !p->W || !p->act_q || !p->act_ds || !p->dst) return MI355_E_NULL;
     const int64_t bs = mi355_blck_size(p->type);
     if (bs == 0 || p->type == MI355_TYPE_F32 || p->type == MI355_TYPE_F16 || p->type == MI355_TYPE_Q8_1) return MI355_E_TYPE;
@@ -431,7 +488,14 @@ extern "C" int mi355_mul_mat_vec_q(const mi355_mmvq_args * p, void * stream) {
     const uintptr_t wal = (uintptr_t)p->W | (uintptr_t)p->w_row_stride | (uintptr_t)p->w_ch_stride;
     if (wal & (a16 ? 15 : 1)) return MI355_E_ALIGN;
     if (p->w_row_stride < mi355_row_size(p->type, p->k)) return MI355_E_SHAPE;
+    return MI355_OK;
+}
+
+extern "C" int mi355_mul_mat_vec_q(const mi355_mmvq_args * p, void * stream) {
+    const int rc = validate(p);
+    if (rc != MI355_OK) return rc;
     if (p->m == 0) return MI355_OK;
+    if (p->nchannels == 1 && !p->ids) return mi355_mul_mat_vec_q_group(p, 1, stream);   // one kernel for the plain case
 
     KArgs a;
     a.W = (const uint8_t *)p->W; a.w_row_stride = p->w_row_stride; a.w_ch_stride = p->w_ch_stride;
@@ -446,6 +510,40 @@ extern "C" int mi355_mul_mat_vec_q(const mi355_mmvq_args * p, void * stream) {
         case MI355_TYPE_Q4_K: return dispatch_cols<MI355_TYPE_Q4_K>(a, p->ncols, p->nchannels, s);
         case MI355_TYPE_Q5_K: return dispatch_cols<MI355_TYPE_Q5_K>(a, p->ncols, p->nchannels, s);
         case MI355_TYPE_Q6_K: return dispatch_cols<MI355_TYPE_Q6_K>(a, p->ncols, p->nchannels, s);
+    }
+    return MI355_E_TYPE;
+}
+
+extern "C" int mi355_mul_mat_vec_q_group(const mi355_mmvq_args * p, int n_mats, void * stream) {
+    if (!p) return MI355_E_NULL;
+    if (n_mats < 1 || n_mats > MI355_MMVQ_MAX_GROUP) return MI355_E_SHAPE;
+    KGroup a;
+    memset(&a, 0, sizeof(a));
+    int64_t blocks = 0;
+    int n = 0;
+    for (int i = 0; i < n_mats; i++) {
+        const int rc = validate(&p[i]);
+        if (rc != MI355_OK) return rc;
+        if (p[i].nchannels != 1 || p[i].ids) return MI355_E_UNSUPPORTED;
+        if (p[i].type != p[0].type || p[i].k != p[0].k || p[i].ncols != p[0].ncols || p[i].act_q != p[0].act_q ||
+            p[i].act_ds != p[0].act_ds) return MI355_E_SHAPE;
+        if (p[i].m == 0) continue;
+        a.W[n] = (const uint8_t *)p[i].W; a.w_row_stride[n] = p[i].w_row_stride;
+        a.dst[n] = p[i].dst; a.dst_col_stride[n] = p[i].dst_col_stride; a.m[n] = (int)p[i].m;
+        blocks += (p[i].m + 3) / 4;
+        if (blocks > 0x7fffffff) return MI355_E_SHAPE;
+        a.blk_end[n] = (int)blocks;
+        n++;
+    }
+    if (n == 0) return MI355_OK;
+    a.n = n; a.k = (int)p[0].k; a.act_q = p[0].act_q; a.act_ds = p[0].act_ds;
+    hipStream_t s = (hipStream_t)stream;
+    switch (p[0].type) {
+        case MI355_TYPE_Q4_0: return dispatch_group_cols<MI355_TYPE_Q4_0>(a, p[0].ncols, s);
+        case MI355_TYPE_Q8_0: return dispatch_group_cols<MI355_TYPE_Q8_0>(a, p[0].ncols, s);
+        case MI355_TYPE_Q4_K: return dispatch_group_cols<MI355_TYPE_Q4_K>(a, p[0].ncols, s);
+        case MI355_TYPE_Q5_K: return dispatch_group_cols<MI355_TYPE_Q5_K>(a, p[0].ncols, s);
+        case MI355_TYPE_Q6_K: return dispatch_group_cols<MI355_TYPE_Q6_K>(a, p[0].ncols, s);
     }
     return MI355_E_TYPE;
 }

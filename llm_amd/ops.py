@@ -74,6 +74,43 @@ def mul_mat_vec_q(t, w, m, k, aq, ads, ncols, dst=None, w_row_stride=None):
     return dst
 
 
+def mul_mat_vec_q_group(t, ws, ms, k, aq, ads, ncols):
+    """Grouped decode mat-vec: several weight matrices (same type and k) on the same pre-quantized activations in
+    ONE launch (mi355_mul_mat_vec_q_group).  ws: list of uint8 block tensors, ms: rows of each -> list of [ncols, m]."""
+    outs, arr = [], (K.MmvqArgs * len(ws))()
+    for i, (w, m) in enumerate(zip(ws, ms)):
+        _u8(w)
+        dst = torch.empty((ncols, m), dtype=torch.float32, device=w.device)
+        a = arr[i]
+        a.type, a.W, a.w_row_stride, a.w_ch_stride = t, w.data_ptr(), B.row_size(t, k), 0
+        a.act_q, a.act_ds, a.act_ch_stride = aq.data_ptr(), ads.data_ptr(), 0
+        a.dst, a.dst_col_stride, a.dst_ch_stride = dst.data_ptr(), dst.stride(0), 0
+        a.m, a.k, a.ncols, a.nchannels, a.ch_ratio = m, k, ncols, 1, 1
+        outs.append(dst)
+    K.check(K.lib.mi355_mul_mat_vec_q_group(arr, len(ws), _stream()), "mi355_mul_mat_vec_q_group")
+    return outs
+
+
+def act_bf16(b):
+    """f32 [n, k] (row stride free, 16-byte aligned) -> bf16 [n, k] as uint16 (mi355_act_bf16)."""
+    assert b.is_cuda and b.dtype == torch.float32 and b.dim() == 2 and b.stride(1) == 1
+    n, k = b.shape
+    y = torch.empty((n, k), dtype=torch.int16, device=b.device)
+    K.check(K.lib.mi355_act_bf16(b.data_ptr(), y.data_ptr(), k, n, 1, 1, b.stride(0) * 4, 0, 0, _stream()), "mi355_act_bf16")
+    return y
+
+
+def mul_mat_dq(t, w, b, m):
+    """Prefill GEMM through the dequantize-in-LDS bf16 MFMA kernel: b = [n, k] f32 -> [n, m] f32."""
+    _u8(w)
+    n, k = b.shape
+    y = act_bf16(b)
+    dst = torch.empty((n, m), dtype=torch.float32, device=b.device)
+    K.check(K.lib.mi355_mul_mat_dq(t, w.data_ptr(), B.row_size(t, k), y.data_ptr(), k, dst.data_ptr(), m, m, k, n,
+                                   _stream()), "mi355_mul_mat_dq")
+    return dst
+
+
 def mul_mat(t, w, b, m, workspace=None):
     """ggml_mul_mat: w = [m rows] blocks of type t (uint8), b = [n, k] f32 -> [n, m] f32."""
     _u8(w)

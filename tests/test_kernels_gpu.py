@@ -154,6 +154,44 @@ def test_mmq_int8_mfma_vs_oracle_contract(ops, t, m, k, n):
     assert O.nmse(O.mul_mat(t, w, x, m, k, n, "cpu"), got) <= 5e-4
 
 
+@pytest.mark.parametrize("t", B.WEIGHT_TYPES)
+@pytest.mark.parametrize("m,k,n", [(128, 256, 128), (130, 1024, 33), (64, 512, 9), (300, 2048, 200), (257, 256, 129), (1024, 4096, 512)])
+def test_mmdq_bf16_mfma_vs_dequantized_reference(ops, t, m, k, n):
+    """dequantize-in-LDS bf16 MFMA GEMM vs exact dequant(W) @ x in f64 (the ggml contract, ggml.c:2971-2986).
+    Error model: two bf16 roundings per product -> NMSE ~ 3e-6; the op's budget is 5e-4 (test-backend-ops)."""
+    if k % B.BLCK_SIZE[t]:
+        pytest.skip("k not a multiple of the block size")
+    rng = np.random.default_rng(m + k + n)
+    w = B.random_blocks(t, m, k, seed=m * 7 + n)
+    x = rng.standard_normal((n, k)).astype(np.float32)
+    got = ops.mul_mat_dq(t, dev(w), dev(x), m).cpu().numpy()
+    wf = O.dequantize_row(t, w, m * k).reshape(m, k).astype(np.float64)
+    ref = x.astype(np.float64) @ wf.T
+    err = float(((got - ref) ** 2).sum() / (ref ** 2).sum())
+    assert np.isfinite(got).all() and err < 2e-5, err
+    if n <= 64 and m <= 300:   # and against the reference's CPU arithmetic (q8 activations) within the op's budget
+        assert O.nmse(O.mul_mat(t, w, x, m, k, n, "cpu"), got) <= 5e-4
+
+
+def test_mmdq_strided_activations_and_errors(ops):
+    import llm_amd.kernels as K
+    rng = np.random.default_rng(5)
+    m, k, n = 192, 512, 40
+    w = B.random_blocks(B.Q4_K, m, k, seed=3)
+    xfull = rng.standard_normal((n, 2 * k)).astype(np.float32)      # row-padded view: stride 2k floats
+    xd = dev(xfull)
+    got = ops.mul_mat_dq(B.Q4_K, dev(w), xd[:, :k], m).cpu().numpy()
+    ref = ops.mul_mat_dq(B.Q4_K, dev(w), dev(xfull[:, :k].copy()), m).cpu().numpy()
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+    # the bf16 rounding itself is exact round-to-nearest-even
+    y = ops.act_bf16(xd[:, :k]).cpu().numpy().view(np.uint16)
+    exp = torch.from_numpy(xfull[:, :k].copy()).to(torch.bfloat16).view(torch.int16).numpy().view(np.uint16)
+    assert np.array_equal(y, exp)
+    assert K.lib.mi355_mul_mat_dq(B.Q4_K, 16, 16, 16, 288, 16, 1, 1, 256 + 32, 1, None) == -2   # k % 256
+    assert K.lib.mi355_mul_mat_dq(B.Q4_0, 16, 18, 16, 32, 16, 1, 1, 32, 1, None) == -6         # k % 64 -> caller falls back
+    assert K.lib.mi355_mul_mat_dq(B.Q4_K, None, 16, 16, 256, 16, 1, 1, 256, 1, None) == -4
+
+
 def test_mmq_matches_matvec_path_at_model_shape(ops):
     # pp512-shaped launch vs the decode kernel on the same data (first 8 columns)
     t, m, k, n = B.Q4_K, 1024, 4096, 512
@@ -176,6 +214,38 @@ def test_mul_mat_large_batch_falls_back_to_column_groups(ops):
 
 
 # ---------------------------------------------------------------- MUL_MAT_ID (decode-sized)
+@pytest.mark.parametrize("t", B.WEIGHT_TYPES)
+@pytest.mark.parametrize("ms,k,n", [((4096, 1024, 1024), 4096, 1), ((130, 7, 64, 1), 512, 3), ((300,), 2048, 8), ((2816, 2816), 1024, 2)])
+def test_mmvq_group_is_bit_identical_to_separate_launches(ops, t, ms, k, n):
+    """grouped QKV / gate+up launch (mi355_mul_mat_vec_q_group) == one launch per matrix, to the bit"""
+    rng = np.random.default_rng(k + n)
+    x = dev(rng.standard_normal((n, k)).astype(np.float32))
+    aq, ads = ops.quantize_act(x)
+    ws = [dev(B.random_blocks(t, m, k, seed=100 + i)) for i, m in enumerate(ms)]
+    sep = [ops.mul_mat_vec_q(t, w, m, k, aq, ads, n).cpu().numpy() for w, m in zip(ws, ms)]
+    grp = [o.cpu().numpy() for o in ops.mul_mat_vec_q_group(t, ws, list(ms), k, aq, ads, n)]
+    for a, b in zip(sep, grp):
+        assert np.isfinite(a).all() and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def test_mmvq_group_argument_errors(ops):
+    import llm_amd.kernels as K
+    arr = (K.MmvqArgs * 5)()
+    assert K.lib.mi355_mul_mat_vec_q_group(arr, 5, None) == -2          # more than MI355_MMVQ_MAX_GROUP
+    assert K.lib.mi355_mul_mat_vec_q_group(arr, 1, None) == -4          # NULL pointers
+    x = dev(np.zeros((1, 512), np.float32))
+    aq, ads = ops.quantize_act(x)
+    w = dev(B.random_blocks(B.Q4_K, 8, 512, seed=1))
+    w2 = dev(B.random_blocks(B.Q4_K, 8, 256, seed=2))
+    d = dev(np.zeros((1, 8), np.float32))
+    for i, (ww, kk) in enumerate(((w, 512), (w2, 256))):
+        a = arr[i]
+        a.type, a.W, a.w_row_stride = B.Q4_K, ww.data_ptr(), B.row_size(B.Q4_K, kk)
+        a.act_q, a.act_ds, a.dst, a.dst_col_stride = aq.data_ptr(), ads.data_ptr(), d.data_ptr(), 8
+        a.m, a.k, a.ncols, a.nchannels, a.ch_ratio = 8, kk, 1, 1, 1
+    assert K.lib.mi355_mul_mat_vec_q_group(arr, 2, None) == -2          # different k inside one group
+
+
 def _mmid_cases():
     g = load_gold("mul_mat_id.gold")
     return [k[len("shape."):] for k in g if k.startswith("shape.")]
