@@ -216,6 +216,181 @@ fattn_combine_kernel(const FArgs a) {
     o[d] = O / L;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Prefill: tile kernel on the f16 matrix cores (v_mfma_f32_32x32x16_f16), f16 K/V, no ALiBi / softcap.
+//   workgroup = 128 threads = 2 waves; a wave owns 32 query rows of one head, the workgroup walks the KV
+//   range in blocks of 64 rows staged in LDS (K row-major; V transposed and permuted so that both MFMA
+//   operands are single ds_read_b128).
+//   S^T[kv][q] = K Q^T is computed transposed on purpose: the accumulator layout then puts one query per
+//   lane (column) and 16 kv rows in its registers, so the online-softmax row reductions are in-register
+//   plus one cross-half shuffle, and exp(S^T) packed to f16 is already the B operand of O^T = V^T P^T.
+//   The kv order inside a 16-wide MFMA step is whatever the accumulator layout delivers,
+//       kv(t, s, half, j) = 32 t + (j & 3) + 8 (2 s + (j >> 2)) + 4 half,
+//   and V^T is stored in LDS in exactly that order.  Blocks whose mask tile is entirely -inf (the upper
+//   triangle of causal prefill) skip all MFMA work.
+// ------------------------------------------------------------------------------------------------
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+constexpr int MMA_BQ = 64, MMA_BKV = 64, MMA_THREADS = 128;
+
+template <int D>
+__global__ void __launch_bounds__(MMA_THREADS)
+fattn_mma_kernel(const FArgs a) {
+    constexpr int KP = D * 2 + 16;          // K tile row pitch (bytes)
+    constexpr int VP = MMA_BKV * 2 + 16;    // V^T tile row pitch (bytes)
+    constexpr int DT = D / 32, KS = D / 16;
+    __shared__ __attribute__((aligned(16))) uint8_t Ks[MMA_BKV * KP];
+    __shared__ __attribute__((aligned(16))) uint8_t Vt[D * VP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int h = blockIdx.y, i3 = blockIdx.z;
+    const int hk = h / (a.n_head / a.n_head_kv);
+    const int q = blockIdx.x * MMA_BQ + wave * 32 + lr;
+    const int qc = q < a.n_q ? q : a.n_q - 1;
+
+    // Q^T operand: this lane's query row, features 16 ks + 8 lh .. + 8, pre-scaled, f16
+    half8 qf[KS];
+    {
+        const float * qp = (const float *)(a.q + (int64_t)qc * a.q_nb1 + (int64_t)h * a.q_nb2 + (int64_t)i3 * a.q_nb3);
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) {
+            const v4f x0 = *(const v4f *)(qp + 16 * ks + 8 * lh), x1 = *(const v4f *)(qp + 16 * ks + 8 * lh + 4);
+            qf[ks][0] = (_Float16)(x0.x * a.scale); qf[ks][1] = (_Float16)(x0.y * a.scale);
+            qf[ks][2] = (_Float16)(x0.z * a.scale); qf[ks][3] = (_Float16)(x0.w * a.scale);
+            qf[ks][4] = (_Float16)(x1.x * a.scale); qf[ks][5] = (_Float16)(x1.y * a.scale);
+            qf[ks][6] = (_Float16)(x1.z * a.scale); qf[ks][7] = (_Float16)(x1.w * a.scale);
+        }
+    }
+    const __half * mrow = a.mask ? (const __half *)(a.mask + (int64_t)qc * a.m_nb1 + (int64_t)(h % a.m_ne2) * a.m_nb2 +
+                                                    (int64_t)(i3 % a.m_ne3) * a.m_nb3) : nullptr;
+    const char * kbase = a.k + (int64_t)hk * a.k_nb2 + (int64_t)i3 * a.k_nb3;
+    const char * vbase = a.v + (int64_t)hk * a.v_nb2 + (int64_t)i3 * a.v_nb3;
+
+    v16f o[DT];
+#pragma unroll
+    for (int i = 0; i < DT; i++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) o[i][r] = 0.0f;
+    float m = -INFINITY, l = 0.0f;
+
+    constexpr int CH = MMA_BKV * D * 2 / 16 / MMA_THREADS;   // 16-byte chunks per thread per tile
+    for (int kv0 = 0; kv0 < a.n_kv; kv0 += MMA_BKV) {
+        __syncthreads();                                     // previous block fully consumed
+        // ---- stage K (row-major) and V (transposed + permuted)
+#pragma unroll
+        for (int i = 0; i < CH; i++) {
+            const int c = tid + MMA_THREADS * i;
+            {
+                const int row = c / (D / 8), cc = c % (D / 8);
+                const int kv = kv0 + row < a.n_kv ? kv0 + row : a.n_kv - 1;
+                *(v4i *)(Ks + row * KP + cc * 16) = *(const v4i *)(kbase + (int64_t)kv * a.k_nb1 + cc * 16);
+            }
+            {
+                const int row = c % MMA_BKV, cc = c / MMA_BKV;   // consecutive lanes: consecutive kv rows, same features
+                const int kv = kv0 + row < a.n_kv ? kv0 + row : a.n_kv - 1;
+                const v4i raw = *(const v4i *)(vbase + (int64_t)kv * a.v_nb1 + cc * 16);
+                const int kv32 = row & 31;
+                const int pos = (row & 32) + (kv32 >> 4) * 16 + ((kv32 >> 2) & 1) * 8 + ((kv32 & 3) | (((kv32 >> 3) & 1) << 2));
+                const uint16_t * hv = (const uint16_t *)&raw;
+#pragma unroll
+                for (int e = 0; e < 8; e++) *(uint16_t *)(Vt + (cc * 8 + e) * VP + pos * 2) = hv[e];
+            }
+        }
+        __syncthreads();
+
+        // ---- mask tile of this wave: 2 S^T tiles x 16 kv rows per lane
+        float mv[2][16];
+        bool any = false;
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const int kvl = kv0 + 32 * t + 8 * g + 4 * lh;     // 4 consecutive kv rows
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const int kv = kvl + e;
+                    float v = kv < a.n_kv ? 0.0f : -INFINITY;
+                    if (mrow && kv < a.n_kv) v = __half2float(mrow[kv]);
+                    mv[t][4 * g + e] = v;
+                    any |= v != -INFINITY;
+                }
+            }
+        if (!__any(any)) continue;     // whole tile masked out for every query of this wave (uniform per wave; the
+                                       // barriers sit at the top of the loop, which every wave still reaches)
+
+        // ---- S^T = K Q^T
+        v16f sacc[2];
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) sacc[t][r] = 0.0f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ks++) {
+                const half8 kf = *(const half8 *)(Ks + (32 * t + lr) * KP + ks * 32 + lh * 16);
+                sacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], sacc[t], 0, 0, 0);
+            }
+        }
+        // ---- online softmax for query column lr
+        float mx = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) { sacc[t][r] += mv[t][r]; mx = fmaxf(mx, sacc[t][r]); }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mn = fmaxf(m, mx);
+        const float msafe = mn == -INFINITY ? 0.0f : mn;          // fully masked so far: every p below is exp(-inf) = 0
+        const float corr = __expf(m - msafe);                      // m = -inf -> 0
+        float ps = 0.0f;
+        half8 pf[2][2];
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const float p = __expf(sacc[t][r] - msafe);
+                ps += p;
+                pf[t][r >> 3][r & 7] = (_Float16)p;
+            }
+        ps += __shfl_xor(ps, 32, 64);
+        l = l * corr + ps;
+        m = mn;
+#pragma unroll
+        for (int i = 0; i < DT; i++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) o[i][r] *= corr;
+        // ---- O^T += V^T P^T
+#pragma unroll
+        for (int i = 0; i < DT; i++)
+#pragma unroll
+            for (int t = 0; t < 2; t++)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; s2++) {
+                    const half8 vf = *(const half8 *)(Vt + (32 * i + lr) * VP + (32 * t + 16 * s2 + 8 * lh) * 2);
+                    o[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[t][s2], o[i], 0, 0, 0);
+                }
+    }
+
+    if (q < a.n_q) {
+        const float inv = 1.0f / l;
+        float * op = (float *)(a.dst + (int64_t)h * a.d_nb1 + (int64_t)q * a.d_nb2 + (int64_t)i3 * a.d_nb3);
+#pragma unroll
+        for (int i = 0; i < DT; i++)
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                v4f v = {o[i][4 * g] * inv, o[i][4 * g + 1] * inv, o[i][4 * g + 2] * inv, o[i][4 * g + 3] * inv};
+                *(v4f *)(op + 32 * i + 8 * g + 4 * lh) = v;
+            }
+    }
+}
+
+template <int D>
+static int launch_mma(const FArgs & a, hipStream_t s) {
+    const dim3 grid((unsigned)((a.n_q + MMA_BQ - 1) / MMA_BQ), (unsigned)a.n_head, (unsigned)a.ne3);
+    MI355_LAUNCH("fattn_mma", (fattn_mma_kernel<D>), grid, dim3(MMA_THREADS), 0, s, a);
+    MI355_CHECK_LAUNCH();
+    return MI355_OK;
+}
+
 template <int D, int R, int TK, int TV>
 static int launch_vec(const FArgs & a, hipStream_t s) {
     constexpr int NW = FA_THREADS / 64;
@@ -287,6 +462,13 @@ int mi355_flash_attn_ext(const mi355_fattn_args * p, void * workspace, int64_t w
     a.m0 = powf(2.0f, -(p->max_bias) / a.n_head_log2);
     a.m1 = powf(2.0f, -(p->max_bias / 2.0f) / a.n_head_log2);
 
+    // prefill-sized batches of f16 KV without ALiBi / softcap: matrix-core tile kernel
+    if (p->type_k == MI355_TYPE_F16 && p->type_v == MI355_TYPE_F16 && (p->d == 128 || p->d == 64) && p->n_q >= 32 &&
+        !(p->max_bias > 0.0f) && p->logit_softcap == 0.0f && p->n_head <= 65535 && p->ne3 <= 65535 &&
+        ((p->d_nb1 | p->d_nb2 | p->d_nb3 | (int64_t)(uintptr_t)p->dst) & 15) == 0 && (!p->mask || (p->m_nb1 & 1) == 0)) {
+        a.nsplit = 1; a.part = nullptr;
+        return p->d == 128 ? launch_mma<128>(a, (hipStream_t)stream) : launch_mma<64>(a, (hipStream_t)stream);
+    }
     // KV split.  The KV loop is a chain of memory round trips (one per G = 512/(d/8) rows), so for decode-sized
     // grids the range is cut until every workgroup has about one round trip of rows -- all loads of the op are
     // then in flight at once -- up to 64 slices, bounded by the workspace; the partials are merged by
