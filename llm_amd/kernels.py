@@ -37,6 +37,19 @@ class MmvqArgs(C.Structure):
     ]
 
 
+class FattnArgs(C.Structure):
+    """mi355_fattn_args (include/mi355_kernels.h)"""
+    _fields_ = [
+        ("q", _vp), ("q_nb1", _i64), ("q_nb2", _i64), ("q_nb3", _i64),
+        ("k", _vp), ("type_k", _i32), ("k_nb1", _i64), ("k_nb2", _i64), ("k_nb3", _i64),
+        ("v", _vp), ("type_v", _i32), ("v_nb1", _i64), ("v_nb2", _i64), ("v_nb3", _i64),
+        ("mask", _vp), ("m_nb1", _i64), ("m_nb2", _i64), ("m_nb3", _i64), ("m_ne2", _i64), ("m_ne3", _i64),
+        ("dst", _vp), ("d_nb1", _i64), ("d_nb2", _i64), ("d_nb3", _i64),
+        ("d", _i64), ("n_q", _i64), ("n_kv", _i64), ("n_head", _i64), ("n_head_kv", _i64), ("ne3", _i64),
+        ("scale", C.c_float), ("max_bias", C.c_float), ("logit_softcap", C.c_float),
+    ]
+
+
 lib.mi355_abi_version.restype = C.c_int
 lib.mi355_error_string.restype = C.c_char_p
 lib.mi355_error_string.argtypes = [C.c_int]
@@ -52,6 +65,9 @@ lib.mi355_quantize_row_q8_1.argtypes = [_vp, _vp] + [_i64] * 7 + [_vp]
 lib.mi355_quantize_act.argtypes = [_vp, _vp, _vp] + [_i64] * 7 + [_vp]
 lib.mi355_dequantize_row.argtypes = [C.c_int, _vp, _vp, _i64, _vp]
 lib.mi355_mul_mat_vec_q.argtypes = [C.POINTER(MmvqArgs), _vp]
+lib.mi355_flash_attn_ext_workspace_bytes.restype = _i64
+lib.mi355_flash_attn_ext_workspace_bytes.argtypes = [C.POINTER(FattnArgs)]
+lib.mi355_flash_attn_ext.argtypes = [C.POINTER(FattnArgs), _vp, _i64, _vp]
 lib.mi355_act_bf16.argtypes = [_vp, _vp, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _vp]
 lib.mi355_mul_mat_dq.argtypes = [C.c_int, _vp, C.c_int64, _vp, C.c_int64, _vp, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _vp]
 lib.mi355_mul_mat_vec_q_group.argtypes = [C.POINTER(MmvqArgs), C.c_int, _vp]

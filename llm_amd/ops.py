@@ -143,3 +143,29 @@ def mul_mat_id(t, as_, b, ids, m, n_expert):
     a.ids, a.ids_stride, a.ids_nused, a.act_ne1, a.n_expert = ids.data_ptr(), ids.stride(0), n_used, b_ne1, n_expert
     K.check(K.lib.mi355_mul_mat_vec_q(a, _stream()), "mi355_mul_mat_vec_q(ids)")
     return dst
+
+
+def flash_attn_ext(q, k, v, mask, type_kv, n_kv, scale, max_bias=0.0, logit_softcap=0.0, use_workspace=True):
+    """ggml_flash_attn_ext, batch 1.  q: [n_head, n_q, d] f32; k, v: [n_head_kv, n_kv, row_bytes] uint8 rows of
+    type_kv (F16 / Q8_0 / Q4_0); mask: [n_q_pad, n_kv] f16 bits (int16) or None -> [n_q, n_head, d] f32."""
+    assert q.is_cuda and q.dtype == torch.float32 and q.is_contiguous() and k.is_contiguous() and v.is_contiguous()
+    n_head, n_q, d = q.shape
+    n_head_kv = k.shape[0]
+    dst = torch.empty((n_q, n_head, d), dtype=torch.float32, device=q.device)
+    a = K.FattnArgs()
+    a.q, a.q_nb1, a.q_nb2, a.q_nb3 = q.data_ptr(), d * 4, n_q * d * 4, n_head * n_q * d * 4
+    rb = k.shape[2] * k.element_size()
+    a.k, a.type_k, a.k_nb1, a.k_nb2, a.k_nb3 = k.data_ptr(), type_kv, rb, rb * k.shape[1], rb * k.shape[1] * n_head_kv
+    a.v, a.type_v, a.v_nb1, a.v_nb2, a.v_nb3 = v.data_ptr(), type_kv, rb, rb * v.shape[1], rb * v.shape[1] * n_head_kv
+    if mask is not None:
+        assert mask.is_contiguous() and mask.element_size() == 2
+        a.mask, a.m_nb1, a.m_nb2, a.m_nb3, a.m_ne2, a.m_ne3 = mask.data_ptr(), mask.shape[1] * 2, mask.numel() * 2, mask.numel() * 2, 1, 1
+    a.dst, a.d_nb1, a.d_nb2, a.d_nb3 = dst.data_ptr(), d * 4, n_head * d * 4, n_q * n_head * d * 4
+    a.d, a.n_q, a.n_kv, a.n_head, a.n_head_kv, a.ne3 = d, n_q, n_kv, n_head, n_head_kv, 1
+    a.scale, a.max_bias, a.logit_softcap = scale, max_bias, logit_softcap
+    ws, wsb = None, 0
+    if use_workspace:
+        wsb = K.lib.mi355_flash_attn_ext_workspace_bytes(a)
+        ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=q.device)
+    K.check(K.lib.mi355_flash_attn_ext(a, ws.data_ptr() if ws is not None else None, wsb, _stream()), "mi355_flash_attn_ext")
+    return dst

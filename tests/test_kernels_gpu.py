@@ -265,6 +265,50 @@ def test_mul_mat_id_golden(ops, tag):
 
 
 # ---------------------------------------------------------------- error behaviour through the C ABI
+def _fa_cases():
+    g = load_gold("flash_attn_ext.gold")
+    return [k[len("shape."):] for k in g if k.startswith("shape.")]
+
+
+@pytest.mark.parametrize("tag", _fa_cases())
+def test_flash_attn_golden(ops, tag):
+    """FLASH_ATTN_EXT through the C ABI vs the ggml-cpu outputs held in tests/golden (NMSE <= 5e-4,
+    tests/test-backend-ops.cpp:3599-3601) and vs the oracle's f64 evaluation."""
+    g = load_gold("flash_attn_ext.gold")
+    d, nh, nhkv, nq, nkv, tkv, has_mask, nqp = (int(x) for x in g["shape." + tag])
+    scale, max_bias, softcap = (float(x) for x in g["params." + tag])
+    q = dev(np.frombuffer(g["q." + tag], np.float32).reshape(nh, nq, d))
+    k = dev(np.frombuffer(g["k." + tag], np.uint8).reshape(nhkv, nkv, -1))
+    v = dev(np.frombuffer(g["v." + tag], np.uint8).reshape(nhkv, nkv, -1))
+    mask = dev(np.frombuffer(g["mask." + tag], np.int16).reshape(nqp, nkv)) if has_mask else None
+    want = np.frombuffer(g["dst." + tag], np.float32).reshape(nq, nh, d)
+    for use_ws in (True, False):
+        got = ops.flash_attn_ext(q, k, v, mask, tkv, nkv, scale, max_bias, softcap, use_workspace=use_ws).cpu().numpy()
+        assert np.isfinite(got).all() and O.nmse(want, got) <= 5e-4, (tag, use_ws)
+
+
+@pytest.mark.parametrize("d,nh,nhkv,nq,nkv,causal", [(128, 8, 2, 96, 200, True), (128, 4, 4, 33, 64, False), (64, 8, 1, 130, 333, True),
+                                                      (128, 32, 8, 512, 512, True), (128, 8, 2, 1, 300, False), (128, 8, 2, 4, 4096, False)])
+def test_flash_attn_f16_vs_f64_oracle(ops, d, nh, nhkv, nq, nkv, causal):
+    """prefill shapes take the matrix-core tile kernel (n_q >= 32), decode shapes the split-KV vec kernel; both
+    against the oracle's double-precision evaluation of the op on the same f16 K/V."""
+    rng = np.random.default_rng(d + nq + nkv)
+    q = rng.standard_normal((nh, nq, d)).astype(np.float32)
+    k = rng.standard_normal((nhkv, nkv, d)).astype(np.float16)
+    v = rng.standard_normal((nhkv, nkv, d)).astype(np.float16)
+    nqp = (nq + 63) // 64 * 64
+    mask = np.zeros((nqp, nkv), np.float16)
+    if causal:
+        off = nkv - nq
+        for i in range(nq):
+            mask[i, max(0, i + off + 1):] = -np.inf
+    scale = 1.0 / np.sqrt(d)
+    ku, vu = k.view(np.uint8).reshape(nhkv, nkv, -1), v.view(np.uint8).reshape(nhkv, nkv, -1)
+    got = ops.flash_attn_ext(dev(q), dev(ku), dev(vu), dev(mask.view(np.int16)), B.F16, nkv, scale).cpu().numpy()
+    ref = O.flash_attn_ext(q, ku, vu, mask.view(np.uint16), O.F16, O.F16, d, d, nq, nkv, nh, nhkv, scale, exact=True)
+    assert np.isfinite(got).all() and O.nmse(ref, got) <= 2e-5, O.nmse(ref, got)
+
+
 def test_errors_are_reported_not_launched(ops):
     import llm_amd.kernels as K
     w = torch.zeros(144 * 4 + 16, dtype=torch.uint8, device="cuda")
