@@ -15,14 +15,15 @@
 //
 // Tiling: workgroup = 256 threads = 4 waves, output tile 128 (weight rows) x 128 (activation columns),
 // K step 64.  Each wave owns 64 x 64 = 2 x 2 MFMA tiles.  LDS rows have a 144-byte pitch (128 B of
-// bf16 + 16) so the 16-byte operand reads of 32 consecutive rows spread over all banks.  Global loads
-// of stage s+1 are issued into registers before the MFMAs of stage s (single LDS buffer, register
-// prefetch).
+// bf16 + 16) so the 16-byte operand reads of 32 consecutive rows spread over all banks.  LDS is double
+// buffered with one barrier per stage: a wave dequantizes stage s+1 into the idle buffer and requests the
+// global loads of stage s+2 before it issues the MFMAs of stage s.  (Fetching two stages ahead in a second
+// register set was measured slower: 276-332 VGPRs drop the occupancy to one wave per SIMD.)
 #include "common.h"
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int BN = 128, BK = 64;   // BM (weight rows per workgroup) is a template parameter: 128, or 64 when M is small
 constexpr int PITCH = BK * 2 + 16;   // bytes per LDS row
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -104,6 +105,7 @@ static __device__ __forceinline__ float ubyte(int w, int i) { return (float)((w 
 // dequantize the 32 weights to f32 (same formulas as dequantize_row_*, ggml-quants.c)
 template <int TYPE>
 static __device__ __forceinline__ void dequant32(const Raw<TYPE> & r, int k, float * f) {
+#pragma clang fp contract(fast)   // the result is rounded to bf16 anyway: one v_fma per weight instead of mul + sub
     if constexpr (TYPE == MI355_TYPE_Q4_K || TYPE == MI355_TYPE_Q5_K) {
         const int j = (k >> 5) & 7, sh = (j & 1) * 4;
         float dsc, dm;
@@ -159,14 +161,16 @@ static __device__ __forceinline__ void store_bf16x32(uint8_t * dst, const float 
     }
 }
 
-template <int TYPE>
+template <int TYPE, int BM>
 __global__ void __launch_bounds__(256)
 mmdq_kernel(const DArgs a) {
-    __shared__ __attribute__((aligned(16))) uint8_t Lw[BM * PITCH];
-    __shared__ __attribute__((aligned(16))) uint8_t La[BN * PITCH];
+    constexpr int WAVES_M = BM / 64, WAVES_N = 4 / WAVES_M;   // every wave owns 64 weight rows x (BN / WAVES_N) columns
+    constexpr int TN = BN / WAVES_N / 32;                      // 32-column MFMA tiles per wave: 2 (BM 128) or 1 (BM 64)
+    __shared__ __attribute__((aligned(16))) uint8_t Lw[2][BM * PITCH];
+    __shared__ __attribute__((aligned(16))) uint8_t La[2][BN * PITCH];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
-    const int wm_ = wave & 1, wn_ = wave >> 1;       // wave's 64 x 64 sub-tile
+    const int wm_ = wave % WAVES_M, wn_ = wave / WAVES_M;
     const int lr = lane & 31, lh = lane >> 5;
 
     // staging role: row / column (tid >> 1), 32-value half (tid & 1)
@@ -177,48 +181,55 @@ mmdq_kernel(const DArgs a) {
     const bool col_ok = col < a.n;
     const uint16_t * xcol = a.x + (int64_t)(col_ok ? col : 0) * a.x_row_stride;
 
-    v16f acc[2][2];
+    const bool w_stager = sr < BM;              // BM = 64: the upper half of the workgroup stages activations only
+    v16f acc[2][TN];
 #pragma unroll
     for (int i = 0; i < 2; i++)
 #pragma unroll
-        for (int j = 0; j < 2; j++)
+        for (int j = 0; j < TN; j++)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
 
-    Raw<TYPE> wraw = load_raw<TYPE>(wrow, hf * 32);
+    Raw<TYPE> wraw;
     v4i xraw[4];
+    auto fetch = [&](int k) {          // global -> registers: this thread's 32 weights and 32 activations of stage k
+        if (w_stager) wraw = load_raw<TYPE>(wrow, k + hf * 32);
 #pragma unroll
-    for (int i = 0; i < 4; i++) xraw[i] = ((const v4i *)(xcol + hf * 32))[i];
-
-    for (int k0 = 0; k0 < a.k; k0 += BK) {
-        // registers -> LDS (dequantized / rounded to bf16)
-        {
+        for (int i = 0; i < 4; i++) xraw[i] = ((const v4i *)(xcol + k + hf * 32))[i];
+    };
+    auto stash = [&](int k, int buf) { // registers -> LDS buffer `buf` (weights dequantized and rounded to bf16)
+        if (w_stager) {
             float f[32];
-            dequant32<TYPE>(wraw, k0 + hf * 32, f);
-            store_bf16x32(Lw + sr * PITCH + hf * 64, f);
-            const v4i z = {0, 0, 0, 0};
-#pragma unroll
-            for (int i = 0; i < 4; i++) *(v4i *)(La + sr * PITCH + hf * 64 + 16 * i) = col_ok ? xraw[i] : z;
+            dequant32<TYPE>(wraw, k + hf * 32, f);
+            store_bf16x32(Lw[buf] + sr * PITCH + hf * 64, f);
         }
-        __syncthreads();
-        // next stage's global loads fly during the MFMAs
-        if (k0 + BK < a.k) {
-            wraw = load_raw<TYPE>(wrow, k0 + BK + hf * 32);
+        const v4i z = {0, 0, 0, 0};
 #pragma unroll
-            for (int i = 0; i < 4; i++) xraw[i] = ((const v4i *)(xcol + k0 + BK + hf * 32))[i];
+        for (int i = 0; i < 4; i++) *(v4i *)(La[buf] + sr * PITCH + hf * 64 + 16 * i) = col_ok ? xraw[i] : z;
+    };
+
+    // Double-buffered LDS, one barrier per stage: while the MFMAs of stage s read buffer s&1, the same wave
+    // dequantizes stage s+1 (fetched one iteration earlier) into the other buffer and requests stage s+2.
+    fetch(0);
+    stash(0, 0);
+    if (BK < a.k) fetch(BK);
+    __syncthreads();
+    for (int k0 = 0, buf = 0; k0 < a.k; k0 += BK, buf ^= 1) {
+        if (k0 + BK < a.k) {
+            stash(k0 + BK, buf ^ 1);
+            if (k0 + 2 * BK < a.k) fetch(k0 + 2 * BK);
         }
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ks++) {
-            bf16x8 af[2], wf[2];
+            bf16x8 af[TN], wf[2];
 #pragma unroll
-            for (int t = 0; t < 2; t++) {
-                af[t] = *(const bf16x8 *)(La + (wn_ * 64 + t * 32 + lr) * PITCH + ks * 32 + lh * 16);
-                wf[t] = *(const bf16x8 *)(Lw + (wm_ * 64 + t * 32 + lr) * PITCH + ks * 32 + lh * 16);
-            }
+            for (int t = 0; t < TN; t++) af[t] = *(const bf16x8 *)(La[buf] + (wn_ * 32 * TN + t * 32 + lr) * PITCH + ks * 32 + lh * 16);
+#pragma unroll
+            for (int t = 0; t < 2; t++)  wf[t] = *(const bf16x8 *)(Lw[buf] + (wm_ * 64 + t * 32 + lr) * PITCH + ks * 32 + lh * 16);
 #pragma unroll
             for (int tm = 0; tm < 2; tm++)
 #pragma unroll
-                for (int tn = 0; tn < 2; tn++)
+                for (int tn = 0; tn < TN; tn++)
                     acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tn], wf[tm], acc[tm][tn], 0, 0, 0);
         }
         __syncthreads();
@@ -229,10 +240,10 @@ mmdq_kernel(const DArgs a) {
     for (int tm = 0; tm < 2; tm++) {
         const int m = m0 + wm_ * 64 + tm * 32 + lr;
 #pragma unroll
-        for (int tn = 0; tn < 2; tn++)
+        for (int tn = 0; tn < TN; tn++)
 #pragma unroll
             for (int r = 0; r < 16; r++) {
-                const int n = n0 + wn_ * 64 + tn * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int n = n0 + wn_ * 32 * TN + tn * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 if (m < a.m && n < a.n) a.dst[(int64_t)n * a.dst_col_stride + m] = acc[tm][tn][r];
             }
     }
@@ -255,8 +266,13 @@ act_bf16_kernel(const char * x, uint16_t * y, int k, int ne1, int ne2, int64_t n
 
 template <int TYPE>
 static int launch(const DArgs & a, hipStream_t s, const char * tag) {
-    const dim3 grid((unsigned)((a.n + BN - 1) / BN), (unsigned)((a.m + BM - 1) / BM));
-    MI355_LAUNCH(tag, (mmdq_kernel<TYPE>), grid, dim3(256), 0, s, a);
+    // 128-row tiles reuse each staged activation tile twice as often; 64-row tiles when those would leave CUs idle
+    const int64_t nb = (a.n + BN - 1) / BN;
+    if (nb * ((a.m + 127) / 128) >= 384) {
+        MI355_LAUNCH(tag, (mmdq_kernel<TYPE, 128>), dim3((unsigned)nb, (unsigned)((a.m + 127) / 128)), dim3(256), 0, s, a);
+    } else {
+        MI355_LAUNCH(tag, (mmdq_kernel<TYPE, 64>), dim3((unsigned)nb, (unsigned)((a.m + 63) / 64)), dim3(256), 0, s, a);
+    }
     MI355_CHECK_LAUNCH();
     return MI355_OK;
 }
@@ -285,7 +301,7 @@ extern "C" int mi355_mul_mat_dq(int type, const void * W, int64_t w_row_stride, 
     if (bs == 0 || type == MI355_TYPE_F32 || type == MI355_TYPE_F16 || type == MI355_TYPE_Q8_1) return MI355_E_TYPE;
     if (m < 0 || n < 0 || k <= 0 || k % bs != 0 || m > 0x7fffffff || n > 0x7fffffff || k > 0x7fffffff) return MI355_E_SHAPE;
     if (k % BK != 0) return MI355_E_UNSUPPORTED;          // caller falls back to the mat-vec kernel
-    if ((n + BN - 1) / BN > 0x7fffffff / 2 || (m + BM - 1) / BM > 65535) return MI355_E_UNSUPPORTED;
+    if ((n + BN - 1) / BN > 0x7fffffff / 2 || (m + 63) / 64 > 65535) return MI355_E_UNSUPPORTED;
     if (((uintptr_t)x & 15) || (x_row_stride & 7) || ((uintptr_t)dst & 3) || x_row_stride < k) return MI355_E_ALIGN;
     const bool a16 = type == MI355_TYPE_Q4_K || type == MI355_TYPE_Q5_K;
     if (((uintptr_t)W | (uintptr_t)w_row_stride) & (a16 ? 15 : 1)) return MI355_E_ALIGN;
