@@ -146,6 +146,28 @@ MI355_API int mi355_mul_mat_vec_q(const mi355_mmvq_args *args, void *stream);
 #define MI355_MMVQ_MAX_GROUP 4
 MI355_API int mi355_mul_mat_vec_q_group(const mi355_mmvq_args *args, int n_mats, void *stream);
 
+/* Attention-input stage of one decode token in ONE launch: q = rope(Wq x), k = rope(Wk x), v = Wv x, with k and v
+ * written straight into their KV-cache rows (f16 or f32).  Replaces, for n_tokens == 1, the node sequence
+ * MUL_MAT(wq) ROPE MUL_MAT(wk) ROPE MUL_MAT(wv) CPY(k) CPY(v) of llm_build_llama (src/llama-model.cpp:4898-5052), i.e.
+ * 3 x mul_mat_vec_q + 2 x rope + 2 x cpy launches of the reference.  Bit-identical to running those kernels one
+ * by one.  wq/wk share type_qk, wv has type_v (Q4_K_M gives wv Q6_K or Q5_K in some layers); rows of every matrix
+ * a multiple of 8; head_dim = ne0 of the rope (rows per head); rope parameters as in mi355_rope_f32 (pos[0] is the
+ * token position).  MI355_E_UNSUPPORTED for type pairs / shapes outside this, callers then run the nodes singly. */
+typedef struct mi355_qkv_rope_args {
+    int32_t type_qk, type_v;
+    const void *wq, *wk, *wv;
+    int64_t wq_row_stride, wk_row_stride, wv_row_stride;   /* bytes */
+    int64_t m_q, m_k, m_v, k;
+    const int8_t *act_q; const float *act_ds;              /* activations of the token (mi355_quantize_act) */
+    float *q_out;                                          /* f32 [m_q] */
+    void  *k_out; void *v_out;                             /* [m_k], [m_v] of k_out_type / v_out_type */
+    int32_t k_out_type, v_out_type;                        /* MI355_TYPE_F16 or MI355_TYPE_F32 */
+    const int32_t *pos; const float *freq_factors;         /* device; freq_factors may be NULL */
+    int32_t head_dim, n_dims, mode, n_ctx_orig;
+    float freq_base, freq_scale, ext_factor, attn_factor, beta_fast, beta_slow;
+} mi355_qkv_rope_args;
+MI355_API int mi355_qkv_rope_matvec(const mi355_qkv_rope_args *args, void *stream);
+
 /* Prefill tile kernel (int8 MFMA): dst[c][r] = sum_k W[r][k] * act[c][k] for any n (meant for n > 8).
  * Same operands as the mat-vec (one channel).  Returns MI355_E_UNSUPPORTED when k % 128 != 0 (callers
  * then use the mat-vec kernel over column groups).  Replaces ggml_cuda_mul_mat_q / mul_mat_q

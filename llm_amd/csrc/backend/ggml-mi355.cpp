@@ -1080,12 +1080,129 @@ static void mi355_mul_mat_group(mi355_backend_ctx * ctx, ggml_cgraph * cgraph, c
     MI_CHECK(mi355_mul_mat_vec_q_group(a, cnt, ctx->stream));
 }
 
+// ------------------------------------------------------------------------------------------------
+// Fused attention input of a decode step.  llm_build_llama (src/llama-model.cpp:4898-5052) spells it as
+//     Qcur = MUL_MAT(wq, x)  RESHAPE  ROPE      Kcur = MUL_MAT(wk, x)  RESHAPE  ROPE      Vcur = MUL_MAT(wv, x)  RESHAPE
+//     CPY(rope(Kcur) -> view of cache_k)        CPY(Vcur -> view of cache_v)
+// (Kcur and Vcur even reuse Qcur's memory, so these mat-vecs cannot simply be grouped.)  When exactly this shape
+// is found for a single token, with f16/f32 cache rows and no other reader of the intermediates, one launch of
+// mi355_qkv_rope_matvec produces rope(Qcur) and both cache rows; Qcur, Kcur, Vcur and rope(Kcur) are never stored.
+// ------------------------------------------------------------------------------------------------
+static const ggml_tensor * view_root(const ggml_tensor * t) { return t->view_src ? t->view_src : t; }
+
+static bool mi355_try_fuse_qkv_rope(mi355_backend_ctx * ctx, ggml_cgraph * cgraph, int i, std::vector<char> & done) {
+    const int n = ggml_graph_n_nodes(cgraph);
+    ggml_tensor * mq = ggml_graph_node(cgraph, i);
+    if (!matvec_groupable(mq) || mq->src[1]->ne[1] != 1) return false;
+    const ggml_tensor * x = mq->src[1];
+    ggml_tensor * rq = nullptr, * mk = nullptr, * rk = nullptr, * mv = nullptr, * ck = nullptr, * cv = nullptr;
+    int idx[7] = {i, -1, -1, -1, -1, -1, -1}, last = -1;
+    const int horizon = i + 24 < n ? i + 24 : n;
+    for (int j = i + 1; j < horizon; j++) {
+        ggml_tensor * t = ggml_graph_node(cgraph, j);
+        if (done[j]) return false;
+        if (is_view_op(t) || ggml_is_empty(t)) continue;
+        if (t->op == GGML_OP_ROPE) {
+            const ggml_tensor * r = view_root(t->src[0]);
+            if (r == mq && !rq)            { rq = t; idx[1] = j; }
+            else if (mk && r == mk && !rk) { rk = t; idx[3] = j; }
+            else return false;
+        } else if (t->op == GGML_OP_MUL_MAT) {
+            if (!matvec_groupable(t) || t->src[1] != x) return false;
+            if (!mk)      { mk = t; idx[2] = j; }
+            else if (!mv) { mv = t; idx[4] = j; }
+            else return false;
+        } else if (t->op == GGML_OP_CPY) {
+            const ggml_tensor * r = view_root(t->src[0]);
+            if (rk && r == rk && !ck)      { ck = t; idx[5] = j; }
+            else if (mv && r == mv && !cv) { cv = t; idx[6] = j; }
+            else return false;
+        } else {
+            return false;
+        }
+        if (rq && mk && rk && mv && ck && cv) { last = j; break; }
+    }
+    if (last < 0) return false;
+    // shapes and types
+    const ggml_tensor * wq = mq->src[0], * wk = mk->src[0], * wv = mv->src[0];
+    if (wq->type != wk->type || wq->ne[0] != wk->ne[0] || wq->ne[0] != wv->ne[0]) return false;
+    const int64_t K = wq->ne[0], Mq = wq->ne[1], Mk = wk->ne[1], Mv = wv->ne[1], hd = rq->ne[0];
+    if (Mq % 8 || Mk % 8 || Mv % 8 || hd != rk->ne[0] || hd <= 0 || Mq % hd || Mk % hd) return false;
+    for (ggml_tensor * r : {rq, rk}) {
+        if (r->type != GGML_TYPE_F32 || !ggml_is_contiguous(r) || !ggml_is_contiguous(r->src[0]) || r->ne[2] != 1 || r->ne[3] != 1) return false;
+        if (r->src[1] != rq->src[1] || r->src[2] != rq->src[2]) return false;
+        if (memcmp(r->op_params, rq->op_params, 11 * sizeof(int32_t)) != 0) return false;
+        if (r->src[1]->type != GGML_TYPE_I32 || (r->src[2] && r->src[2]->type != GGML_TYPE_F32)) return false;
+    }
+    if (rq->src[0]->data != mq->data || rk->src[0]->data != mk->data) return false;
+    if (ggml_nelements(rq) != Mq || ggml_nelements(rk) != Mk) return false;
+    const int32_t * rp = (const int32_t *)rq->op_params;
+    if (rp[2] != 0 && rp[2] != 2) return false;
+    for (ggml_tensor * c : {ck, cv}) {
+        if ((c->type != GGML_TYPE_F16 && c->type != GGML_TYPE_F32) || !ggml_is_contiguous(c) || !ggml_is_contiguous(c->src[0])) return false;
+        if (c->src[0]->type != GGML_TYPE_F32) return false;
+    }
+    if (ck->src[0]->data != rk->data || cv->src[0]->data != mv->data || ggml_nelements(ck) != Mk || ggml_nelements(cv) != Mv) return false;
+    // nobody else may read the tensors that will not be materialised
+    const ggml_tensor * hidden[4] = {mq, mk, mv, rk};
+    for (const ggml_tensor * h : hidden) if (h->flags & GGML_TENSOR_FLAG_OUTPUT) return false;
+    for (int j = i + 1; j < n; j++) {
+        const ggml_tensor * t = ggml_graph_node(cgraph, j);
+        if (is_view_op(t)) { if (t->flags & GGML_TENSOR_FLAG_OUTPUT) for (const ggml_tensor * h : hidden) if (view_root(t) == h) return false; continue; }
+        bool in_pattern = false;
+        for (int m = 1; m < 7; m++) if (idx[m] == j) in_pattern = true;
+        if (in_pattern) continue;
+        for (int sidx = 0; sidx < GGML_MAX_SRC; sidx++) {
+            if (!t->src[sidx]) continue;
+            for (const ggml_tensor * h : hidden) if (view_root(t->src[sidx]) == h) return false;
+        }
+    }
+    // activations of the token, q8_1
+    const size_t qb = align_up((size_t)mi355_act_q_bytes(K, 1), 256), db = align_up((size_t)mi355_act_ds_bytes(K, 1), 256);
+    char * ws = (char *)ctx->get_scratch(0, qb + db);
+    mi355_qkv_rope_args a;
+    memset(&a, 0, sizeof(a));
+    a.type_qk = (int32_t)wq->type; a.type_v = (int32_t)wv->type;
+    a.wq = wq->data; a.wk = wk->data; a.wv = wv->data;
+    a.wq_row_stride = (int64_t)wq->nb[1]; a.wk_row_stride = (int64_t)wk->nb[1]; a.wv_row_stride = (int64_t)wv->nb[1];
+    a.m_q = Mq; a.m_k = Mk; a.m_v = Mv; a.k = K;
+    a.act_q = (const int8_t *)ws; a.act_ds = (const float *)(ws + qb);
+    a.q_out = (float *)rq->data; a.k_out = ck->data; a.v_out = cv->data;
+    a.k_out_type = (int32_t)ck->type; a.v_out_type = (int32_t)cv->type;
+    a.pos = (const int32_t *)rq->src[1]->data; a.freq_factors = rq->src[2] ? (const float *)rq->src[2]->data : nullptr;
+    a.head_dim = (int32_t)hd; a.n_dims = rp[1]; a.mode = rp[2]; a.n_ctx_orig = rp[4];
+    memcpy(&a.freq_base, rp + 5, 4); memcpy(&a.freq_scale, rp + 6, 4); memcpy(&a.ext_factor, rp + 7, 4);
+    memcpy(&a.attn_factor, rp + 8, 4); memcpy(&a.beta_fast, rp + 9, 4); memcpy(&a.beta_slow, rp + 10, 4);
+    // dry validation first (argument errors are reported before anything is launched): an unsupported type pair or
+    // shape leaves the graph to the unfused path
+    const bool need_quant = !ctx->act_cached(x);
+    if (need_quant) {
+        MI_CHECK(mi355_quantize_act((const float *)x->data, (int8_t *)ws, (float *)(ws + qb), K, 1, 1, 1, x->nb[1], x->nb[2], x->nb[3], ctx->stream));
+        ctx->act_remember(x);
+    }
+    const int rc = mi355_qkv_rope_matvec(&a, ctx->stream);
+    if (rc == MI355_E_UNSUPPORTED || rc == MI355_E_SHAPE || rc == MI355_E_ALIGN) return false;
+    MI_CHECK(rc);
+    for (int m = 1; m < 7; m++) done[idx[m]] = 1;
+    ctx->act_invalidate_if_written(rq);
+    return true;
+}
+
 static enum ggml_status mi355_backend_graph_compute(ggml_backend_t backend, ggml_cgraph * cgraph) {
     mi355_backend_ctx * ctx = (mi355_backend_ctx *)backend->context;
     mi355_set_device(ctx->device);
     ctx->act_cache.valid = false; // tensors may have been rewritten through set_tensor / copies between calls
     const int n = ggml_graph_n_nodes(cgraph);
     const bool fuse = getenv("GGML_MI355_NO_FUSE") == nullptr;
+    if (getenv("GGML_MI355_DUMP_GRAPH")) {   // diagnostics: the node list this backend was handed
+        for (int i = 0; i < n; i++) {
+            const ggml_tensor * t = ggml_graph_node(cgraph, i);
+            fprintf(stderr, "[mi355] %4d %-14s %-28s [%lld,%lld,%lld,%lld] %p", i, ggml_op_name(t->op), t->name, (long long)t->ne[0],
+                    (long long)t->ne[1], (long long)t->ne[2], (long long)t->ne[3], t->data);
+            for (int s2 = 0; s2 < GGML_MAX_SRC; s2++) if (t->src[s2]) fprintf(stderr, "  <- %s(%p)", t->src[s2]->name, t->src[s2]->data);
+            fprintf(stderr, "\n");
+        }
+    }
     std::vector<char> done(n, 0);    // nodes already computed by a hoisting fusion
     for (int i = 0; i < n; i++) {
         ggml_tensor * node = ggml_graph_node(cgraph, i);
@@ -1102,6 +1219,8 @@ static enum ggml_status mi355_backend_graph_compute(ggml_backend_t backend, ggml
             continue;
         }
         ctx->act_invalidate_if_written(node);
+        // fusion: Q/K/V projections + rope + KV-cache store of one token in one launch
+        if (fuse && node->op == GGML_OP_MUL_MAT && mi355_try_fuse_qkv_rope(ctx, cgraph, i, done)) continue;
         // fusion: decode mat-vecs that share their activation run as one grouped launch
         if (fuse && matvec_groupable(node)) {
             int members[MI355_MMVQ_MAX_GROUP];

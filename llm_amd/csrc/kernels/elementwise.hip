@@ -5,6 +5,7 @@
 // include/mi355_kernels.h; nothing here is derived from ggml-cuda.
 #include "common.h"
 #include "deq_elem.h"
+#include "rope.h"
 
 namespace {
 
@@ -133,26 +134,6 @@ rms_norm_kernel(const T4 x, const T4 y, const T4 sum, const float * __restrict__
 }
 
 // ---------------------------------------------------------------- rope
-struct RopeP {
-    int n_dims, mode, ne0;
-    float theta_scale, freq_scale, ext_factor, attn_factor, corr0, corr1;
-};
-
-static __device__ __forceinline__ void rope_yarn(float theta_extrap, const RopeP & p, int i0, float & c, float & s) {
-    // rope_yarn, ggml-cpu/ops.cpp:5862-5877
-    float theta_interp = p.freq_scale * theta_extrap;
-    float theta = theta_interp;
-    float mscale = p.attn_factor;
-    if (p.ext_factor != 0.0f) {
-        const float y = (i0 / 2 - p.corr0) / fmaxf(0.001f, p.corr1 - p.corr0);
-        const float ramp_mix = (1.0f - fminf(1.0f, fmaxf(0.0f, y))) * p.ext_factor;
-        theta = theta_interp * (1 - ramp_mix) + theta_extrap * ramp_mix;
-        mscale *= 1.0f + 0.1f * logf(1.0f / p.freq_scale);
-    }
-    c = cosf(theta) * mscale;
-    s = sinf(theta) * mscale;
-}
-
 // one lane per rotated pair; rows = (head i1, token i2, batch i3)
 __global__ void __launch_bounds__(256)
 rope_kernel(const T4 x, const int32_t * __restrict__ pos, const float * __restrict__ ff, const T4 d, const RopeP p, int64_t npairs) {
@@ -173,9 +154,8 @@ rope_kernel(const T4 x, const int32_t * __restrict__ pos, const float * __restri
         }
         // theta = pos * theta_scale^(i0/2) (the CPU builds it by repeated multiplication; powf agrees to ~1 ulp
         // of the angle, inside the op's 1e-7 NMSE budget for the positions llama.cpp uses)
-        const float theta_base = (float)pos[i2] * powf(p.theta_scale, (float)ic);
         float c, s;
-        rope_yarn(theta_base / (ff ? ff[ic] : 1.0f), p, i0, c, s);
+        rope_cos_sin(p, pos[i2], ff, ic, c, s);
         if (p.mode & 2) { // NEOX: pairs (ic, ic + n_dims/2)
             const float x0 = ((const float *)xs)[ic], x1 = ((const float *)xs)[ic + p.n_dims / 2];
             ((float *)ds)[ic]                = x0 * c - x1 * s;
@@ -405,14 +385,7 @@ int mi355_rope_f32(const mi355_tensor * x, const int32_t * pos, const float * fr
     if (x->type != MI355_TYPE_F32 || dst->type != MI355_TYPE_F32) return MI355_E_TYPE;
     if (!same_shape(x, dst) || x->nb[0] != 4 || dst->nb[0] != 4 || n_dims > x->ne[0] || (n_dims & 1) || (x->ne[0] & 1)) return MI355_E_SHAPE;
     if (mode != 0 && mode != 2) return MI355_E_UNSUPPORTED; // mrope / vision are not on this path
-    RopeP p;
-    p.n_dims = n_dims; p.mode = mode; p.ne0 = (int)x->ne[0];
-    p.theta_scale = powf(freq_base, -2.0f / n_dims);
-    p.freq_scale = freq_scale; p.ext_factor = ext_factor; p.attn_factor = attn_factor;
-    // ggml_rope_yarn_corr_dims, ggml.c:4002-4014
-    auto corr_dim = [&](float n_rot) { return n_dims * logf(n_ctx_orig / (n_rot * 2 * 3.14159265358979323846f)) / (2 * logf(freq_base)); };
-    const float start = floorf(corr_dim(beta_fast)), end = ceilf(corr_dim(beta_slow));
-    p.corr0 = start > 0 ? start : 0; p.corr1 = end < n_dims - 1 ? end : n_dims - 1;
+    const RopeP p = rope_params(n_dims, mode, (int)x->ne[0], n_ctx_orig, freq_base, freq_scale, ext_factor, attn_factor, beta_fast, beta_slow);
     const int64_t npairs = nelem(x) / 2;
     if (npairs == 0) return MI355_OK;
     MI355_LAUNCH("rope", rope_kernel, dim3(grid_for(npairs)), dim3(256), 0, (hipStream_t)stream, t4(x), pos, freq_factors, t4(dst), p, npairs);

@@ -24,6 +24,7 @@
 //     d8 * dW_j * sum((qW - off)*q8)                     (q4_0: off 8, q6_K: off 32, q8_0: off 0)
 // i.e. exactly dequant(W) . dequant_q8_1(x) up to f32 summation order.
 #include "common.h"
+#include "rope.h"
 #include <stdlib.h>
 #include <string>
 #include <string.h>
@@ -409,6 +410,106 @@ mmvq_group_kernel(const KGroup a) {
                                   a.k, a.dst[mi], a.dst_col_stride[mi], lds);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Fused attention-input stage of a decode step: Q, K and V projections of one token, the rotary embedding of Q
+// and K, and the store of K and V into the KV cache -- ONE launch for what the graph spells as 3 MUL_MAT +
+// 2 ROPE + 2 CPY nodes (7 launches).  A wave owns the two weight rows of one rotated pair (both rows read the
+// same activations, so the LDS reads are shared), lane 0 rotates the pair and stores it: Q as f32, K and V as
+// f16 (or f32) straight into the cache rows.  Row sums, rotation and conversion use the same code as the
+// separate kernels, so the results are bit-identical to the unfused graph.
+// ------------------------------------------------------------------------------------------------
+template <int TYPE, bool LDSACT>
+static __device__ __forceinline__ void mmvq_row2(const uint8_t * w0, const uint8_t * w1, const int8_t * gq, const float * gds,
+                                                 int k, uint8_t * lds, float & s0, float & s1) {
+    typedef Unit<TYPE> U;
+    const int lane = threadIdx.x & 63;
+    const int nunits = k / U::ELEMS;
+    const int niter  = (nunits + 63) >> 6;
+    const int u0 = lane < nunits ? lane : nunits - 1;
+    typename U::Raw c0 = U::load(w0, u0), c1 = U::load(w1, u0);
+    if (LDSACT) {
+        const int nq = k / 16, nds = k / QK;
+        for (int i = threadIdx.x; i < nq; i += 256) ((v4i *)lds)[i] = ((const v4i *)gq)[i];
+        v2f * lds_ds = (v2f *)(lds + (size_t)k);
+        for (int i = threadIdx.x; i < nds; i += 256) lds_ds[i] = ((const v2f *)gds)[i];
+        __syncthreads();
+    }
+    float acc0 = 0.0f, acc1 = 0.0f;
+    for (int it = 0; it < niter; it++) {
+        const int  u_raw = it * 64 + lane;
+        const bool valid = u_raw < nunits;
+        const int  u     = valid ? u_raw : nunits - 1;
+        typename U::Raw n0, n1;
+        if (it + 1 < niter) {
+            const int un = u_raw + 64 < nunits ? u_raw + 64 : nunits - 1;
+            n0 = U::load(w0, un); n1 = U::load(w1, un);
+        }
+        typename U::Act av;
+        if (LDSACT) {
+            const auto lq  = (const __attribute__((address_space(3))) int8_t *)lds;
+            const auto lds_ = (const __attribute__((address_space(3))) float *)(lds + (size_t)k);
+            av = U::load_act(ActLds{lq, lds_}, u);
+        } else {
+            av = U::load_act(ActPtr{gq, gds}, u);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const float v0 = U::dot(U::decode(c0, u), av);
+        const float v1 = U::dot(U::decode(c1, u), av);
+        acc0 += valid ? v0 : 0.0f;
+        acc1 += valid ? v1 : 0.0f;
+        if (it + 1 < niter) { c0 = n0; c1 = n1; }
+    }
+    s0 = wave_sum(acc0);
+    s1 = wave_sum(acc1);
+}
+
+struct KQkv {
+    const uint8_t * W[3]; int64_t w_row_stride[3];
+    int blk_end[3];                      // workgroups [blk_end[i-1], blk_end[i]) belong to matrix i (0 Q, 1 K, 2 V)
+    const int8_t * act_q; const float * act_ds; int k;
+    float * q_out; void * k_out; void * v_out; int k_f16, v_f16;
+    const int32_t * pos; const float * ff; RopeP rp;
+};
+
+template <int TA, int TB>
+__global__ void __launch_bounds__(256)
+mmvq_qkv_rope_kernel(const KQkv a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int mat = 0, blk0 = 0;
+#pragma unroll
+    for (int i = 0; i < 2; i++) if ((int)blockIdx.x >= a.blk_end[i]) { mat = i + 1; blk0 = a.blk_end[i]; }
+    const int pair = ((int)blockIdx.x - blk0) * 4 + wave;
+    int r0, r1, ic = 0;
+    bool rot = false;
+    if (mat < 2) {
+        const int half = a.rp.ne0 / 2, h = pair / half;
+        ic = pair % half;
+        if (2 * ic >= a.rp.n_dims) { r0 = h * a.rp.ne0 + 2 * ic; r1 = r0 + 1; }                      // passed through
+        else if (a.rp.mode & 2)    { r0 = h * a.rp.ne0 + ic; r1 = r0 + a.rp.n_dims / 2; rot = true; } // NEOX
+        else                       { r0 = h * a.rp.ne0 + 2 * ic; r1 = r0 + 1; rot = true; }           // NORMAL
+    } else {
+        r0 = 2 * pair; r1 = r0 + 1;
+    }
+    float c = 1.0f, sn = 0.0f;
+    if (rot) rope_cos_sin(a.rp, a.pos[0], a.ff, ic, c, sn);
+    const uint8_t * w = a.W[mat];
+    const int64_t rs = a.w_row_stride[mat];
+    float s0, s1;
+    if (mat < 2) mmvq_row2<TA, true>(w + r0 * rs, w + r1 * rs, a.act_q, a.act_ds, a.k, lds, s0, s1);
+    else         mmvq_row2<TB, true>(w + r0 * rs, w + r1 * rs, a.act_q, a.act_ds, a.k, lds, s0, s1);
+    if (lane == 0) {
+        float y0 = s0, y1 = s1;
+        if (rot) { y0 = s0 * c - s1 * sn; y1 = s0 * sn + s1 * c; }
+        if (mat == 0) { a.q_out[r0] = y0; a.q_out[r1] = y1; }
+        else {
+            void * o = mat == 1 ? a.k_out : a.v_out;
+            if (mat == 1 ? a.k_f16 : a.v_f16) { ((__half *)o)[r0] = __float2half_rn(y0); ((__half *)o)[r1] = __float2half_rn(y1); }
+            else                              { ((float *)o)[r0] = y0; ((float *)o)[r1] = y1; }
+        }
+    }
+}
+
 static const char * type_name(int t) {
     switch (t) {
         case MI355_TYPE_Q4_0: return "q4_0"; case MI355_TYPE_Q8_0: return "q8_0"; case MI355_TYPE_Q4_K: return "q4_K";
@@ -546,4 +647,52 @@ extern "C" int mi355_mul_mat_vec_q_group(const mi355_mmvq_args * p, int n_mats, 
         case MI355_TYPE_Q6_K: return dispatch_group_cols<MI355_TYPE_Q6_K>(a, p[0].ncols, s);
     }
     return MI355_E_TYPE;
+}
+
+template <int TA, int TB>
+static int launch_qkv(const KQkv & a, hipStream_t stream) {
+    const size_t need = (size_t)a.k + (size_t)a.k / QK * 8;
+    if (need > LDS_ACT_LIMIT) return MI355_E_UNSUPPORTED;
+    MI355_LAUNCH("mmvq_qkv_rope", (mmvq_qkv_rope_kernel<TA, TB>), dim3((unsigned)a.blk_end[2]), dim3(256), need, stream, a);
+    MI355_CHECK_LAUNCH();
+    return MI355_OK;
+}
+
+extern "C" int mi355_qkv_rope_matvec(const mi355_qkv_rope_args * p, void * stream) {
+    if (!p || !p->wq || !p->wk || !p->wv || !p->act_q || !p->act_ds || !p->q_out || !p->k_out || !p->v_out || !p->pos) return MI355_E_NULL;
+    const int64_t bsa = mi355_blck_size(p->type_qk), bsb = mi355_blck_size(p->type_v);
+    auto weight = [](int t) { return t == MI355_TYPE_Q4_0 || t == MI355_TYPE_Q8_0 || t == MI355_TYPE_Q4_K || t == MI355_TYPE_Q5_K || t == MI355_TYPE_Q6_K; };
+    if (!weight(p->type_qk) || !weight(p->type_v)) return MI355_E_TYPE;
+    if ((p->k_out_type != MI355_TYPE_F16 && p->k_out_type != MI355_TYPE_F32) || (p->v_out_type != MI355_TYPE_F16 && p->v_out_type != MI355_TYPE_F32)) return MI355_E_TYPE;
+    if (p->k <= 0 || p->k % bsa != 0 || p->k % bsb != 0 || p->k > 0x7fffffff) return MI355_E_SHAPE;
+    if (p->m_q <= 0 || p->m_k <= 0 || p->m_v <= 0 || p->m_q % 8 || p->m_k % 8 || p->m_v % 8 || p->m_q + p->m_k + p->m_v > 0x3fffffff) return MI355_E_SHAPE;
+    if (p->head_dim < 2 || (p->head_dim & 1) || p->m_q % p->head_dim || p->m_k % p->head_dim || p->n_dims < 2 || (p->n_dims & 1) || p->n_dims > p->head_dim) return MI355_E_SHAPE;
+    if (p->mode != 0 && p->mode != 2) return MI355_E_UNSUPPORTED;
+    if (((uintptr_t)p->act_q & 15) || ((uintptr_t)p->act_ds & 7) || ((uintptr_t)p->q_out & 3) || ((uintptr_t)p->k_out & 3) || ((uintptr_t)p->v_out & 3)) return MI355_E_ALIGN;
+    if (p->k % QK_K == 0 && ((uintptr_t)p->act_ds & 15)) return MI355_E_ALIGN;
+    const bool a16 = p->type_qk == MI355_TYPE_Q4_K || p->type_qk == MI355_TYPE_Q5_K, b16 = p->type_v == MI355_TYPE_Q4_K || p->type_v == MI355_TYPE_Q5_K;
+    if (((uintptr_t)p->wq | (uintptr_t)p->wk | (uintptr_t)p->wq_row_stride | (uintptr_t)p->wk_row_stride) & (a16 ? 15 : 1)) return MI355_E_ALIGN;
+    if (((uintptr_t)p->wv | (uintptr_t)p->wv_row_stride) & (b16 ? 15 : 1)) return MI355_E_ALIGN;
+    if (p->wq_row_stride < mi355_row_size(p->type_qk, p->k) || p->wk_row_stride < mi355_row_size(p->type_qk, p->k) ||
+        p->wv_row_stride < mi355_row_size(p->type_v, p->k)) return MI355_E_SHAPE;
+    KQkv a;
+    a.W[0] = (const uint8_t *)p->wq; a.W[1] = (const uint8_t *)p->wk; a.W[2] = (const uint8_t *)p->wv;
+    a.w_row_stride[0] = p->wq_row_stride; a.w_row_stride[1] = p->wk_row_stride; a.w_row_stride[2] = p->wv_row_stride;
+    a.blk_end[0] = (int)(p->m_q / 8); a.blk_end[1] = a.blk_end[0] + (int)(p->m_k / 8); a.blk_end[2] = a.blk_end[1] + (int)(p->m_v / 8);
+    a.act_q = p->act_q; a.act_ds = p->act_ds; a.k = (int)p->k;
+    a.q_out = p->q_out; a.k_out = p->k_out; a.v_out = p->v_out;
+    a.k_f16 = p->k_out_type == MI355_TYPE_F16; a.v_f16 = p->v_out_type == MI355_TYPE_F16;
+    a.pos = p->pos; a.ff = p->freq_factors;
+    a.rp = rope_params(p->n_dims, p->mode, p->head_dim, p->n_ctx_orig, p->freq_base, p->freq_scale, p->ext_factor, p->attn_factor,
+                       p->beta_fast, p->beta_slow);
+    hipStream_t s = (hipStream_t)stream;
+    const int ta = p->type_qk, tb = p->type_v;
+    if (ta == MI355_TYPE_Q4_K && tb == MI355_TYPE_Q4_K) return launch_qkv<MI355_TYPE_Q4_K, MI355_TYPE_Q4_K>(a, s);
+    if (ta == MI355_TYPE_Q4_K && tb == MI355_TYPE_Q6_K) return launch_qkv<MI355_TYPE_Q4_K, MI355_TYPE_Q6_K>(a, s);
+    if (ta == MI355_TYPE_Q4_K && tb == MI355_TYPE_Q5_K) return launch_qkv<MI355_TYPE_Q4_K, MI355_TYPE_Q5_K>(a, s);
+    if (ta == MI355_TYPE_Q5_K && tb == MI355_TYPE_Q5_K) return launch_qkv<MI355_TYPE_Q5_K, MI355_TYPE_Q5_K>(a, s);
+    if (ta == MI355_TYPE_Q6_K && tb == MI355_TYPE_Q6_K) return launch_qkv<MI355_TYPE_Q6_K, MI355_TYPE_Q6_K>(a, s);
+    if (ta == MI355_TYPE_Q8_0 && tb == MI355_TYPE_Q8_0) return launch_qkv<MI355_TYPE_Q8_0, MI355_TYPE_Q8_0>(a, s);
+    if (ta == MI355_TYPE_Q4_0 && tb == MI355_TYPE_Q4_0) return launch_qkv<MI355_TYPE_Q4_0, MI355_TYPE_Q4_0>(a, s);
+    return MI355_E_UNSUPPORTED;
 }

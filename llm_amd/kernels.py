@@ -21,7 +21,7 @@ EXPORTS = [
     "mi355_abi_version", "mi355_error_string", "mi355_blck_size", "mi355_type_size", "mi355_row_size",
     "mi355_quantize_row_q8_1", "mi355_act_q_bytes", "mi355_act_ds_bytes", "mi355_quantize_act",
     "mi355_timing_enable", "mi355_timing_reset", "mi355_timing_read", "mi355_timing_report",
-    "mi355_binary_f32", "mi355_rms_norm_f32", "mi355_rms_norm_mul_f32", "mi355_rms_norm_mul_quant_f32", "mi355_glu_quant_f32", "mi355_add_rms_norm_mul_f32", "mi355_mul_mat_vec_q_group", "mi355_rope_f32", "mi355_glu_f32", "mi355_cpy", "mi355_get_rows",
+    "mi355_binary_f32", "mi355_rms_norm_f32", "mi355_rms_norm_mul_f32", "mi355_rms_norm_mul_quant_f32", "mi355_glu_quant_f32", "mi355_add_rms_norm_mul_f32", "mi355_mul_mat_vec_q_group", "mi355_qkv_rope_matvec", "mi355_rope_f32", "mi355_glu_f32", "mi355_cpy", "mi355_get_rows",
     "mi355_scale_f32", "mi355_soft_max_f32", "mi355_flash_attn_ext_workspace_bytes", "mi355_flash_attn_ext",
     "mi355_dequantize_row", "mi355_mul_mat_vec_q", "mi355_mul_mat_q", "mi355_mul_mat_dq", "mi355_act_bf16", "mi355_mul_mat_workspace_bytes", "mi355_mul_mat",
 ]
@@ -34,6 +34,37 @@ class MmvqArgs(C.Structure):
         ("dst", _vp), ("dst_col_stride", _i64), ("dst_ch_stride", _i64),
         ("m", _i64), ("k", _i64), ("ncols", _i32), ("nchannels", _i32), ("ch_ratio", _i32),
         ("ids", _vp), ("ids_stride", _i32), ("ids_nused", _i32), ("act_ne1", _i32), ("n_expert", _i32),
+    ]
+
+
+class Tensor(C.Structure):
+    """mi355_tensor: data, ggml type id, 4 extents (ne[0] fastest), 4 byte strides"""
+    _fields_ = [("data", _vp), ("type", _i32), ("ne", _i64 * 4), ("nb", _i64 * 4)]
+
+    @staticmethod
+    def of(t, type_id=0):
+        """describe a contiguous torch tensor (up to 4-D, last dim fastest) ggml-style"""
+        shape = list(t.shape)[::-1] + [1] * (4 - t.dim())
+        r = Tensor()
+        r.data, r.type = t.data_ptr(), type_id
+        nb = t.element_size()
+        for i in range(4):
+            r.ne[i], r.nb[i] = shape[i], nb
+            nb *= shape[i]
+        return r
+
+
+class QkvRopeArgs(C.Structure):
+    """mi355_qkv_rope_args (include/mi355_kernels.h)"""
+    _fields_ = [
+        ("type_qk", _i32), ("type_v", _i32), ("wq", _vp), ("wk", _vp), ("wv", _vp),
+        ("wq_row_stride", _i64), ("wk_row_stride", _i64), ("wv_row_stride", _i64),
+        ("m_q", _i64), ("m_k", _i64), ("m_v", _i64), ("k", _i64),
+        ("act_q", _vp), ("act_ds", _vp), ("q_out", _vp), ("k_out", _vp), ("v_out", _vp),
+        ("k_out_type", _i32), ("v_out_type", _i32), ("pos", _vp), ("freq_factors", _vp),
+        ("head_dim", _i32), ("n_dims", _i32), ("mode", _i32), ("n_ctx_orig", _i32),
+        ("freq_base", C.c_float), ("freq_scale", C.c_float), ("ext_factor", C.c_float), ("attn_factor", C.c_float),
+        ("beta_fast", C.c_float), ("beta_slow", C.c_float),
     ]
 
 
@@ -70,6 +101,8 @@ lib.mi355_flash_attn_ext_workspace_bytes.argtypes = [C.POINTER(FattnArgs)]
 lib.mi355_flash_attn_ext.argtypes = [C.POINTER(FattnArgs), _vp, _i64, _vp]
 lib.mi355_act_bf16.argtypes = [_vp, _vp, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _vp]
 lib.mi355_mul_mat_dq.argtypes = [C.c_int, _vp, C.c_int64, _vp, C.c_int64, _vp, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _vp]
+lib.mi355_rope_f32.argtypes = [C.POINTER(Tensor), _vp, _vp, C.POINTER(Tensor), C.c_int, C.c_int, C.c_int] + [C.c_float] * 6 + [_vp]
+lib.mi355_qkv_rope_matvec.argtypes = [C.POINTER(QkvRopeArgs), _vp]
 lib.mi355_mul_mat_vec_q_group.argtypes = [C.POINTER(MmvqArgs), C.c_int, _vp]
 lib.mi355_mul_mat_q.argtypes = [C.c_int, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp]
 lib.mi355_mul_mat.argtypes = [C.c_int, _vp, _i64, _vp, _vp, _i64, _i64, _i64, _vp, _i64, _vp]

@@ -169,3 +169,35 @@ def flash_attn_ext(q, k, v, mask, type_kv, n_kv, scale, max_bias=0.0, logit_soft
         ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=q.device)
     K.check(K.lib.mi355_flash_attn_ext(a, ws.data_ptr() if ws is not None else None, wsb, _stream()), "mi355_flash_attn_ext")
     return dst
+
+
+def rope(x, pos, n_dims, mode, n_ctx_orig=8192, freq_base=10000.0, freq_scale=1.0, ext_factor=0.0, attn_factor=1.0,
+         beta_fast=32.0, beta_slow=1.0, freq_factors=None):
+    """ggml_rope_ext on x = [n_tokens, n_head, head_dim] f32 (contiguous), pos = [n_tokens] int32."""
+    assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and pos.dtype == torch.int32
+    dst = torch.empty_like(x)
+    tx, td = K.Tensor.of(x), K.Tensor.of(dst)
+    K.check(K.lib.mi355_rope_f32(tx, pos.data_ptr(), freq_factors.data_ptr() if freq_factors is not None else None, td, n_dims, mode,
+                                 n_ctx_orig, freq_base, freq_scale, ext_factor, attn_factor, beta_fast, beta_slow, _stream()), "mi355_rope_f32")
+    return dst
+
+
+def qkv_rope_matvec(type_qk, type_v, wq, wk, wv, m_q, m_k, m_v, k, aq, ads, pos, head_dim, n_dims, mode, kv_dtype=torch.float16,
+                    n_ctx_orig=8192, freq_base=10000.0, freq_scale=1.0, ext_factor=0.0, attn_factor=1.0, beta_fast=32.0,
+                    beta_slow=1.0, freq_factors=None):
+    """Fused decode attention input (mi355_qkv_rope_matvec): -> (q f32 [m_q], k [m_k], v [m_v] of kv_dtype)."""
+    q = torch.empty(m_q, dtype=torch.float32, device=wq.device)
+    ko = torch.empty(m_k, dtype=kv_dtype, device=wq.device)
+    vo = torch.empty(m_v, dtype=kv_dtype, device=wq.device)
+    a = K.QkvRopeArgs()
+    a.type_qk, a.type_v, a.wq, a.wk, a.wv = type_qk, type_v, wq.data_ptr(), wk.data_ptr(), wv.data_ptr()
+    a.wq_row_stride = a.wk_row_stride = B.row_size(type_qk, k)
+    a.wv_row_stride = B.row_size(type_v, k)
+    a.m_q, a.m_k, a.m_v, a.k = m_q, m_k, m_v, k
+    a.act_q, a.act_ds, a.q_out, a.k_out, a.v_out = aq.data_ptr(), ads.data_ptr(), q.data_ptr(), ko.data_ptr(), vo.data_ptr()
+    a.k_out_type = a.v_out_type = B.F16 if kv_dtype == torch.float16 else B.F32
+    a.pos, a.freq_factors = pos.data_ptr(), freq_factors.data_ptr() if freq_factors is not None else None
+    a.head_dim, a.n_dims, a.mode, a.n_ctx_orig = head_dim, n_dims, mode, n_ctx_orig
+    a.freq_base, a.freq_scale, a.ext_factor, a.attn_factor, a.beta_fast, a.beta_slow = freq_base, freq_scale, ext_factor, attn_factor, beta_fast, beta_slow
+    K.check(K.lib.mi355_qkv_rope_matvec(a, _stream()), "mi355_qkv_rope_matvec")
+    return q, ko, vo
