@@ -66,4 +66,32 @@ static __device__ __forceinline__ void quant4_soa(const float v[4], int8_t * q_d
     if (leader) { v2f ds; ds.x = __half2float(__float2half_rn(d)); ds.y = (float)sum; *(v2f *)ds_dst = ds; }
 }
 
+// 16 consecutive values of a row (half a 32-block; the partner lane, lane ^ 1, holds the other half) -> q8_1 SoA.
+// Same arithmetic as quant4_soa / quantize_row_q8_1_ref; `leader` (the even lane) writes {fp16(d), sum}.
+static __device__ __forceinline__ void quant16_soa(const float v[16], int8_t * q_dst, float * ds_dst, bool leader) {
+    float amax = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 16; j++) amax = fmaxf(amax, fabsf(v[j]));
+    amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
+    const float d  = __fdiv_rn(amax, 127.0f);
+    const float id = d != 0.0f ? __fdiv_rn(1.0f, d) : 0.0f;
+    int sum = 0;
+    v4i packed;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        uint32_t word = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const float r = roundf(__fmul_rn(v[4 * w + j], id));
+            const int q = fabsf(r) < 2147483648.0f ? (int)(int8_t)(int)r : 0;
+            sum += q;
+            word |= (uint32_t)(q & 0xff) << (8 * j);
+        }
+        packed[w] = (int)word;
+    }
+    sum += __shfl_xor(sum, 1, 64);
+    *(v4i *)q_dst = packed;
+    if (leader) { v2f ds; ds.x = __half2float(__float2half_rn(d)); ds.y = (float)sum; *(v2f *)ds_dst = ds; }
+}
+
 #define MI355_CHECK_LAUNCH() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)

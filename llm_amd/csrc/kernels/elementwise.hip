@@ -89,6 +89,50 @@ rms_norm_kernel(const T4 x, const T4 y, const T4 sum, const float * __restrict__
     const float * xr = (const float *)(x.data + i1 * x.nb[1] + i2 * x.nb[2] + i3 * x.nb[3]);
     float * dr = (float *)(d.data + i1 * d.nb[1] + i2 * d.nb[2] + i3 * d.nb[3]);
     const int n = (int)x.ne[0];
+    if (vec && (n & 15) == 0) {
+        // a thread owns chunks of 16 consecutive floats (chunk c = tid + 256 j): half a q8_1 block, so the fused
+        // quantization needs one lane-pair exchange per block instead of an 8-lane tree per 4 values
+        constexpr int MAXC = 2;                 // n <= 8192
+        const int nc = n >> 4;
+        v4f v[MAXC][4], wv[MAXC][4];
+        float s = 0.0f;
+        const float * yr = HAS_ADD ? (const float *)(y.data + i1 * y.nb[1] + i2 * y.nb[2] + i3 * y.nb[3]) : nullptr;
+        float * sr = HAS_ADD ? (float *)(sum.data + i1 * sum.nb[1] + i2 * sum.nb[2] + i3 * sum.nb[3]) : nullptr;
+#pragma unroll
+        for (int j = 0; j < MAXC; j++) {
+            const int c = threadIdx.x + j * 256;
+            if (c < nc) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    v[j][q] = ((const v4f *)xr)[4 * c + q];
+                    if (HAS_W) wv[j][q] = ((const v4f *)w)[4 * c + q];   // requested now: its latency hides behind the reduction
+                    if (HAS_ADD) {
+                        v[j][q] = v[j][q] + ((const v4f *)yr)[4 * c + q];
+                        ((v4f *)sr)[4 * c + q] = v[j][q];
+                    }
+                    s += v[j][q].x * v[j][q].x + v[j][q].y * v[j][q].y + v[j][q].z * v[j][q].z + v[j][q].w * v[j][q].w;
+                }
+            }
+        }
+        s = block_sum(s, sh);
+        const float scale = 1.0f / sqrtf(s / (float)n + eps);
+#pragma unroll
+        for (int j = 0; j < MAXC; j++) {
+            const int c = threadIdx.x + j * 256;
+            if (c < nc) {
+                float o[16];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    v4f t = v[j][q] * scale;            // (x * scale) then * w: the op order of the unfused graph
+                    if (HAS_W) t = t * wv[j][q];
+                    ((v4f *)dr)[4 * c + q] = t;
+                    o[4 * q] = t.x; o[4 * q + 1] = t.y; o[4 * q + 2] = t.z; o[4 * q + 3] = t.w;
+                }
+                if (aq) quant16_soa(o, aq + (int64_t)row * n + 16 * c, ads + ((int64_t)row * (n / QK) + (c >> 1)) * 2, (c & 1) == 0);
+            }
+        }
+        return;
+    }
     if (vec) {
         constexpr int MAXV = 8;
         const int n4 = n >> 2;
@@ -99,7 +143,7 @@ rms_norm_kernel(const T4 x, const T4 y, const T4 sum, const float * __restrict__
             const int i = threadIdx.x + j * 256;
             if (i < n4) {
                 v[j] = ((const v4f *)xr)[i];
-                if (HAS_W) wv[j] = ((const v4f *)w)[i];   // requested now so its latency hides behind the reduction
+                if (HAS_W) wv[j] = ((const v4f *)w)[i];
                 if (HAS_ADD) {
                     const float * yr = (const float *)(y.data + i1 * y.nb[1] + i2 * y.nb[2] + i3 * y.nb[3]);
                     v[j] = v[j] + ((const v4f *)yr)[i];
@@ -115,13 +159,9 @@ rms_norm_kernel(const T4 x, const T4 y, const T4 sum, const float * __restrict__
         for (int j = 0; j < MAXV; j++) {
             const int i = threadIdx.x + j * 256;
             if (i < n4) {
-                v4f o = v[j] * scale;            // (x * scale) then * w: the op order of the unfused graph
+                v4f o = v[j] * scale;
                 if (HAS_W) o = o * wv[j];
                 ((v4f *)dr)[i] = o;
-                if (aq) { // fused q8_1 quantization of the row for the MUL_MATs that consume it
-                    const float ov[4] = {o.x, o.y, o.z, o.w};
-                    quant4_soa(ov, aq + (int64_t)row * n + 4 * i, ads + ((int64_t)row * (n / QK) + (i >> 3)) * 2, (i & 7) == 0);
-                }
             }
         }
         return;

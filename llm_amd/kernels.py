@@ -101,6 +101,16 @@ lib.mi355_flash_attn_ext_workspace_bytes.argtypes = [C.POINTER(FattnArgs)]
 lib.mi355_flash_attn_ext.argtypes = [C.POINTER(FattnArgs), _vp, _i64, _vp]
 lib.mi355_act_bf16.argtypes = [_vp, _vp, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _vp]
 lib.mi355_mul_mat_dq.argtypes = [C.c_int, _vp, C.c_int64, _vp, C.c_int64, _vp, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _vp]
+_T = C.POINTER(Tensor)
+lib.mi355_rms_norm_f32.argtypes = [_T, _T, C.c_float, _vp]
+lib.mi355_rms_norm_mul_f32.argtypes = [_T, _vp, _T, C.c_float, _vp]
+lib.mi355_rms_norm_mul_quant_f32.argtypes = [_T, _vp, _T, C.c_float, _vp, _vp, _vp]
+lib.mi355_add_rms_norm_mul_f32.argtypes = [_T, _T, _T, _vp, _T, C.c_float, _vp, _vp, _vp]
+lib.mi355_scale_f32.argtypes = [_T, _T, C.c_float, C.c_float, _vp]
+lib.mi355_binary_f32.argtypes = [C.c_int, _T, _T, _T, _vp]
+lib.mi355_glu_f32.argtypes = [C.c_int, _T, _T, _T, C.c_int, _vp]
+lib.mi355_glu_quant_f32.argtypes = [C.c_int, _T, _T, _T, C.c_int, _vp, _vp, _vp]
+lib.mi355_cpy.argtypes = [_T, _T, _vp]
 lib.mi355_rope_f32.argtypes = [C.POINTER(Tensor), _vp, _vp, C.POINTER(Tensor), C.c_int, C.c_int, C.c_int] + [C.c_float] * 6 + [_vp]
 lib.mi355_qkv_rope_matvec.argtypes = [C.POINTER(QkvRopeArgs), _vp]
 lib.mi355_mul_mat_vec_q_group.argtypes = [C.POINTER(MmvqArgs), C.c_int, _vp]

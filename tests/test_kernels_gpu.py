@@ -274,6 +274,43 @@ def test_qkv_rope_fused_is_bit_identical_to_separate_kernels(ops, tqk, tv, mode,
     assert torch.equal(kf.view(it), kr.view(it)) and torch.equal(vf.view(it), vr.view(it))
 
 
+@pytest.mark.parametrize("rows,n", [(1, 4096), (3, 1024), (8, 8192), (2, 96), (1, 4128)])
+@pytest.mark.parametrize("with_add", [False, True])
+def test_fused_norm_matches_separate_ops(ops, rows, n, with_add):
+    """[ADD ->] RMS_NORM -> MUL(weight) [-> q8_1] in one launch: the f32 outputs equal the separate kernels' bit for
+    bit and the fused q8_1 form equals mi355_quantize_act of that output; values agree with numpy (ops.cpp rms_norm)."""
+    import llm_amd.kernels as K
+    rng = np.random.default_rng(rows * n)
+    x, y, w = (dev(rng.standard_normal(sh).astype(np.float32)) for sh in ((rows, n), (rows, n), (n,)))
+    T, s = K.Tensor.of, torch.cuda.current_stream().cuda_stream
+    su, d, d2, nrm = (torch.empty_like(x) for _ in range(4))
+    aq = torch.empty((rows, n), dtype=torch.int8, device="cuda")
+    ads = torch.empty((rows, n // 32, 2), dtype=torch.float32, device="cuda")
+    quant = n % 32 == 0
+    if with_add:
+        K.check(K.lib.mi355_add_rms_norm_mul_f32(T(x), T(y), T(su), w.data_ptr(), T(d), 1e-5, aq.data_ptr() if quant else None,
+                                                 ads.data_ptr() if quant else None, s), "add_rms_norm_mul")
+        K.check(K.lib.mi355_binary_f32(0, T(x), T(y), T(d2), s), "add")
+        assert torch.equal(su.view(torch.int32), d2.view(torch.int32))
+        xin = su
+    else:
+        if quant:
+            K.check(K.lib.mi355_rms_norm_mul_quant_f32(T(x), w.data_ptr(), T(d), 1e-5, aq.data_ptr(), ads.data_ptr(), s), "rms_norm_mul_quant")
+        else:
+            K.check(K.lib.mi355_rms_norm_mul_f32(T(x), w.data_ptr(), T(d), 1e-5, s), "rms_norm_mul")
+        xin = x
+    # separate kernels: RMS_NORM, then MUL with the broadcast weight
+    K.check(K.lib.mi355_rms_norm_f32(T(xin), T(nrm), 1e-5, s), "rms_norm")
+    K.check(K.lib.mi355_binary_f32(1, T(nrm), T(w), T(d2), s), "mul")
+    assert torch.equal(d.view(torch.int32), d2.view(torch.int32))
+    xi = xin.cpu().numpy().astype(np.float64)
+    ref = xi / np.sqrt((xi ** 2).mean(axis=1, keepdims=True) + 1e-5) * w.cpu().numpy()
+    assert np.allclose(d.cpu().numpy(), ref, rtol=2e-5, atol=1e-6)
+    if quant:
+        aq2, ads2 = ops.quantize_act(d)
+        assert torch.equal(aq, aq2.view(rows, n)) and torch.equal(ads.view(-1).view(torch.int32), ads2.view(-1).view(torch.int32))
+
+
 def _mmid_cases():
     g = load_gold("mul_mat_id.gold")
     return [k[len("shape."):] for k in g if k.startswith("shape.")]
