@@ -275,8 +275,10 @@ MI355_API int mi355_soft_max_f32(const mi355_tensor *x, const mi355_tensor *mask
  *   k, v     [d, n_kv, n_head_kv, ne3]  byte strides *_nb1..3 (views of the KV cache)
  *   mask f16 [n_kv, >= n_q, m_ne2, m_ne3] or NULL; -inf entries are skipped
  *   dst  f32 [d, n_head, n_q, ne3]      byte strides d_nb1 (head), d_nb2 (token), d_nb3
- * workspace (optional): lets long contexts split the KV range over several workgroups
- * (mi355_flash_attn_ext_workspace_bytes gives the largest size the launcher can use).
+ * workspace (optional, 16-byte aligned): lets decode-sized batches split the KV range over many workgroups
+ * (mi355_flash_attn_ext_workspace_bytes gives the largest size the launcher can use).  Its first 64 KiB hold the
+ * slices' arrival counters: the buffer must be ZERO-FILLED before its first use; every call leaves the counters
+ * at zero again.  Calls that share a workspace must be ordered on one stream.
  */
 typedef struct mi355_fattn_args {
     const float *q;    int64_t q_nb1, q_nb2, q_nb3;
@@ -290,6 +292,11 @@ typedef struct mi355_fattn_args {
 
 MI355_API int64_t mi355_flash_attn_ext_workspace_bytes(const mi355_fattn_args *args);
 MI355_API int     mi355_flash_attn_ext(const mi355_fattn_args *args, void *workspace, int64_t workspace_bytes, void *stream);
+/* same, and additionally the q8_1 form of dst in the internal activation layout (row = token, k = n_head * d), so
+ * the attention-output MUL_MAT needs no quantization launch.  Decode-sized batches only (n_q < 32), else
+ * MI355_E_UNSUPPORTED.  act_q / act_ds as in mi355_quantize_act. */
+MI355_API int     mi355_flash_attn_ext_quant(const mi355_fattn_args *args, void *workspace, int64_t workspace_bytes,
+                                             int8_t *act_q, float *act_ds, void *stream);
 
 #ifdef __cplusplus
 }

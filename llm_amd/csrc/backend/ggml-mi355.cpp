@@ -540,6 +540,8 @@ struct mi355_backend_ctx {
         if (which == 0) act_cache.valid = false;
         scratch_size[which] = (need + (8u << 20)) & ~((size_t)(1u << 20) - 1);
         HIP_CHECK(hipMalloc(&scratch[which], scratch_size[which]));
+        // the flash-attention workspace starts with arrival counters that must be zero before the first use
+        if (which == 1) HIP_CHECK(hipMemsetAsync(scratch[which], 0, scratch_size[which], stream));
         return scratch[which];
     }
 
@@ -868,12 +870,29 @@ static bool mi355_flash_attn_supported(const ggml_tensor * op) {
 static void mi355_flash_attn(mi355_backend_ctx * ctx, ggml_tensor * dst) {
     mi355_fattn_args a;
     fattn_args_from(dst, &a);
-    // a workspace lets long contexts split the KV range; only worth having for decode-sized batches
+    // a workspace lets the KV range be split; only worth having for decode-sized batches
     void * ws = nullptr;
     int64_t ws_bytes = 0;
     if (a.n_kv >= 128 && a.n_head_kv * a.n_q * a.ne3 < 512) {
         ws_bytes = mi355_flash_attn_ext_workspace_bytes(&a);
         ws = ctx->get_scratch(1, (size_t)ws_bytes);
+    }
+    // decode: the result (all heads of a token = one activation row) feeds the attention-output MUL_MAT; emit its
+    // q8_1 form from the same kernel
+    const int64_t K = a.d * a.n_head, rows = a.n_q * a.ne3;
+    if (rows <= 8 && ggml_is_contiguous(dst) && getenv("GGML_MI355_NO_FUSE") == nullptr) {
+        const size_t qb = align_up((size_t)mi355_act_q_bytes(K, rows), 256), db = align_up((size_t)mi355_act_ds_bytes(K, rows), 256);
+        char * act = (char *)ctx->get_scratch(0, qb + db);
+        const int rc = mi355_flash_attn_ext_quant(&a, ws, ws_bytes, (int8_t *)act, (float *)(act + qb), ctx->stream);
+        if (rc == MI355_OK) {
+            // remembered under the shape its consumer uses: kqv_out = [n_head * d, n_tokens]
+            ggml_tensor as_rows = *dst;
+            as_rows.ne[0] = K; as_rows.ne[1] = a.n_q; as_rows.ne[2] = a.ne3; as_rows.ne[3] = 1;
+            as_rows.nb[0] = sizeof(float); as_rows.nb[1] = K * sizeof(float); as_rows.nb[2] = as_rows.nb[1] * a.n_q; as_rows.nb[3] = as_rows.nb[2] * a.ne3;
+            ctx->act_remember(&as_rows);
+            return;
+        }
+        if (rc != MI355_E_UNSUPPORTED) MI_CHECK(rc);
     }
     MI_CHECK(mi355_flash_attn_ext(&a, ws, ws_bytes, ctx->stream));
 }

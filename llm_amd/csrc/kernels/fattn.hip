@@ -11,8 +11,8 @@
 //     load of f16, or 8 bytes of q8_0), so a wave-load covers 64/LPR complete, contiguous rows.
 //   * every lane group runs its own online softmax (running max / sum / 8-wide f32 accumulator per
 //     query head) over rows g, g+G, ...; the G groups are merged through LDS at the end.
-//   * long contexts: the KV range is split over `nsplit` workgroups that write (m, l, acc) partials
-//     to a workspace; a second kernel merges them (same rescaling rule).
+//   * the KV range is split over `nsplit` workgroups that write (m, l, acc) partials to a workspace and meet
+//     at an arrival counter; the workgroup that arrives last merges them (same rescaling rule) -- one launch.
 // All accumulation is f32 (the CPU oracle accumulates f16 V in fp16; NMSE budget 5e-4).
 #include "common.h"
 
@@ -29,6 +29,8 @@ struct FArgs {
     uint32_t n_head_log2;
     int nsplit;
     float * part; // [ne3][n_q][n_head][nsplit][D + 2] when nsplit > 1
+    int * counters; // [ne3][n_q][gridDim.x] arrival counters of the KV slices (all zero between launches)
+    int8_t * act_q; float * act_ds; // optional: q8_1 form of dst (token row = all heads), written with the result
 };
 
 // 8 consecutive features of a K/V row as f32
@@ -64,6 +66,29 @@ static __device__ __forceinline__ void load8(const char * row, int j, float * ou
 static __device__ __forceinline__ float alibi_slope(const FArgs & a, uint32_t h) {
     if (!(a.max_bias > 0.0f)) return 1.0f;
     return h < a.n_head_log2 ? powf(a.m0, h + 1) : powf(a.m1, 2 * (h - a.n_head_log2) + 1);
+}
+
+// one output element (head h, token iq, feature d) and, if asked for, its q8_1 form: the 32 lanes that hold a
+// 32-block (d / 32 of one head; lanes are consecutive in d) quantize it together exactly as quantize_row_q8_1_ref
+template <int D>
+static __device__ __forceinline__ void fattn_store(const FArgs & a, int h, int iq, int i3, int d, float v) {
+    float * o = (float *)(a.dst + (int64_t)h * a.d_nb1 + (int64_t)iq * a.d_nb2 + (int64_t)i3 * a.d_nb3);
+    o[d] = v;
+    if (a.act_q) {
+        float amax = fabsf(v);
+#pragma unroll
+        for (int s = 1; s < 32; s <<= 1) amax = fmaxf(amax, __shfl_xor(amax, s, 64));
+        const float dd = __fdiv_rn(amax, 127.0f);
+        const float id = dd != 0.0f ? __fdiv_rn(1.0f, dd) : 0.0f;
+        const float r = roundf(__fmul_rn(v, id));
+        const int q = fabsf(r) < 2147483648.0f ? (int)(int8_t)(int)r : 0;
+        int sum = q;
+#pragma unroll
+        for (int s = 1; s < 32; s <<= 1) sum += __shfl_xor(sum, s, 64);
+        const int64_t row = (int64_t)i3 * a.n_q + iq, kk = (int64_t)a.n_head * D, e = (int64_t)h * D + d;
+        a.act_q[row * kk + e] = (int8_t)q;
+        if ((d & 31) == 0) { v2f ds; ds.x = __half2float(__float2half_rn(dd)); ds.y = (float)sum; *(v2f *)(a.act_ds + (row * (kk / 32) + e / 32) * 2) = ds; }
+    }
 }
 
 constexpr int FA_THREADS = 512; // 8 waves: the KV loop is a chain of dependent loads, so rows are spread wide
@@ -188,32 +213,46 @@ fattn_vec_kernel(const FArgs a) {
             O += base[gg * (D + 2) + d] * w;
         }
         if (a.nsplit == 1) {
-            float * o = (float *)(a.dst + h * a.d_nb1 + iq * a.d_nb2 + i3 * a.d_nb3);
-            o[d] = O / L;
+            fattn_store<D>(a, h, iq, i3, d, O / L);
         } else {
             float * p = a.part + ((((size_t)i3 * a.n_q + iq) * a.n_head + h) * a.nsplit + split) * (D + 2);
             p[d] = O;
             if (d == 0) { p[D] = M; p[D + 1] = L; }
         }
     }
-}
+    if (a.nsplit == 1) return;
 
-template <int D>
-__global__ void __launch_bounds__(D)
-fattn_combine_kernel(const FArgs a) {
-    const int h = blockIdx.x, iq = blockIdx.y, i3 = blockIdx.z, d = threadIdx.x;
-    const float * p = a.part + (((size_t)i3 * a.n_q + iq) * a.n_head + h) * a.nsplit * (D + 2);
-    float M = -INFINITY;
-    for (int s = 0; s < a.nsplit; s++) M = fmaxf(M, p[s * (D + 2) + D]);
-    float L = 0.0f, O = 0.0f;
-    for (int s = 0; s < a.nsplit; s++) {
-        const float ms = p[s * (D + 2) + D];
-        const float w = ms == -INFINITY ? 0.0f : expf(ms - M);
-        L += p[s * (D + 2) + D + 1] * w;
-        O += p[s * (D + 2) + d] * w;
+    // The slices of one (kv-head group, token) meet at an arrival counter; whoever arrives last merges all partials
+    // and writes the result, so there is no second launch.  Hand-off (one release and one acquire per workgroup, not
+    // per wave -- a device-scope fence writes back / invalidates caches and costs microseconds): the barrier waits
+    // for every wave's partial stores, then ONE lane counts the arrival with an acq_rel device-scope atomic, which
+    // publishes the workgroup's stores and, in the merging workgroup, drops this CU's stale L1 lines.
+    __shared__ int last_flag;
+    __syncthreads();
+    if (tid == 0) {
+        int * cnt = a.counters + ((size_t)i3 * a.n_q + iq) * gridDim.x + blockIdx.x;
+        const int old = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        last_flag = old == a.nsplit - 1;
+        if (last_flag) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-armed for the next launch
     }
-    float * o = (float *)(a.dst + h * a.d_nb1 + iq * a.d_nb2 + i3 * a.d_nb3);
-    o[d] = O / L;
+    __syncthreads();
+    if (!last_flag) return;
+    for (int idx = tid; idx < R * D; idx += FA_THREADS) {
+        const int r = idx / D, d = idx % D;
+        const int h = h0 + r;
+        if (h >= hk * ratio + ratio) continue;
+        const float * p = a.part + (((size_t)i3 * a.n_q + iq) * a.n_head + h) * a.nsplit * (D + 2);
+        float M = -INFINITY;
+        for (int s = 0; s < a.nsplit; s++) M = fmaxf(M, p[s * (D + 2) + D]);
+        float L = 0.0f, O = 0.0f;
+        for (int s = 0; s < a.nsplit; s++) {
+            const float ms = p[s * (D + 2) + D];
+            const float w = ms == -INFINITY ? 0.0f : expf(ms - M);
+            L += p[s * (D + 2) + D + 1] * w;
+            O += p[s * (D + 2) + d] * w;
+        }
+        fattn_store<D>(a, h, iq, i3, d, O / L);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -405,10 +444,6 @@ static int launch_vec(const FArgs & a, hipStream_t s) {
     }
     MI355_LAUNCH("fattn_vec", (fattn_vec_kernel<D, R, TK, TV>), grid, dim3(FA_THREADS), sh, s, a);
     MI355_CHECK_LAUNCH();
-    if (a.nsplit > 1) {
-        MI355_LAUNCH("fattn_combine", (fattn_combine_kernel<D>), dim3((unsigned)a.n_head, (unsigned)a.n_q, (unsigned)a.ne3), dim3(D), 0, s, a);
-        MI355_CHECK_LAUNCH();
-    }
     return MI355_OK;
 }
 
@@ -433,13 +468,21 @@ static int dispatch_types(const FArgs & a, int tk, int tv, hipStream_t s) {
 
 extern "C" {
 
+// workspace = [MI355_FATTN_WS_HEADER bytes of arrival counters][partials]
+constexpr int64_t WS_HEADER = 65536;
+
 int64_t mi355_flash_attn_ext_workspace_bytes(const mi355_fattn_args * p) {
     if (!p) return -1;
-    // partials for the largest split the launcher may choose
-    return (int64_t)p->ne3 * p->n_q * p->n_head * 64 * (p->d + 2) * (int64_t)sizeof(float);
+    // header + partials for the largest split the launcher may choose
+    return WS_HEADER + (int64_t)p->ne3 * p->n_q * p->n_head * 64 * (p->d + 2) * (int64_t)sizeof(float);
 }
 
 int mi355_flash_attn_ext(const mi355_fattn_args * p, void * workspace, int64_t workspace_bytes, void * stream) {
+    return mi355_flash_attn_ext_quant(p, workspace, workspace_bytes, nullptr, nullptr, stream);
+}
+
+int mi355_flash_attn_ext_quant(const mi355_fattn_args * p, void * workspace, int64_t workspace_bytes, int8_t * act_q, float * act_ds,
+                               void * stream) {
     if (!p || !p->q || !p->k || !p->v || !p->dst) return MI355_E_NULL;
     if (p->d != 64 && p->d != 128 && p->d != 256) return MI355_E_UNSUPPORTED;
     if (p->n_head_kv < 1 || p->n_head % p->n_head_kv != 0 || p->n_q < 0 || p->n_kv < 0 || p->ne3 < 1) return MI355_E_SHAPE;
@@ -448,9 +491,12 @@ int mi355_flash_attn_ext(const mi355_fattn_args * p, void * workspace, int64_t w
     if (((uintptr_t)p->q | (uintptr_t)p->q_nb1 | (uintptr_t)p->q_nb2 | (uintptr_t)p->q_nb3) & 15) return MI355_E_ALIGN;
     if (p->type_k == MI355_TYPE_F16 && (((uintptr_t)p->k | (uintptr_t)p->k_nb1 | (uintptr_t)p->k_nb2 | (uintptr_t)p->k_nb3) & 15)) return MI355_E_ALIGN;
     if (p->type_v == MI355_TYPE_F16 && (((uintptr_t)p->v | (uintptr_t)p->v_nb1 | (uintptr_t)p->v_nb2 | (uintptr_t)p->v_nb3) & 15)) return MI355_E_ALIGN;
+    if ((act_q == nullptr) != (act_ds == nullptr)) return MI355_E_NULL;
+    if (act_q && (((uintptr_t)act_q & 15) || ((uintptr_t)act_ds & 7))) return MI355_E_ALIGN;
     if (p->n_q == 0 || p->n_head == 0) return MI355_OK;
 
     FArgs a;
+    a.act_q = act_q; a.act_ds = act_ds; a.counters = nullptr;
     a.q = (const char *)p->q; a.q_nb1 = p->q_nb1; a.q_nb2 = p->q_nb2; a.q_nb3 = p->q_nb3;
     a.k = (const char *)p->k; a.k_nb1 = p->k_nb1; a.k_nb2 = p->k_nb2; a.k_nb3 = p->k_nb3;
     a.v = (const char *)p->v; a.v_nb1 = p->v_nb1; a.v_nb2 = p->v_nb2; a.v_nb3 = p->v_nb3;
@@ -466,27 +512,32 @@ int mi355_flash_attn_ext(const mi355_fattn_args * p, void * workspace, int64_t w
     if (p->type_k == MI355_TYPE_F16 && p->type_v == MI355_TYPE_F16 && (p->d == 128 || p->d == 64) && p->n_q >= 32 &&
         !(p->max_bias > 0.0f) && p->logit_softcap == 0.0f && p->n_head <= 65535 && p->ne3 <= 65535 &&
         ((p->d_nb1 | p->d_nb2 | p->d_nb3 | (int64_t)(uintptr_t)p->dst) & 15) == 0 && (!p->mask || (p->m_nb1 & 1) == 0)) {
+        if (act_q) return MI355_E_UNSUPPORTED;   // the fused q8_1 output exists for decode-sized batches only
         a.nsplit = 1; a.part = nullptr;
         return p->d == 128 ? launch_mma<128>(a, (hipStream_t)stream) : launch_mma<64>(a, (hipStream_t)stream);
     }
     // KV split.  The KV loop is a chain of memory round trips (one per G = 512/(d/8) rows), so for decode-sized
     // grids the range is cut until every workgroup has about one round trip of rows -- all loads of the op are
     // then in flight at once -- up to 64 slices, bounded by the workspace; the partials are merged by
-    // fattn_combine_kernel.
     int nsplit = 1;
     const int64_t base_wgs = (int64_t)p->n_head_kv * p->n_q * p->ne3;
     const int64_t G = FA_THREADS / (p->d / 8);
-    if (workspace && base_wgs < 512 && p->n_kv >= 4 * G) {
+    const int64_t ratio = p->n_head / p->n_head_kv;
+    const int64_t rr = ratio >= 8 && p->d <= 128 ? 8 : ratio >= 4 ? 4 : ratio >= 2 ? 2 : 1;      // R chosen by dispatch_r
+    const int64_t n_counters = (int64_t)p->ne3 * p->n_q * p->n_head_kv * ((ratio + rr - 1) / rr);
+    if (workspace && workspace_bytes > WS_HEADER && ((uintptr_t)workspace & 15) == 0 && n_counters * 4 <= WS_HEADER &&
+        base_wgs < 512 && p->n_kv >= 4 * G) {
         int64_t want = (p->n_kv + G - 1) / G;
         const int64_t fill = 2048 / (base_wgs > 0 ? base_wgs : 1);   // no point beyond ~8 workgroups per CU
         if (want > fill) want = fill;
         if (want > 64) want = 64;
         const int64_t per = (int64_t)p->ne3 * p->n_q * p->n_head * (p->d + 2) * (int64_t)sizeof(float);
-        if (per > 0 && want * per > workspace_bytes) want = workspace_bytes / per;
+        if (per > 0 && want * per > workspace_bytes - WS_HEADER) want = (workspace_bytes - WS_HEADER) / per;
         if (want > 1) nsplit = (int)want;
     }
     a.nsplit = nsplit;
-    a.part = (float *)workspace;
+    a.counters = (int *)workspace;
+    a.part = (float *)((char *)workspace + WS_HEADER);
     hipStream_t s = (hipStream_t)stream;
     switch (p->d) {
         case 64:  return dispatch_types<64>(a, p->type_k, p->type_v, s);

@@ -145,7 +145,7 @@ def mul_mat_id(t, as_, b, ids, m, n_expert):
     return dst
 
 
-def flash_attn_ext(q, k, v, mask, type_kv, n_kv, scale, max_bias=0.0, logit_softcap=0.0, use_workspace=True):
+def flash_attn_ext(q, k, v, mask, type_kv, n_kv, scale, max_bias=0.0, logit_softcap=0.0, use_workspace=True, quant=False):
     """ggml_flash_attn_ext, batch 1.  q: [n_head, n_q, d] f32; k, v: [n_head_kv, n_kv, row_bytes] uint8 rows of
     type_kv (F16 / Q8_0 / Q4_0); mask: [n_q_pad, n_kv] f16 bits (int16) or None -> [n_q, n_head, d] f32."""
     assert q.is_cuda and q.dtype == torch.float32 and q.is_contiguous() and k.is_contiguous() and v.is_contiguous()
@@ -166,7 +166,14 @@ def flash_attn_ext(q, k, v, mask, type_kv, n_kv, scale, max_bias=0.0, logit_soft
     ws, wsb = None, 0
     if use_workspace:
         wsb = K.lib.mi355_flash_attn_ext_workspace_bytes(a)
-        ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=q.device)
+        ws = torch.zeros(max(wsb, 16), dtype=torch.uint8, device=q.device)   # arrival counters must start at zero
+    if quant:
+        aq = torch.empty((n_q, n_head * d), dtype=torch.int8, device=q.device)
+        ads = torch.empty((n_q, n_head * d // 32, 2), dtype=torch.float32, device=q.device)
+        for _ in range(2):   # twice on the same workspace: the counters must have returned to zero
+            K.check(K.lib.mi355_flash_attn_ext_quant(a, ws.data_ptr() if ws is not None else None, wsb, aq.data_ptr(), ads.data_ptr(),
+                                                     _stream()), "mi355_flash_attn_ext_quant")
+        return dst, aq, ads
     K.check(K.lib.mi355_flash_attn_ext(a, ws.data_ptr() if ws is not None else None, wsb, _stream()), "mi355_flash_attn_ext")
     return dst
 

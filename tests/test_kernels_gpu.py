@@ -374,6 +374,23 @@ def test_flash_attn_f16_vs_f64_oracle(ops, d, nh, nhkv, nq, nkv, causal):
     assert np.isfinite(got).all() and O.nmse(ref, got) <= 2e-5, O.nmse(ref, got)
 
 
+@pytest.mark.parametrize("nq,nkv,use_ws", [(1, 300, True), (1, 300, False), (4, 4096, True), (8, 96, True)])
+def test_flash_attn_fused_q8_1_output(ops, nq, nkv, use_ws):
+    """mi355_flash_attn_ext_quant: dst equals the plain call bit for bit and the fused q8_1 form equals
+    mi355_quantize_act(dst); run twice on one workspace (the arrival counters re-arm themselves)."""
+    d, nh, nhkv = 128, 8, 2
+    rng = np.random.default_rng(nq + nkv)
+    q = dev(rng.standard_normal((nh, nq, d)).astype(np.float32))
+    k = dev(rng.standard_normal((nhkv, nkv, d)).astype(np.float16).view(np.uint8).reshape(nhkv, nkv, -1))
+    v = dev(rng.standard_normal((nhkv, nkv, d)).astype(np.float16).view(np.uint8).reshape(nhkv, nkv, -1))
+    mask = dev(np.zeros((64, nkv), np.float16).view(np.int16))
+    plain = ops.flash_attn_ext(q, k, v, mask, B.F16, nkv, 0.088, use_workspace=use_ws)
+    dst, aq, ads = ops.flash_attn_ext(q, k, v, mask, B.F16, nkv, 0.088, use_workspace=use_ws, quant=True)
+    assert torch.equal(plain.view(torch.int32), dst.view(torch.int32))
+    aq2, ads2 = ops.quantize_act(dst.view(nq, nh * d))
+    assert torch.equal(aq, aq2) and torch.equal(ads.view(torch.int32), ads2.view(torch.int32))
+
+
 def test_errors_are_reported_not_launched(ops):
     import llm_amd.kernels as K
     w = torch.zeros(144 * 4 + 16, dtype=torch.uint8, device="cuda")
