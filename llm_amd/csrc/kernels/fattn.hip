@@ -242,14 +242,27 @@ fattn_vec_kernel(const FArgs a) {
         const int h = h0 + r;
         if (h >= hk * ratio + ratio) continue;
         const float * p = a.part + (((size_t)i3 * a.n_q + iq) * a.n_head + h) * a.nsplit * (D + 2);
-        float M = -INFINITY;
-        for (int s = 0; s < a.nsplit; s++) M = fmaxf(M, p[s * (D + 2) + D]);
-        float L = 0.0f, O = 0.0f;
-        for (int s = 0; s < a.nsplit; s++) {
-            const float ms = p[s * (D + 2) + D];
-            const float w = ms == -INFINITY ? 0.0f : expf(ms - M);
-            L += p[s * (D + 2) + D + 1] * w;
-            O += p[s * (D + 2) + d] * w;
+        // eight slices at a time with all their loads issued before the first use: the partials sit in L2 / HBM and
+        // a load-use-load chain over the slices would cost one memory round trip per slice
+        float M = -INFINITY, L = 0.0f, O = 0.0f;
+        for (int s0 = 0; s0 < a.nsplit; s0 += 8) {
+            float mv[8], lv[8], ov[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int sc = s0 + u < a.nsplit ? s0 + u : a.nsplit - 1;
+                mv[u] = p[sc * (D + 2) + D]; lv[u] = p[sc * (D + 2) + D + 1]; ov[u] = p[sc * (D + 2) + d];
+            }
+            float mb = M;
+#pragma unroll
+            for (int u = 0; u < 8; u++) if (s0 + u < a.nsplit) mb = fmaxf(mb, mv[u]);
+            const float c0 = M == -INFINITY ? 0.0f : expf(M - mb);
+            L *= c0; O *= c0;
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const float w = (s0 + u < a.nsplit && mv[u] != -INFINITY) ? expf(mv[u] - mb) : 0.0f;
+                L += lv[u] * w; O += ov[u] * w;
+            }
+            M = mb;
         }
         fattn_store<D>(a, h, iq, i3, d, O / L);
     }
