@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TBO = os.path.join(ROOT, "oracle", "_ref", "test-backend-ops")
 PLUGIN = os.path.join(ROOT, "llm_amd", "lib", "libggml-mi355.so")
 
-OPS = ["MUL_MAT", "MUL_MAT_ID", "FLASH_ATTN_EXT", "ADD", "MUL", "RMS_NORM", "ROPE", "GLU", "CPY", "CONT", "GET_ROWS",
+OPS = ["MUL_MAT", "MUL_MAT_ID", "FLASH_ATTN_EXT", "ADD", "MUL", "RMS_NORM", "ROPE", "REGLU", "GEGLU", "SWIGLU", "CPY", "CONT", "GET_ROWS",
        "SCALE", "SOFT_MAX"]
 # lower bounds on the number of cases that must actually RUN on the device (not "not supported")
 MIN_RUN = {"MUL_MAT": 100, "MUL_MAT_ID": 100, "FLASH_ATTN_EXT": 1000, "ROPE": 50, "SOFT_MAX": 100}
