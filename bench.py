@@ -210,7 +210,7 @@ def main():
     avg_us = tot_us / n_launch
     achieved = q4k_bytes / tot_us * 1e-3
     kernels = {tag: {"launches": n, "avg_us": round(us / n, 3)} for tag, (n, us) in K.timing_report().items() if n}
-    roofline = {"bound": "hbm", "kernel": "mmvq_kernel<q4_K, ncols=1>", "achieved": round(achieved, 1),
+    roofline = {"bound": "hbm", "kernel": "mmvq_group_kernel<q4_K, ncols=1>", "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
                 "traffic": None, "launches": n_launch, "avg_launch_us": round(avg_us, 3),
                 "algorithmic_bytes_per_launch": round(q4k_bytes / n_launch), "all_kernels": kernels}
