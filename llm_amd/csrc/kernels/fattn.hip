@@ -269,7 +269,8 @@ fattn_vec_kernel(const FArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Prefill: tile kernel on the f16 matrix cores (v_mfma_f32_32x32x16_f16), f16 K/V, no ALiBi / softcap.
+// Prefill: tile kernel on the f16 matrix cores (v_mfma_f32_32x32x16_f16); f16 K/V, or q8_0 / q4_0 K/V dequantized
+// to f16 while a block is staged; no ALiBi / softcap.
 //   workgroup = 128 threads = 2 waves; a wave owns 32 query rows of one head, the workgroup walks the KV
 //   range in blocks of 64 rows staged in LDS (K row-major; V transposed and permuted so that both MFMA
 //   operands are single ds_read_b128).
@@ -286,7 +287,20 @@ typedef float v16f __attribute__((ext_vector_type(16)));
 
 constexpr int MMA_BQ = 64, MMA_BKV = 64, MMA_THREADS = 128;
 
-template <int D>
+// 8 consecutive features of a K/V row as f16 (16 bytes): f16 rows are copied, q8_0 / q4_0 rows are dequantized
+// (d * q in f32, as the vec kernel does) and rounded to f16
+template <int TYPE>
+static __device__ __forceinline__ v4i load8h(const char * row, int j) {
+    if (TYPE == MI355_TYPE_F16) return *(const v4i *)(row + j * 16);
+    float f[8];
+    load8<TYPE>(row, j, f);
+    half8 h;
+#pragma unroll
+    for (int i = 0; i < 8; i++) h[i] = (_Float16)f[i];
+    return *(const v4i *)&h;
+}
+
+template <int D, int TKV>
 __global__ void __launch_bounds__(MMA_THREADS)
 fattn_mma_kernel(const FArgs a) {
     constexpr int KP = D * 2 + 16;          // K tile row pitch (bytes)
@@ -336,12 +350,12 @@ fattn_mma_kernel(const FArgs a) {
             {
                 const int row = c / (D / 8), cc = c % (D / 8);
                 const int kv = kv0 + row < a.n_kv ? kv0 + row : a.n_kv - 1;
-                *(v4i *)(Ks + row * KP + cc * 16) = *(const v4i *)(kbase + (int64_t)kv * a.k_nb1 + cc * 16);
+                *(v4i *)(Ks + row * KP + cc * 16) = load8h<TKV>(kbase + (int64_t)kv * a.k_nb1, cc);
             }
             {
                 const int row = c % MMA_BKV, cc = c / MMA_BKV;   // consecutive lanes: consecutive kv rows, same features
                 const int kv = kv0 + row < a.n_kv ? kv0 + row : a.n_kv - 1;
-                const v4i raw = *(const v4i *)(vbase + (int64_t)kv * a.v_nb1 + cc * 16);
+                const v4i raw = load8h<TKV>(vbase + (int64_t)kv * a.v_nb1, cc);
                 const int kv32 = row & 31;
                 const int pos = (row & 32) + (kv32 >> 4) * 16 + ((kv32 >> 2) & 1) * 8 + ((kv32 & 3) | (((kv32 >> 3) & 1) << 2));
                 const uint16_t * hv = (const uint16_t *)&raw;
@@ -436,9 +450,11 @@ fattn_mma_kernel(const FArgs a) {
 }
 
 template <int D>
-static int launch_mma(const FArgs & a, hipStream_t s) {
+static int launch_mma(const FArgs & a, int tkv, hipStream_t s) {
     const dim3 grid((unsigned)((a.n_q + MMA_BQ - 1) / MMA_BQ), (unsigned)a.n_head, (unsigned)a.ne3);
-    MI355_LAUNCH("fattn_mma", (fattn_mma_kernel<D>), grid, dim3(MMA_THREADS), 0, s, a);
+    if (tkv == MI355_TYPE_F16)       MI355_LAUNCH("fattn_mma", (fattn_mma_kernel<D, MI355_TYPE_F16>), grid, dim3(MMA_THREADS), 0, s, a);
+    else if (tkv == MI355_TYPE_Q8_0) MI355_LAUNCH("fattn_mma", (fattn_mma_kernel<D, MI355_TYPE_Q8_0>), grid, dim3(MMA_THREADS), 0, s, a);
+    else                             MI355_LAUNCH("fattn_mma", (fattn_mma_kernel<D, MI355_TYPE_Q4_0>), grid, dim3(MMA_THREADS), 0, s, a);
     MI355_CHECK_LAUNCH();
     return MI355_OK;
 }
@@ -522,12 +538,13 @@ int mi355_flash_attn_ext_quant(const mi355_fattn_args * p, void * workspace, int
     a.m1 = powf(2.0f, -(p->max_bias / 2.0f) / a.n_head_log2);
 
     // prefill-sized batches of f16 KV without ALiBi / softcap: matrix-core tile kernel
-    if (p->type_k == MI355_TYPE_F16 && p->type_v == MI355_TYPE_F16 && (p->d == 128 || p->d == 64) && p->n_q >= 32 &&
+    if (p->type_k == p->type_v && (p->type_k == MI355_TYPE_F16 || p->type_k == MI355_TYPE_Q8_0 || p->type_k == MI355_TYPE_Q4_0) &&
+        (p->d == 128 || p->d == 64) && p->n_q >= 32 &&
         !(p->max_bias > 0.0f) && p->logit_softcap == 0.0f && p->n_head <= 65535 && p->ne3 <= 65535 &&
         ((p->d_nb1 | p->d_nb2 | p->d_nb3 | (int64_t)(uintptr_t)p->dst) & 15) == 0 && (!p->mask || (p->m_nb1 & 1) == 0)) {
         if (act_q) return MI355_E_UNSUPPORTED;   // the fused q8_1 output exists for decode-sized batches only
         a.nsplit = 1; a.part = nullptr;
-        return p->d == 128 ? launch_mma<128>(a, (hipStream_t)stream) : launch_mma<64>(a, (hipStream_t)stream);
+        return p->d == 128 ? launch_mma<128>(a, p->type_k, (hipStream_t)stream) : launch_mma<64>(a, p->type_k, (hipStream_t)stream);
     }
     // KV split.  The KV loop is a chain of memory round trips (one per G = 512/(d/8) rows), so for decode-sized
     // grids the range is cut until every workgroup has about one round trip of rows -- all loads of the op are

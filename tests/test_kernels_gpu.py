@@ -374,6 +374,26 @@ def test_flash_attn_f16_vs_f64_oracle(ops, d, nh, nhkv, nq, nkv, causal):
     assert np.isfinite(got).all() and O.nmse(ref, got) <= 2e-5, O.nmse(ref, got)
 
 
+@pytest.mark.parametrize("tkv", [B.Q8_0, B.Q4_0])
+@pytest.mark.parametrize("d,nh,nhkv,nq,nkv", [(128, 8, 2, 96, 200), (64, 4, 4, 33, 130), (128, 8, 2, 3, 300)])
+def test_flash_attn_quantized_kv_vs_f64_oracle(ops, tkv, d, nh, nhkv, nq, nkv):
+    """q8_0 / q4_0 KV cache: the tile kernel dequantizes K/V blocks to f16 while staging (n_q >= 32), the vec
+    kernel in registers (decode); both vs the oracle's f64 evaluation on the same quantized rows."""
+    rng = np.random.default_rng(d + nq + nkv + tkv)
+    q = rng.standard_normal((nh, nq, d)).astype(np.float32)
+    scale_blocks = 20.0   # random_blocks' scales are weight-sized; attention rows are O(1)
+    k = B.random_blocks(tkv, nhkv * nkv, d, seed=11).reshape(nhkv, nkv, -1)
+    v = B.random_blocks(tkv, nhkv * nkv, d, seed=12).reshape(nhkv, nkv, -1)
+    nqp = (nq + 63) // 64 * 64
+    mask = np.zeros((nqp, nkv), np.float16)
+    off = nkv - nq
+    for i in range(nq):
+        mask[i, i + off + 1:] = -np.inf
+    got = ops.flash_attn_ext(dev(q), dev(k), dev(v), dev(mask.view(np.int16)), tkv, nkv, scale_blocks).cpu().numpy()
+    ref = O.flash_attn_ext(q, k, v, mask.view(np.uint16), tkv, tkv, d, d, nq, nkv, nh, nhkv, scale_blocks, exact=True)
+    assert np.isfinite(got).all() and O.nmse(ref, got) <= 5e-5, O.nmse(ref, got)
+
+
 @pytest.mark.parametrize("nq,nkv,use_ws", [(1, 300, True), (1, 300, False), (4, 4096, True), (8, 96, True)])
 def test_flash_attn_fused_q8_1_output(ops, nq, nkv, use_ws):
     """mi355_flash_attn_ext_quant: dst equals the plain call bit for bit and the fused q8_1 form equals

@@ -60,8 +60,8 @@ int main(int argc, char ** argv) {
 
     // size the context: every tensor lives in it until the file is written
     size_t total = 0;
-    auto rs = [&](ggml_type t, int64_t k, int64_t m) { return ggml_row_size(t, k) * m + 256; };
-    total += rs(GGML_TYPE_Q6_K, d.n_embd, d.n_vocab) * 2;
+    auto rs = [&](ggml_type t, int64_t k, int64_t m) { return ggml_row_size(t, k) * m + 1024; };
+    total += rs(GGML_TYPE_Q8_0, d.n_embd, d.n_vocab) * 2;   // upper bound over the ftypes (token_embd + output)
     for (int i = 0; i < d.n_layer; i++)
         total += rs(GGML_TYPE_Q8_0, d.n_embd, d.n_embd) * 2 + rs(GGML_TYPE_Q8_0, d.n_embd, kv_dim) * 2 + rs(GGML_TYPE_Q8_0, d.n_embd, d.n_ff) * 2 +
                  rs(GGML_TYPE_Q8_0, d.n_ff, d.n_embd) + 3 * (d.n_embd * 4 + 256);
