@@ -188,6 +188,19 @@ MI355_API int mi355_act_bf16(const float *x, uint16_t *y, int64_t k, int64_t ne1
 MI355_API int mi355_mul_mat_dq(int type, const void *W, int64_t w_row_stride, const uint16_t *act_bf16, int64_t act_row_stride,
                                float *dst, int64_t dst_col_stride, int64_t m, int64_t k, int64_t n, void *stream);
 
+/* MUL_MAT_ID (ggml.c:3000-3036) for prefill-sized batches: dst[t][s][:] = as[ids[t][s]] . b[t][s % b_ne1].
+ * The (token, slot) pairs are bucketed by expert ON THE DEVICE (one small kernel; the reference synchronises the
+ * stream and sorts on the host, ggml-cuda/mmq.cu:141-223) and all experts run in ONE launch of the bf16-MFMA GEMM
+ * over gathered columns, so every touched expert matrix is read once.  as: n_expert matrices w_expert_stride bytes
+ * apart; b: f32 [n_tokens][b_ne1][k] with byte strides b_nb1 (slot) and b_nb2 (token), 16-byte aligned;
+ * ids: device int32, ids_stride elements between tokens; dst: f32 [n_tokens][n_used][m] contiguous.
+ * Out-of-range expert ids are skipped (dst untouched).  k % 64 == 0, n_expert <= 256, else MI355_E_UNSUPPORTED / SHAPE. */
+MI355_API int64_t mi355_mul_mat_id_dq_workspace_bytes(int64_t k, int64_t n_tokens, int64_t b_ne1, int64_t n_used, int64_t n_expert);
+MI355_API int mi355_mul_mat_id_dq(int type, const void *as, int64_t w_row_stride, int64_t w_expert_stride, const float *b,
+                                  int64_t b_nb1, int64_t b_nb2, const int32_t *ids, int64_t ids_stride, float *dst, int64_t m,
+                                  int64_t k, int64_t n_expert, int64_t n_used, int64_t n_tokens, int64_t b_ne1, void *workspace,
+                                  int64_t workspace_bytes, void *stream);
+
 /* Convenience for the common case (2-D contiguous W, contiguous f32 x[n][k], dst[n][m]):
  * quantizes x into `workspace` (>= mi355_mul_mat_workspace_bytes(k, n)) and runs the mat-vec
  * (n <= 8) or the MFMA tile kernel (n > 8).  Two launches on `stream`. */

@@ -796,6 +796,22 @@ static void mi355_mul_mat_id(mi355_backend_ctx * ctx, ggml_tensor * dst) {
     const int64_t b_ne1 = b->ne[1], n_tokens = b->ne[2];
     const int64_t n_used = ids->ne[0];
     if (n_tokens == 0 || M == 0) return;
+    // prefill-sized batches: bucket the (token, slot) pairs by expert on the device and run one bf16-MFMA GEMM over all
+    // experts, so every touched expert matrix is read once.  Below ~64 pairs the per-pair mat-vec (each pair streams
+    // its expert's rows, mostly from the Infinity Cache) is faster than dequantizing whole tiles for a few columns.
+    if (n_tokens * n_used >= 64 && K % 64 == 0 && n_expert <= 256 && dst->nb[1] == (size_t)M * sizeof(float) &&
+        dst->nb[2] == (size_t)M * n_used * sizeof(float) && ((((uintptr_t)b->data) | b->nb[1] | b->nb[2]) & 15) == 0 &&
+        getenv("GGML_MI355_MMQ_INT8") == nullptr) {
+        const int64_t need = mi355_mul_mat_id_dq_workspace_bytes(K, n_tokens, b_ne1, n_used, n_expert);
+        void * ws = ctx->get_scratch(0, (size_t)need);
+        ctx->act_cache.valid = false;     // the workspace replaces whatever activations were cached in scratch[0]
+        const int rc = mi355_mul_mat_id_dq((int)as->type, as->data, (int64_t)as->nb[1], (int64_t)as->nb[2], (const float *)b->data,
+                                           (int64_t)b->nb[1], (int64_t)b->nb[2], (const int32_t *)ids->data,
+                                           (int64_t)(ids->nb[1] / sizeof(int32_t)), (float *)dst->data, M, K, n_expert, n_used, n_tokens,
+                                           b_ne1, ws, need, ctx->stream);
+        if (rc == MI355_OK) return;
+        if (rc != MI355_E_UNSUPPORTED) MI_CHECK(rc);
+    }
     const int64_t rows = b_ne1 * n_tokens;
     const size_t qb = align_up((size_t)mi355_act_q_bytes(K, rows), 256);
     const size_t db = align_up((size_t)mi355_act_ds_bytes(K, rows), 256);

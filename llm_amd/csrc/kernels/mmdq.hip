@@ -34,6 +34,12 @@ struct DArgs {
     const uint16_t * x; int64_t x_row_stride;  // bf16 activations (mi355_act_bf16), elements between columns
     float * dst; int64_t dst_col_stride;
     int m, n, k;
+    // MUL_MAT_ID mode (IDS): columns are the (token, slot) pairs routed to one expert, listed by moe_bucket_kernel
+    const int * sorted;      // [n_pairs] pair ids grouped by expert
+    const int * off;         // [n_expert + 1] first entry of every expert in `sorted`
+    const int * tile_off;    // [n_expert + 1] first column tile of every expert
+    int n_expert, n_used, act_ne1;
+    int64_t w_expert_stride;
 };
 
 // 32 consecutive weights of one row, raw, as loaded from global memory
@@ -161,13 +167,14 @@ static __device__ __forceinline__ void store_bf16x32(uint8_t * dst, const float 
     }
 }
 
-template <int TYPE, int BM>
+template <int TYPE, int BM, bool IDS>
 __global__ void __launch_bounds__(256)
 mmdq_kernel(const DArgs a) {
     constexpr int WAVES_M = BM / 64, WAVES_N = 4 / WAVES_M;   // every wave owns 64 weight rows x (BN / WAVES_N) columns
     constexpr int TN = BN / WAVES_N / 32;                      // 32-column MFMA tiles per wave: 2 (BM 128) or 1 (BM 64)
     __shared__ __attribute__((aligned(16))) uint8_t Lw[2][BM * PITCH];
     __shared__ __attribute__((aligned(16))) uint8_t La[2][BN * PITCH];
+    __shared__ int s_pair[IDS ? BN : 1];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
     const int wm_ = wave % WAVES_M, wn_ = wave / WAVES_M;
@@ -177,9 +184,27 @@ mmdq_kernel(const DArgs a) {
     const int sr = tid >> 1, hf = tid & 1;
     const int wr = m0 + sr < a.m ? m0 + sr : a.m - 1;
     const uint8_t * wrow = a.W + (int64_t)wr * a.w_row_stride;
-    const int col = n0 + sr;
-    const bool col_ok = col < a.n;
-    const uint16_t * xcol = a.x + (int64_t)(col_ok ? col : 0) * a.x_row_stride;
+    bool col_ok;
+    const uint16_t * xcol;
+    if (IDS) {
+        // column tile blockIdx.x -> (expert, tile inside the expert); the grid is sized for the worst case
+        const int ti = blockIdx.x;
+        if (ti >= a.tile_off[a.n_expert]) return;
+        int e = 0;
+        while (a.tile_off[e + 1] <= ti) e++;
+        const int base = a.off[e] + (ti - a.tile_off[e]) * BN, cnt = a.off[e + 1] - base;
+        if (tid < BN) s_pair[tid] = tid < cnt ? a.sorted[base + tid] : -1;
+        __syncthreads();
+        const int pair = s_pair[sr];
+        col_ok = pair >= 0;
+        const int tok = col_ok ? pair / a.n_used : 0, slot = col_ok ? pair % a.n_used : 0;
+        xcol = a.x + (int64_t)(tok * a.act_ne1 + slot % a.act_ne1) * a.x_row_stride;
+        wrow += (int64_t)e * a.w_expert_stride;
+    } else {
+        const int col = n0 + sr;
+        col_ok = col < a.n;
+        xcol = a.x + (int64_t)(col_ok ? col : 0) * a.x_row_stride;
+    }
 
     const bool w_stager = sr < BM;              // BM = 64: the upper half of the workgroup stages activations only
     v16f acc[2][TN];
@@ -243,8 +268,9 @@ mmdq_kernel(const DArgs a) {
         for (int tn = 0; tn < TN; tn++)
 #pragma unroll
             for (int r = 0; r < 16; r++) {
-                const int n = n0 + wn_ * 32 * TN + tn * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (m < a.m && n < a.n) a.dst[(int64_t)n * a.dst_col_stride + m] = acc[tm][tn][r];
+                const int nl = wn_ * 32 * TN + tn * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int n = IDS ? s_pair[nl] : n0 + nl;
+                if (m < a.m && (IDS ? n >= 0 : n < a.n)) a.dst[(int64_t)n * a.dst_col_stride + m] = acc[tm][tn][r];
             }
     }
 }
@@ -269,10 +295,48 @@ static int launch(const DArgs & a, hipStream_t s, const char * tag) {
     // 128-row tiles reuse each staged activation tile twice as often; 64-row tiles when those would leave CUs idle
     const int64_t nb = (a.n + BN - 1) / BN;
     if (nb * ((a.m + 127) / 128) >= 384) {
-        MI355_LAUNCH(tag, (mmdq_kernel<TYPE, 128>), dim3((unsigned)nb, (unsigned)((a.m + 127) / 128)), dim3(256), 0, s, a);
+        MI355_LAUNCH(tag, (mmdq_kernel<TYPE, 128, false>), dim3((unsigned)nb, (unsigned)((a.m + 127) / 128)), dim3(256), 0, s, a);
     } else {
-        MI355_LAUNCH(tag, (mmdq_kernel<TYPE, 64>), dim3((unsigned)nb, (unsigned)((a.m + 63) / 64)), dim3(256), 0, s, a);
+        MI355_LAUNCH(tag, (mmdq_kernel<TYPE, 64, false>), dim3((unsigned)nb, (unsigned)((a.m + 63) / 64)), dim3(256), 0, s, a);
     }
+    MI355_CHECK_LAUNCH();
+    return MI355_OK;
+}
+
+// ---- MUL_MAT_ID for prefill-sized batches: route on the device, then one GEMM launch over all experts.
+// One workgroup counts the (token, slot) pairs per expert in LDS, prefix-sums them into `off` (entries of `sorted`)
+// and `tile_off` (128-column tiles), and scatters the pair ids.  The reference does this sort on the host after a
+// stream synchronisation (ggml-cuda/mmq.cu:141-223).  Pairs with an out-of-range expert id are dropped.
+__global__ void __launch_bounds__(1024)
+moe_bucket_kernel(const int32_t * ids, int64_t ids_stride, int n_tokens, int n_used, int n_expert, int * sorted, int * off, int * tile_off) {
+    __shared__ int cnt[257], cur[257];
+    const int tid = threadIdx.x, np = n_tokens * n_used;
+    for (int e = tid; e <= n_expert; e += 1024) cnt[e] = 0;
+    __syncthreads();
+    for (int p = tid; p < np; p += 1024) {
+        const int e = ids[(int64_t)(p / n_used) * ids_stride + p % n_used];
+        if (e >= 0 && e < n_expert) atomicAdd(&cnt[e], 1);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int o = 0, t = 0;
+        for (int e = 0; e < n_expert; e++) {
+            off[e] = o; tile_off[e] = t; cur[e] = o;
+            o += cnt[e]; t += (cnt[e] + BN - 1) / BN;
+        }
+        off[n_expert] = o; tile_off[n_expert] = t;
+    }
+    __syncthreads();
+    for (int p = tid; p < np; p += 1024) {
+        const int e = ids[(int64_t)(p / n_used) * ids_stride + p % n_used];
+        if (e >= 0 && e < n_expert) sorted[atomicAdd(&cur[e], 1)] = p;
+    }
+}
+
+template <int TYPE>
+static int launch_ids(const DArgs & a, int max_tiles, hipStream_t s, const char * tag) {
+    if (a.m >= 1024) MI355_LAUNCH(tag, (mmdq_kernel<TYPE, 128, true>), dim3((unsigned)max_tiles, (unsigned)((a.m + 127) / 128)), dim3(256), 0, s, a);
+    else             MI355_LAUNCH(tag, (mmdq_kernel<TYPE, 64, true>), dim3((unsigned)max_tiles, (unsigned)((a.m + 63) / 64)), dim3(256), 0, s, a);
     MI355_CHECK_LAUNCH();
     return MI355_OK;
 }
@@ -310,6 +374,7 @@ extern "C" int mi355_mul_mat_dq(int type, const void * W, int64_t w_row_stride, 
     DArgs a;
     a.W = (const uint8_t *)W; a.w_row_stride = w_row_stride; a.x = x; a.x_row_stride = x_row_stride;
     a.dst = dst; a.dst_col_stride = dst_col_stride; a.m = (int)m; a.n = (int)n; a.k = (int)k;
+    a.sorted = a.off = a.tile_off = nullptr; a.n_expert = a.n_used = a.act_ne1 = 0; a.w_expert_stride = 0;
     hipStream_t s = (hipStream_t)stream;
     switch (type) {
         case MI355_TYPE_Q4_0: return launch<MI355_TYPE_Q4_0>(a, s, "mmdq_q4_0");
@@ -317,6 +382,55 @@ extern "C" int mi355_mul_mat_dq(int type, const void * W, int64_t w_row_stride, 
         case MI355_TYPE_Q4_K: return launch<MI355_TYPE_Q4_K>(a, s, "mmdq_q4_K");
         case MI355_TYPE_Q5_K: return launch<MI355_TYPE_Q5_K>(a, s, "mmdq_q5_K");
         case MI355_TYPE_Q6_K: return launch<MI355_TYPE_Q6_K>(a, s, "mmdq_q6_K");
+    }
+    return MI355_E_TYPE;
+}
+
+// workspace of mi355_mul_mat_id_dq: bf16 activations [n_tokens * b_ne1][k], then the routing tables
+static int64_t id_ws_act_bytes(int64_t k, int64_t n_tokens, int64_t b_ne1) { return (n_tokens * b_ne1 * k * 2 + 255) / 256 * 256; }
+
+extern "C" int64_t mi355_mul_mat_id_dq_workspace_bytes(int64_t k, int64_t n_tokens, int64_t b_ne1, int64_t n_used, int64_t n_expert) {
+    if (k <= 0 || n_tokens < 0 || b_ne1 < 1 || n_used < 1 || n_expert < 1) return -1;
+    return id_ws_act_bytes(k, n_tokens, b_ne1) + (n_tokens * n_used + 2 * (n_expert + 1)) * 4 + 256;
+}
+
+extern "C" int mi355_mul_mat_id_dq(int type, const void * as, int64_t w_row_stride, int64_t w_expert_stride, const float * b,
+                                   int64_t b_nb1, int64_t b_nb2, const int32_t * ids, int64_t ids_stride, float * dst, int64_t m,
+                                   int64_t k, int64_t n_expert, int64_t n_used, int64_t n_tokens, int64_t b_ne1, void * workspace,
+                                   int64_t workspace_bytes, void * stream) {
+    if (!as || !b || !ids || !dst || !workspace) return MI355_E_NULL;
+    const int64_t bs = mi355_blck_size(type);
+    if (bs == 0 || type == MI355_TYPE_F32 || type == MI355_TYPE_F16 || type == MI355_TYPE_Q8_1) return MI355_E_TYPE;
+    if (m < 0 || k <= 0 || k % bs != 0 || n_expert < 1 || n_expert > 256 || n_used < 1 || n_tokens < 0 || (b_ne1 != 1 && b_ne1 != n_used) ||
+        m > 0x7fffffff || k > 0x7fffffff || n_tokens * n_used > 0x3fffffff) return MI355_E_SHAPE;
+    if (k % BK != 0) return MI355_E_UNSUPPORTED;
+    if (workspace_bytes < mi355_mul_mat_id_dq_workspace_bytes(k, n_tokens, b_ne1, n_used, n_expert)) return MI355_E_WORKSPACE;
+    if (((uintptr_t)workspace & 15) || ((uintptr_t)dst & 3) || ((uintptr_t)ids & 3)) return MI355_E_ALIGN;
+    const bool a16 = type == MI355_TYPE_Q4_K || type == MI355_TYPE_Q5_K;
+    if (((uintptr_t)as | (uintptr_t)w_row_stride | (uintptr_t)w_expert_stride) & (a16 ? 15 : 1)) return MI355_E_ALIGN;
+    if (w_row_stride < mi355_row_size(type, k)) return MI355_E_SHAPE;
+    if (m == 0 || n_tokens == 0) return MI355_OK;
+    hipStream_t s = (hipStream_t)stream;
+    uint16_t * act = (uint16_t *)workspace;
+    int * sorted = (int *)((char *)workspace + id_ws_act_bytes(k, n_tokens, b_ne1));
+    int * off = sorted + n_tokens * n_used, * tile_off = off + n_expert + 1;
+    int rc = mi355_act_bf16(b, act, k, b_ne1, n_tokens, 1, b_nb1, b_nb2, 0, stream);
+    if (rc != MI355_OK) return rc;
+    MI355_LAUNCH("moe_bucket", moe_bucket_kernel, dim3(1), dim3(1024), 0, s, ids, ids_stride, (int)n_tokens, (int)n_used, (int)n_expert,
+                 sorted, off, tile_off);
+    MI355_CHECK_LAUNCH();
+    DArgs a;
+    a.W = (const uint8_t *)as; a.w_row_stride = w_row_stride; a.x = act; a.x_row_stride = k;
+    a.dst = dst; a.dst_col_stride = m; a.m = (int)m; a.n = (int)(n_tokens * n_used); a.k = (int)k;
+    a.sorted = sorted; a.off = off; a.tile_off = tile_off; a.n_expert = (int)n_expert; a.n_used = (int)n_used; a.act_ne1 = (int)b_ne1;
+    a.w_expert_stride = w_expert_stride;
+    const int max_tiles = (int)((n_tokens * n_used + BN - 1) / BN + n_expert);   // sum over experts of ceil(cnt_e / BN) never exceeds this
+    switch (type) {
+        case MI355_TYPE_Q4_0: return launch_ids<MI355_TYPE_Q4_0>(a, max_tiles, s, "mmdq_id_q4_0");
+        case MI355_TYPE_Q8_0: return launch_ids<MI355_TYPE_Q8_0>(a, max_tiles, s, "mmdq_id_q8_0");
+        case MI355_TYPE_Q4_K: return launch_ids<MI355_TYPE_Q4_K>(a, max_tiles, s, "mmdq_id_q4_K");
+        case MI355_TYPE_Q5_K: return launch_ids<MI355_TYPE_Q5_K>(a, max_tiles, s, "mmdq_id_q5_K");
+        case MI355_TYPE_Q6_K: return launch_ids<MI355_TYPE_Q6_K>(a, max_tiles, s, "mmdq_id_q6_K");
     }
     return MI355_E_TYPE;
 }

@@ -208,3 +208,20 @@ def qkv_rope_matvec(type_qk, type_v, wq, wk, wv, m_q, m_k, m_v, k, aq, ads, pos,
     a.freq_base, a.freq_scale, a.ext_factor, a.attn_factor, a.beta_fast, a.beta_slow = freq_base, freq_scale, ext_factor, attn_factor, beta_fast, beta_slow
     K.check(K.lib.mi355_qkv_rope_matvec(a, _stream()), "mi355_qkv_rope_matvec")
     return q, ko, vo
+
+
+def mul_mat_id_dq(t, as_, b, ids, m, n_expert):
+    """ggml_mul_mat_id for prefill-sized batches (device-side expert bucketing + one bf16-MFMA GEMM launch):
+    as_ = [n_expert][m rows] blocks, b = [n_tokens, b_ne1, k] f32, ids = [n_tokens, n_used] int32 -> [n_tokens, n_used, m] f32."""
+    _u8(as_)
+    assert b.dim() == 3 and b.is_contiguous() and ids.dtype == torch.int32 and ids.dim() == 2 and ids.is_contiguous()
+    n_tok, b_ne1, k = b.shape
+    n_used = ids.shape[1]
+    rs = B.row_size(t, k)
+    need = K.lib.mi355_mul_mat_id_dq_workspace_bytes(k, n_tok, b_ne1, n_used, n_expert)
+    ws = torch.empty(need, dtype=torch.uint8, device=b.device)
+    dst = torch.full((n_tok, n_used, m), float("nan"), dtype=torch.float32, device=b.device)
+    K.check(K.lib.mi355_mul_mat_id_dq(t, as_.data_ptr(), rs, rs * m, b.data_ptr(), k * 4, b_ne1 * k * 4, ids.data_ptr(), n_used,
+                                      dst.data_ptr(), m, k, n_expert, n_used, n_tok, b_ne1, ws.data_ptr(), need, _stream()),
+            "mi355_mul_mat_id_dq")
+    return dst

@@ -411,6 +411,31 @@ def test_flash_attn_fused_q8_1_output(ops, nq, nkv, use_ws):
     assert torch.equal(aq, aq2) and torch.equal(ads.view(torch.int32), ads2.view(torch.int32))
 
 
+@pytest.mark.parametrize("t", B.WEIGHT_TYPES)
+@pytest.mark.parametrize("m,k,n_exp,n_used,n_tok,b1", [(192, 256, 8, 2, 40, 1), (130, 512, 4, 2, 200, 2), (64, 256, 8, 3, 33, 3), (256, 1024, 8, 2, 512, 1)])
+def test_mul_mat_id_grouped_gemm(ops, t, m, k, n_exp, n_used, n_tok, b1):
+    """prefill-sized MUL_MAT_ID: device-side bucketing by expert + one bf16-MFMA GEMM launch, vs exact
+    dequant(as[ids]) . b in f64 (budget of the op: NMSE 5e-4, tests/test-backend-ops.cpp:2357-2359), and vs the
+    per-pair mat-vec path; skewed routing (one expert takes half the pairs) and an unused expert included."""
+    if k % B.BLCK_SIZE[t]:
+        pytest.skip("k not a multiple of the block size")
+    rng = np.random.default_rng(m + k + n_tok)
+    w = B.random_blocks(t, n_exp * m, k, seed=5)
+    b = rng.standard_normal((n_tok, b1, k)).astype(np.float32)
+    ids = np.stack([rng.permutation(n_exp - 1)[:n_used] for _ in range(n_tok)]).astype(np.int32)   # expert n_exp-1 is never used
+    ids[: n_tok // 2, 0] = 0; ids[: n_tok // 2, 1] = 1 + (np.arange(n_tok // 2) % max(1, n_exp - 2))  # skew towards expert 0
+    got = ops.mul_mat_id_dq(t, dev(w), dev(b), dev(ids), m, n_exp).cpu().numpy()
+    wf = O.dequantize_row(t, w, n_exp * m * k).reshape(n_exp, m, k).astype(np.float64)
+    ref = np.empty((n_tok, n_used, m))
+    for tt in range(n_tok):
+        for s_ in range(n_used):
+            ref[tt, s_] = wf[ids[tt, s_]] @ b[tt, s_ % b1].astype(np.float64)
+    err = float(((got - ref) ** 2).sum() / (ref ** 2).sum())
+    assert np.isfinite(got).all() and err < 2e-5, err
+    vec = ops.mul_mat_id(t, dev(w), dev(b), dev(ids), m, n_exp).cpu().numpy()
+    assert O.nmse(vec, got) <= 5e-4
+
+
 def test_errors_are_reported_not_launched(ops):
     import llm_amd.kernels as K
     w = torch.zeros(144 * 4 + 16, dtype=torch.uint8, device="cuda")
