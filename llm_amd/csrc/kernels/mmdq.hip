@@ -235,14 +235,16 @@ mmdq_kernel(const DArgs a) {
 
     // Double-buffered LDS, one barrier per stage: while the MFMAs of stage s read buffer s&1, the same wave
     // dequantizes stage s+1 (fetched one iteration earlier) into the other buffer and requests stage s+2.
-    fetch(0);
-    stash(0, 0);
-    if (BK < a.k) fetch(BK);
+    // split-K (gridDim.z == 2): this workgroup covers half of K and adds its partial tile into a zeroed dst
+    const int kbeg = (int)blockIdx.z * (a.k / (int)gridDim.z), kend = kbeg + a.k / (int)gridDim.z;
+    fetch(kbeg);
+    stash(kbeg, 0);
+    if (kbeg + BK < kend) fetch(kbeg + BK);
     __syncthreads();
-    for (int k0 = 0, buf = 0; k0 < a.k; k0 += BK, buf ^= 1) {
-        if (k0 + BK < a.k) {
+    for (int k0 = kbeg, buf = 0; k0 < kend; k0 += BK, buf ^= 1) {
+        if (k0 + BK < kend) {
             stash(k0 + BK, buf ^ 1);
-            if (k0 + 2 * BK < a.k) fetch(k0 + 2 * BK);
+            if (k0 + 2 * BK < kend) fetch(k0 + 2 * BK);
         }
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ks++) {
@@ -270,7 +272,11 @@ mmdq_kernel(const DArgs a) {
             for (int r = 0; r < 16; r++) {
                 const int nl = wn_ * 32 * TN + tn * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 const int n = IDS ? s_pair[nl] : n0 + nl;
-                if (m < a.m && (IDS ? n >= 0 : n < a.n)) a.dst[(int64_t)n * a.dst_col_stride + m] = acc[tm][tn][r];
+                if (m < a.m && (IDS ? n >= 0 : n < a.n)) {
+                    float * o = a.dst + (int64_t)n * a.dst_col_stride + m;
+                    if (gridDim.z > 1) atomicAdd(o, acc[tm][tn][r]);   // two addends onto 0: the sum does not depend on the order
+                    else *o = acc[tm][tn][r];
+                }
             }
     }
 }
@@ -297,7 +303,17 @@ static int launch(const DArgs & a, hipStream_t s, const char * tag) {
     if (nb * ((a.m + 127) / 128) >= 384) {
         MI355_LAUNCH(tag, (mmdq_kernel<TYPE, 128, false>), dim3((unsigned)nb, (unsigned)((a.m + 127) / 128)), dim3(256), 0, s, a);
     } else {
-        MI355_LAUNCH(tag, (mmdq_kernel<TYPE, 64, false>), dim3((unsigned)nb, (unsigned)((a.m + 63) / 64)), dim3(256), 0, s, a);
+        // few tiles (M <= ~6K at N = 512): also split K in two so that every CU holds two workgroups.  The halves are
+        // added into a zeroed dst with float atomics; with exactly two addends the result is order-independent.
+        const int64_t tiles = nb * ((a.m + 63) / 64);
+        const unsigned kz = tiles < 448 && a.k % (2 * BK) == 0 && a.k >= 1024 ? 2 : 1;
+        if (kz > 1) {
+            hipError_t e = a.dst_col_stride == a.m
+                ? hipMemsetAsync(a.dst, 0, (size_t)a.n * a.m * sizeof(float), s)
+                : hipMemset2DAsync(a.dst, (size_t)a.dst_col_stride * sizeof(float), 0, (size_t)a.m * sizeof(float), (size_t)a.n, s);
+            if (e != hipSuccess) return (int)e;
+        }
+        MI355_LAUNCH(tag, (mmdq_kernel<TYPE, 64, false>), dim3((unsigned)nb, (unsigned)((a.m + 63) / 64), kz), dim3(256), 0, s, a);
     }
     MI355_CHECK_LAUNCH();
     return MI355_OK;
