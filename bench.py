@@ -210,9 +210,19 @@ def main():
     avg_us = tot_us / n_launch
     achieved = q4k_bytes / tot_us * 1e-3
     kernels = {tag: {"launches": n, "avg_us": round(us / n, 3)} for tag, (n, us) in K.timing_report().items() if n}
+    # HBM bytes per launch of that kernel from the PMC counters: collected in a run of its own (rocprofv3 --pmc cannot be
+    # combined with this timed run) by tools/pmc_traffic.sh on this same workload and committed under profiles/.
+    traffic = None
+    if world == 1 and not args.no_group:
+        try:
+            tr = json.load(open(os.path.join(ROOT, "profiles", "r01_bench_traffic.json")))
+            traffic = tr["traffic_bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            traffic = None
     roofline = {"bound": "hbm", "kernel": "mmvq_group_kernel<q4_K, ncols=1>", "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
-                "traffic": None, "launches": n_launch, "avg_launch_us": round(avg_us, 3),
+                "traffic": traffic, "traffic_source": "profiles/r01_bench_traffic.json (rocprofv3 --pmc FETCH_SIZE x2, separate pass)" if traffic else None,
+                "launches": n_launch, "avg_launch_us": round(avg_us, 3),
                 "algorithmic_bytes_per_launch": round(q4k_bytes / n_launch), "all_kernels": kernels}
     n_launches = sum(1 for p in plan) + sum(1 for p in plan if p[0] is not None)
 

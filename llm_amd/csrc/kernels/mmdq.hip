@@ -168,10 +168,11 @@ static __device__ __forceinline__ void store_bf16x32(uint8_t * dst, const float 
 }
 
 template <int TYPE, int BM, bool IDS>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(BM == 256 ? 512 : 256)
 mmdq_kernel(const DArgs a) {
-    constexpr int WAVES_M = BM / 64, WAVES_N = 4 / WAVES_M;   // every wave owns 64 weight rows x (BN / WAVES_N) columns
-    constexpr int TN = BN / WAVES_N / 32;                      // 32-column MFMA tiles per wave: 2 (BM 128) or 1 (BM 64)
+    constexpr int NT = BM == 256 ? 512 : 256;                  // threads: 8 waves for the 256-row tile, else 4
+    constexpr int WAVES_M = BM / 64, WAVES_N = NT / 64 / WAVES_M; // every wave owns 64 weight rows x (BN / WAVES_N) columns
+    constexpr int TN = BN / WAVES_N / 32;                      // 32-column MFMA tiles per wave: 1 (BM 64) or 2 (BM 128, 256)
     __shared__ __attribute__((aligned(16))) uint8_t Lw[2][BM * PITCH];
     __shared__ __attribute__((aligned(16))) uint8_t La[2][BN * PITCH];
     __shared__ int s_pair[IDS ? BN : 1];
@@ -195,7 +196,7 @@ mmdq_kernel(const DArgs a) {
         const int base = a.off[e] + (ti - a.tile_off[e]) * BN, cnt = a.off[e + 1] - base;
         if (tid < BN) s_pair[tid] = tid < cnt ? a.sorted[base + tid] : -1;
         __syncthreads();
-        const int pair = s_pair[sr];
+        const int pair = sr < BN ? s_pair[sr] : -1;
         col_ok = pair >= 0;
         const int tok = col_ok ? pair / a.n_used : 0, slot = col_ok ? pair % a.n_used : 0;
         xcol = a.x + (int64_t)(tok * a.act_ne1 + slot % a.act_ne1) * a.x_row_stride;
@@ -207,6 +208,7 @@ mmdq_kernel(const DArgs a) {
     }
 
     const bool w_stager = sr < BM;              // BM = 64: the upper half of the workgroup stages activations only
+    const bool a_stager = sr < BN;              // BM = 256 (512 threads): the upper half stages weights only
     v16f acc[2][TN];
 #pragma unroll
     for (int i = 0; i < 2; i++)
@@ -219,8 +221,10 @@ mmdq_kernel(const DArgs a) {
     v4i xraw[4];
     auto fetch = [&](int k) {          // global -> registers: this thread's 32 weights and 32 activations of stage k
         if (w_stager) wraw = load_raw<TYPE>(wrow, k + hf * 32);
+        if (a_stager) {
 #pragma unroll
-        for (int i = 0; i < 4; i++) xraw[i] = ((const v4i *)(xcol + k + hf * 32))[i];
+            for (int i = 0; i < 4; i++) xraw[i] = ((const v4i *)(xcol + k + hf * 32))[i];
+        }
     };
     auto stash = [&](int k, int buf) { // registers -> LDS buffer `buf` (weights dequantized and rounded to bf16)
         if (w_stager) {
@@ -228,9 +232,11 @@ mmdq_kernel(const DArgs a) {
             dequant32<TYPE>(wraw, k + hf * 32, f);
             store_bf16x32(Lw[buf] + sr * PITCH + hf * 64, f);
         }
-        const v4i z = {0, 0, 0, 0};
+        if (a_stager) {
+            const v4i z = {0, 0, 0, 0};
 #pragma unroll
-        for (int i = 0; i < 4; i++) *(v4i *)(La[buf] + sr * PITCH + hf * 64 + 16 * i) = col_ok ? xraw[i] : z;
+            for (int i = 0; i < 4; i++) *(v4i *)(La[buf] + sr * PITCH + hf * 64 + 16 * i) = col_ok ? xraw[i] : z;
+        }
     };
 
     // Double-buffered LDS, one barrier per stage: while the MFMAs of stage s read buffer s&1, the same wave
@@ -300,7 +306,11 @@ template <int TYPE>
 static int launch(const DArgs & a, hipStream_t s, const char * tag) {
     // 128-row tiles reuse each staged activation tile twice as often; 64-row tiles when those would leave CUs idle
     const int64_t nb = (a.n + BN - 1) / BN;
-    if (nb * ((a.m + 127) / 128) >= 384) {
+    // The loop is bound by the CU-side load path (~10 B/cycle/CU): every workgroup re-reads its activation tile, so
+    // the bytes moved per flop fall with the tile height.  256-row tiles (8 waves) when they still cover the chip.
+    if (nb * ((a.m + 255) / 256) >= 200) {
+        MI355_LAUNCH(tag, (mmdq_kernel<TYPE, 256, false>), dim3((unsigned)nb, (unsigned)((a.m + 255) / 256)), dim3(512), 0, s, a);
+    } else if (nb * ((a.m + 127) / 128) >= 384) {
         MI355_LAUNCH(tag, (mmdq_kernel<TYPE, 128, false>), dim3((unsigned)nb, (unsigned)((a.m + 127) / 128)), dim3(256), 0, s, a);
     } else {
         // few tiles (M <= ~6K at N = 512): also split K in two so that every CU holds two workgroups.  The halves are
