@@ -93,9 +93,22 @@ def main():
         if world == 1 and args.gpus > 1:
             print(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus}", file=sys.stderr)
             sys.exit(2)
-    torch.cuda.set_device(local_rank)
+    # MI355_BENCH_BACKEND=gloo is a rehearsal switch for boxes with fewer GPUs than ranks (ranks then share devices and
+    # the all-gather goes through gloo); the measured configuration is always nccl = RCCL, one rank per GPU
+    backend = os.environ.get("MI355_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank if backend == "nccl" else local_rank % max(ndev, 1)
+    torch.cuda.set_device(dev_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
+
+    def say(msg):
+        if rank == 0:
+            print(f"[bench] {msg}", file=sys.stderr, flush=True)
+    say(f"process group ready: world {world}, backend {backend if world > 1 else 'none'}")
 
     import llm_amd.blocks as B
     import llm_amd.kernels as K
@@ -118,6 +131,8 @@ def main():
     acts = {k: (torch.empty((1, k), dtype=torch.int8, device="cuda"),
                 torch.empty((1, k // 32, 2), dtype=torch.float32, device="cuda")) for k in xs}
     outs = [torch.empty((1, hi - lo), dtype=torch.float32, device="cuda") for lo, hi in rows]
+
+    say(f"{len(mats)} weight matrices resident ({sum(w.numel() for w in weights) / 1e9:.2f} GB on this rank)")
 
     def quantize(k, stream):
         aq, ads = acts[k]
@@ -146,20 +161,43 @@ def main():
             prev[3].append(i)
         else:
             plan.append([need_q, None, 0, [i]])
+    # N > 1: the row slices a launch produces are exchanged with ONE all-gather per launch.  Slices of a matrix are
+    # equal on all ranks whenever M is a multiple of 128 * N (all 8B matrices but output.weight); the launch's
+    # outputs are then views into one send buffer and the gather needs no staging; otherwise the padded path of
+    # llm_amd/split.py is used for that matrix.
+    gathers = []   # per plan entry: (send, recv) or None
     for p in plan:
+        equal = world > 1 and all(len({hi - lo for lo, hi in row_split(mats[i].m, world)}) == 1 for i in p[3])
+        if equal:
+            sizes = [rows[i][1] - rows[i][0] for i in p[3]]
+            send = torch.empty(sum(sizes), dtype=torch.float32, device="cuda")
+            recv = torch.empty(world * sum(sizes), dtype=torch.float32, device="cuda")
+            off = 0
+            for i, n_ in zip(p[3], sizes):
+                outs[i] = send[off:off + n_].view(1, n_)
+                off += n_
+            gathers.append((send, recv))
+        else:
+            gathers.append(None)
         arr = (K.MmvqArgs * len(p[3]))(*[mm_arg(mats[i], weights[i], outs[i]) for i in p[3]])
         p[1], p[2] = arr, len(p[3])
 
     def step():
         """one decode token's mat-vecs on the current stream"""
         stream = torch.cuda.current_stream().cuda_stream
-        for need_q, arr, n, idx in plan:
+        for (need_q, arr, n, idx), g in zip(plan, gathers):
             if need_q is not None:
                 quantize(need_q, stream)
             K.check(K.lib.mi355_mul_mat_vec_q_group(arr, n, stream), "mi355_mul_mat_vec_q_group")
             if world > 1:
-                for i in idx:
-                    all_gather_rows(outs[i], mats[i].m, rank, world, dist)
+                # rehearsal backends (gloo) gather through host memory; nccl = RCCL gathers device buffers over xGMI
+                if g is not None and backend == "nccl":
+                    dist.all_gather_into_tensor(g[1], g[0])
+                elif g is not None:
+                    dist.all_gather_into_tensor(g[1].cpu(), g[0].cpu())
+                else:
+                    for i in idx:
+                        all_gather_rows(outs[i] if backend == "nccl" else outs[i].cpu(), mats[i].m, rank, world, dist)
 
     def barrier():
         if world > 1:
@@ -181,6 +219,7 @@ def main():
     for _ in range(args.warmup):
         run()
     barrier()
+    say("warm-up done, timing")
     t0 = time.perf_counter()
     for _ in range(args.steps):
         run()
