@@ -168,6 +168,29 @@ typedef struct mi355_qkv_rope_args {
 } mi355_qkv_rope_args;
 MI355_API int mi355_qkv_rope_matvec(const mi355_qkv_rope_args *args, void *stream);
 
+/* "Skinny" MUL_MAT, 1 <= n <= 32 activation columns per call, on the int8 matrix cores: same operands and
+ * arithmetic contract as mi355_mul_mat_vec_q (one channel), but one v_mfma_i32_32x32x32_i8 covers 32 rows x 32 columns
+ * of a 32-block, so the time per weight byte does not grow with n (the mat-vec kernel drops to 9 % of the HBM
+ * roofline at 8 columns).  Replaces mul_mat_vec_q with ncols_dst > 1 (mmvq.cu:137-224) and the small-mmq_x end of
+ * mul_mat_q (mmq.cuh:3095-3175).  k % 256 == 0 and n <= 32, else MI355_E_UNSUPPORTED (callers loop over passes of 32
+ * columns or use the other kernels).  dst[c*dst_col_stride + r]. */
+MI355_API int mi355_mul_mat_skinny(int type, const void *W, int64_t w_row_stride, const int8_t *act_q, const float *act_ds,
+                                   float *dst, int64_t dst_col_stride, int64_t m, int64_t k, int64_t n, void *stream);
+
+/* q8_K activations, the per-256 quantization ggml-cpu pairs with the K-quants (quantize_row_q8_K_ref,
+ * ggml-quants.c:2471-2508; bit-exact), as three planes: q int8 [rows][k], d f32 [rows][k/256], bsums int16 [rows][k/16].
+ * x is addressed like mi355_quantize_act's (4-D, byte strides, 16-byte aligned rows); k % 256 == 0. */
+MI355_API int mi355_quantize_act_q8k(const float *x, int8_t *q, float *d, int16_t *bsums, int64_t k, int64_t ne1, int64_t ne2,
+                                     int64_t ne3, int64_t nb1, int64_t nb2, int64_t nb3, void *stream);
+
+/* Skinny MUL_MAT of a K-quant (Q4_K, Q5_K; others MI355_E_UNSUPPORTED) on q8_K activations, n <= 32 columns: the
+ * arithmetic of ggml_vec_dot_q4_K_q8_K / q5_K_q8_K (ggml-cpu/quants.c; the ggml-cpu contract of MUL_MAT,
+ * ggml-cpu.c:1196-1388) with the integer sub-block scales folded into the int8 MFMA operands, so there is one
+ * f32 rescale per 256 weights instead of one per 32.  dst[c*dst_col_stride + r]. */
+MI355_API int mi355_mul_mat_skinny_k(int type, const void *W, int64_t w_row_stride, const int8_t *act_q, const float *act_d,
+                                     const int16_t *act_bsums, float *dst, int64_t dst_col_stride, int64_t m, int64_t k,
+                                     int64_t n, void *stream);
+
 /* Prefill tile kernel (int8 MFMA): dst[c][r] = sum_k W[r][k] * act[c][k] for any n (meant for n > 8).
  * Same operands as the mat-vec (one channel).  Returns MI355_E_UNSUPPORTED when k % 128 != 0 (callers
  * then use the mat-vec kernel over column groups).  Replaces ggml_cuda_mul_mat_q / mul_mat_q

@@ -496,7 +496,7 @@ struct mi355_backend_ctx {
     // the same src1 (wq/wk/wv, gate/up) quantize it once.  Dropped as soon as any node writes into it.
     struct {
         bool valid = false;
-        int fmt = 0;                // 0: q8_1 SoA (mi355_quantize_act), 1: bf16 rows (mi355_act_bf16)
+        int fmt = 0;                // 0: q8_1 SoA (mi355_quantize_act), 1: bf16 rows (mi355_act_bf16), 2: q8_K planes (mi355_quantize_act_q8k)
         const void * data = nullptr;
         size_t span = 0;
         int64_t ne[4] = {0, 0, 0, 0};
@@ -652,39 +652,85 @@ static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 // MUL_MAT on block-quantized src0 (reference dispatch: ggml_cuda_mul_mat, ggml-cuda.cu:1988-2063;
 // contract ggml.c:2971-2986; oracle ggml_compute_forward_mul_mat, ggml-cpu.c:1196-1388)
-// the launches of one MUL_MAT over rows [row_low, row_low + M) of the weight matrix whose first owned row is at
-// W: int8-MFMA tile kernel for prefill-sized N, mat-vec kernel in groups of 8 columns otherwise
+//
+// Kernel per batch size N (columns of src1), from tools/bench_skinny.py on MI355X (weights 4096..14336 squared-ish):
+//   N <= 3 (K-quants) / N <= 8 (others)   mat-vec (mmvq.hip), q8_1 activations, HBM-bound at N = 1
+//   up to 64 (128 when K >= 8192)         skinny int8-MFMA kernels (mmsk.hip) in passes of 32 columns: q4_K / q5_K on
+//                                         q8_K activations with the sub-block scales folded into the operands,
+//                                         the other types on q8_1 with a per-block f32 rescale (up to 32 / 64)
+//   beyond                                dequantize-in-LDS bf16 MFMA GEMM (mmdq.hip), bf16 activations
+// GGML_MI355_MMQ_INT8=1 keeps prefill on the int8 MFMA tile kernel (mmq.hip), GGML_MI355_NO_SKINNY=1 removes the
+// middle row.  The choice depends on (type, N, K) only, never on the row count, so a row-split matrix takes the same
+// path (and produces the same bits) as the unsplit one.
+enum mi355_mm_path { MM_VEC = 0, MM_DQ = 1, MM_SKINNY_K = 2, MM_SKINNY = 3, MM_Q_INT8 = 4 };
+// activation format each path consumes (act_cache.fmt): 0 q8_1 SoA, 1 bf16 rows, 2 q8_K planes
+static int mm_path_fmt(int path) { return path == MM_DQ ? 1 : path == MM_SKINNY_K ? 2 : 0; }
+
+static int mi355_mul_mat_path(const ggml_tensor * src0, const ggml_tensor * src1) {
+    static const bool int8_mmq = getenv("GGML_MI355_MMQ_INT8") != nullptr;
+    static const bool no_skinny = getenv("GGML_MI355_NO_SKINNY") != nullptr;
+    const int64_t K = src0->ne[0], N = src1->ne[1];
+    const bool aligned = (((uintptr_t)src1->data | src1->nb[1] | src1->nb[2] | src1->nb[3]) & 15) == 0;
+    if (!no_skinny && K % 256 == 0 && aligned && !(N > 8 && int8_mmq)) {
+        const bool kq = src0->type == GGML_TYPE_Q4_K || src0->type == GGML_TYPE_Q5_K;
+        if (kq  && N >= 4 && N <= (K >= 8192 ? 128 : 64)) return MM_SKINNY_K;
+        if (!kq && N > 8  && N <= (K >= 8192 ? 64 : 32))  return MM_SKINNY;
+    }
+    if (N > 8 && int8_mmq && K % 128 == 0) return MM_Q_INT8;
+    if (N > 8 && K % 64 == 0 && aligned && !int8_mmq) return MM_DQ;
+    return MM_VEC;
+}
+
+// planes of the activation scratch for `rows` rows of length K in the format of `path` (each 256-byte aligned)
+struct mi355_act_layout { size_t b0, b1, b2; size_t total() const { return b0 + b1 + b2; } };
+static mi355_act_layout mi355_act_planes(int path, int64_t K, int64_t rows) {
+    mi355_act_layout l = {0, 0, 0};
+    switch (mm_path_fmt(path)) {
+        case 1: l.b0 = align_up((size_t)rows * K * 2, 256); break;
+        case 2: l.b0 = align_up((size_t)rows * K, 256); l.b1 = align_up((size_t)rows * (K / 256) * 4, 256); l.b2 = align_up((size_t)rows * (K / 16) * 2, 256); break;
+        default: l.b0 = align_up((size_t)mi355_act_q_bytes(K, rows), 256); l.b1 = align_up((size_t)mi355_act_ds_bytes(K, rows), 256); break;
+    }
+    return l;
+}
+
+// the launches of one MUL_MAT over rows [row_low, row_low + M) of the weight matrix whose first owned row is at W;
+// `act` holds all of src1 in the format of `path`
 static void mi355_mul_mat_launch(const ggml_tensor * dst, const char * W, int64_t row_low, int64_t M,
-                                 const int8_t * aq, const float * ads, hipStream_t stream, bool bf16 = false) {
+                                 const char * act, int path, hipStream_t stream) {
     const ggml_tensor * src0 = dst->src[0];
     const ggml_tensor * src1 = dst->src[1];
     const int64_t K = src0->ne[0], ne02 = src0->ne[2], ne03 = src0->ne[3];
     const int64_t N = src1->ne[1], ne12 = src1->ne[2], ne13 = src1->ne[3];
     const int64_t r2 = ne12 / ne02, r3 = ne13 / ne03;
+    const mi355_act_layout L = mi355_act_planes(path, K, N * ne12 * ne13);
+    const int8_t * aq = (const int8_t *)act;
+    const float * ads = (const float *)(act + L.b0);
     char * dbase = (char *)dst->data + row_low * sizeof(float);
-    if (bf16) {
-        // prefill: dequantize-in-LDS bf16 MFMA GEMM on activations rounded to bf16 (aq holds them), one launch per channel
-        const uint16_t * ab = (const uint16_t *)aq;
+    const int64_t dcol = (int64_t)(dst->nb[1] / sizeof(float));
+    if (path != MM_VEC) {
+        // one launch (or pass of 32 columns) per broadcast channel
         for (int64_t i13 = 0; i13 < ne13; i13++) {
             for (int64_t i12 = 0; i12 < ne12; i12++) {
                 const char * Wc = W + (i13 / r3) * src0->nb[3] + (i12 / r2) * src0->nb[2];
                 const int64_t arow = (i13 * ne12 + i12) * N;
                 float * d = (float *)(dbase + i13 * dst->nb[3] + i12 * dst->nb[2]);
-                MI_CHECK(mi355_mul_mat_dq((int)src0->type, Wc, (int64_t)src0->nb[1], ab + arow * K, K, d,
-                                          (int64_t)(dst->nb[1] / sizeof(float)), M, K, N, stream));
-            }
-        }
-        return;
-    }
-    if (N > 8 && K % 128 == 0) {
-        // prefill: int8-MFMA tile kernel, one launch per broadcast channel
-        for (int64_t i13 = 0; i13 < ne13; i13++) {
-            for (int64_t i12 = 0; i12 < ne12; i12++) {
-                const char * Wc = W + (i13 / r3) * src0->nb[3] + (i12 / r2) * src0->nb[2];
-                const int64_t arow = (i13 * ne12 + i12) * N;
-                float * d = (float *)(dbase + i13 * dst->nb[3] + i12 * dst->nb[2]);
-                MI_CHECK(mi355_mul_mat_q((int)src0->type, Wc, (int64_t)src0->nb[1], aq + arow * K, ads + arow * (K / 32) * 2, d,
-                                         (int64_t)(dst->nb[1] / sizeof(float)), M, K, N, stream));
+                if (path == MM_DQ) {
+                    MI_CHECK(mi355_mul_mat_dq((int)src0->type, Wc, (int64_t)src0->nb[1], (const uint16_t *)act + arow * K, K, d, dcol, M, K, N, stream));
+                } else if (path == MM_Q_INT8) {
+                    MI_CHECK(mi355_mul_mat_q((int)src0->type, Wc, (int64_t)src0->nb[1], aq + arow * K, ads + arow * (K / 32) * 2, d, dcol, M, K, N, stream));
+                } else {
+                    for (int64_t c0 = 0; c0 < N; c0 += 32) {
+                        const int64_t r = arow + c0, nc = N - c0 < 32 ? N - c0 : 32;
+                        if (path == MM_SKINNY_K) {
+                            const int16_t * bs = (const int16_t *)(act + L.b0 + L.b1);
+                            MI_CHECK(mi355_mul_mat_skinny_k((int)src0->type, Wc, (int64_t)src0->nb[1], aq + r * K, ads + r * (K / 256), bs + r * (K / 16),
+                                                            d + c0 * dcol, dcol, M, K, nc, stream));
+                        } else {
+                            MI_CHECK(mi355_mul_mat_skinny((int)src0->type, Wc, (int64_t)src0->nb[1], aq + r * K, ads + r * (K / 32) * 2,
+                                                          d + c0 * dcol, dcol, M, K, nc, stream));
+                        }
+                    }
+                }
             }
         }
         return;
@@ -700,8 +746,8 @@ static void mi355_mul_mat_launch(const ggml_tensor * dst, const char * W, int64_
             a.act_q  = aq + (i13 * ne12 * N + c0) * K;
             a.act_ds = ads + (i13 * ne12 * N + c0) * (K / 32) * 2;
             a.act_ch_stride = N;
-            a.dst = (float *)(dbase + i13 * dst->nb[3]) + c0 * (dst->nb[1] / sizeof(float));
-            a.dst_col_stride = (int64_t)(dst->nb[1] / sizeof(float));
+            a.dst = (float *)(dbase + i13 * dst->nb[3]) + c0 * dcol;
+            a.dst_col_stride = dcol;
             a.dst_ch_stride  = (int64_t)(dst->nb[2] / sizeof(float));
             a.m = M; a.k = K;
             a.ncols = (int32_t)(N - c0 < 8 ? N - c0 : 8);
@@ -720,26 +766,23 @@ static void mi355_mul_mat(mi355_backend_ctx * ctx, ggml_tensor * dst) {
     const int64_t rows = N * ne12 * ne13;
     if (rows == 0 || M == 0) return;
 
-    // Activations for all of src1 (strided / permuted src1 is handled by the converters), once per distinct src1:
-    // prefill-sized N: rounded to bf16 for the dequantize-in-LDS MFMA GEMM; otherwise q8_1 for the mat-vec kernel
-    // (GGML_MI355_MMQ_INT8=1 keeps prefill on the int8 MFMA tile kernel, which consumes q8_1 as well).
-    static const bool int8_mmq = getenv("GGML_MI355_MMQ_INT8") != nullptr;
-    const bool bf16 = N > 8 && K % 64 == 0 && !int8_mmq &&
-                      ((((uintptr_t)src1->data | src1->nb[1] | src1->nb[2] | src1->nb[3]) & 15) == 0);
-    size_t qb, db;
-    if (bf16) { qb = align_up((size_t)rows * K * 2, 256); db = 0; }
-    else      { qb = align_up((size_t)mi355_act_q_bytes(K, rows), 256); db = align_up((size_t)mi355_act_ds_bytes(K, rows), 256); }
-    char * ws = (char *)ctx->get_scratch(0, qb + db);
-    int8_t * aq  = (int8_t *)ws;
-    float  * ads = (float *)(ws + qb);
-    if (!ctx->act_cached(src1, bf16) || getenv("GGML_MI355_NO_FUSE")) {
-        if (bf16) MI_CHECK(mi355_act_bf16((const float *)src1->data, (uint16_t *)ws, K, N, ne12, ne13, src1->nb[1], src1->nb[2], src1->nb[3], ctx->stream));
-        else      MI_CHECK(mi355_quantize_act((const float *)src1->data, aq, ads, K, N, ne12, ne13, src1->nb[1], src1->nb[2], src1->nb[3], ctx->stream));
-        ctx->act_remember(src1, bf16);
+    // Activations for all of src1 (strided / permuted src1 is handled by the converters), once per distinct src1 and
+    // format: q8_1 for the mat-vec, q8_K for the K-quant skinny kernel, bf16 for the prefill GEMM.
+    const int path = mi355_mul_mat_path(src0, src1), fmt = mm_path_fmt(path);
+    const mi355_act_layout L = mi355_act_planes(path, K, rows);
+    const size_t qb = L.total(), db = 0;
+    char * ws = (char *)ctx->get_scratch(0, qb);
+    if (!ctx->act_cached(src1, fmt) || getenv("GGML_MI355_NO_FUSE")) {
+        const float * x = (const float *)src1->data;
+        if (fmt == 1)      MI_CHECK(mi355_act_bf16(x, (uint16_t *)ws, K, N, ne12, ne13, src1->nb[1], src1->nb[2], src1->nb[3], ctx->stream));
+        else if (fmt == 2) MI_CHECK(mi355_quantize_act_q8k(x, (int8_t *)ws, (float *)(ws + L.b0), (int16_t *)(ws + L.b0 + L.b1), K, N, ne12, ne13,
+                                                           src1->nb[1], src1->nb[2], src1->nb[3], ctx->stream));
+        else               MI_CHECK(mi355_quantize_act(x, (int8_t *)ws, (float *)(ws + L.b0), K, N, ne12, ne13, src1->nb[1], src1->nb[2], src1->nb[3], ctx->stream));
+        ctx->act_remember(src1, fmt);
     }
 
     if (!tensor_is_split(src0)) {
-        mi355_mul_mat_launch(dst, (const char *)src0->data, 0, M, aq, ads, ctx->stream, bf16);
+        mi355_mul_mat_launch(dst, (const char *)src0->data, 0, M, ws, path, ctx->stream);
         return;
     }
 
@@ -770,13 +813,13 @@ static void mi355_mul_mat(mi355_backend_ctx * ctx, ggml_tensor * dst) {
             p.act_version = ctx->act_version;
         }
         mi355_mul_mat_launch(dst, (const char *)extra->data[d], extra->row_low[d], extra->row_high[d] - extra->row_low[d],
-                             (const int8_t *)p.act, (const float *)((const char *)p.act + qb), p.stream, bf16);
+                             (const char *)p.act, path, p.stream);
         HIP_CHECK(hipEventRecord(p.done, p.stream));
     }
     mi355_set_device(ctx->device);
     if (extra->data[ctx->device]) {
         mi355_mul_mat_launch(dst, (const char *)extra->data[ctx->device], extra->row_low[ctx->device],
-                             extra->row_high[ctx->device] - extra->row_low[ctx->device], aq, ads, ctx->stream, bf16);
+                             extra->row_high[ctx->device] - extra->row_low[ctx->device], ws, path, ctx->stream);
     }
     for (int d = 0; d < ndev; d++) {
         if (d == ctx->device || !extra->data[d]) continue;
@@ -1050,6 +1093,7 @@ static bool matvec_groupable(const ggml_tensor * node) {
     const ggml_tensor * a = node->src[0], * b = node->src[1];
     if (!is_weight_type(a->type) || tensor_is_split(a) || a->op != GGML_OP_NONE || a->view_src) return false;
     if (a->ne[2] != 1 || a->ne[3] != 1 || b->ne[2] != 1 || b->ne[3] != 1 || b->ne[1] < 1 || b->ne[1] > 8) return false;
+    if (mi355_mul_mat_path(a, b) != MM_VEC) return false;      // e.g. 4..8 columns of a K-quant: the skinny MFMA kernel is faster
     return ggml_is_contiguous(node) && a->ne[1] > 0;
 }
 

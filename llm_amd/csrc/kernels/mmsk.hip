@@ -1,0 +1,628 @@
+// mmsk.hip -- "skinny" MUL_MAT for 2 <= N <= 32 activation columns per pass (batched decode, short prompts,
+// speculative decoding, per-expert columns of MUL_MAT_ID) on the int8 matrix cores.
+//
+// Same contract and arithmetic as the mat-vec (mmvq.hip: q8_1 activations, i32 dot per 32-block, f32 scales);
+// replaces mul_mat_vec_q with ncols_dst 2..8 (ggml/src/ggml-cuda/mmvq.cu:137-224) and the small-batch end of
+// mul_mat_q (mmq.cuh:3095-3175, mmq_x 8..32).  The mat-vec kernel spends one v_dot4 per 4 weights PER COLUMN, so
+// it falls from the HBM roofline at 1 column to 9 % of it at 8; here one v_mfma_i32_32x32x32_i8 covers 32 weight
+// rows x 32 columns x one 32-block, and the cost per weight byte does not depend on N (<= 32).
+//
+// Roofline: HBM (weights streamed once per pass of 32 columns); the per-block f32 rescale (about 64 VALU
+// instructions per MFMA) is sized to run at about the CU-side load limit (~9 B/cycle/CU).
+//
+// Shape of the kernel
+//   * workgroup = 512 threads = 8 waves, all on the same 32 weight rows; wave w takes super-steps (256 weights of
+//     K) w, w+8, ...; the 8 partial 32x32 tiles are added through LDS at the end.  When M/32 workgroups cannot
+//     fill the chip, K is also split over 2 workgroups whose tiles are added into a zeroed dst with float atomics
+//     (two addends: the sum does not depend on the order).
+//   * weights go global -> registers directly in MFMA operand layout: lane (row = lane & 31, half = lane >> 5)
+//     loads the 16 weights [16 half, 16 half + 16) of a 32-block of ITS row (one dwordx4 for two q4_K blocks),
+//     unpacks them to int8 with a few bit ops; next super-step's loads are issued before the current MFMAs.
+//   * activations (q8_1 SoA, mi355_quantize_act) are read per block straight from global / L2: lane
+//     (col = lane & 31, half) loads 16 int8 + {d, sum} of its column; columns >= N repeat column N-1.
+//   * C[r] of lane (col, half) is row (r&3) + 8 (r>>2) + 4 half: the activation scale is a per-lane scalar, the
+//     weight scales of the 16 rows come from a small per-wave LDS table written by the lanes that own the rows.
+#include "common.h"
+
+namespace {
+
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+constexpr int SK_WAVES = 8, SK_THREADS = SK_WAVES * 64;
+
+struct SArgs {
+    const uint8_t * W; int64_t w_row_stride;
+    const int8_t * aq; const float * ads;     // [n][k], [n][k/32][2]
+    float * dst; int64_t dst_col_stride;
+    int m, n, k;
+};
+
+// per-wave LDS scale table: [8 blocks of the super-step][2 sub-groups (q6_K)][32 rows]
+struct WaveTab { float ws[8][2][32]; float wm[8][32]; };
+
+template <int TYPE> struct SK;
+
+// ---- Q4_K / Q5_K: super-step = one 256-weight super-block
+template <int TYPE> struct SKK45 {
+    static constexpr int SUB = 1;
+    static constexpr bool MINS = true;
+    static constexpr int BS = TYPE == MI355_TYPE_Q4_K ? 144 : 176;
+    static constexpr int QO = TYPE == MI355_TYPE_Q4_K ? 16 : 48;
+    struct Raw { v4i q[4]; v4i qh; v4i hdr; };
+    static __device__ __forceinline__ Raw load(const uint8_t * row, int sb, int lh) {
+        const uint8_t * blk = row + (int64_t)sb * BS;
+        Raw r;
+#pragma unroll
+        for (int g = 0; g < 4; g++) r.q[g] = *(const v4i *)(blk + QO + g * 32 + lh * 16);
+        if (TYPE == MI355_TYPE_Q5_K) r.qh = *(const v4i *)(blk + 16 + lh * 16);
+        r.hdr = *(const v4i *)blk;
+        return r;
+    }
+    // int8 operand of block j for this lane's 16 weights; sub unused
+    static __device__ __forceinline__ v4i frag(const Raw & r, int j, int, int) {
+        v4i x = (r.q[j >> 1] >> (4 * (j & 1))) & 0x0f0f0f0f;
+        if (TYPE == MI355_TYPE_Q5_K) x |= ((r.qh >> j) & 0x01010101) << 4;
+        return x;
+    }
+    static __device__ __forceinline__ void scales(const Raw & r, WaveTab & t, int lr) {
+        const uint32_t u0 = r.hdr.y, u1 = r.hdr.z, u2 = r.hdr.w;
+        const float d = h2f((uint16_t)(r.hdr.x & 0xffff)), dmin = h2f((uint16_t)((uint32_t)r.hdr.x >> 16));
+#pragma unroll
+        for (int j = 0; j < 8; j++) {   // get_scale_min_k4, ggml-quants.c:625-632
+            uint32_t sc, m;
+            if (j < 4) { sc = (u0 >> (8 * j)) & 0x3f; m = (u1 >> (8 * j)) & 0x3f; }
+            else {
+                sc = ((u2 >> (8 * (j - 4))) & 0x0f) | (((u0 >> (8 * (j - 4) + 6)) & 0x03) << 4);
+                m  = ((u2 >> (8 * (j - 4) + 4)) & 0x0f) | (((u1 >> (8 * (j - 4) + 6)) & 0x03) << 4);
+            }
+            t.ws[j][0][lr] = d * (float)sc;
+            t.wm[j][lr]    = dmin * (float)m;
+        }
+    }
+};
+template <> struct SK<MI355_TYPE_Q4_K> : SKK45<MI355_TYPE_Q4_K> {};
+template <> struct SK<MI355_TYPE_Q5_K> : SKK45<MI355_TYPE_Q5_K> {};
+
+// ---- Q6_K: 16-weight scale groups -> the two halves of a 32-block (lane halves) carry different scales:
+// two MFMAs per block, each with the other half's operand zeroed (SUB = 2)
+template <> struct SK<MI355_TYPE_Q6_K> {
+    static constexpr int SUB = 2;
+    static constexpr bool MINS = false;
+    struct Raw { v4i ql[4]; v4i qh[2]; v4i sc; uint16_t d; };
+    static __device__ __forceinline__ Raw load(const uint8_t * row, int sb, int lh) {
+        const uint8_t * blk = row + (int64_t)sb * 210;
+        Raw r;
+#pragma unroll
+        for (int c = 0; c < 4; c++) r.ql[c] = ld16_a2(blk + 32 * c + lh * 16);     // ql[64 n + 32 (q&1) + l], c = 2n + (q&1)
+#pragma unroll
+        for (int n = 0; n < 2; n++) r.qh[n] = ld16_a2(blk + 128 + 32 * n + lh * 16);
+        r.sc = ld16_a2(blk + 192);
+        r.d  = ld_u16(blk + 208);
+        return r;
+    }
+    static __device__ __forceinline__ v4i frag(const Raw & r, int j, int lh, int sub) {
+        // block j = 4 n + q: ql chunk 2n + (q&1), nibble q>>1; qh[n] >> 2q (dequantize_row_q6_K, ggml-quants.c:1695-1711)
+        const int n = j >> 2, q = j & 3;
+        v4i x = ((r.ql[2 * n + (q & 1)] >> (4 * (q >> 1))) & 0x0f0f0f0f) | (((r.qh[n] >> (2 * q)) & 0x03030303) << 4);
+#pragma unroll
+        for (int i = 0; i < 4; i++) x[i] = sub_bytes(x[i], 0x20202020);
+        const v4i z = {0, 0, 0, 0};
+        return lh == sub ? x : z;
+    }
+    static __device__ __forceinline__ void scales(const Raw & r, WaveTab & t, int lr) {
+        const float d = h2f(r.d);
+        const int8_t * sc = (const int8_t *)&r.sc;      // sc[8 n + 2 q + half]
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            t.ws[j][0][lr] = d * (float)sc[2 * j];
+            t.ws[j][1][lr] = d * (float)sc[2 * j + 1];
+        }
+    }
+};
+
+// ---- Q8_0 / Q4_0: super-step = 8 consecutive 32-blocks
+template <> struct SK<MI355_TYPE_Q8_0> {
+    static constexpr int SUB = 1;
+    static constexpr bool MINS = false;
+    struct Raw { v4i q[8]; uint16_t d[8]; };
+    static __device__ __forceinline__ Raw load(const uint8_t * row, int sb, int lh) {
+        Raw r;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const uint8_t * blk = row + (int64_t)(sb * 8 + j) * 34;
+            r.q[j] = ld16_a2(blk + 2 + lh * 16);
+            r.d[j] = ld_u16(blk);
+        }
+        return r;
+    }
+    static __device__ __forceinline__ v4i frag(const Raw & r, int j, int, int) { return r.q[j]; }
+    static __device__ __forceinline__ void scales(const Raw & r, WaveTab & t, int lr) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) t.ws[j][0][lr] = h2f(r.d[j]);
+    }
+};
+template <> struct SK<MI355_TYPE_Q4_0> {
+    static constexpr int SUB = 1;
+    static constexpr bool MINS = false;
+    struct Raw { v4i q[8]; uint16_t d[8]; };
+    static __device__ __forceinline__ Raw load(const uint8_t * row, int sb, int) {
+        Raw r;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const uint8_t * blk = row + (int64_t)(sb * 8 + j) * 18;
+            r.q[j] = ld16_a2(blk + 2);      // both halves need the same 16 bytes: low nibbles = weights 0..15, high = 16..31
+            r.d[j] = ld_u16(blk);
+        }
+        return r;
+    }
+    static __device__ __forceinline__ v4i frag(const Raw & r, int j, int lh, int) {
+        v4i x = (r.q[j] >> (4 * lh)) & 0x0f0f0f0f;
+#pragma unroll
+        for (int i = 0; i < 4; i++) x[i] = sub_bytes(x[i], 0x08080808);
+        return x;
+    }
+    static __device__ __forceinline__ void scales(const Raw & r, WaveTab & t, int lr) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) t.ws[j][0][lr] = h2f(r.d[j]);
+    }
+};
+
+template <int TYPE>
+__global__ void __launch_bounds__(SK_THREADS)
+mmsk_kernel(const SArgs a) {
+    typedef SK<TYPE> T;
+    __shared__ WaveTab tab[SK_WAVES];
+    __shared__ float red[SK_WAVES][16][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int m0 = blockIdx.x * 32;
+    const int row = m0 + lr < a.m ? m0 + lr : a.m - 1;
+    const uint8_t * wrow = a.W + (int64_t)row * a.w_row_stride;
+    const int col = lr < a.n ? lr : a.n - 1;
+    const int8_t * aq = a.aq + (int64_t)col * a.k + lh * 16;
+    const float * ads = a.ads + (int64_t)col * (a.k / QK) * 2;
+
+    // super-steps of this workgroup (K split over gridDim.y workgroups) and of this wave
+    const int nsb = a.k / 256, per = (nsb + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int sb0 = (int)blockIdx.y * per, sb1 = sb0 + per < nsb ? sb0 + per : nsb;
+
+    float acc[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[r] = 0.0f;
+
+    WaveTab & t = tab[wave];
+    int sb = sb0 + wave;
+    typename T::Raw cur;
+    if (sb < sb1) cur = T::load(wrow, sb, lh);
+    for (; sb < sb1; sb += SK_WAVES) {
+        typename T::Raw nxt;
+        if (sb + SK_WAVES < sb1) nxt = T::load(wrow, sb + SK_WAVES, lh);
+        // activations of the 8 blocks: 16 int8 of this lane's column and half, {d, sum}
+        v4i bq[8];
+        v2f bd[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            bq[j] = *(const v4i *)(aq + (int64_t)(sb * 8 + j) * 32);
+            bd[j] = *(const v2f *)(ads + (int64_t)(sb * 8 + j) * 2);
+        }
+        if (lh == 0) T::scales(cur, t, lr);      // lanes 0..31 own rows 0..31 (the upper half holds the same rows)
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const float d8 = bd[j].x, s8 = bd[j].x * bd[j].y;
+#pragma unroll
+            for (int sub = 0; sub < T::SUB; sub++) {
+                const v16i zero = {0};
+                const v16i c = __builtin_amdgcn_mfma_i32_32x32x32_i8(T::frag(cur, j, lh, sub), bq[j], zero, 0, 0, 0);
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    const v4f ws = *(const v4f *)&t.ws[j][sub][8 * g + 4 * lh];
+#pragma unroll
+                    for (int e = 0; e < 4; e++) acc[4 * g + e] = __builtin_fmaf(ws[e], d8 * (float)c[4 * g + e], acc[4 * g + e]);
+                }
+            }
+            if (T::MINS) {
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    const v4f wm = *(const v4f *)&t.wm[j][8 * g + 4 * lh];
+#pragma unroll
+                    for (int e = 0; e < 4; e++) acc[4 * g + e] = __builtin_fmaf(-wm[e], s8, acc[4 * g + e]);
+                }
+            }
+        }
+        if (sb + SK_WAVES < sb1) cur = nxt;
+    }
+
+    // add the 8 waves' tiles
+#pragma unroll
+    for (int r = 0; r < 16; r++) red[wave][r][lane] = acc[r];
+    __syncthreads();
+    for (int e = tid; e < 16 * 64; e += SK_THREADS) {
+        const int r = e >> 6, l = e & 63;
+        float s = 0.0f;
+#pragma unroll
+        for (int w = 0; w < SK_WAVES; w++) s += red[w][r][l];
+        const int orow = m0 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), ocol = l & 31;
+        if (orow < a.m && ocol < a.n) {
+            float * o = a.dst + (int64_t)ocol * a.dst_col_stride + orow;
+            if (gridDim.y > 1) atomicAdd(o, s); else *o = s;
+        }
+    }
+}
+
+template <int TYPE>
+static int launch(const SArgs & a, hipStream_t s, const char * tag) {
+    const unsigned nb = (unsigned)((a.m + 31) / 32);
+    const unsigned ky = nb < 256 && a.k >= 2048 ? 2 : 1;      // few row tiles: split K over two workgroups
+    if (ky > 1) {
+        hipError_t e = a.dst_col_stride == a.m
+            ? hipMemsetAsync(a.dst, 0, (size_t)a.n * a.m * sizeof(float), s)
+            : hipMemset2DAsync(a.dst, (size_t)a.dst_col_stride * sizeof(float), 0, (size_t)a.m * sizeof(float), (size_t)a.n, s);
+        if (e != hipSuccess) return (int)e;
+    }
+    MI355_LAUNCH(tag, (mmsk_kernel<TYPE>), dim3(nb, ky), dim3(SK_THREADS), 0, s, a);
+    MI355_CHECK_LAUNCH();
+    return MI355_OK;
+}
+
+
+// =====================================================================================================================
+// K-quants on q8_K activations: no per-block rescale at all.
+//
+// The f32 rescale above costs ~64 VALU instructions per MFMA, and that, not HBM, bounds the kernel (measured 1.8 TB/s
+// on q4_K).  The K-quants carry INTEGER sub-block scales under one f16 super-block scale, and ggml's own CPU contract for
+// them quantizes the activations per 256 values (q8_K: quantize_row_q8_K_ref, ggml-quants.c:2471-2508;
+// ggml_vec_dot_q4_K_q8_K, ggml-cpu/quants.c).  With one activation scale per super-block the whole super-block sum
+//     sum_j sc_j * (q_j . a_j)
+// is an integer and can stay on the matrix core: the 6-bit sc_j is split into P digits of B bits, digit * q fits a
+// signed byte (7 * 15 = 105 for q4_K with 2 x 3 bits; 3 * 31 = 93 for q5_K with 3 x 2 bits) and is one
+// v_pk_mul_lo_u16 per 4 weights (no carry crosses a byte), and P MFMAs per 32-block accumulate in i32 over all 8
+// blocks.  One conversion per super-block: acc += d_row * d8_col * float(C_0 + (C_1 << B) + ...).
+// The min term sum_j (dmin m_j)_row * (d8 bsum_j)_col is a K = 8 f32 product: 4 x v_mfma_f32_32x32x2_f32 per super-block
+// into one accumulator that lives through the whole K loop.
+struct S2Args {
+    const uint8_t * W; int64_t w_row_stride;
+    const int8_t * aq; const float * ad; const int16_t * bs;     // [n][k], [n][k/256], [n][k/16]
+    float * dst; int64_t dst_col_stride;
+    int m, n, k;
+#ifdef SK_STAMPS
+    long long * stamps;      // diagnostic build only (lab/mmsk_stamps.hip): [workgroup][wave][8] s_memtime / s_memrealtime
+#endif
+};
+
+#ifdef SK_STAMPS
+#define SK_STAMP(i) do { if (lane == 0) st_[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define SK_STAMP(i) do { } while (0)
+#endif
+
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+// per-byte x * digit for bytes x, digit with x * digit < 256: v_pk_mul_lo_u16 on the two 16-bit halves
+static __device__ __forceinline__ int pk_bytes_mul(int x, int rep) {
+    return __builtin_bit_cast(int, (us2)(__builtin_bit_cast(us2, x) * __builtin_bit_cast(us2, rep)));
+}
+
+// Operand path: a lane of the MFMA owns one weight ROW (and one activation COLUMN), so loading operands straight
+// from global memory makes every load instruction touch 32 different cache lines for 16-32 bytes each; the lines
+// have to survive in the 32 KB L1 until the other 4 loads of the super-step come for the rest of them, and with 8
+// waves x 2 super-steps in flight they do not (measured: 2.4 TB/s, no change from prefetching or fewer waves).
+// So each wave stages its super-step through a private LDS region with COALESCED loads -- consecutive lanes read
+// consecutive 16-byte chunks of a row's 144/176-byte super-block (7 / 5 rows per instruction), and 4 columns x
+// 256 bytes of activations per instruction -- and reads the operands back row-per-lane with ds_read_b128 (pitches
+// 144 / 176 / 272 bytes: conflict-free).  The region is private to the wave: LDS operations of one wave execute in
+// order, so no workgroup barrier is involved.  Each wave takes a CONTIGUOUS range of super-blocks.
+template <int TYPE, int WAVES>
+__global__ void __launch_bounds__(WAVES * 64)
+mmsk2_kernel(const S2Args a) {
+    typedef SK<TYPE> T;
+    constexpr int P = TYPE == MI355_TYPE_Q4_K ? 2 : 3, B = TYPE == MI355_TYPE_Q4_K ? 3 : 2;
+    constexpr int BS = T::BS, QO = T::QO;
+    constexpr int CH = BS / 16, RPI = 64 / CH, NI = (32 + RPI - 1) / RPI;      // 16-byte chunks per row; rows per load; loads
+    constexpr int APITCH = 272, WBYTES = 32 * BS, ABYTES = 32 * APITCH, REGION = WBYTES + ABYTES + 16;   // + a dump slot
+    static_assert(REGION >= 16 * 64 * 4, "the staging region doubles as the reduction buffer");
+    __shared__ __attribute__((aligned(16))) uint8_t lds[WAVES * REGION];
+    __shared__ float drow[WAVES][32];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // scalar: everything derived from it stays in SGPRs
+    const int lr = lane & 31, lh = lane >> 5;
+    const int m0 = blockIdx.x * 32;
+    uint8_t * Lw = lds + wave * REGION, * La = Lw + WBYTES;
+#ifdef SK_STAMPS
+    long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (lane == 0) st_[7] = __builtin_amdgcn_s_memrealtime();
+#endif
+    SK_STAMP(0);
+
+    // Staging roles.  Addresses are a wave-uniform base (advanced per super-block in SGPRs) plus a 32-bit lane offset
+    // that never changes, so the loop spends no vector instructions on addressing.  Lanes without a chunk (lane 63
+    // of 7 x 9, rows past 31) load chunk 0 and write it to the dump slot instead of being masked off.
+    const uint8_t * wbase = a.W + (int64_t)m0 * a.w_row_stride;
+    const int wr_ = lane / CH, wc_ = lane % CH;
+    uint32_t woff[NI], wlds[NI];
+#pragma unroll
+    for (int i = 0; i < NI; i++) {
+        const int r = i * RPI + wr_;
+        const bool v = lane < RPI * CH && r < 32;
+        const int rr = m0 + r < a.m ? r : a.m - 1 - m0;      // rows past the end repeat the last row (never stored)
+        woff[i] = v ? (uint32_t)rr * (uint32_t)a.w_row_stride + wc_ * 16 : 0u;
+        wlds[i] = v ? r * BS + wc_ * 16 : WBYTES + ABYTES;
+    }
+    uint32_t aoff[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const int c = i * 4 + (lane >> 4);
+        aoff[i] = (uint32_t)(c < a.n ? c : a.n - 1) * (uint32_t)a.k + (lane & 15) * 16;      // columns >= n repeat column n-1
+    }
+    const int col = lr < a.n ? lr : a.n - 1;
+    const uint32_t doff = (uint32_t)col * (uint32_t)(a.k / 256) * 4;
+    const uint32_t soff = (uint32_t)col * (uint32_t)(a.k / 8) + lh * 16;      // bsums of blocks 4 lh .. 4 lh + 3 (two int16 each)
+
+    // super-blocks of this workgroup (K split over gridDim.y workgroups) and, contiguously, of this wave
+    const int nsb = a.k / 256, per = (nsb + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int sb0 = (int)blockIdx.y * per, sb1 = sb0 + per < nsb ? sb0 + per : nsb;
+    const int perw = (sb1 - sb0 + WAVES - 1) / WAVES;
+    const int my0 = sb0 + wave * perw, my1 = my0 + perw < sb1 ? my0 + perw : sb1;
+
+    v16f acc;
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[r] = 0.0f;
+
+    // Operands in flight: both are requested one super-step ahead.  (Requesting the weights two steps ahead -- a second
+    // register set, activations issued first so that their wait does not retire the younger weights -- measured
+    // 14.4 -> 14.0 us on 14336 x 4096: in-kernel stamps show a step costs ~3000 cycles of issue for two waves per SIMD,
+    // which already covers the ~2 us memory latency.)
+    struct StageW { v4i w[NI]; };
+    struct StageA { v4i q[8]; v4i s; float d; };
+    auto fetch_w = [&](int sb_) {
+        StageW r;
+        const uint8_t * wb = wbase + (int64_t)sb_ * BS;
+#pragma unroll
+        for (int i = 0; i < NI; i++) r.w[i] = *(const v4i *)(wb + woff[i]);
+        return r;
+    };
+    auto fetch_a = [&](int sb_) {
+        StageA r;
+        const int8_t * ab = a.aq + (int64_t)sb_ * 256;
+#pragma unroll
+        for (int i = 0; i < 8; i++) r.q[i] = *(const v4i *)(ab + aoff[i]);
+        r.s = *(const v4i *)((const uint8_t *)a.bs + (int64_t)sb_ * 32 + soff);
+        r.d = *(const float *)((const uint8_t *)a.ad + (int64_t)sb_ * 4 + doff);
+        return r;
+    };
+    const int last = my1 - 1;
+    auto clampsb = [&](int sb_) { return sb_ < last ? sb_ : last; };      // past the end: re-read the last one (harmless)
+
+    StageA sa;
+    auto step = [&](int sb, StageW & sw) {
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int i = 0; i < NI; i++) *(v4i *)(Lw + wlds[i]) = sw.w[i];
+#pragma unroll
+        for (int i = 0; i < 8; i++) *(v4i *)(La + (i * 4 + (lane >> 4)) * APITCH + (lane & 15) * 16) = sa.q[i];
+        const float d8 = sa.d;
+        const v4i sv = sa.s;
+        __builtin_amdgcn_wave_barrier();
+        sa = fetch_a(clampsb(sb + 1));
+        sw = fetch_w(clampsb(sb + 1));
+
+        const uint8_t * wl = Lw + lr * BS;
+        const v4i hdr = *(const v4i *)wl;
+        typename T::Raw cur;
+#pragma unroll
+        for (int g = 0; g < 4; g++) cur.q[g] = *(const v4i *)(wl + QO + g * 32 + lh * 16);
+        if (TYPE == MI355_TYPE_Q5_K) cur.qh = *(const v4i *)(wl + 16 + lh * 16);
+
+        // this lane's row: 8 scales and 8 mins as packed bytes (get_scale_min_k4, ggml-quants.c:625-632)
+        const uint32_t u0 = hdr.y, u1 = hdr.z, u2 = hdr.w;
+        const uint32_t scw[2] = { u0 & 0x3f3f3f3fu, (u2 & 0x0f0f0f0fu) | ((u0 >> 2) & 0x30303030u) };
+        const uint32_t mw[2]  = { u1 & 0x3f3f3f3fu, ((u2 >> 4) & 0x0f0f0f0fu) | ((u1 >> 2) & 0x30303030u) };
+        const float d = h2f((uint16_t)(hdr.x & 0xffff)), ndmin = -h2f((uint16_t)((uint32_t)hdr.x >> 16));
+        if (lh == 0) drow[wave][lr] = d;
+
+        // min term, subtracted on the matrix core: the k index of the f32 MFMA is the lane half; step i covers
+        // blocks i (lower half) and 4 + i
+        const uint32_t mh = lh ? mw[1] : mw[0];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int sum = (sv[i] << 16 >> 16) + (sv[i] >> 16);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ndmin * (float)((mh >> (8 * i)) & 0xffu), d8 * (float)sum, acc, 0, 0, 0);
+        }
+
+        // digit p of the 8 scales, still packed; v_perm_b32 copies digit j into both 16-bit halves of a word
+        uint32_t digw[P][2];
+#pragma unroll
+        for (int p = 0; p < P; p++)
+#pragma unroll
+            for (int h = 0; h < 2; h++) digw[p][h] = (scw[h] >> (B * p)) & (((1u << B) - 1) * 0x01010101u);
+
+        v16i C[P];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const v4i x = T::frag(cur, j, lh, 0);
+            const v4i bq = *(const v4i *)(La + lr * APITCH + j * 32 + lh * 16);
+#pragma unroll
+            for (int p = 0; p < P; p++) {
+                const int rep = (int)__builtin_amdgcn_perm(0u, digw[p][j >> 2], 0x0c000c00u | (uint32_t)(j & 3) | ((uint32_t)(j & 3) << 16));
+                v4i xp;
+#pragma unroll
+                for (int i = 0; i < 4; i++) xp[i] = pk_bytes_mul(x[i], rep);
+                const v16i zero = {0};
+                C[p] = __builtin_amdgcn_mfma_i32_32x32x32_i8(xp, bq, j == 0 ? zero : C[p], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const v4f dr = *(const v4f *)&drow[wave][8 * g + 4 * lh];
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                int t = C[0][4 * g + e];
+#pragma unroll
+                for (int p = 1; p < P; p++) t += C[p][4 * g + e] << (B * p);
+                acc[4 * g + e] = __builtin_fmaf(dr[e], d8 * (float)t, acc[4 * g + e]);
+            }
+        }
+    };
+
+    if (my0 < my1) {
+        StageW w0 = fetch_w(my0);
+        sa = fetch_a(my0);
+        SK_STAMP(1);
+        for (int sb = my0; sb < my1; sb++) {
+            step(sb, w0);
+            if (sb == my0) SK_STAMP(2);
+        }
+    }
+
+    // add the waves' tiles (the staging regions are dead: reuse them)
+    SK_STAMP(3);
+    __syncthreads();
+    SK_STAMP(4);
+    float * red = (float *)lds;      // [WAVES][16][64]
+#pragma unroll
+    for (int r = 0; r < 16; r++) red[(wave * 16 + r) * 64 + lane] = acc[r];
+    __syncthreads();
+    for (int e = tid; e < 16 * 64; e += WAVES * 64) {
+        const int r = e >> 6, l = e & 63;
+        float s = 0.0f;
+#pragma unroll
+        for (int w = 0; w < WAVES; w++) s += red[(w * 16 + r) * 64 + l];
+        const int orow = m0 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), ocol = l & 31;
+        if (orow < a.m && ocol < a.n) {
+            float * o = a.dst + (int64_t)ocol * a.dst_col_stride + orow;
+            if (gridDim.y > 1) atomicAdd(o, s); else *o = s;
+        }
+    }
+#ifdef SK_STAMPS
+    SK_STAMP(5);
+    if (lane == 0 && a.stamps) {
+        st_[6] = __builtin_amdgcn_s_memrealtime();
+        long long * o = a.stamps + ((int64_t)(blockIdx.x * gridDim.y + blockIdx.y) * WAVES + wave) * 8;
+        for (int i = 0; i < 8; i++) o[i] = st_[i];
+    }
+#endif
+}
+
+template <int TYPE>
+static int launch2(const S2Args & a, hipStream_t s, const char * tag) {
+    const unsigned nb = (unsigned)((a.m + 31) / 32);
+    const unsigned ky = nb < 256 && a.k >= 2048 ? 2 : 1;
+    if (ky > 1) {
+        hipError_t e = a.dst_col_stride == a.m
+            ? hipMemsetAsync(a.dst, 0, (size_t)a.n * a.m * sizeof(float), s)
+            : hipMemset2DAsync(a.dst, (size_t)a.dst_col_stride * sizeof(float), 0, (size_t)a.m * sizeof(float), (size_t)a.n, s);
+        if (e != hipSuccess) return (int)e;
+    }
+    MI355_LAUNCH(tag, (mmsk2_kernel<TYPE, 8>), dim3(nb, ky), dim3(512), 0, s, a);
+    MI355_CHECK_LAUNCH();
+    return MI355_OK;
+}
+
+// q8_K activation quantization (quantize_row_q8_K_ref, ggml-quants.c:2471-2508), one wave per 256 values, 4 per lane.
+// SoA output: q int8 [rows][k], d f32 [rows][k/256], bsums int16 [rows][k/16].
+__global__ void __launch_bounds__(256)
+quant_q8k_kernel(const char * x, int8_t * q, float * dd, int16_t * bs, int k, int ne1, int ne2, int64_t nb1, int64_t nb2, int64_t nb3, int64_t total) {
+    const int64_t blk = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (blk >= total) return;
+    const int lane = threadIdx.x & 63, bpr = k / 256;
+    const int64_t row = blk / bpr;
+    const int ib = (int)(blk % bpr);
+    const int i1 = (int)(row % ne1), i2 = (int)((row / ne1) % ne2);
+    const int64_t i3 = row / ((int64_t)ne1 * ne2);
+    const v4f v = *(const v4f *)((const float *)(x + i1 * nb1 + i2 * nb2 + i3 * nb3) + ib * 256 + lane * 4);
+    // the value of largest magnitude, first occurrence on ties (the reference scans with a strict >)
+    float ax = 0.0f, mine = 0.0f;
+    int idx = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) { const float t = fabsf(v[j]); if (t > ax) { ax = t; idx = j; mine = v[j]; } }
+    float amax = ax;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+    int first = ax == amax ? lane * 4 + idx : 1024;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) first = min(first, __shfl_xor(first, o, 64));
+    const float maxv = __shfl(mine, (first >> 2) & 63, 64);
+    int packed = 0, sum = 0;
+    float d = 0.0f;
+    if (amax != 0.0f) {
+        const float iscale = __fdiv_rn(-127.0f, maxv);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            // nearest_int (ggml-quants.c:559-565): round to nearest even through the 2^23 + 2^22 magic number
+            const float val = __fadd_rn(__fmul_rn(iscale, v[j]), 12582912.0f);
+            int qi = (__float_as_int(val) & 0x007fffff) - 0x00400000;
+            qi = qi < 127 ? qi : 127;
+            sum += qi;
+            packed |= (qi & 0xff) << (8 * j);
+        }
+        d = __fdiv_rn(1.0f, iscale);
+    }
+    sum += __shfl_xor(sum, 1, 64);
+    sum += __shfl_xor(sum, 2, 64);
+    *(int *)(q + row * k + ib * 256 + lane * 4) = packed;
+    if ((lane & 3) == 0) bs[row * (k / 16) + ib * 16 + (lane >> 2)] = (int16_t)sum;
+    if (lane == 0) dd[row * bpr + ib] = d;
+}
+
+} // namespace
+
+extern "C" int mi355_mul_mat_skinny(int type, const void * W, int64_t w_row_stride, const int8_t * act_q, const float * act_ds,
+                                    float * dst, int64_t dst_col_stride, int64_t m, int64_t k, int64_t n, void * stream) {
+    if (!W || !act_q || !act_ds || !dst) return MI355_E_NULL;
+    const int64_t bs = mi355_blck_size(type);
+    if (bs == 0 || type == MI355_TYPE_F32 || type == MI355_TYPE_F16 || type == MI355_TYPE_Q8_1) return MI355_E_TYPE;
+    if (m < 0 || n < 0 || k <= 0 || k % bs != 0 || m > 0x7fffffff || k > 0x7fffffff || dst_col_stride < m) return MI355_E_SHAPE;
+    if (k % 256 != 0 || n > 32) return MI355_E_UNSUPPORTED;      // callers split wider batches into passes of 32 columns
+    if (((uintptr_t)act_q & 15) || ((uintptr_t)act_ds & 7) || ((uintptr_t)dst & 3)) return MI355_E_ALIGN;
+    const bool a16 = type == MI355_TYPE_Q4_K || type == MI355_TYPE_Q5_K;
+    if (((uintptr_t)W | (uintptr_t)w_row_stride) & (a16 ? 15 : 1)) return MI355_E_ALIGN;
+    if (w_row_stride < mi355_row_size(type, k)) return MI355_E_SHAPE;
+    if (m == 0 || n == 0) return MI355_OK;
+    SArgs a;
+    a.W = (const uint8_t *)W; a.w_row_stride = w_row_stride; a.aq = act_q; a.ads = act_ds;
+    a.dst = dst; a.dst_col_stride = dst_col_stride; a.m = (int)m; a.n = (int)n; a.k = (int)k;
+    hipStream_t s = (hipStream_t)stream;
+    switch (type) {
+        case MI355_TYPE_Q4_0: return launch<MI355_TYPE_Q4_0>(a, s, "mmsk_q4_0");
+        case MI355_TYPE_Q8_0: return launch<MI355_TYPE_Q8_0>(a, s, "mmsk_q8_0");
+        case MI355_TYPE_Q4_K: return launch<MI355_TYPE_Q4_K>(a, s, "mmsk_q4_K");
+        case MI355_TYPE_Q5_K: return launch<MI355_TYPE_Q5_K>(a, s, "mmsk_q5_K");
+        case MI355_TYPE_Q6_K: return launch<MI355_TYPE_Q6_K>(a, s, "mmsk_q6_K");
+    }
+    return MI355_E_TYPE;
+}
+
+extern "C" int mi355_quantize_act_q8k(const float * x, int8_t * q, float * d, int16_t * bsums, int64_t k, int64_t ne1, int64_t ne2, int64_t ne3,
+                                      int64_t nb1, int64_t nb2, int64_t nb3, void * stream) {
+    if (!x || !q || !d || !bsums) return MI355_E_NULL;
+    if (k <= 0 || k % 256 != 0 || ne1 < 0 || ne2 < 0 || ne3 < 0 || k > 0x7fffffff || ne1 > 0x7fffffff || ne2 > 0x7fffffff) return MI355_E_SHAPE;
+    const int64_t rows = ne1 * ne2 * ne3;
+    if (((uintptr_t)x | (uintptr_t)nb1 | (uintptr_t)nb2 | (uintptr_t)nb3) & 15) return MI355_E_ALIGN;
+    if (((uintptr_t)q & 15) || ((uintptr_t)d & 3) || ((uintptr_t)bsums & 15)) return MI355_E_ALIGN;
+    if (rows == 0) return MI355_OK;
+    const int64_t total = rows * (k / 256);
+    if ((total + 3) / 4 > 0x7fffffff) return MI355_E_SHAPE;
+    MI355_LAUNCH("quantize_q8_K", quant_q8k_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                 (const char *)x, q, d, bsums, (int)k, (int)ne1, (int)ne2, nb1, nb2, nb3, total);
+    MI355_CHECK_LAUNCH();
+    return MI355_OK;
+}
+
+extern "C" int mi355_mul_mat_skinny_k(int type, const void * W, int64_t w_row_stride, const int8_t * act_q, const float * act_d,
+                                      const int16_t * act_bsums, float * dst, int64_t dst_col_stride, int64_t m, int64_t k, int64_t n,
+                                      void * stream) {
+    if (!W || !act_q || !act_d || !act_bsums || !dst) return MI355_E_NULL;
+    if (type != MI355_TYPE_Q4_K && type != MI355_TYPE_Q5_K) return mi355_blck_size(type) ? MI355_E_UNSUPPORTED : MI355_E_TYPE;
+    if (m < 0 || n < 0 || k <= 0 || k % 256 != 0 || m > 0x7fffffff || k > 0x7fffffff || dst_col_stride < m) return MI355_E_SHAPE;
+    if (n > 32) return MI355_E_UNSUPPORTED;
+    if (w_row_stride > 0x3ffffff || k > 0x3ffffff) return MI355_E_UNSUPPORTED;      // 32-bit lane offsets: 32 rows / 32 columns
+    if (((uintptr_t)act_q & 15) || ((uintptr_t)act_d & 3) || ((uintptr_t)act_bsums & 15) || ((uintptr_t)dst & 3)) return MI355_E_ALIGN;
+    if (((uintptr_t)W | (uintptr_t)w_row_stride) & 15) return MI355_E_ALIGN;
+    if (w_row_stride < mi355_row_size(type, k)) return MI355_E_SHAPE;
+    if (m == 0 || n == 0) return MI355_OK;
+    S2Args a;
+    a.W = (const uint8_t *)W; a.w_row_stride = w_row_stride; a.aq = act_q; a.ad = act_d; a.bs = act_bsums;
+    a.dst = dst; a.dst_col_stride = dst_col_stride; a.m = (int)m; a.n = (int)n; a.k = (int)k;
+    hipStream_t s = (hipStream_t)stream;
+    if (type == MI355_TYPE_Q4_K) return launch2<MI355_TYPE_Q4_K>(a, s, "mmsk2_q4_K");
+    return launch2<MI355_TYPE_Q5_K>(a, s, "mmsk2_q5_K");
+}

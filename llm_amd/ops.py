@@ -225,3 +225,39 @@ def mul_mat_id_dq(t, as_, b, ids, m, n_expert):
                                       dst.data_ptr(), m, k, n_expert, n_used, n_tok, b_ne1, ws.data_ptr(), need, _stream()),
             "mi355_mul_mat_id_dq")
     return dst
+
+
+def mul_mat_skinny(t, w, b, m):
+    """MUL_MAT for small batches through the int8-MFMA skinny kernel, in passes of 32 columns: b = [n, k] f32 -> [n, m]."""
+    _u8(w)
+    n, k = b.shape
+    aq, ads = quantize_act(b)
+    dst = torch.empty((n, m), dtype=torch.float32, device=b.device)
+    for c0 in range(0, n, 32):
+        nc = min(32, n - c0)
+        K.check(K.lib.mi355_mul_mat_skinny(t, w.data_ptr(), B.row_size(t, k), aq[c0:].data_ptr(), ads[c0:].data_ptr(),
+                                           dst[c0:].data_ptr(), m, m, k, nc, _stream()), "mi355_mul_mat_skinny")
+    return dst
+
+
+def quantize_act_q8k(x):
+    """[n, k] f32 -> q8_K planes (int8 [n, k], f32 [n, k/256], int16 [n, k/16])."""
+    n, k = x.shape
+    q = torch.empty((n, k), dtype=torch.int8, device=x.device)
+    d = torch.empty((n, k // 256), dtype=torch.float32, device=x.device)
+    bs = torch.empty((n, k // 16), dtype=torch.int16, device=x.device)
+    K.check(K.lib.mi355_quantize_act_q8k(x.data_ptr(), q.data_ptr(), d.data_ptr(), bs.data_ptr(), k, n, 1, 1, x.stride(0) * 4, 0, 0, _stream()),
+            "mi355_quantize_act_q8k")
+    return q, d, bs
+
+
+def mul_mat_skinny_k(t, w, b, m):
+    """K-quant MUL_MAT on q8_K activations through the digit-split int8-MFMA kernel, passes of 32 columns."""
+    _u8(w)
+    n, k = b.shape
+    q, d, bs = quantize_act_q8k(b)
+    dst = torch.empty((n, m), dtype=torch.float32, device=b.device)
+    for c0 in range(0, n, 32):
+        K.check(K.lib.mi355_mul_mat_skinny_k(t, w.data_ptr(), B.row_size(t, k), q[c0:].data_ptr(), d[c0:].data_ptr(), bs[c0:].data_ptr(),
+                                             dst[c0:].data_ptr(), m, m, k, min(32, n - c0), _stream()), "mi355_mul_mat_skinny_k")
+    return dst

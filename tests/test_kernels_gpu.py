@@ -192,6 +192,68 @@ def test_mmdq_strided_activations_and_errors(ops):
     assert K.lib.mi355_mul_mat_dq(B.Q4_K, None, 16, 16, 256, 16, 1, 1, 256, 1, None) == -4
 
 
+@pytest.mark.parametrize("t", B.WEIGHT_TYPES)
+@pytest.mark.parametrize("m,k,n", [(32, 256, 1), (130, 512, 2), (4096, 4096, 8), (257, 2048, 31), (1024, 4096, 32), (96, 1024, 70), (2816, 14336, 5)])
+def test_skinny_int8_mfma_vs_oracle_contract(ops, t, m, k, n):
+    """small-batch MUL_MAT on the int8 matrix cores: same integers as the q8_1 contract (oracle, double accumulation),
+    only the f32 summation order differs -> NMSE <= 1e-10; and within the op's budget of the ggml-cpu arithmetic."""
+    rng = np.random.default_rng(m + k + n)
+    w = B.random_blocks(t, m, k, seed=m + n)
+    x = rng.standard_normal((n, k)).astype(np.float32)
+    got = ops.mul_mat_skinny(t, dev(w), dev(x), m).cpu().numpy()
+    ref = O.mul_mat(t, w, x, m, k, n, "q8_1")
+    assert np.isfinite(got).all() and O.nmse(ref, got) <= 1e-10, O.nmse(ref, got)
+    if m * n <= 40000:
+        assert O.nmse(O.mul_mat(t, w, x, m, k, n, "cpu"), got) <= 5e-4
+
+
+def _q8k_planes(x):
+    """oracle q8_K blocks of x [n, k] -> (q int8 [n, k], d f32 [n, k/256], bsums int16 [n, k/16])"""
+    n, k = x.shape
+    blk = np.stack([O.quantize_row(O.Q8_K, x[i]) for i in range(n)]).reshape(n, k // 256, 292)
+    d = blk[:, :, :4].copy().view(np.float32).reshape(n, k // 256)
+    q = blk[:, :, 4:260].copy().view(np.int8).reshape(n, k)
+    bs = blk[:, :, 260:].copy().view(np.int16).reshape(n, k // 16)
+    return q, d, bs
+
+
+@pytest.mark.parametrize("n,k", [(1, 256), (7, 4096), (33, 1024)])
+def test_quantize_q8k_bit_exact(ops, n, k):
+    """q8_K activations == quantize_row_q8_K_ref (oracle pinned by the reference's golden vectors), including ties
+    between +max and -max (first occurrence wins), all-zero blocks and values that round to +128 (clamped to 127)."""
+    rng = np.random.default_rng(n * k)
+    x = rng.standard_normal((n, k)).astype(np.float32) * rng.choice([1e-3, 1.0, 300.0], size=(n, 1)).astype(np.float32)
+    x[0, :256] = 0.0
+    if n > 1:
+        x[1, 5] = 9.0; x[1, 77] = -9.0          # tie, positive first
+        x[2, 300] = -7.5; x[2, 301] = 7.5       # tie, negative first: +7.5 * (-127 / -7.5) = 127
+        x[3, :256] = np.linspace(-1, 1, 256)
+    q, d, bs = ops.quantize_act_q8k(dev(x))
+    rq, rd, rbs = _q8k_planes(x)
+    assert np.array_equal(q.cpu().numpy(), rq)
+    assert np.array_equal(d.cpu().numpy().view(np.uint32), rd.view(np.uint32))
+    assert np.array_equal(bs.cpu().numpy(), rbs)
+
+
+@pytest.mark.parametrize("t", [B.Q4_K, B.Q5_K])
+@pytest.mark.parametrize("m,k,n", [(32, 256, 1), (130, 512, 2), (4096, 4096, 8), (257, 2048, 31), (1024, 4096, 32), (96, 1024, 70), (2816, 14336, 5)])
+def test_skinny_k_digit_split_vs_q8k_contract(ops, t, m, k, n):
+    """K-quant MUL_MAT with the sub-block scales folded into the MFMA operands: the integers are those of
+    ggml_vec_dot_q*_K_q8_K, so against dequantize(W) . dequantize(q8_K(x)) in f64 only f32 rounding remains
+    (NMSE <= 1e-10), and the ggml-cpu oracle (f32, its own summation order) agrees to the same level."""
+    rng = np.random.default_rng(m + k + n)
+    w = B.random_blocks(t, m, k, seed=m + n)
+    x = rng.standard_normal((n, k)).astype(np.float32)
+    got = ops.mul_mat_skinny_k(t, dev(w), dev(x), m).cpu().numpy()
+    wf = np.stack([O.dequantize_row(t, w[i], k) for i in range(m)]).astype(np.float64)
+    q, d, _ = _q8k_planes(x)
+    xa = q.astype(np.float64).reshape(n, k // 256, 256) * d.astype(np.float64)[:, :, None]
+    ref = (xa.reshape(n, k) @ wf.T).astype(np.float32)
+    assert np.isfinite(got).all() and O.nmse(ref, got) <= 1e-10, O.nmse(ref, got)
+    if m * n <= 40000:
+        assert O.nmse(O.mul_mat(t, w, x, m, k, n, "cpu"), got) <= 1e-10
+
+
 def test_mmq_matches_matvec_path_at_model_shape(ops):
     # pp512-shaped launch vs the decode kernel on the same data (first 8 columns)
     t, m, k, n = B.Q4_K, 1024, 4096, 512
