@@ -191,6 +191,14 @@ MI355_API int mi355_mul_mat_skinny_k(int type, const void *W, int64_t w_row_stri
                                      const int16_t *act_bsums, float *dst, int64_t dst_col_stride, int64_t m, int64_t k,
                                      int64_t n, void *stream);
 
+/* Prefill MUL_MAT of a K-quant (Q4_K, Q5_K; others MI355_E_UNSUPPORTED) on q8_K activations, any n: the tile-kernel
+ * form of mi355_mul_mat_skinny_k (64 rows x 128 columns per workgroup, digit planes prepared once per weight while the
+ * tile is staged, one f32 fold per 256 weights).  Replaces mul_mat_q (mmq.cuh:2606-2841) for these types.
+ * k % 256 == 0.  dst[c*dst_col_stride + r]. */
+MI355_API int mi355_mul_mat_qk(int type, const void *W, int64_t w_row_stride, const int8_t *act_q, const float *act_d,
+                               const int16_t *act_bsums, float *dst, int64_t dst_col_stride, int64_t m, int64_t k,
+                               int64_t n, void *stream);
+
 /* Prefill tile kernel (int8 MFMA): dst[c][r] = sum_k W[r][k] * act[c][k] for any n (meant for n > 8).
  * Same operands as the mat-vec (one channel).  Returns MI355_E_UNSUPPORTED when k % 128 != 0 (callers
  * then use the mat-vec kernel over column groups).  Replaces ggml_cuda_mul_mat_q / mul_mat_q

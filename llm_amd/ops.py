@@ -261,3 +261,14 @@ def mul_mat_skinny_k(t, w, b, m):
         K.check(K.lib.mi355_mul_mat_skinny_k(t, w.data_ptr(), B.row_size(t, k), q[c0:].data_ptr(), d[c0:].data_ptr(), bs[c0:].data_ptr(),
                                              dst[c0:].data_ptr(), m, m, k, min(32, n - c0), _stream()), "mi355_mul_mat_skinny_k")
     return dst
+
+
+def mul_mat_qk(t, w, b, m):
+    """K-quant prefill MUL_MAT on q8_K activations (digit-split int8-MFMA tile kernel): b = [n, k] f32 -> [n, m]."""
+    _u8(w)
+    n, k = b.shape
+    q, d, bs = quantize_act_q8k(b)
+    dst = torch.empty((n, m), dtype=torch.float32, device=b.device)
+    K.check(K.lib.mi355_mul_mat_qk(t, w.data_ptr(), B.row_size(t, k), q.data_ptr(), d.data_ptr(), bs.data_ptr(), dst.data_ptr(), m, m, k, n,
+                                   _stream()), "mi355_mul_mat_qk")
+    return dst

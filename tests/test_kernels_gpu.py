@@ -254,6 +254,24 @@ def test_skinny_k_digit_split_vs_q8k_contract(ops, t, m, k, n):
         assert O.nmse(O.mul_mat(t, w, x, m, k, n, "cpu"), got) <= 1e-10
 
 
+@pytest.mark.parametrize("t", [B.Q4_K, B.Q5_K])
+@pytest.mark.parametrize("m,k,n", [(64, 256, 128), (1, 256, 1), (130, 512, 200), (4096, 4096, 9), (257, 2048, 131), (96, 1024, 512), (1024, 14336, 65)])
+def test_mmqk_digit_split_tile_kernel_vs_q8k_contract(ops, t, m, k, n):
+    """prefill form of the digit-split kernel: same integers as ggml_vec_dot_q*_K_q8_K -> against
+    dequantize(W) . dequantize(q8_K(x)) in f64 only f32 rounding remains (NMSE <= 1e-10)."""
+    rng = np.random.default_rng(m + k + n)
+    w = B.random_blocks(t, m, k, seed=m + n)
+    x = rng.standard_normal((n, k)).astype(np.float32)
+    got = ops.mul_mat_qk(t, dev(w), dev(x), m).cpu().numpy()
+    wf = np.stack([O.dequantize_row(t, w[i], k) for i in range(m)]).astype(np.float64)
+    q, d, _ = _q8k_planes(x)
+    xa = q.astype(np.float64).reshape(n, k // 256, 256) * d.astype(np.float64)[:, :, None]
+    ref = (xa.reshape(n, k) @ wf.T).astype(np.float32)
+    assert np.isfinite(got).all() and O.nmse(ref, got) <= 1e-10, O.nmse(ref, got)
+    if m * n <= 40000:
+        assert O.nmse(O.mul_mat(t, w, x, m, k, n, "cpu"), got) <= 1e-10
+
+
 def test_mmq_matches_matvec_path_at_model_shape(ops):
     # pp512-shaped launch vs the decode kernel on the same data (first 8 columns)
     t, m, k, n = B.Q4_K, 1024, 4096, 512

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Prefill GEMM micro-benchmark: TFLOP/s of mi355_mul_mat_dq (bf16 MFMA) and mi355_mul_mat_q (int8 MFMA) on the
+"""Prefill GEMM micro-benchmark: TFLOP/s of mi355_mul_mat_dq (bf16 MFMA) and mi355_mul_mat_q (int8 MFMA) / mi355_mul_mat_qk (digit-split int8 MFMA, "qk") on the
 Llama-3-8B shapes at N = 512 (flops = 2*M*N*K, tests/test-backend-ops.cpp:2262-2265).  usage: bench_gemm.py [N]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -9,9 +9,11 @@ import llm_amd.blocks as B, llm_amd.kernels as K, llm_amd.ops as ops
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 which = sys.argv[2] if len(sys.argv) > 2 else "dq"
+only = tuple(int(v) for v in sys.argv[3].split(",")) if len(sys.argv) > 3 else None      # "type,m,k": one shape only
 s = torch.cuda.current_stream().cuda_stream
 for t, m, k in ((B.Q4_K, 4096, 4096), (B.Q4_K, 14336, 4096), (B.Q4_K, 4096, 14336), (B.Q6_K, 4096, 14336), (B.Q6_K, 128256, 4096),
                 (B.Q8_0, 14336, 4096), (B.Q4_0, 14336, 4096), (B.Q5_K, 1024, 8192)):
+    if only and (t, m, k) != only: continue
     w = torch.from_numpy(B.random_blocks(t, min(m, 16384), k, seed=1)).cuda()
     mm = min(m, 16384)
     x = torch.randn((n, k), device="cuda")
@@ -19,6 +21,10 @@ for t, m, k in ((B.Q4_K, 4096, 4096), (B.Q4_K, 14336, 4096), (B.Q4_K, 4096, 1433
     if which == "dq":
         y = ops.act_bf16(x)
         run = lambda: K.check(K.lib.mi355_mul_mat_dq(t, w.data_ptr(), B.row_size(t, k), y.data_ptr(), k, dst.data_ptr(), mm, mm, k, n, s), "dq")
+    elif which == "qk":
+        if t not in (B.Q4_K, B.Q5_K): continue
+        q8, d8, bs8 = ops.quantize_act_q8k(x)
+        run = lambda: K.check(K.lib.mi355_mul_mat_qk(t, w.data_ptr(), B.row_size(t, k), q8.data_ptr(), d8.data_ptr(), bs8.data_ptr(), dst.data_ptr(), mm, mm, k, n, s), "qk")
     else:
         aq, ads = ops.quantize_act(x)
         run = lambda: K.check(K.lib.mi355_mul_mat_q(t, w.data_ptr(), B.row_size(t, k), aq.data_ptr(), ads.data_ptr(), dst.data_ptr(), mm, mm, k, n, s), "q")
