@@ -191,6 +191,18 @@ MI355_API int mi355_mul_mat_skinny_k(int type, const void *W, int64_t w_row_stri
                                      const int16_t *act_bsums, float *dst, int64_t dst_col_stride, int64_t m, int64_t k,
                                      int64_t n, void *stream);
 
+/* MUL_MAT_ID for a few to a few hundred (token, slot) pairs -- the regime of SURVEY config 5 (8x7B, T = 8..64): the
+ * pairs are bucketed by expert on the device and every expert's matrix is streamed once per 32 of its columns through
+ * the skinny int8-MFMA kernels (Q4_K / Q5_K on q8_K activations, the other types on q8_1).  Same arguments as
+ * mi355_mul_mat_id_dq; k % 256 == 0.  Replaces ggml_cuda_mul_mat_id (ggml-cuda.cu:2065-2206) incl. its host-side sort
+ * (mmq.cu:141-223).  dst[(t*n_used + s)*m + r]. */
+MI355_API int64_t mi355_mul_mat_id_skinny_workspace_bytes(int type, int64_t k, int64_t n_tokens, int64_t b_ne1, int64_t n_used,
+                                                          int64_t n_expert);
+MI355_API int mi355_mul_mat_id_skinny(int type, const void *as, int64_t w_row_stride, int64_t w_expert_stride, const float *b,
+                                      int64_t b_nb1, int64_t b_nb2, const int32_t *ids, int64_t ids_stride, float *dst, int64_t m,
+                                      int64_t k, int64_t n_expert, int64_t n_used, int64_t n_tokens, int64_t b_ne1, void *workspace,
+                                      int64_t workspace_bytes, void *stream);
+
 /* Prefill MUL_MAT of a K-quant (Q4_K, Q5_K; others MI355_E_UNSUPPORTED) on q8_K activations, any n: the tile-kernel
  * form of mi355_mul_mat_skinny_k (64 rows x 128 columns per workgroup, digit planes prepared once per weight while the
  * tile is staged, one f32 fold per 256 weights).  Replaces mul_mat_q (mmq.cuh:2606-2841) for these types.
@@ -304,6 +316,19 @@ MI355_API int mi355_get_rows(const mi355_tensor *src, const mi355_tensor *ids, c
 
 /* dst = x * scale + bias (f32, contiguous).  ggml_cuda_op_scale (ggml-cuda/scale.cu). */
 MI355_API int mi355_scale_f32(const mi355_tensor *x, const mi355_tensor *dst, float scale, float bias, void *stream);
+
+/* dst (i32, same shape) = indices that sort each row of x (f32, rows of at most 1024 values), ascending or descending;
+ * ties by index.  ggml_cuda_op_argsort (ggml-cuda/argsort.cu); oracle ggml_compute_forward_argsort_f32 (ggml-cpu/ops.cpp).
+ * ggml_top_k is this op plus a view (ggml.c: ggml_top_k). */
+MI355_API int mi355_argsort_f32(const mi355_tensor *x, const mi355_tensor *dst, int descending, void *stream);
+
+/* dst[0, i1, i2, i3] = sum over i0 of x.  ggml_cuda_op_sum_rows (ggml-cuda/sumrows.cu). */
+MI355_API int mi355_sum_rows_f32(const mi355_tensor *x, const mi355_tensor *dst, void *stream);
+
+/* MUL_MAT with f32 weights, for small matrices such as the MoE router (ffn_gate_inp, 8 x 4096; llama-graph.cpp:660-676):
+ * dst[m, n, i2, i3] = sum_k a[k, m, i2 / r2, i3 / r3] * b[k, n, i2, i3], one wave per output element.  Replaces the cuBLAS
+ * branch of ggml_cuda_mul_mat (ggml-cuda.cu:1988-2063) for this case only. */
+MI355_API int mi355_mul_mat_f32(const mi355_tensor *a, const mi355_tensor *b, const mi355_tensor *dst, void *stream);
 
 /* row softmax with optional f16/f32 mask and ALiBi slope: dst = softmax(x*scale + slope*mask).
  * ggml_cuda_op_soft_max (ggml-cuda/softmax.cu); oracle ggml_compute_forward_soft_max_f32 (ggml-cpu/ops.cpp). */

@@ -758,9 +758,16 @@ static void mi355_mul_mat_launch(const ggml_tensor * dst, const char * W, int64_
     }
 }
 
+static mi355_tensor to_mi355_tensor(const ggml_tensor * t);
+
 static void mi355_mul_mat(mi355_backend_ctx * ctx, ggml_tensor * dst) {
     const ggml_tensor * src0 = dst->src[0];
     const ggml_tensor * src1 = dst->src[1];
+    if (src0->type == GGML_TYPE_F32) {
+        mi355_tensor ta = to_mi355_tensor(src0), tb = to_mi355_tensor(src1), td = to_mi355_tensor(dst);
+        MI_CHECK(mi355_mul_mat_f32(&ta, &tb, &td, ctx->stream));
+        return;
+    }
     const int64_t K = src0->ne[0], M = src0->ne[1];
     const int64_t N = src1->ne[1], ne12 = src1->ne[2], ne13 = src1->ne[3];
     const int64_t rows = N * ne12 * ne13;
@@ -839,12 +846,28 @@ static void mi355_mul_mat_id(mi355_backend_ctx * ctx, ggml_tensor * dst) {
     const int64_t b_ne1 = b->ne[1], n_tokens = b->ne[2];
     const int64_t n_used = ids->ne[0];
     if (n_tokens == 0 || M == 0) return;
+    // a few to a few hundred pairs (SURVEY config 5, T = 8..64): bucket by expert on the device, then every expert's matrix
+    // is streamed once per 32 of its columns through the skinny int8-MFMA kernels
+    static const int64_t sk_max = getenv("GGML_MI355_MOE_SKINNY_MAX") ? atoll(getenv("GGML_MI355_MOE_SKINNY_MAX")) : 256;
+    const bool dense_dst = dst->nb[1] == (size_t)M * sizeof(float) && dst->nb[2] == (size_t)M * n_used * sizeof(float) &&
+                           ((((uintptr_t)b->data) | b->nb[1] | b->nb[2]) & 15) == 0;
+    // (measured on 8x7B Q4_K_M: below ~20 pairs the per-pair mat-vec wins -- 16 pairs: 548 vs 521 t/s -- above 256 the GEMM)
+    if (n_tokens * n_used >= 20 && n_tokens * n_used <= sk_max && K % 256 == 0 && n_expert <= 256 && dense_dst &&
+        getenv("GGML_MI355_NO_SKINNY") == nullptr) {
+        const int64_t need = mi355_mul_mat_id_skinny_workspace_bytes((int)as->type, K, n_tokens, b_ne1, n_used, n_expert);
+        void * ws = ctx->get_scratch(0, (size_t)need);
+        ctx->act_cache.valid = false;
+        const int rc = mi355_mul_mat_id_skinny((int)as->type, as->data, (int64_t)as->nb[1], (int64_t)as->nb[2], (const float *)b->data,
+                                               (int64_t)b->nb[1], (int64_t)b->nb[2], (const int32_t *)ids->data,
+                                               (int64_t)(ids->nb[1] / sizeof(int32_t)), (float *)dst->data, M, K, n_expert, n_used,
+                                               n_tokens, b_ne1, ws, need, ctx->stream);
+        if (rc == MI355_OK) return;
+        if (rc != MI355_E_UNSUPPORTED) MI_CHECK(rc);
+    }
     // prefill-sized batches: bucket the (token, slot) pairs by expert on the device and run one bf16-MFMA GEMM over all
     // experts, so every touched expert matrix is read once.  Below ~64 pairs the per-pair mat-vec (each pair streams
     // its expert's rows, mostly from the Infinity Cache) is faster than dequantizing whole tiles for a few columns.
-    if (n_tokens * n_used >= 64 && K % 64 == 0 && n_expert <= 256 && dst->nb[1] == (size_t)M * sizeof(float) &&
-        dst->nb[2] == (size_t)M * n_used * sizeof(float) && ((((uintptr_t)b->data) | b->nb[1] | b->nb[2]) & 15) == 0 &&
-        getenv("GGML_MI355_MMQ_INT8") == nullptr) {
+    if (n_tokens * n_used >= 64 && K % 64 == 0 && n_expert <= 256 && dense_dst && getenv("GGML_MI355_MMQ_INT8") == nullptr) {
         const int64_t need = mi355_mul_mat_id_dq_workspace_bytes(K, n_tokens, b_ne1, n_used, n_expert);
         void * ws = ctx->get_scratch(0, (size_t)need);
         ctx->act_cache.valid = false;     // the workspace replaces whatever activations were cached in scratch[0]
@@ -1433,6 +1456,11 @@ static bool mi355_dev_supports_op(ggml_backend_dev_t dev, const ggml_tensor * op
                 int64_t lo, hi;
                 mi355_row_split(((mi355_split_buft_ctx *)a->buffer->buft->context)->split, ggml_nrows(a), device, &lo, &hi);
                 if (lo == hi) return false;
+            }
+            if (a->type == GGML_TYPE_F32) {
+                // small f32 matrices (the MoE router, llama-graph.cpp:660-676): one wave per output element
+                return !tensor_is_split(a) && b->type == GGML_TYPE_F32 && op->type == GGML_TYPE_F32 && a->nb[0] == sizeof(float) &&
+                       b->nb[0] == sizeof(float) && b->ne[2] % a->ne[2] == 0 && b->ne[3] % a->ne[3] == 0 && a->ne[1] <= 1024;
             }
             if (!is_weight_type(a->type) || b->type != GGML_TYPE_F32 || op->type != GGML_TYPE_F32) return false;
             if (a->nb[0] != ggml_type_size(a->type) || b->nb[0] != sizeof(float)) return false; // rows contiguous

@@ -76,6 +76,10 @@ bool mi355_ops_supported(const ggml_tensor * op) {
         case GGML_OP_SOFT_MAX:
             return is_f32(a) && is_f32(op) && a->nb[0] == sizeof(float) && ggml_is_contiguous(op) &&
                    (!b || ((b->type == GGML_TYPE_F16 || b->type == GGML_TYPE_F32) && b->nb[0] == ggml_type_size(b->type)));
+        case GGML_OP_ARGSORT:
+            return is_f32(a) && op->type == GGML_TYPE_I32 && a->ne[0] <= 1024 && a->nb[0] == sizeof(float) && op->nb[0] == sizeof(int32_t);
+        case GGML_OP_SUM_ROWS:
+            return is_f32(a) && is_f32(op);
         default:
             return false;
     }
@@ -148,6 +152,16 @@ bool mi355_ops_forward(ggml_tensor * node, hipStream_t stream) {
             mi355_tensor ta = T(a), tb;
             if (b) tb = T(b);
             MI_CHECK(mi355_soft_max_f32(&ta, b ? &tb : nullptr, &td, scale, max_bias, stream));
+            return true;
+        }
+        case GGML_OP_ARGSORT: {
+            mi355_tensor ta = T(a);
+            MI_CHECK(mi355_argsort_f32(&ta, &td, ((const int32_t *)node->op_params)[0] == (int32_t)GGML_SORT_ORDER_DESC, stream));
+            return true;
+        }
+        case GGML_OP_SUM_ROWS: {
+            mi355_tensor ta = T(a);
+            MI_CHECK(mi355_sum_rows_f32(&ta, &td, stream));
             return true;
         }
         default:

@@ -561,3 +561,113 @@ int mi355_soft_max_f32(const mi355_tensor * x, const mi355_tensor * mask, const 
 }
 
 } // extern "C"
+
+
+// ------------------------------------------------------------------------------------------------
+// The small ops of a Mixture-of-Experts router (llama-graph.cpp:650-795): logits = MUL_MAT(f32 gate_inp, x),
+// SOFT_MAX, top-k = ARGSORT(desc) + view, GET_ROWS of the probabilities, SUM_ROWS + DIV to renormalise.
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+// bitonic argsort of one row per workgroup in LDS (rows of at most 1024 values, padded to a power of two; padding
+// sorts to the end).  Ties are ordered by index, so the result is deterministic.
+__global__ void __launch_bounds__(1024)
+argsort_kernel(const T4 x, const T4 dst, int npad, int desc) {
+    __shared__ int idx[1024];
+    const int col = threadIdx.x;
+    const int64_t row = blockIdx.x;
+    const int64_t i1 = row % x.ne[1], i2 = (row / x.ne[1]) % x.ne[2], i3 = row / (x.ne[1] * x.ne[2]);
+    const float * xr = (const float *)(x.data + i1 * x.nb[1] + i2 * x.nb[2] + i3 * x.nb[3]);
+    const int n = (int)x.ne[0];
+    idx[col] = col;
+    __syncthreads();
+    // "a sorts after b" in the requested order; indices >= n are padding and sort after everything
+    auto after = [&](int a, int b) {
+        if (a >= n) return b < n || a > b;
+        if (b >= n) return false;
+        const float va = xr[a], vb = xr[b];
+        if (va == vb) return a > b;
+        return desc ? va < vb : va > vb;
+    };
+    for (int k = 2; k <= npad; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            const int ixj = col ^ j;
+            if (ixj > col) {
+                const int a = idx[col], b = idx[ixj];
+                const bool up = (col & k) == 0;      // ascending run: the smaller goes first
+                if (up ? after(a, b) : after(b, a)) { idx[col] = b; idx[ixj] = a; }
+            }
+            __syncthreads();
+        }
+    }
+    if (col < n) ((int32_t *)(dst.data + i1 * dst.nb[1] + i2 * dst.nb[2] + i3 * dst.nb[3]))[col] = idx[col];
+}
+
+// one wave per row
+__global__ void __launch_bounds__(256)
+sum_rows_kernel(const T4 x, const T4 dst, int64_t rows) {
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const int64_t i1 = row % x.ne[1], i2 = (row / x.ne[1]) % x.ne[2], i3 = row / (x.ne[1] * x.ne[2]);
+    const char * xr = x.data + i1 * x.nb[1] + i2 * x.nb[2] + i3 * x.nb[3];
+    float s = 0.0f;
+    for (int64_t i = lane; i < x.ne[0]; i += 64) s += *(const float *)(xr + i * x.nb[0]);
+    s = wave_sum(s);
+    if (lane == 0) *(float *)(dst.data + i1 * dst.nb[1] + i2 * dst.nb[2] + i3 * dst.nb[3]) = s;
+}
+
+// f32 x f32 MUL_MAT for small weight matrices (the MoE router: 8 x 4096): one wave per output element
+__global__ void __launch_bounds__(256)
+mul_mat_f32_kernel(const T4 a, const T4 b, const T4 d, int64_t total) {
+    const int64_t o = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (o >= total) return;
+    const int lane = threadIdx.x & 63;
+    const int64_t m = o % d.ne[0], n = (o / d.ne[0]) % d.ne[1], i2 = (o / (d.ne[0] * d.ne[1])) % d.ne[2], i3 = o / (d.ne[0] * d.ne[1] * d.ne[2]);
+    const float * ar = (const float *)(a.data + m * a.nb[1] + (i2 / (b.ne[2] / a.ne[2])) * a.nb[2] + (i3 / (b.ne[3] / a.ne[3])) * a.nb[3]);
+    const float * br = (const float *)(b.data + n * b.nb[1] + i2 * b.nb[2] + i3 * b.nb[3]);
+    float s = 0.0f;
+    for (int64_t k = lane; k < a.ne[0]; k += 64) s += ar[k] * br[k];
+    s = wave_sum(s);
+    if (lane == 0) *(float *)(d.data + m * d.nb[0] + n * d.nb[1] + i2 * d.nb[2] + i3 * d.nb[3]) = s;
+}
+
+} // namespace
+
+extern "C" int mi355_argsort_f32(const mi355_tensor * x, const mi355_tensor * dst, int descending, void * stream) {
+    if (!x || !dst || !x->data || !dst->data) return MI355_E_NULL;
+    if (x->type != MI355_TYPE_F32 || x->nb[0] != 4 || dst->nb[0] != 4 || !same_shape(x, dst)) return MI355_E_SHAPE;
+    if (x->ne[0] > 1024) return MI355_E_UNSUPPORTED;
+    const int64_t rows = nrows(x);
+    if (rows == 0 || x->ne[0] == 0) return MI355_OK;
+    if (rows > 0x7fffffff) return MI355_E_SHAPE;
+    int npad = 1;
+    while (npad < x->ne[0]) npad <<= 1;
+    MI355_LAUNCH("argsort", argsort_kernel, dim3((unsigned)rows), dim3(npad < 64 ? 64 : npad), 0, (hipStream_t)stream, t4(x), t4(dst), npad, descending);
+    MI355_CHECK_LAUNCH();
+    return MI355_OK;
+}
+
+extern "C" int mi355_sum_rows_f32(const mi355_tensor * x, const mi355_tensor * dst, void * stream) {
+    if (!x || !dst || !x->data || !dst->data) return MI355_E_NULL;
+    if (x->type != MI355_TYPE_F32 || dst->ne[0] != 1 || dst->ne[1] != x->ne[1] || dst->ne[2] != x->ne[2] || dst->ne[3] != x->ne[3]) return MI355_E_SHAPE;
+    const int64_t rows = nrows(x);
+    if (rows == 0) return MI355_OK;
+    if ((rows + 3) / 4 > 0x7fffffff) return MI355_E_SHAPE;
+    MI355_LAUNCH("sum_rows", sum_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, t4(x), t4(dst), rows);
+    MI355_CHECK_LAUNCH();
+    return MI355_OK;
+}
+
+extern "C" int mi355_mul_mat_f32(const mi355_tensor * a, const mi355_tensor * b, const mi355_tensor * dst, void * stream) {
+    if (!a || !b || !dst || !a->data || !b->data || !dst->data) return MI355_E_NULL;
+    if (a->type != MI355_TYPE_F32 || b->type != MI355_TYPE_F32) return MI355_E_TYPE;
+    if (a->nb[0] != 4 || b->nb[0] != 4 || a->ne[0] != b->ne[0] || dst->ne[0] != a->ne[1] || dst->ne[1] != b->ne[1] || dst->ne[2] != b->ne[2] ||
+        dst->ne[3] != b->ne[3] || a->ne[2] < 1 || a->ne[3] < 1 || b->ne[2] % a->ne[2] != 0 || b->ne[3] % a->ne[3] != 0) return MI355_E_SHAPE;
+    const int64_t total = nelem(dst);
+    if (total == 0) return MI355_OK;
+    if ((total + 3) / 4 > 0x7fffffff) return MI355_E_SHAPE;
+    MI355_LAUNCH("mul_mat_f32", mul_mat_f32_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, (hipStream_t)stream, t4(a), t4(b), t4(dst), total);
+    MI355_CHECK_LAUNCH();
+    return MI355_OK;
+}

@@ -20,6 +20,7 @@
 // global loads of stage s+2 before it issues the MFMAs of stage s.  (Fetching two stages ahead in a second
 // register set was measured slower: 276-332 VGPRs drop the occupancy to one wave per SIMD.)
 #include "common.h"
+#include "moe_bucket.h"
 
 namespace {
 
@@ -329,36 +330,7 @@ static int launch(const DArgs & a, hipStream_t s, const char * tag) {
     return MI355_OK;
 }
 
-// ---- MUL_MAT_ID for prefill-sized batches: route on the device, then one GEMM launch over all experts.
-// One workgroup counts the (token, slot) pairs per expert in LDS, prefix-sums them into `off` (entries of `sorted`)
-// and `tile_off` (128-column tiles), and scatters the pair ids.  The reference does this sort on the host after a
-// stream synchronisation (ggml-cuda/mmq.cu:141-223).  Pairs with an out-of-range expert id are dropped.
-__global__ void __launch_bounds__(1024)
-moe_bucket_kernel(const int32_t * ids, int64_t ids_stride, int n_tokens, int n_used, int n_expert, int * sorted, int * off, int * tile_off) {
-    __shared__ int cnt[257], cur[257];
-    const int tid = threadIdx.x, np = n_tokens * n_used;
-    for (int e = tid; e <= n_expert; e += 1024) cnt[e] = 0;
-    __syncthreads();
-    for (int p = tid; p < np; p += 1024) {
-        const int e = ids[(int64_t)(p / n_used) * ids_stride + p % n_used];
-        if (e >= 0 && e < n_expert) atomicAdd(&cnt[e], 1);
-    }
-    __syncthreads();
-    if (tid == 0) {
-        int o = 0, t = 0;
-        for (int e = 0; e < n_expert; e++) {
-            off[e] = o; tile_off[e] = t; cur[e] = o;
-            o += cnt[e]; t += (cnt[e] + BN - 1) / BN;
-        }
-        off[n_expert] = o; tile_off[n_expert] = t;
-    }
-    __syncthreads();
-    for (int p = tid; p < np; p += 1024) {
-        const int e = ids[(int64_t)(p / n_used) * ids_stride + p % n_used];
-        if (e >= 0 && e < n_expert) sorted[atomicAdd(&cur[e], 1)] = p;
-    }
-}
-
+// ---- MUL_MAT_ID for prefill-sized batches: route on the device (moe_bucket.h), then one GEMM launch over all experts.
 template <int TYPE>
 static int launch_ids(const DArgs & a, int max_tiles, hipStream_t s, const char * tag) {
     if (a.m >= 1024) MI355_LAUNCH(tag, (mmdq_kernel<TYPE, 128, true>), dim3((unsigned)max_tiles, (unsigned)((a.m + 127) / 128)), dim3(256), 0, s, a);
@@ -442,7 +414,7 @@ extern "C" int mi355_mul_mat_id_dq(int type, const void * as, int64_t w_row_stri
     int * off = sorted + n_tokens * n_used, * tile_off = off + n_expert + 1;
     int rc = mi355_act_bf16(b, act, k, b_ne1, n_tokens, 1, b_nb1, b_nb2, 0, stream);
     if (rc != MI355_OK) return rc;
-    MI355_LAUNCH("moe_bucket", moe_bucket_kernel, dim3(1), dim3(1024), 0, s, ids, ids_stride, (int)n_tokens, (int)n_used, (int)n_expert,
+    MI355_LAUNCH("moe_bucket", moe_bucket_kernel, dim3(1), dim3(1024), 0, s, ids, ids_stride, (int)n_tokens, (int)n_used, (int)n_expert, BN,
                  sorted, off, tile_off);
     MI355_CHECK_LAUNCH();
     DArgs a;

@@ -23,6 +23,7 @@
 //   * C[r] of lane (col, half) is row (r&3) + 8 (r>>2) + 4 half: the activation scale is a per-lane scalar, the
 //     weight scales of the 16 rows come from a small per-wave LDS table written by the lanes that own the rows.
 #include "common.h"
+#include "moe_bucket.h"
 
 namespace {
 
@@ -35,6 +36,7 @@ struct SArgs {
     const int8_t * aq; const float * ads;     // [n][k], [n][k/32][2]
     float * dst; int64_t dst_col_stride;
     int m, n, k;
+    IdsArgs ids;      // MUL_MAT_ID mode when ids.sorted != nullptr: blockIdx.y = pass of 32 gathered columns of one expert
 };
 
 // per-wave LDS scale table: [8 blocks of the super-step][2 sub-groups (q6_K)][32 rows]
@@ -167,6 +169,34 @@ template <> struct SK<MI355_TYPE_Q4_0> {
     }
 };
 
+// The 32 columns of a workgroup.  Plain MUL_MAT: columns 0 .. n-1 of the pass (columns >= n repeat column n-1 and are
+// never stored), K possibly split over gridDim.y workgroups.  MUL_MAT_ID: blockIdx.y is a pass of up to 32 (token,
+// slot) pairs routed to one expert (moe_bucket.h): activation row = token * act_ne1 + slot % act_ne1, dst column = the
+// pair id, weights = that expert's matrix.  Returns false (uniformly) for a pass beyond the last one.
+struct ColMap { int ncol, ky_idx, ky_cnt; int64_t w_off; };
+static __device__ __forceinline__ bool col_map(const IdsArgs & I, int n, int tid, int * s_row, int * s_pair, ColMap & cm) {
+    if (I.sorted) {
+        const int ti = blockIdx.y;
+        if (ti >= I.tile_off[I.n_expert]) return false;
+        int e = 0;
+        while (I.tile_off[e + 1] <= ti) e++;
+        const int base = I.off[e] + (ti - I.tile_off[e]) * 32, left = I.off[e + 1] - base;
+        cm.ncol = left < 32 ? left : 32;
+        if (tid < 32) {
+            const int pair = I.sorted[base + (tid < cm.ncol ? tid : cm.ncol - 1)];
+            s_pair[tid] = pair;
+            s_row[tid]  = (pair / I.n_used) * I.act_ne1 + (pair % I.n_used) % I.act_ne1;
+        }
+        cm.w_off = (int64_t)e * I.w_expert_stride; cm.ky_idx = 0; cm.ky_cnt = 1;
+    } else {
+        cm.ncol = n;
+        if (tid < 32) { const int c = tid < n ? tid : n - 1; s_row[tid] = c; s_pair[tid] = c; }
+        cm.w_off = 0; cm.ky_idx = (int)blockIdx.y; cm.ky_cnt = (int)gridDim.y;
+    }
+    __syncthreads();
+    return true;
+}
+
 template <int TYPE>
 __global__ void __launch_bounds__(SK_THREADS)
 mmsk_kernel(const SArgs a) {
@@ -176,15 +206,18 @@ mmsk_kernel(const SArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 31, lh = lane >> 5;
     const int m0 = blockIdx.x * 32;
+    __shared__ int s_row[32], s_pair[32];
+    ColMap cm;
+    if (!col_map(a.ids, a.n, tid, s_row, s_pair, cm)) return;
     const int row = m0 + lr < a.m ? m0 + lr : a.m - 1;
-    const uint8_t * wrow = a.W + (int64_t)row * a.w_row_stride;
-    const int col = lr < a.n ? lr : a.n - 1;
+    const uint8_t * wrow = a.W + cm.w_off + (int64_t)row * a.w_row_stride;
+    const int col = s_row[lr];
     const int8_t * aq = a.aq + (int64_t)col * a.k + lh * 16;
     const float * ads = a.ads + (int64_t)col * (a.k / QK) * 2;
 
-    // super-steps of this workgroup (K split over gridDim.y workgroups) and of this wave
-    const int nsb = a.k / 256, per = (nsb + (int)gridDim.y - 1) / (int)gridDim.y;
-    const int sb0 = (int)blockIdx.y * per, sb1 = sb0 + per < nsb ? sb0 + per : nsb;
+    // super-steps of this workgroup (K split over ky_cnt workgroups) and of this wave
+    const int nsb = a.k / 256, per = (nsb + cm.ky_cnt - 1) / cm.ky_cnt;
+    const int sb0 = cm.ky_idx * per, sb1 = sb0 + per < nsb ? sb0 + per : nsb;
 
     float acc[16];
 #pragma unroll
@@ -242,9 +275,9 @@ mmsk_kernel(const SArgs a) {
 #pragma unroll
         for (int w = 0; w < SK_WAVES; w++) s += red[w][r][l];
         const int orow = m0 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), ocol = l & 31;
-        if (orow < a.m && ocol < a.n) {
-            float * o = a.dst + (int64_t)ocol * a.dst_col_stride + orow;
-            if (gridDim.y > 1) atomicAdd(o, s); else *o = s;
+        if (orow < a.m && ocol < cm.ncol) {
+            float * o = a.dst + (int64_t)s_pair[ocol] * a.dst_col_stride + orow;
+            if (cm.ky_cnt > 1) atomicAdd(o, s); else *o = s;
         }
     }
 }
@@ -284,6 +317,7 @@ struct S2Args {
     const int8_t * aq; const float * ad; const int16_t * bs;     // [n][k], [n][k/256], [n][k/16]
     float * dst; int64_t dst_col_stride;
     int m, n, k;
+    IdsArgs ids;
 #ifdef SK_STAMPS
     long long * stamps;      // diagnostic build only (lab/mmsk_stamps.hip): [workgroup][wave][8] s_memtime / s_memrealtime
 #endif
@@ -327,6 +361,9 @@ mmsk2_kernel(const S2Args a) {
     const int lr = lane & 31, lh = lane >> 5;
     const int m0 = blockIdx.x * 32;
     uint8_t * Lw = lds + wave * REGION, * La = Lw + WBYTES;
+    __shared__ int s_row[32], s_pair[32];
+    ColMap cm;
+    if (!col_map(a.ids, a.n, tid, s_row, s_pair, cm)) return;
 #ifdef SK_STAMPS
     long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (lane == 0) st_[7] = __builtin_amdgcn_s_memrealtime();
@@ -336,7 +373,7 @@ mmsk2_kernel(const S2Args a) {
     // Staging roles.  Addresses are a wave-uniform base (advanced per super-block in SGPRs) plus a 32-bit lane offset
     // that never changes, so the loop spends no vector instructions on addressing.  Lanes without a chunk (lane 63
     // of 7 x 9, rows past 31) load chunk 0 and write it to the dump slot instead of being masked off.
-    const uint8_t * wbase = a.W + (int64_t)m0 * a.w_row_stride;
+    const uint8_t * wbase = a.W + cm.w_off + (int64_t)m0 * a.w_row_stride;
     const int wr_ = lane / CH, wc_ = lane % CH;
     uint32_t woff[NI], wlds[NI];
 #pragma unroll
@@ -350,16 +387,15 @@ mmsk2_kernel(const S2Args a) {
     uint32_t aoff[8];
 #pragma unroll
     for (int i = 0; i < 8; i++) {
-        const int c = i * 4 + (lane >> 4);
-        aoff[i] = (uint32_t)(c < a.n ? c : a.n - 1) * (uint32_t)a.k + (lane & 15) * 16;      // columns >= n repeat column n-1
+        aoff[i] = (uint32_t)s_row[i * 4 + (lane >> 4)] * (uint32_t)a.k + (lane & 15) * 16;
     }
-    const int col = lr < a.n ? lr : a.n - 1;
+    const int col = s_row[lr];
     const uint32_t doff = (uint32_t)col * (uint32_t)(a.k / 256) * 4;
     const uint32_t soff = (uint32_t)col * (uint32_t)(a.k / 8) + lh * 16;      // bsums of blocks 4 lh .. 4 lh + 3 (two int16 each)
 
     // super-blocks of this workgroup (K split over gridDim.y workgroups) and, contiguously, of this wave
-    const int nsb = a.k / 256, per = (nsb + (int)gridDim.y - 1) / (int)gridDim.y;
-    const int sb0 = (int)blockIdx.y * per, sb1 = sb0 + per < nsb ? sb0 + per : nsb;
+    const int nsb = a.k / 256, per = (nsb + cm.ky_cnt - 1) / cm.ky_cnt;
+    const int sb0 = cm.ky_idx * per, sb1 = sb0 + per < nsb ? sb0 + per : nsb;
     const int perw = (sb1 - sb0 + WAVES - 1) / WAVES;
     const int my0 = sb0 + wave * perw, my1 = my0 + perw < sb1 ? my0 + perw : sb1;
 
@@ -487,9 +523,9 @@ mmsk2_kernel(const S2Args a) {
 #pragma unroll
         for (int w = 0; w < WAVES; w++) s += red[(w * 16 + r) * 64 + l];
         const int orow = m0 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), ocol = l & 31;
-        if (orow < a.m && ocol < a.n) {
-            float * o = a.dst + (int64_t)ocol * a.dst_col_stride + orow;
-            if (gridDim.y > 1) atomicAdd(o, s); else *o = s;
+        if (orow < a.m && ocol < cm.ncol) {
+            float * o = a.dst + (int64_t)s_pair[ocol] * a.dst_col_stride + orow;
+            if (cm.ky_cnt > 1) atomicAdd(o, s); else *o = s;
         }
     }
 #ifdef SK_STAMPS
@@ -577,7 +613,7 @@ extern "C" int mi355_mul_mat_skinny(int type, const void * W, int64_t w_row_stri
     if (((uintptr_t)W | (uintptr_t)w_row_stride) & (a16 ? 15 : 1)) return MI355_E_ALIGN;
     if (w_row_stride < mi355_row_size(type, k)) return MI355_E_SHAPE;
     if (m == 0 || n == 0) return MI355_OK;
-    SArgs a;
+    SArgs a = {};
     a.W = (const uint8_t *)W; a.w_row_stride = w_row_stride; a.aq = act_q; a.ads = act_ds;
     a.dst = dst; a.dst_col_stride = dst_col_stride; a.m = (int)m; a.n = (int)n; a.k = (int)k;
     hipStream_t s = (hipStream_t)stream;
@@ -619,10 +655,83 @@ extern "C" int mi355_mul_mat_skinny_k(int type, const void * W, int64_t w_row_st
     if (((uintptr_t)W | (uintptr_t)w_row_stride) & 15) return MI355_E_ALIGN;
     if (w_row_stride < mi355_row_size(type, k)) return MI355_E_SHAPE;
     if (m == 0 || n == 0) return MI355_OK;
-    S2Args a;
+    S2Args a = {};
     a.W = (const uint8_t *)W; a.w_row_stride = w_row_stride; a.aq = act_q; a.ad = act_d; a.bs = act_bsums;
     a.dst = dst; a.dst_col_stride = dst_col_stride; a.m = (int)m; a.n = (int)n; a.k = (int)k;
     hipStream_t s = (hipStream_t)stream;
     if (type == MI355_TYPE_Q4_K) return launch2<MI355_TYPE_Q4_K>(a, s, "mmsk2_q4_K");
     return launch2<MI355_TYPE_Q5_K>(a, s, "mmsk2_q5_K");
+}
+
+
+// ---- MUL_MAT_ID for 2 .. a few hundred (token, slot) pairs: every expert's matrix is streamed ONCE per 32 of its
+// columns (the mat-vec path reads it once per pair; the grouped GEMM fills a 128-column tile with a handful of columns)
+static int64_t ids_ws_layout(int type, int64_t k, int64_t rows, int64_t * b0, int64_t * b1, int64_t * b2) {
+    auto up = [](int64_t x) { return (x + 255) / 256 * 256; };
+    if (type == MI355_TYPE_Q4_K || type == MI355_TYPE_Q5_K) { *b0 = up(rows * k); *b1 = up(rows * (k / 256) * 4); *b2 = up(rows * (k / 16) * 2); }
+    else                                                    { *b0 = up(rows * k); *b1 = up(rows * (k / 32) * 8);  *b2 = 0; }
+    return *b0 + *b1 + *b2;
+}
+
+extern "C" int64_t mi355_mul_mat_id_skinny_workspace_bytes(int type, int64_t k, int64_t n_tokens, int64_t b_ne1, int64_t n_used, int64_t n_expert) {
+    if (k <= 0 || n_tokens < 0 || b_ne1 < 1 || n_used < 1 || n_expert < 1) return -1;
+    int64_t b0, b1, b2;
+    return ids_ws_layout(type, k, n_tokens * b_ne1, &b0, &b1, &b2) + (n_tokens * n_used + 2 * (n_expert + 1)) * 4 + 256;
+}
+
+extern "C" int mi355_mul_mat_id_skinny(int type, const void * as, int64_t w_row_stride, int64_t w_expert_stride, const float * b,
+                                       int64_t b_nb1, int64_t b_nb2, const int32_t * ids, int64_t ids_stride, float * dst, int64_t m,
+                                       int64_t k, int64_t n_expert, int64_t n_used, int64_t n_tokens, int64_t b_ne1, void * workspace,
+                                       int64_t workspace_bytes, void * stream) {
+    if (!as || !b || !ids || !dst || !workspace) return MI355_E_NULL;
+    const int64_t bs = mi355_blck_size(type);
+    if (bs == 0 || type == MI355_TYPE_F32 || type == MI355_TYPE_F16 || type == MI355_TYPE_Q8_1) return MI355_E_TYPE;
+    if (m < 0 || k <= 0 || k % bs != 0 || n_expert < 1 || n_expert > 256 || n_used < 1 || n_tokens < 0 || (b_ne1 != 1 && b_ne1 != n_used) ||
+        m > 0x7fffffff || k > 0x3ffffff || n_tokens * n_used > 0x3fffffff || w_row_stride > 0x3ffffff) return MI355_E_SHAPE;
+    if (k % 256 != 0) return MI355_E_UNSUPPORTED;
+    if (workspace_bytes < mi355_mul_mat_id_skinny_workspace_bytes(type, k, n_tokens, b_ne1, n_used, n_expert)) return MI355_E_WORKSPACE;
+    if (((uintptr_t)workspace & 15) || ((uintptr_t)dst & 3) || ((uintptr_t)ids & 3)) return MI355_E_ALIGN;
+    const bool kq = type == MI355_TYPE_Q4_K || type == MI355_TYPE_Q5_K;
+    if (((uintptr_t)as | (uintptr_t)w_row_stride | (uintptr_t)w_expert_stride) & (kq ? 15 : 1)) return MI355_E_ALIGN;
+    if (w_row_stride < mi355_row_size(type, k)) return MI355_E_SHAPE;
+    if (m == 0 || n_tokens == 0) return MI355_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t rows = n_tokens * b_ne1;
+    int64_t b0, b1, b2;
+    const int64_t act_bytes = ids_ws_layout(type, k, rows, &b0, &b1, &b2);
+    char * ws = (char *)workspace;
+    int * sorted = (int *)(ws + act_bytes);
+    int * off = sorted + n_tokens * n_used, * tile_off = off + n_expert + 1;
+    // activations of all tokens, then the routing tables
+    int rc = kq ? mi355_quantize_act_q8k(b, (int8_t *)ws, (float *)(ws + b0), (int16_t *)(ws + b0 + b1), k, b_ne1, n_tokens, 1, b_nb1, b_nb2, 0, stream)
+                : mi355_quantize_act(b, (int8_t *)ws, (float *)(ws + b0), k, b_ne1, n_tokens, 1, b_nb1, b_nb2, 0, stream);
+    if (rc != MI355_OK) return rc;
+    MI355_LAUNCH("moe_bucket", moe_bucket_kernel, dim3(1), dim3(1024), 0, s, ids, ids_stride, (int)n_tokens, (int)n_used, (int)n_expert, 32,
+                 sorted, off, tile_off);
+    MI355_CHECK_LAUNCH();
+    IdsArgs I;
+    I.sorted = sorted; I.off = off; I.tile_off = tile_off; I.n_expert = (int)n_expert; I.n_used = (int)n_used; I.act_ne1 = (int)b_ne1;
+    I.w_expert_stride = w_expert_stride;
+    const unsigned nb = (unsigned)((m + 31) / 32);
+    const unsigned max_tiles = (unsigned)((n_tokens * n_used + 31) / 32 + n_expert);   // sum over experts of ceil(cnt_e / 32) never exceeds this
+    if (max_tiles > 65535) return MI355_E_UNSUPPORTED;
+    if (kq) {
+        S2Args a = {};
+        a.W = (const uint8_t *)as; a.w_row_stride = w_row_stride; a.aq = (const int8_t *)ws; a.ad = (const float *)(ws + b0);
+        a.bs = (const int16_t *)(ws + b0 + b1); a.dst = dst; a.dst_col_stride = m; a.m = (int)m; a.n = 32; a.k = (int)k; a.ids = I;
+        if (type == MI355_TYPE_Q4_K) MI355_LAUNCH("mmsk2_id_q4_K", (mmsk2_kernel<MI355_TYPE_Q4_K, 8>), dim3(nb, max_tiles), dim3(512), 0, s, a);
+        else                         MI355_LAUNCH("mmsk2_id_q5_K", (mmsk2_kernel<MI355_TYPE_Q5_K, 8>), dim3(nb, max_tiles), dim3(512), 0, s, a);
+    } else {
+        SArgs a = {};
+        a.W = (const uint8_t *)as; a.w_row_stride = w_row_stride; a.aq = (const int8_t *)ws; a.ads = (const float *)(ws + b0);
+        a.dst = dst; a.dst_col_stride = m; a.m = (int)m; a.n = 32; a.k = (int)k; a.ids = I;
+        switch (type) {
+            case MI355_TYPE_Q6_K: MI355_LAUNCH("mmsk_id_q6_K", (mmsk_kernel<MI355_TYPE_Q6_K>), dim3(nb, max_tiles), dim3(SK_THREADS), 0, s, a); break;
+            case MI355_TYPE_Q8_0: MI355_LAUNCH("mmsk_id_q8_0", (mmsk_kernel<MI355_TYPE_Q8_0>), dim3(nb, max_tiles), dim3(SK_THREADS), 0, s, a); break;
+            case MI355_TYPE_Q4_0: MI355_LAUNCH("mmsk_id_q4_0", (mmsk_kernel<MI355_TYPE_Q4_0>), dim3(nb, max_tiles), dim3(SK_THREADS), 0, s, a); break;
+            default: return MI355_E_TYPE;
+        }
+    }
+    MI355_CHECK_LAUNCH();
+    return MI355_OK;
 }

@@ -26,7 +26,7 @@ int main(int argc, char ** argv) {
     const unsigned nb = (m + 31) / 32, ky = nb < 256 && k >= 2048 ? 2 : 1;
     const size_t nst = (size_t)nb * ky * WAVES * 8;
     hipMalloc(&stamps, nst * 8);
-    S2Args a; a.W = W; a.w_row_stride = rs; a.aq = aq; a.ad = ad; a.bs = bs; a.dst = dst; a.dst_col_stride = m; a.m = m; a.n = n; a.k = k; a.stamps = stamps;
+    S2Args a = {}; a.W = W; a.w_row_stride = rs; a.aq = aq; a.ad = ad; a.bs = bs; a.dst = dst; a.dst_col_stride = m; a.m = m; a.n = n; a.k = k; a.stamps = stamps;
     for (int it = 0; it < 5; it++) {
         hipMemset(dst, 0, (size_t)32 * m * 4);
         hipLaunchKernelGGL((mmsk2_kernel<MI355_TYPE_Q4_K, 8>), dim3(nb, ky), dim3(512), 0, 0, a);

@@ -227,6 +227,23 @@ def mul_mat_id_dq(t, as_, b, ids, m, n_expert):
     return dst
 
 
+def mul_mat_id_skinny(t, as_, b, ids, m, n_expert):
+    """ggml_mul_mat_id for small batches (device-side bucketing + skinny int8-MFMA kernels, every expert streamed once
+    per 32 of its columns); same arguments and result layout as mul_mat_id_dq."""
+    _u8(as_)
+    assert b.dim() == 3 and b.is_contiguous() and ids.dtype == torch.int32 and ids.dim() == 2 and ids.is_contiguous()
+    n_tok, b_ne1, k = b.shape
+    n_used = ids.shape[1]
+    rs = B.row_size(t, k)
+    need = K.lib.mi355_mul_mat_id_skinny_workspace_bytes(t, k, n_tok, b_ne1, n_used, n_expert)
+    ws = torch.empty(need, dtype=torch.uint8, device=b.device)
+    dst = torch.full((n_tok, n_used, m), float("nan"), dtype=torch.float32, device=b.device)
+    K.check(K.lib.mi355_mul_mat_id_skinny(t, as_.data_ptr(), rs, rs * m, b.data_ptr(), k * 4, b_ne1 * k * 4, ids.data_ptr(), n_used,
+                                          dst.data_ptr(), m, k, n_expert, n_used, n_tok, b_ne1, ws.data_ptr(), need, _stream()),
+            "mi355_mul_mat_id_skinny")
+    return dst
+
+
 def mul_mat_skinny(t, w, b, m):
     """MUL_MAT for small batches through the int8-MFMA skinny kernel, in passes of 32 columns: b = [n, k] f32 -> [n, m]."""
     _u8(w)

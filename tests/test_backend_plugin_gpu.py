@@ -15,7 +15,7 @@ TBO = os.path.join(ROOT, "oracle", "_ref", "test-backend-ops")
 PLUGIN = os.path.join(ROOT, "llm_amd", "lib", "libggml-mi355.so")
 
 OPS = ["MUL_MAT", "MUL_MAT_ID", "FLASH_ATTN_EXT", "ADD", "MUL", "RMS_NORM", "ROPE", "REGLU", "GEGLU", "SWIGLU", "CPY", "CONT", "GET_ROWS",
-       "SCALE", "SOFT_MAX"]
+       "SCALE", "SOFT_MAX", "ARGSORT", "SUM_ROWS"]
 # lower bounds on the number of cases that must actually RUN on the device (not "not supported")
 MIN_RUN = {"MUL_MAT": 100, "MUL_MAT_ID": 100, "FLASH_ATTN_EXT": 1000, "ROPE": 50, "SOFT_MAX": 100}
 
@@ -46,6 +46,27 @@ def test_llama_graph_end_to_end_has_no_cpu_compute_split():
     assert r.returncode == 0, r.stderr[-3000:]
     assert "graph splits = 2" in r.stderr + r.stdout
     assert '"devices": "CPU, MI355_0"' in r.stdout
+
+
+def test_mixtral_style_graph_runs_entirely_on_the_device(tmp_path):
+    """tiny random 8-expert llama GGUF (router MUL_MAT f32 -> SOFT_MAX -> ARGSORT/top-k -> GET_ROWS -> SUM_ROWS/DIV ->
+    MUL_MAT_ID x3 -> weighted sum): no CPU compute split, and logits close to ggml-cpu's.  The routing is discrete: a
+    near-tie between the 2nd and 3rd expert may resolve differently on the two backends, hence the loose bound."""
+    import numpy as np
+    tool = os.path.join(ROOT, "tools", "run_llama_bench.sh")
+    r = subprocess.run([tool, "tinymoe", "Q4_K_M", "-p", "64", "-n", "8", "-r", "1"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "graph splits = 2" in r.stderr + r.stdout, (r.stderr + r.stdout)[-3000:]
+    outs = {}
+    for name, ngl in (("cpu", "0"), ("gpu", "99")):
+        path = str(tmp_path / f"moe_logits_{name}.bin")
+        r = subprocess.run([tool, "tinymoe", "Q4_K_M", "-ngl", ngl, "--dump-logits", path], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        outs[name] = np.fromfile(path, dtype=np.float32).reshape(7, -1)
+    a, b = outs["cpu"], outs["gpu"]
+    assert np.isfinite(b).all()
+    nmse = float(((a - b) ** 2).sum() / (a ** 2).sum())
+    assert nmse < 5e-2, nmse
 
 
 @pytest.mark.parametrize("ftype,ctk", [("Q4_K_M", "f16"), ("Q8_0", "q8_0"), ("Q4_0", "f16")])

@@ -516,6 +516,31 @@ def test_mul_mat_id_grouped_gemm(ops, t, m, k, n_exp, n_used, n_tok, b1):
     assert O.nmse(vec, got) <= 5e-4
 
 
+@pytest.mark.parametrize("t", B.WEIGHT_TYPES)
+@pytest.mark.parametrize("m,k,n_exp,n_used,n_tok,b1", [(96, 256, 4, 2, 1, 1), (130, 512, 8, 2, 8, 1), (257, 1024, 8, 2, 64, 2), (64, 2048, 8, 3, 100, 1),
+                                                       (512, 4096, 8, 2, 16, 1)])
+def test_mul_mat_id_skinny(ops, t, m, k, n_exp, n_used, n_tok, b1):
+    """MUL_MAT_ID at config-5 batch sizes (T = 8..64): bucketing on the device, every expert streamed once per 32 of its
+    columns through the skinny int8-MFMA kernels.  vs exact dequant(as[ids]) . b in f64 within the op's budget (the
+    activations are q8_K / q8_1 quantized: ~1e-5), and vs the per-pair mat-vec path; skewed routing (one expert takes
+    half the pairs, more than one pass of 32) and an unused expert included; rows not written stay NaN-free."""
+    rng = np.random.default_rng(m + k + n_tok)
+    w = B.random_blocks(t, n_exp * m, k, seed=5)
+    b = rng.standard_normal((n_tok, b1, k)).astype(np.float32)
+    ids = np.stack([rng.permutation(n_exp - 1)[:n_used] for _ in range(n_tok)]).astype(np.int32)   # expert n_exp-1 is never used
+    ids[: n_tok // 2, 0] = 0; ids[: n_tok // 2, 1] = 1 + (np.arange(n_tok // 2) % max(1, n_exp - 2))  # skew towards expert 0
+    got = ops.mul_mat_id_skinny(t, dev(w), dev(b), dev(ids), m, n_exp).cpu().numpy()
+    wf = O.dequantize_row(t, w, n_exp * m * k).reshape(n_exp, m, k).astype(np.float64)
+    ref = np.empty((n_tok, n_used, m))
+    for tt in range(n_tok):
+        for s_ in range(n_used):
+            ref[tt, s_] = wf[ids[tt, s_]] @ b[tt, s_ % b1].astype(np.float64)
+    err = float(((got - ref) ** 2).sum() / (ref ** 2).sum())
+    assert np.isfinite(got).all() and err < 5e-4, err
+    vec = ops.mul_mat_id(t, dev(w), dev(b), dev(ids), m, n_exp).cpu().numpy()
+    assert O.nmse(vec, got) <= 5e-4
+
+
 def test_errors_are_reported_not_launched(ops):
     import llm_amd.kernels as K
     w = torch.zeros(144 * 4 + 16, dtype=torch.uint8, device="cuda")

@@ -4,7 +4,9 @@
 // src/llama-model.cpp:447-596; type map per src/llama-quant.cpp:178-404; tokenizer "no_vocab"
 // (src/llama-vocab.cpp:1383-1403).  Weights are random *valid* blocks (random quants, finite fp16
 // scales), norms are 1.0.
-//   make-random-gguf <out.gguf> <8b|70b|tiny> [Q4_K_M|Q8_0|Q4_0]
+//   make-random-gguf <out.gguf> <8b|70b|8x7b|tiny|tinymoe> [Q4_K_M|Q8_0|Q4_0]
+// 8x7b / tinymoe are Mixtral-style (llama architecture with 8 experts, 2 used): ffn_gate_inp f32, ffn_*_exps 3-D;
+// Q4_K_M for 8 experts bumps attn_k / attn_v to Q8_0 and attn_output to Q5_K (llama-quant.cpp:300-311,370-378).
 #include "ggml.h"
 #include "gguf.h"
 
@@ -14,7 +16,7 @@
 #include <string>
 #include <vector>
 
-struct Dims { int n_embd, n_layer, n_head, n_head_kv, n_ff, n_vocab; bool is_70b; };
+struct Dims { int n_embd, n_layer, n_head, n_head_kv, n_ff, n_vocab; bool is_70b; int n_expert = 0, n_expert_used = 0; };
 
 static uint64_t rng_state = 0x9E3779B97F4A7C15ull;
 static inline uint64_t rnd() { rng_state ^= rng_state << 13; rng_state ^= rng_state >> 7; rng_state ^= rng_state << 17; return rng_state; }
@@ -47,12 +49,14 @@ static void fill_blocks(ggml_tensor * t) {
 }
 
 int main(int argc, char ** argv) {
-    if (argc < 3) { fprintf(stderr, "usage: %s out.gguf 8b|70b|tiny [Q4_K_M|Q8_0|Q4_0]\n", argv[0]); return 2; }
+    if (argc < 3) { fprintf(stderr, "usage: %s out.gguf 8b|70b|8x7b|tiny|tinymoe [Q4_K_M|Q8_0|Q4_0]\n", argv[0]); return 2; }
     const std::string out = argv[1], model = argv[2], ftype = argc > 3 ? argv[3] : "Q4_K_M";
     Dims d;
     if (model == "8b")        d = {4096, 32, 32, 8, 14336, 128256, false};
     else if (model == "70b")  d = {8192, 80, 64, 8, 28672, 128256, true};
     else if (model == "tiny") d = {1024, 4, 8, 2, 2816, 32000, false};
+    else if (model == "8x7b")    { d = {4096, 32, 32, 8, 14336, 32000, false}; d.n_expert = 8; d.n_expert_used = 2; }
+    else if (model == "tinymoe") { d = {1024, 4, 8, 2, 2816, 32000, false};    d.n_expert = 8; d.n_expert_used = 2; }
     else { fprintf(stderr, "unknown model %s\n", model.c_str()); return 2; }
     const ggml_type base = ftype == "Q8_0" ? GGML_TYPE_Q8_0 : ftype == "Q4_0" ? GGML_TYPE_Q4_0 : GGML_TYPE_Q4_K;
     const bool km = ftype == "Q4_K_M";
@@ -65,6 +69,7 @@ int main(int argc, char ** argv) {
     for (int i = 0; i < d.n_layer; i++)
         total += rs(GGML_TYPE_Q8_0, d.n_embd, d.n_embd) * 2 + rs(GGML_TYPE_Q8_0, d.n_embd, kv_dim) * 2 + rs(GGML_TYPE_Q8_0, d.n_embd, d.n_ff) * 2 +
                  rs(GGML_TYPE_Q8_0, d.n_ff, d.n_embd) + 3 * (d.n_embd * 4 + 256);
+    if (d.n_expert) total = total * d.n_expert + (size_t)d.n_layer * (d.n_embd * d.n_expert * 4 + 1024);   // generous upper bound
     ggml_init_params ip = {total + (64u << 20), nullptr, false};
     ggml_context * ctx = ggml_init(ip);
     if (!ctx) { fprintf(stderr, "ggml_init failed (%zu bytes)\n", total); return 1; }
@@ -84,9 +89,19 @@ int main(int argc, char ** argv) {
     gguf_set_val_u32(g, "llama.vocab_size", d.n_vocab);
     gguf_set_val_u32(g, "general.file_type", km ? 15 : (base == GGML_TYPE_Q8_0 ? 7 : 2));
     gguf_set_val_str(g, "tokenizer.ggml.model", "no_vocab");
+    if (d.n_expert) {
+        gguf_set_val_u32(g, "llama.expert_count", d.n_expert);
+        gguf_set_val_u32(g, "llama.expert_used_count", d.n_expert_used);
+    }
 
     auto add_w = [&](const std::string & name, ggml_type t, int64_t k, int64_t m) {
         ggml_tensor * x = ggml_new_tensor_2d(ctx, t, k, m);
+        ggml_set_name(x, name.c_str());
+        fill_blocks(x);
+        gguf_add_tensor(g, x);
+    };
+    auto add_w3 = [&](const std::string & name, ggml_type t, int64_t k, int64_t m, int64_t e) {
+        ggml_tensor * x = ggml_new_tensor_3d(ctx, t, k, m, e);
         ggml_set_name(x, name.c_str());
         fill_blocks(x);
         gguf_add_tensor(g, x);
@@ -107,14 +122,26 @@ int main(int argc, char ** argv) {
         }
         const std::string p = "blk." + std::to_string(il) + ".";
         add_norm(p + "attn_norm.weight");
+        const bool e8 = km && d.n_expert == 8;
         add_w(p + "attn_q.weight", base, d.n_embd, d.n_embd);
-        add_w(p + "attn_k.weight", base, d.n_embd, kv_dim);
-        add_w(p + "attn_v.weight", t_v, d.n_embd, kv_dim);
-        add_w(p + "attn_output.weight", base, d.n_embd, d.n_embd);
+        add_w(p + "attn_k.weight", e8 ? GGML_TYPE_Q8_0 : base, d.n_embd, kv_dim);
+        add_w(p + "attn_v.weight", e8 ? GGML_TYPE_Q8_0 : t_v, d.n_embd, kv_dim);
+        add_w(p + "attn_output.weight", e8 ? GGML_TYPE_Q5_K : base, d.n_embd, d.n_embd);
         add_norm(p + "ffn_norm.weight");
-        add_w(p + "ffn_gate.weight", base, d.n_embd, d.n_ff);
-        add_w(p + "ffn_up.weight", base, d.n_embd, d.n_ff);
-        add_w(p + "ffn_down.weight", t_down, d.n_ff, d.n_embd);
+        if (d.n_expert) {
+            ggml_tensor * r = ggml_new_tensor_2d(ctx, GGML_TYPE_F32, d.n_embd, d.n_expert);      // router, never quantized
+            ggml_set_name(r, (p + "ffn_gate_inp.weight").c_str());
+            for (int64_t i = 0; i < (int64_t)d.n_embd * d.n_expert; i++)
+                ((float *)r->data)[i] = ((float)(rnd() >> 40) * (1.0f / 16777216.0f) - 0.5f) * 0.1f;
+            gguf_add_tensor(g, r);
+            add_w3(p + "ffn_gate_exps.weight", base, d.n_embd, d.n_ff, d.n_expert);
+            add_w3(p + "ffn_up_exps.weight", base, d.n_embd, d.n_ff, d.n_expert);
+            add_w3(p + "ffn_down_exps.weight", t_down, d.n_ff, d.n_embd, d.n_expert);
+        } else {
+            add_w(p + "ffn_gate.weight", base, d.n_embd, d.n_ff);
+            add_w(p + "ffn_up.weight", base, d.n_embd, d.n_ff);
+            add_w(p + "ffn_down.weight", t_down, d.n_ff, d.n_embd);
+        }
     }
     add_norm("output_norm.weight");
     add_w("output.weight", km ? GGML_TYPE_Q6_K : base, d.n_embd, d.n_vocab);
