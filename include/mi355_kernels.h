@@ -165,6 +165,8 @@ typedef struct mi355_qkv_rope_args {
     const int32_t *pos; const float *freq_factors;         /* device; freq_factors may be NULL */
     int32_t head_dim, n_dims, mode, n_ctx_orig;
     float freq_base, freq_scale, ext_factor, attn_factor, beta_fast, beta_slow;
+    int32_t type_k;                                        /* type of wk when it differs from wq's (8-expert Q4_K_M: wq Q4_K, wk/wv
+                                                            * Q8_0); 0 = same as type_qk */
 } mi355_qkv_rope_args;
 MI355_API int mi355_qkv_rope_matvec(const mi355_qkv_rope_args *args, void *stream);
 

@@ -1227,7 +1227,7 @@ static bool mi355_try_fuse_qkv_rope(mi355_backend_ctx * ctx, ggml_cgraph * cgrap
     if (last < 0) return false;
     // shapes and types
     const ggml_tensor * wq = mq->src[0], * wk = mk->src[0], * wv = mv->src[0];
-    if (wq->type != wk->type || wq->ne[0] != wk->ne[0] || wq->ne[0] != wv->ne[0]) return false;
+    if (wq->ne[0] != wk->ne[0] || wq->ne[0] != wv->ne[0]) return false;
     const int64_t K = wq->ne[0], Mq = wq->ne[1], Mk = wk->ne[1], Mv = wv->ne[1], hd = rq->ne[0];
     if (Mq % 8 || Mk % 8 || Mv % 8 || hd != rk->ne[0] || hd <= 0 || Mq % hd || Mk % hd) return false;
     for (ggml_tensor * r : {rq, rk}) {
@@ -1265,6 +1265,7 @@ static bool mi355_try_fuse_qkv_rope(mi355_backend_ctx * ctx, ggml_cgraph * cgrap
     mi355_qkv_rope_args a;
     memset(&a, 0, sizeof(a));
     a.type_qk = (int32_t)wq->type; a.type_v = (int32_t)wv->type;
+    a.type_k = wk->type != wq->type ? (int32_t)wk->type : 0;
     a.wq = wq->data; a.wk = wk->data; a.wv = wv->data;
     a.wq_row_stride = (int64_t)wq->nb[1]; a.wk_row_stride = (int64_t)wk->nb[1]; a.wv_row_stride = (int64_t)wv->nb[1];
     a.m_q = Mq; a.m_k = Mk; a.m_v = Mv; a.k = K;

@@ -471,7 +471,7 @@ struct KQkv {
     const int32_t * pos; const float * ff; RopeP rp;
 };
 
-template <int TA, int TB>
+template <int TQ, int TK, int TV>
 __global__ void __launch_bounds__(256)
 mmvq_qkv_rope_kernel(const KQkv a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -496,8 +496,9 @@ mmvq_qkv_rope_kernel(const KQkv a) {
     const uint8_t * w = a.W[mat];
     const int64_t rs = a.w_row_stride[mat];
     float s0, s1;
-    if (mat < 2) mmvq_row2<TA, true>(w + r0 * rs, w + r1 * rs, a.act_q, a.act_ds, a.k, lds, s0, s1);
-    else         mmvq_row2<TB, true>(w + r0 * rs, w + r1 * rs, a.act_q, a.act_ds, a.k, lds, s0, s1);
+    if (mat == 0)      mmvq_row2<TQ, true>(w + r0 * rs, w + r1 * rs, a.act_q, a.act_ds, a.k, lds, s0, s1);
+    else if (mat == 1) mmvq_row2<TK, true>(w + r0 * rs, w + r1 * rs, a.act_q, a.act_ds, a.k, lds, s0, s1);
+    else               mmvq_row2<TV, true>(w + r0 * rs, w + r1 * rs, a.act_q, a.act_ds, a.k, lds, s0, s1);
     if (lane == 0) {
         float y0 = s0, y1 = s1;
         if (rot) { y0 = s0 * c - s1 * sn; y1 = s0 * sn + s1 * c; }
@@ -649,31 +650,34 @@ extern "C" int mi355_mul_mat_vec_q_group(const mi355_mmvq_args * p, int n_mats, 
     return MI355_E_TYPE;
 }
 
-template <int TA, int TB>
+template <int TQ, int TK, int TV>
 static int launch_qkv(const KQkv & a, hipStream_t stream) {
     const size_t need = (size_t)a.k + (size_t)a.k / QK * 8;
     if (need > LDS_ACT_LIMIT) return MI355_E_UNSUPPORTED;
-    MI355_LAUNCH("mmvq_qkv_rope", (mmvq_qkv_rope_kernel<TA, TB>), dim3((unsigned)a.blk_end[2]), dim3(256), need, stream, a);
+    MI355_LAUNCH("mmvq_qkv_rope", (mmvq_qkv_rope_kernel<TQ, TK, TV>), dim3((unsigned)a.blk_end[2]), dim3(256), need, stream, a);
     MI355_CHECK_LAUNCH();
     return MI355_OK;
 }
 
 extern "C" int mi355_qkv_rope_matvec(const mi355_qkv_rope_args * p, void * stream) {
     if (!p || !p->wq || !p->wk || !p->wv || !p->act_q || !p->act_ds || !p->q_out || !p->k_out || !p->v_out || !p->pos) return MI355_E_NULL;
-    const int64_t bsa = mi355_blck_size(p->type_qk), bsb = mi355_blck_size(p->type_v);
+    const int type_k = p->type_k ? p->type_k : p->type_qk;      // 0: wk has wq's type
+    const int64_t bsa = mi355_blck_size(p->type_qk), bsb = mi355_blck_size(p->type_v), bsk = mi355_blck_size(type_k);
     auto weight = [](int t) { return t == MI355_TYPE_Q4_0 || t == MI355_TYPE_Q8_0 || t == MI355_TYPE_Q4_K || t == MI355_TYPE_Q5_K || t == MI355_TYPE_Q6_K; };
-    if (!weight(p->type_qk) || !weight(p->type_v)) return MI355_E_TYPE;
+    if (!weight(p->type_qk) || !weight(p->type_v) || !weight(type_k)) return MI355_E_TYPE;
     if ((p->k_out_type != MI355_TYPE_F16 && p->k_out_type != MI355_TYPE_F32) || (p->v_out_type != MI355_TYPE_F16 && p->v_out_type != MI355_TYPE_F32)) return MI355_E_TYPE;
-    if (p->k <= 0 || p->k % bsa != 0 || p->k % bsb != 0 || p->k > 0x7fffffff) return MI355_E_SHAPE;
+    if (p->k <= 0 || p->k % bsa != 0 || p->k % bsb != 0 || p->k % bsk != 0 || p->k > 0x7fffffff) return MI355_E_SHAPE;
     if (p->m_q <= 0 || p->m_k <= 0 || p->m_v <= 0 || p->m_q % 8 || p->m_k % 8 || p->m_v % 8 || p->m_q + p->m_k + p->m_v > 0x3fffffff) return MI355_E_SHAPE;
     if (p->head_dim < 2 || (p->head_dim & 1) || p->m_q % p->head_dim || p->m_k % p->head_dim || p->n_dims < 2 || (p->n_dims & 1) || p->n_dims > p->head_dim) return MI355_E_SHAPE;
     if (p->mode != 0 && p->mode != 2) return MI355_E_UNSUPPORTED;
     if (((uintptr_t)p->act_q & 15) || ((uintptr_t)p->act_ds & 7) || ((uintptr_t)p->q_out & 3) || ((uintptr_t)p->k_out & 3) || ((uintptr_t)p->v_out & 3)) return MI355_E_ALIGN;
     if (p->k % QK_K == 0 && ((uintptr_t)p->act_ds & 15)) return MI355_E_ALIGN;
     const bool a16 = p->type_qk == MI355_TYPE_Q4_K || p->type_qk == MI355_TYPE_Q5_K, b16 = p->type_v == MI355_TYPE_Q4_K || p->type_v == MI355_TYPE_Q5_K;
-    if (((uintptr_t)p->wq | (uintptr_t)p->wk | (uintptr_t)p->wq_row_stride | (uintptr_t)p->wk_row_stride) & (a16 ? 15 : 1)) return MI355_E_ALIGN;
+    const bool k16 = type_k == MI355_TYPE_Q4_K || type_k == MI355_TYPE_Q5_K;
+    if (((uintptr_t)p->wq | (uintptr_t)p->wq_row_stride) & (a16 ? 15 : 1)) return MI355_E_ALIGN;
+    if (((uintptr_t)p->wk | (uintptr_t)p->wk_row_stride) & (k16 ? 15 : 1)) return MI355_E_ALIGN;
     if (((uintptr_t)p->wv | (uintptr_t)p->wv_row_stride) & (b16 ? 15 : 1)) return MI355_E_ALIGN;
-    if (p->wq_row_stride < mi355_row_size(p->type_qk, p->k) || p->wk_row_stride < mi355_row_size(p->type_qk, p->k) ||
+    if (p->wq_row_stride < mi355_row_size(p->type_qk, p->k) || p->wk_row_stride < mi355_row_size(type_k, p->k) ||
         p->wv_row_stride < mi355_row_size(p->type_v, p->k)) return MI355_E_SHAPE;
     KQkv a;
     a.W[0] = (const uint8_t *)p->wq; a.W[1] = (const uint8_t *)p->wk; a.W[2] = (const uint8_t *)p->wv;
@@ -686,13 +690,17 @@ extern "C" int mi355_qkv_rope_matvec(const mi355_qkv_rope_args * p, void * strea
     a.rp = rope_params(p->n_dims, p->mode, p->head_dim, p->n_ctx_orig, p->freq_base, p->freq_scale, p->ext_factor, p->attn_factor,
                        p->beta_fast, p->beta_slow);
     hipStream_t s = (hipStream_t)stream;
-    const int ta = p->type_qk, tb = p->type_v;
-    if (ta == MI355_TYPE_Q4_K && tb == MI355_TYPE_Q4_K) return launch_qkv<MI355_TYPE_Q4_K, MI355_TYPE_Q4_K>(a, s);
-    if (ta == MI355_TYPE_Q4_K && tb == MI355_TYPE_Q6_K) return launch_qkv<MI355_TYPE_Q4_K, MI355_TYPE_Q6_K>(a, s);
-    if (ta == MI355_TYPE_Q4_K && tb == MI355_TYPE_Q5_K) return launch_qkv<MI355_TYPE_Q4_K, MI355_TYPE_Q5_K>(a, s);
-    if (ta == MI355_TYPE_Q5_K && tb == MI355_TYPE_Q5_K) return launch_qkv<MI355_TYPE_Q5_K, MI355_TYPE_Q5_K>(a, s);
-    if (ta == MI355_TYPE_Q6_K && tb == MI355_TYPE_Q6_K) return launch_qkv<MI355_TYPE_Q6_K, MI355_TYPE_Q6_K>(a, s);
-    if (ta == MI355_TYPE_Q8_0 && tb == MI355_TYPE_Q8_0) return launch_qkv<MI355_TYPE_Q8_0, MI355_TYPE_Q8_0>(a, s);
-    if (ta == MI355_TYPE_Q4_0 && tb == MI355_TYPE_Q4_0) return launch_qkv<MI355_TYPE_Q4_0, MI355_TYPE_Q4_0>(a, s);
+    const int tq = p->type_qk, tv = p->type_v;
+    if (type_k != tq) {      // 8-expert Q4_K_M: wq Q4_K, wk and wv bumped to Q8_0 (llama-quant.cpp:300-311)
+        if (tq == MI355_TYPE_Q4_K && type_k == MI355_TYPE_Q8_0 && tv == MI355_TYPE_Q8_0) return launch_qkv<MI355_TYPE_Q4_K, MI355_TYPE_Q8_0, MI355_TYPE_Q8_0>(a, s);
+        return MI355_E_UNSUPPORTED;
+    }
+    if (tq == MI355_TYPE_Q4_K && tv == MI355_TYPE_Q4_K) return launch_qkv<MI355_TYPE_Q4_K, MI355_TYPE_Q4_K, MI355_TYPE_Q4_K>(a, s);
+    if (tq == MI355_TYPE_Q4_K && tv == MI355_TYPE_Q6_K) return launch_qkv<MI355_TYPE_Q4_K, MI355_TYPE_Q4_K, MI355_TYPE_Q6_K>(a, s);
+    if (tq == MI355_TYPE_Q4_K && tv == MI355_TYPE_Q5_K) return launch_qkv<MI355_TYPE_Q4_K, MI355_TYPE_Q4_K, MI355_TYPE_Q5_K>(a, s);
+    if (tq == MI355_TYPE_Q5_K && tv == MI355_TYPE_Q5_K) return launch_qkv<MI355_TYPE_Q5_K, MI355_TYPE_Q5_K, MI355_TYPE_Q5_K>(a, s);
+    if (tq == MI355_TYPE_Q6_K && tv == MI355_TYPE_Q6_K) return launch_qkv<MI355_TYPE_Q6_K, MI355_TYPE_Q6_K, MI355_TYPE_Q6_K>(a, s);
+    if (tq == MI355_TYPE_Q8_0 && tv == MI355_TYPE_Q8_0) return launch_qkv<MI355_TYPE_Q8_0, MI355_TYPE_Q8_0, MI355_TYPE_Q8_0>(a, s);
+    if (tq == MI355_TYPE_Q4_0 && tv == MI355_TYPE_Q4_0) return launch_qkv<MI355_TYPE_Q4_0, MI355_TYPE_Q4_0, MI355_TYPE_Q4_0>(a, s);
     return MI355_E_UNSUPPORTED;
 }

@@ -64,7 +64,7 @@ class QkvRopeArgs(C.Structure):
         ("k_out_type", _i32), ("v_out_type", _i32), ("pos", _vp), ("freq_factors", _vp),
         ("head_dim", _i32), ("n_dims", _i32), ("mode", _i32), ("n_ctx_orig", _i32),
         ("freq_base", C.c_float), ("freq_scale", C.c_float), ("ext_factor", C.c_float), ("attn_factor", C.c_float),
-        ("beta_fast", C.c_float), ("beta_slow", C.c_float),
+        ("beta_fast", C.c_float), ("beta_slow", C.c_float), ("type_k", C.c_int32),
     ]
 
 

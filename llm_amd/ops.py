@@ -191,14 +191,17 @@ def rope(x, pos, n_dims, mode, n_ctx_orig=8192, freq_base=10000.0, freq_scale=1.
 
 def qkv_rope_matvec(type_qk, type_v, wq, wk, wv, m_q, m_k, m_v, k, aq, ads, pos, head_dim, n_dims, mode, kv_dtype=torch.float16,
                     n_ctx_orig=8192, freq_base=10000.0, freq_scale=1.0, ext_factor=0.0, attn_factor=1.0, beta_fast=32.0,
-                    beta_slow=1.0, freq_factors=None):
-    """Fused decode attention input (mi355_qkv_rope_matvec): -> (q f32 [m_q], k [m_k], v [m_v] of kv_dtype)."""
+                    beta_slow=1.0, freq_factors=None, type_k=None):
+    """Fused decode attention input (mi355_qkv_rope_matvec): -> (q f32 [m_q], k [m_k], v [m_v] of kv_dtype).
+    type_k: type of wk when it differs from wq's (type_qk)."""
     q = torch.empty(m_q, dtype=torch.float32, device=wq.device)
     ko = torch.empty(m_k, dtype=kv_dtype, device=wq.device)
     vo = torch.empty(m_v, dtype=kv_dtype, device=wq.device)
     a = K.QkvRopeArgs()
     a.type_qk, a.type_v, a.wq, a.wk, a.wv = type_qk, type_v, wq.data_ptr(), wk.data_ptr(), wv.data_ptr()
-    a.wq_row_stride = a.wk_row_stride = B.row_size(type_qk, k)
+    a.wq_row_stride = B.row_size(type_qk, k)
+    a.wk_row_stride = B.row_size(type_k if type_k is not None else type_qk, k)
+    a.type_k = type_k if type_k is not None and type_k != type_qk else 0
     a.wv_row_stride = B.row_size(type_v, k)
     a.m_q, a.m_k, a.m_v, a.k = m_q, m_k, m_v, k
     a.act_q, a.act_ds, a.q_out, a.k_out, a.v_out = aq.data_ptr(), ads.data_ptr(), q.data_ptr(), ko.data_ptr(), vo.data_ptr()

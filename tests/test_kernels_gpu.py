@@ -326,22 +326,24 @@ def test_mmvq_group_argument_errors(ops):
     assert K.lib.mi355_mul_mat_vec_q_group(arr, 2, None) == -2          # different k inside one group
 
 
-@pytest.mark.parametrize("tqk,tv", [(B.Q4_K, B.Q4_K), (B.Q4_K, B.Q6_K), (B.Q4_K, B.Q5_K), (B.Q8_0, B.Q8_0), (B.Q4_0, B.Q4_0), (B.Q6_K, B.Q6_K)])
+@pytest.mark.parametrize("tqk,tv,tk", [(B.Q4_K, B.Q4_K, None), (B.Q4_K, B.Q6_K, None), (B.Q4_K, B.Q5_K, None), (B.Q8_0, B.Q8_0, None),
+                                       (B.Q4_0, B.Q4_0, None), (B.Q6_K, B.Q6_K, None), (B.Q4_K, B.Q8_0, B.Q8_0)])
 @pytest.mark.parametrize("mode,n_dims,kv", [(0, 128, "f16"), (2, 128, "f16"), (2, 64, "f32"), (0, 96, "f16")])
-def test_qkv_rope_fused_is_bit_identical_to_separate_kernels(ops, tqk, tv, mode, n_dims, kv):
+def test_qkv_rope_fused_is_bit_identical_to_separate_kernels(ops, tqk, tv, tk, mode, n_dims, kv):
     """mi355_qkv_rope_matvec == mul_mat_vec_q x3 + rope x2 + f32->f16 store, to the bit (Llama-3-8B head layout
     scaled down: 8 heads, 2 KV heads, head_dim 128; NORMAL and NEOX rope, partial rotary dims, YaRN off/on)."""
     k, hd, nh, nkv = 1024, 128, 8, 2
     rng = np.random.default_rng(mode * 7 + n_dims)
     x = dev(rng.standard_normal((1, k)).astype(np.float32))
     aq, ads = ops.quantize_act(x)
-    wq, wk, wv = (dev(B.random_blocks(t, m, k, seed=s)) for t, m, s in ((tqk, nh * hd, 1), (tqk, nkv * hd, 2), (tv, nkv * hd, 3)))
+    tk = tqk if tk is None else tk      # 8-expert Q4_K_M: wq Q4_K, wk / wv Q8_0
+    wq, wk, wv = (dev(B.random_blocks(t, m, k, seed=s)) for t, m, s in ((tqk, nh * hd, 1), (tk, nkv * hd, 2), (tv, nkv * hd, 3)))
     pos = torch.tensor([37], dtype=torch.int32, device="cuda")
     kw = dict(freq_base=500000.0, freq_scale=0.5 if n_dims == 96 else 1.0, ext_factor=1.0 if n_dims == 96 else 0.0, n_ctx_orig=4096)
     qf, kf, vf = ops.qkv_rope_matvec(tqk, tv, wq, wk, wv, nh * hd, nkv * hd, nkv * hd, k, aq, ads, pos, hd, n_dims, mode,
-                                     kv_dtype=torch.float16 if kv == "f16" else torch.float32, **kw)
+                                     kv_dtype=torch.float16 if kv == "f16" else torch.float32, type_k=tk, **kw)
     q0 = ops.mul_mat_vec_q(tqk, wq, nh * hd, k, aq, ads, 1)
-    k0 = ops.mul_mat_vec_q(tqk, wk, nkv * hd, k, aq, ads, 1)
+    k0 = ops.mul_mat_vec_q(tk, wk, nkv * hd, k, aq, ads, 1)
     v0 = ops.mul_mat_vec_q(tv, wv, nkv * hd, k, aq, ads, 1)
     qr = ops.rope(q0.view(1, nh, hd), pos, n_dims, mode, **kw).view(-1)
     kr = ops.rope(k0.view(1, nkv, hd), pos, n_dims, mode, **kw).view(-1)
