@@ -332,6 +332,16 @@ MI355_API int mi355_sum_rows_f32(const mi355_tensor *x, const mi355_tensor *dst,
  * branch of ggml_cuda_mul_mat (ggml-cuda.cu:1988-2063) for this case only. */
 MI355_API int mi355_mul_mat_f32(const mi355_tensor *a, const mi355_tensor *b, const mi355_tensor *dst, void *stream);
 
+/* The router of a MoE layer in one launch, for decode-sized batches (one workgroup per token): logits = gate_inp . x,
+ * probs = softmax(logits), order = argsort(probs, descending), w = probs[order[0..n_used)], wsum = sum(w), wn = w / wsum --
+ * the chain MUL_MAT SOFT_MAX ARGSORT(top-k) GET_ROWS SUM_ROWS DIV of build_moe_ffn (src/llama-graph.cpp:660-720) with every
+ * intermediate written (dense: logits/probs/order [n_tokens][n_expert], w/wn [n_tokens][n_used], wsum [n_tokens]) and each
+ * value computed in the order the separate kernels use, i.e. bit-identical to running them one by one.  Row strides in
+ * bytes; n_expert <= 256. */
+MI355_API int mi355_moe_router_f32(const float *x, int64_t x_row_stride, const float *gate_inp, int64_t gate_row_stride, int64_t k,
+                                   int64_t n_expert, int64_t n_used, int64_t n_tokens, float *logits, float *probs, int32_t *order,
+                                   float *w, float *wsum, float *wn, void *stream);
+
 /* row softmax with optional f16/f32 mask and ALiBi slope: dst = softmax(x*scale + slope*mask).
  * ggml_cuda_op_soft_max (ggml-cuda/softmax.cu); oracle ggml_compute_forward_soft_max_f32 (ggml-cpu/ops.cpp). */
 MI355_API int mi355_soft_max_f32(const mi355_tensor *x, const mi355_tensor *mask, const mi355_tensor *dst,

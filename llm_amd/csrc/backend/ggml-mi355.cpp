@@ -1192,6 +1192,86 @@ static void mi355_mul_mat_group(mi355_backend_ctx * ctx, ggml_cgraph * cgraph, c
 // ------------------------------------------------------------------------------------------------
 static const ggml_tensor * view_root(const ggml_tensor * t) { return t->view_src ? t->view_src : t; }
 
+// MoE router of a decode-sized batch in one launch: MUL_MAT(f32 gate_inp, x) SOFT_MAX ARGSORT(desc) [top-k view] GET_ROWS
+// SUM_ROWS DIV (build_moe_ffn, src/llama-graph.cpp:660-720) -> mi355_moe_router_f32.  Every tensor of the chain is written,
+// with bit-identical values, so no use analysis is needed; the outputs only have to be laid out so that one
+// workgroup's (= one token's) stores cannot land in another token's rows of a different tensor.
+static bool mi355_try_fuse_moe_router(mi355_backend_ctx * ctx, ggml_cgraph * cgraph, int i, std::vector<char> & done) {
+    const int n = ggml_graph_n_nodes(cgraph);
+    ggml_tensor * mm = ggml_graph_node(cgraph, i);
+    const ggml_tensor * g = mm->src[0], * x = mm->src[1];
+    if (g->type != GGML_TYPE_F32 || x->type != GGML_TYPE_F32 || tensor_is_split(g)) return false;
+    const int64_t K = g->ne[0], E = g->ne[1], T = x->ne[1];
+    if (g->ne[2] != 1 || g->ne[3] != 1 || x->ne[2] != 1 || x->ne[3] != 1 || E < 1 || E > 256 || T < 1 || T > 16) return false;
+    if (g->nb[0] != sizeof(float) || x->nb[0] != sizeof(float) || !ggml_is_contiguous(mm)) return false;
+    // The chain's nodes in graph order; llama.cpp's graph puts the three expert MUL_MAT_IDs between the top-k and the
+    // weight gathering, so other nodes may sit in between -- they are remembered and checked below.
+    static const ggml_op seq[5] = {GGML_OP_SOFT_MAX, GGML_OP_ARGSORT, GGML_OP_GET_ROWS, GGML_OP_SUM_ROWS, GGML_OP_DIV};
+    ggml_tensor * t5[5];
+    int idx[5], cnt = 0;
+    std::vector<const ggml_tensor *> between;
+    for (int j = i + 1; j < n && j < i + 40 && cnt < 5; j++) {
+        ggml_tensor * t = ggml_graph_node(cgraph, j);
+        if (done[j]) return false;
+        if (is_view_op(t) || ggml_is_empty(t)) continue;
+        const ggml_tensor * prev = cnt == 0 ? mm : t5[cnt - 1];
+        const bool link = t->op == seq[cnt] && (cnt == 2 ? view_root(t->src[0]) == t5[0]                  // GET_ROWS reads the probabilities
+                                               : cnt == 3 ? view_root(t->src[0]) == t5[2]                  // SUM_ROWS / DIV read the gathered weights
+                                               : cnt == 4 ? view_root(t->src[0]) == t5[2] : t->src[0] == prev);
+        if (link) { t5[cnt] = t; idx[cnt++] = j; }
+        else {
+            if (cnt < 2) return false;      // MUL_MAT, SOFT_MAX, ARGSORT are consecutive
+            between.push_back(t);
+        }
+    }
+    if (cnt < 5) return false;
+    ggml_tensor * sm = t5[0], * as = t5[1], * gr = t5[2], * sr = t5[3], * dv = t5[4];
+    float scale, max_bias;
+    memcpy(&scale, (const float *)sm->op_params + 0, 4); memcpy(&max_bias, (const float *)sm->op_params + 1, 4);
+    if (sm->src[0] != mm || sm->src[1] || scale != 1.0f || max_bias != 0.0f || !ggml_is_contiguous(sm) || sm->type != GGML_TYPE_F32) return false;
+    if (as->src[0] != sm || ((const int32_t *)as->op_params)[0] != (int32_t)GGML_SORT_ORDER_DESC || !ggml_is_contiguous(as)) return false;
+    const ggml_tensor * sel = gr->src[1];      // top-k: a view of the first n_used entries of every argsort row
+    const int64_t U = sel->ne[0];
+    if (view_root(gr->src[0]) != sm || view_root(sel) != as || sel->data != as->data || sel->ne[1] != T || sel->ne[2] != 1 || sel->ne[3] != 1 ||
+        sel->nb[0] != sizeof(int32_t) || sel->nb[1] != (size_t)E * sizeof(int32_t) || U < 1 || U > E) return false;
+    if (gr->src[0]->ne[0] != 1 || gr->src[0]->ne[1] != E || gr->src[0]->ne[2] != T || gr->src[0]->data != sm->data || !ggml_is_contiguous(gr->src[0])) return false;
+    if (gr->type != GGML_TYPE_F32 || !ggml_is_contiguous(gr) || ggml_nelements(gr) != U * T) return false;
+    if (view_root(sr->src[0]) != gr || sr->src[0]->data != gr->data || sr->src[0]->ne[0] != U || sr->src[0]->ne[1] != T || !ggml_is_contiguous(sr->src[0]) ||
+        !ggml_is_contiguous(sr) || ggml_nelements(sr) != T) return false;
+    if (view_root(dv->src[0]) != gr || dv->src[0]->data != gr->data || dv->src[1] != sr || dv->ne[0] != U || dv->ne[1] != T || !ggml_is_contiguous(dv) ||
+        !ggml_is_contiguous(dv->src[0])) return false;
+    // GET_ROWS, SUM_ROWS and DIV run early: no node in between may read or write the bytes they produce
+    for (const ggml_tensor * t : between) {
+        for (const ggml_tensor * o : {(const ggml_tensor *)gr, (const ggml_tensor *)sr, (const ggml_tensor *)dv}) {
+            if (ranges_overlap(t->data, ggml_nbytes(t), o->data, ggml_nbytes(o))) return false;
+            for (int k = 0; k < GGML_MAX_SRC; k++)
+                if (t->src[k] && ranges_overlap(t->src[k]->data, ggml_nbytes(t->src[k]), o->data, ggml_nbytes(o))) return false;
+        }
+        // ... and none may overwrite the probabilities or the order before the (now earlier) gathering would have read them
+        if (ranges_overlap(t->data, ggml_nbytes(t), sm->data, ggml_nbytes(sm)) || ranges_overlap(t->data, ggml_nbytes(t), as->data, ggml_nbytes(as))) return false;
+    }
+    // outputs: pairwise disjoint, or exactly the same rows (in-place reuse by ggml-alloc); inputs untouched
+    const ggml_tensor * outs[6] = {mm, sm, as, gr, sr, dv};
+    const size_t rowb[6] = {(size_t)E * 4, (size_t)E * 4, (size_t)E * 4, (size_t)U * 4, 4, (size_t)U * 4};
+    for (int p = 0; p < 6; p++) {
+        if (ranges_overlap(outs[p]->data, ggml_nbytes(outs[p]), x->data, ggml_nbytes(x)) ||
+            ranges_overlap(outs[p]->data, ggml_nbytes(outs[p]), g->data, ggml_nbytes(g))) return false;
+        for (int q = p + 1; q < 6; q++) {
+            if (!ranges_overlap(outs[p]->data, ggml_nbytes(outs[p]), outs[q]->data, ggml_nbytes(outs[q]))) continue;
+            if (T > 1 && (outs[p]->data != outs[q]->data || rowb[p] != rowb[q])) return false;
+            // one token = one workgroup: logits, probs and order are written in phases separated by barriers, so a later
+            // tensor may reuse an earlier one's memory freely; the last three are written together by one wave
+            if (T == 1 && p >= 3 && !(p == 3 && q == 5 && outs[p]->data == outs[q]->data)) return false;
+        }
+    }
+    MI_CHECK(mi355_moe_router_f32((const float *)x->data, (int64_t)x->nb[1], (const float *)g->data, (int64_t)g->nb[1], K, E, U, T,
+                                  (float *)mm->data, (float *)sm->data, (int32_t *)as->data, (float *)gr->data, (float *)sr->data,
+                                  (float *)dv->data, ctx->stream));
+    for (int m = 0; m < 5; m++) done[idx[m]] = 1;
+    for (const ggml_tensor * o : outs) ctx->act_invalidate_if_written(o);
+    return true;
+}
+
 static bool mi355_try_fuse_qkv_rope(mi355_backend_ctx * ctx, ggml_cgraph * cgraph, int i, std::vector<char> & done) {
     const int n = ggml_graph_n_nodes(cgraph);
     ggml_tensor * mq = ggml_graph_node(cgraph, i);
@@ -1323,6 +1403,7 @@ static enum ggml_status mi355_backend_graph_compute(ggml_backend_t backend, ggml
         }
         ctx->act_invalidate_if_written(node);
         // fusion: Q/K/V projections + rope + KV-cache store of one token in one launch
+        if (fuse && node->op == GGML_OP_MUL_MAT && node->src[0]->type == GGML_TYPE_F32 && mi355_try_fuse_moe_router(ctx, cgraph, i, done)) continue;
         if (fuse && node->op == GGML_OP_MUL_MAT && mi355_try_fuse_qkv_rope(ctx, cgraph, i, done)) continue;
         // fusion: decode mat-vecs that share their activation run as one grouped launch
         if (fuse && matvec_groupable(node)) {

@@ -645,6 +645,91 @@ mul_mat_f32_kernel(const T4 a, const T4 b, const T4 d) {
     if (tid == 0) *(float *)(d.data + m * d.nb[0] + n * d.nb[1] + i2 * d.nb[2] + i3 * d.nb[3]) = part[0] + part[1] + part[2] + part[3];
 }
 
+// The whole router of a MoE layer for decode-sized batches in ONE launch (one workgroup per token):
+//   logits = gate_inp . x, probs = softmax(logits), order = argsort(probs, desc), w = probs[order[0 .. n_used)],
+//   wsum = sum(w), wn = w / wsum
+// i.e. the node chain MUL_MAT SOFT_MAX ARGSORT GET_ROWS SUM_ROWS DIV of build_moe_ffn (llama-graph.cpp:660-720), six
+// launches of ~4 us otherwise.  Every intermediate tensor of the chain is written, and each value is computed with
+// the same operation order as the separate kernels above, so the results are bit-identical to the unfused graph.
+__global__ void __launch_bounds__(256)
+moe_router_kernel(const char * x, int64_t x_stride, const char * gate, int64_t gate_stride, int k, int n_expert, int n_used,
+                  float * logits, float * probs, int32_t * order, float * w, float * wsum, float * wn) {
+    __shared__ float sh[4], p_s[256];
+    __shared__ int ord_s[256];
+    const int tid = threadIdx.x, tok = blockIdx.x;
+    const float * br = (const float *)(x + (int64_t)tok * x_stride);
+    // logits: as mul_mat_f32_kernel (256 threads per output, same per-thread and cross-wave summation order), eight
+    // experts at a time so that their loads are in flight together (one expert after the other took 20 us)
+    __shared__ float part8[8][4];
+    const bool al16 = (((uintptr_t)gate | (uintptr_t)gate_stride | (uintptr_t)br) & 15) == 0;
+    for (int e0 = 0; e0 < n_expert; e0 += 8) {
+        float s[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) s[u] = 0.0f;
+        if (al16) {
+            const int k4 = k / 4;
+            for (int i = tid; i < k4; i += 256) {
+                const v4f b = ((const v4f *)br)[i];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int e = e0 + u < n_expert ? e0 + u : n_expert - 1;
+                    const v4f a = ((const v4f *)(gate + (int64_t)e * gate_stride))[i];
+                    s[u] += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+                }
+            }
+            for (int i = k4 * 4 + tid; i < k; i += 256)
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int e = e0 + u < n_expert ? e0 + u : n_expert - 1;
+                    s[u] += ((const float *)(gate + (int64_t)e * gate_stride))[i] * br[i];
+                }
+        } else {
+            for (int i = tid; i < k; i += 256)
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int e = e0 + u < n_expert ? e0 + u : n_expert - 1;
+                    s[u] += ((const float *)(gate + (int64_t)e * gate_stride))[i] * br[i];
+                }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const float r = wave_sum(s[u]);
+            if ((tid & 63) == 0) part8[u][tid >> 6] = r;
+        }
+        __syncthreads();
+        if (tid < 8 && e0 + tid < n_expert) {
+            const float l = part8[tid][0] + part8[tid][1] + part8[tid][2] + part8[tid][3];
+            logits[(int64_t)tok * n_expert + e0 + tid] = l; p_s[e0 + tid] = l;
+        }
+        __syncthreads();
+    }
+    // softmax: as soft_max_kernel (scale 1, no mask)
+    const float v = tid < n_expert ? p_s[tid] * 1.0f : -INFINITY;
+    const float mx = block_max(v, sh);
+    const float ex = tid < n_expert ? expf(v - mx) : 0.0f;
+    const float sum = block_sum(ex, sh);
+    const float pr = ex * (1.0f / sum);
+    __syncthreads();
+    if (tid < n_expert) { p_s[tid] = pr; probs[(int64_t)tok * n_expert + tid] = pr; }
+    __syncthreads();
+    // argsort, descending, ties by index: position = number of entries that sort before this one
+    if (tid < n_expert) {
+        int rank = 0;
+        for (int j = 0; j < n_expert; j++) rank += (p_s[j] > pr || (p_s[j] == pr && j < tid)) ? 1 : 0;
+        ord_s[rank] = tid;
+    }
+    __syncthreads();
+    if (tid < n_expert) order[(int64_t)tok * n_expert + tid] = ord_s[tid];
+    // gather, sum (as sum_rows_kernel: one wave, lane-strided, butterfly), normalise
+    if (tid < 64) {
+        float s = 0.0f;
+        for (int i = tid; i < n_used; i += 64) { const float wi = p_s[ord_s[i]]; w[(int64_t)tok * n_used + i] = wi; s += wi; }
+        s = wave_sum(s);
+        if (tid == 0) wsum[tok] = s;
+        for (int i = tid; i < n_used; i += 64) wn[(int64_t)tok * n_used + i] = p_s[ord_s[i]] / s;
+    }
+}
+
 } // namespace
 
 extern "C" int mi355_argsort_f32(const mi355_tensor * x, const mi355_tensor * dst, int descending, void * stream) {
@@ -681,6 +766,19 @@ extern "C" int mi355_mul_mat_f32(const mi355_tensor * a, const mi355_tensor * b,
     if (total == 0) return MI355_OK;
     if (total > 0x7fffffff) return MI355_E_SHAPE;
     MI355_LAUNCH("mul_mat_f32", mul_mat_f32_kernel, dim3((unsigned)total), dim3(256), 0, (hipStream_t)stream, t4(a), t4(b), t4(dst));
+    MI355_CHECK_LAUNCH();
+    return MI355_OK;
+}
+
+extern "C" int mi355_moe_router_f32(const float * x, int64_t x_row_stride, const float * gate_inp, int64_t gate_row_stride, int64_t k,
+                                    int64_t n_expert, int64_t n_used, int64_t n_tokens, float * logits, float * probs, int32_t * order,
+                                    float * w, float * wsum, float * wn, void * stream) {
+    if (!x || !gate_inp || !logits || !probs || !order || !w || !wsum || !wn) return MI355_E_NULL;
+    if (k <= 0 || k > 0x7fffffff || n_expert < 1 || n_expert > 256 || n_used < 1 || n_used > n_expert || n_tokens < 0 || n_tokens > 0x7fffffff) return MI355_E_SHAPE;
+    if ((x_row_stride | gate_row_stride) & 3) return MI355_E_ALIGN;
+    if (n_tokens == 0) return MI355_OK;
+    MI355_LAUNCH("moe_router", moe_router_kernel, dim3((unsigned)n_tokens), dim3(256), 0, (hipStream_t)stream, (const char *)x, x_row_stride,
+                 (const char *)gate_inp, gate_row_stride, (int)k, (int)n_expert, (int)n_used, logits, probs, order, w, wsum, wn);
     MI355_CHECK_LAUNCH();
     return MI355_OK;
 }

@@ -90,9 +90,11 @@ def test_llama_logits_match_ggml_cpu(ftype, ctk, tmp_path):
     assert nmse < (1e-2 if ctk == "q8_0" else 2e-3), nmse
 
 
-def test_fusions_are_bit_exact(tmp_path):
-    """The backend's graph-level fusions (RMS_NORM*weight, fused q8_1 quantization, activation cache) keep the
-    f32 op order of the unfused graph: logits with and without them are identical to the bit."""
+@pytest.mark.parametrize("model", ["tiny", "tinymoe"])
+def test_fusions_are_bit_exact(tmp_path, model):
+    """The backend's graph-level fusions (RMS_NORM*weight, fused q8_1 quantization, activation cache, Q/K/V + rope + store,
+    and for the 8-expert model the one-launch MoE router) keep the f32 op order of the unfused graph: logits with and
+    without them are identical to the bit."""
     import numpy as np
     tool = os.path.join(ROOT, "tools", "run_llama_bench.sh")
     outs = []
@@ -101,7 +103,7 @@ def test_fusions_are_bit_exact(tmp_path):
         env = dict(os.environ)
         if nofuse:
             env["GGML_MI355_NO_FUSE"] = "1"
-        r = subprocess.run([tool, "tiny", "Q4_K_M", "--dump-logits", path], capture_output=True, text=True, timeout=600, env=env)
+        r = subprocess.run([tool, model, "Q4_K_M", "--dump-logits", path], capture_output=True, text=True, timeout=600, env=env)
         assert r.returncode == 0, r.stderr[-3000:]
         outs.append(np.fromfile(path, dtype=np.uint32))
     assert np.array_equal(outs[0], outs[1])
