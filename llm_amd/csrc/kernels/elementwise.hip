@@ -47,6 +47,18 @@ static __device__ __forceinline__ float block_sum(float v, float * sh) {
     __syncthreads();
     return sh[0] + sh[1] + sh[2] + sh[3];
 }
+template <int NW>
+static __device__ __forceinline__ float block_sum_n(float v, float * sh) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sh[wave] = v;
+    __syncthreads();
+    float r = sh[0];
+#pragma unroll
+    for (int i = 1; i < NW; i++) r += sh[i];      // NW = 4: ((sh0 + sh1) + sh2) + sh3, as block_sum
+    return r;
+}
 static __device__ __forceinline__ float block_max(float v, float * sh) {
     v = wave_max(v);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -78,11 +90,13 @@ binary_kernel(const T4 a, const T4 b, const T4 d, int64_t n) {
 // y = x * rsqrt(mean(x^2) + eps) [* w]: the row is read once with 128-bit loads and kept in registers
 // (rows up to 8192 floats); rows that are longer or not 16-byte aligned take the two-pass path.
 // HAS_ADD: the row is first formed as x + y and that sum is also stored (residual add feeding the next norm).
-template <bool HAS_W, bool HAS_ADD>
-__global__ void __launch_bounds__(256)
+// NT threads: 256, or 512 for rows of more than 4096 values (one 16-value chunk per thread up to 8192: with 256 threads
+// an 8192-wide row -- Llama-3-70B -- took 8.4 us against 5.0 for 4096)
+template <bool HAS_W, bool HAS_ADD, int NT>
+__global__ void __launch_bounds__(NT)
 rms_norm_kernel(const T4 x, const T4 y, const T4 sum, const float * __restrict__ w, const T4 d, float eps, bool vec,
                 int8_t * __restrict__ aq, float * __restrict__ ads) {
-    __shared__ float sh[4];
+    __shared__ float sh[NT / 64];
     const int row = blockIdx.x;
     const int ne1 = (int)x.ne[1], ne2 = (int)x.ne[2];
     const int i1 = row % ne1, i2 = (row / ne1) % ne2, i3 = row / (ne1 * ne2);
@@ -92,7 +106,7 @@ rms_norm_kernel(const T4 x, const T4 y, const T4 sum, const float * __restrict__
     if (vec && (n & 15) == 0) {
         // a thread owns chunks of 16 consecutive floats (chunk c = tid + 256 j): half a q8_1 block, so the fused
         // quantization needs one lane-pair exchange per block instead of an 8-lane tree per 4 values
-        constexpr int MAXC = 2;                 // n <= 8192
+        constexpr int MAXC = 8192 / 16 / NT > 0 ? 8192 / 16 / NT : 1;      // n <= 8192 (NT 256: 2 chunks, 512: 1)
         const int nc = n >> 4;
         v4f v[MAXC][4], wv[MAXC][4];
         float s = 0.0f;
@@ -100,7 +114,7 @@ rms_norm_kernel(const T4 x, const T4 y, const T4 sum, const float * __restrict__
         float * sr = HAS_ADD ? (float *)(sum.data + i1 * sum.nb[1] + i2 * sum.nb[2] + i3 * sum.nb[3]) : nullptr;
 #pragma unroll
         for (int j = 0; j < MAXC; j++) {
-            const int c = threadIdx.x + j * 256;
+            const int c = threadIdx.x + j * NT;
             if (c < nc) {
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
@@ -114,11 +128,11 @@ rms_norm_kernel(const T4 x, const T4 y, const T4 sum, const float * __restrict__
                 }
             }
         }
-        s = block_sum(s, sh);
+        s = block_sum_n<NT / 64>(s, sh);
         const float scale = 1.0f / sqrtf(s / (float)n + eps);
 #pragma unroll
         for (int j = 0; j < MAXC; j++) {
-            const int c = threadIdx.x + j * 256;
+            const int c = threadIdx.x + j * NT;
             if (c < nc) {
                 float o[16];
 #pragma unroll
@@ -140,7 +154,7 @@ rms_norm_kernel(const T4 x, const T4 y, const T4 sum, const float * __restrict__
         float s = 0.0f;
 #pragma unroll
         for (int j = 0; j < MAXV; j++) {
-            const int i = threadIdx.x + j * 256;
+            const int i = threadIdx.x + j * NT;
             if (i < n4) {
                 v[j] = ((const v4f *)xr)[i];
                 if (HAS_W) wv[j] = ((const v4f *)w)[i];
@@ -153,11 +167,11 @@ rms_norm_kernel(const T4 x, const T4 y, const T4 sum, const float * __restrict__
                 s += v[j].x * v[j].x + v[j].y * v[j].y + v[j].z * v[j].z + v[j].w * v[j].w;
             }
         }
-        s = block_sum(s, sh);
+        s = block_sum_n<NT / 64>(s, sh);
         const float scale = 1.0f / sqrtf(s / (float)n + eps);
 #pragma unroll
         for (int j = 0; j < MAXV; j++) {
-            const int i = threadIdx.x + j * 256;
+            const int i = threadIdx.x + j * NT;
             if (i < n4) {
                 v4f o = v[j] * scale;
                 if (HAS_W) o = o * wv[j];
@@ -167,10 +181,10 @@ rms_norm_kernel(const T4 x, const T4 y, const T4 sum, const float * __restrict__
         return;
     }
     float s = 0.0f;
-    for (int i = threadIdx.x; i < n; i += 256) { const float t = xr[i]; s += t * t; }
-    s = block_sum(s, sh);
+    for (int i = threadIdx.x; i < n; i += NT) { const float t = xr[i]; s += t * t; }
+    s = block_sum_n<NT / 64>(s, sh);
     const float scale = 1.0f / sqrtf(s / (float)n + eps);
-    for (int i = threadIdx.x; i < n; i += 256) { float o = xr[i] * scale; if (HAS_W) o *= w[i]; dr[i] = o; }
+    for (int i = threadIdx.x; i < n; i += NT) { float o = xr[i] * scale; if (HAS_W) o *= w[i]; dr[i] = o; }
 }
 
 // ---------------------------------------------------------------- rope
@@ -386,11 +400,19 @@ static int launch_rms_norm(const mi355_tensor * x, const mi355_tensor * y, const
     const bool vec = (al & 15) == 0 && x->ne[0] % 4 == 0 && x->ne[0] <= 8192;
     if (aq && (!vec || x->ne[0] % QK != 0 || !ads)) return MI355_E_UNSUPPORTED;
     if (y && (!vec || !w)) return MI355_E_UNSUPPORTED;
-    const dim3 grid((unsigned)rows), block(256);
+    const dim3 grid((unsigned)rows);
     hipStream_t s = (hipStream_t)stream;
-    if (y)      MI355_LAUNCH("add_rms_norm_mul", (rms_norm_kernel<true, true>), grid, block, 0, s, t4(x), t4(y), t4(sum), w, t4(dst), eps, vec, aq, ads);
-    else if (w) MI355_LAUNCH("rms_norm_mul", (rms_norm_kernel<true, false>), grid, block, 0, s, t4(x), t4(x), t4(x), w, t4(dst), eps, vec, aq, ads);
-    else        MI355_LAUNCH("rms_norm", (rms_norm_kernel<false, false>), grid, block, 0, s, t4(x), t4(x), t4(x), w, t4(dst), eps, vec, aq, ads);
+    if (x->ne[0] > 4096) {
+        const dim3 block(512);
+        if (y)      MI355_LAUNCH("add_rms_norm_mul", (rms_norm_kernel<true, true, 512>), grid, block, 0, s, t4(x), t4(y), t4(sum), w, t4(dst), eps, vec, aq, ads);
+        else if (w) MI355_LAUNCH("rms_norm_mul", (rms_norm_kernel<true, false, 512>), grid, block, 0, s, t4(x), t4(x), t4(x), w, t4(dst), eps, vec, aq, ads);
+        else        MI355_LAUNCH("rms_norm", (rms_norm_kernel<false, false, 512>), grid, block, 0, s, t4(x), t4(x), t4(x), w, t4(dst), eps, vec, aq, ads);
+    } else {
+        const dim3 block(256);
+        if (y)      MI355_LAUNCH("add_rms_norm_mul", (rms_norm_kernel<true, true, 256>), grid, block, 0, s, t4(x), t4(y), t4(sum), w, t4(dst), eps, vec, aq, ads);
+        else if (w) MI355_LAUNCH("rms_norm_mul", (rms_norm_kernel<true, false, 256>), grid, block, 0, s, t4(x), t4(x), t4(x), w, t4(dst), eps, vec, aq, ads);
+        else        MI355_LAUNCH("rms_norm", (rms_norm_kernel<false, false, 256>), grid, block, 0, s, t4(x), t4(x), t4(x), w, t4(dst), eps, vec, aq, ads);
+    }
     MI355_CHECK_LAUNCH();
     return MI355_OK;
 }
