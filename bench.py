@@ -37,6 +37,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-group", action="store_true", help="one launch per matrix instead of grouped QKV / gate+up launches")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
+    ap.add_argument("--no-glu-fuse", action="store_true", help="grouped gate+up mat-vec and a separate quantization instead of mi355_glu_matvec")
     return ap.parse_args()
 
 
@@ -150,7 +151,25 @@ def main():
         a.m, a.k, a.ncols, a.nchannels, a.ch_ratio = o.shape[1], mt.k, 1, 1, 1
         return a
 
-    plan = []      # (quantize_k or None, ctypes array of MmvqArgs, n, [matrix indices])
+    # ffn gate + up of a layer run as the fused mi355_glu_matvec (both mat-vecs, the gated activation and the q8_1 form
+    # of its result in one launch -- what the plugin does for a decode token), so ffn_down's activation quantization
+    # is not a launch of its own.  Row-split ranks (N > 1) hold slices of both matrices and keep the grouped mat-vec.
+    fuse_glu = world == 1 and not args.no_group and not args.no_glu_fuse
+    hidden = torch.empty((1, dims.n_ff), dtype=torch.float32, device="cuda")
+
+    def glu_arg(ig, iu):
+        mg = mats[ig]
+        a = K.GluMatvecArgs()
+        aq, ads = acts[mg.k]
+        oq, ods = acts[dims.n_ff]
+        a.type, a.glu_op, a.w_gate, a.w_up = mg.type, 2, weights[ig].data_ptr(), weights[iu].data_ptr()
+        a.gate_row_stride = a.up_row_stride = B.row_size(mg.type, mg.k)
+        a.m, a.k, a.act_q, a.act_ds = mg.m, mg.k, aq.data_ptr(), ads.data_ptr()
+        a.gate_out, a.up_out, a.dst = outs[ig].data_ptr(), outs[iu].data_ptr(), hidden.data_ptr()
+        a.out_q, a.out_ds = oq.data_ptr(), ods.data_ptr()
+        return a
+
+    plan = []      # (quantize_k or None, ctypes array of MmvqArgs | GluMatvecArgs, n (0 = fused glu), [matrix indices])
     last_src = None
     for i, mt in enumerate(mats):
         need_q = mt.k if mt.src != last_src else None   # one q8_1 quantization per distinct activation, as in the graph
@@ -179,8 +198,15 @@ def main():
             gathers.append((send, recv))
         else:
             gathers.append(None)
-        arr = (K.MmvqArgs * len(p[3]))(*[mm_arg(mats[i], weights[i], outs[i]) for i in p[3]])
-        p[1], p[2] = arr, len(p[3])
+        names = [mats[i].name.split(".")[-1] for i in p[3]]
+        if fuse_glu and names == ["ffn_gate", "ffn_up"] and mats[p[3][0]].m % 32 == 0 and mats[p[3][0]].m <= 16384:
+            p[1], p[2] = glu_arg(*p[3]), 0
+        else:
+            arr = (K.MmvqArgs * len(p[3]))(*[mm_arg(mats[i], weights[i], outs[i]) for i in p[3]])
+            p[1], p[2] = arr, len(p[3])
+    for prev, p in zip(plan, plan[1:]):
+        if prev[2] == 0 and mats[p[3][0]].src == "ffn_act":
+            p[0] = None          # ffn_down reads the q8_1 activations the fused launch just wrote
 
     def step():
         """one decode token's mat-vecs on the current stream"""
@@ -188,7 +214,10 @@ def main():
         for (need_q, arr, n, idx), g in zip(plan, gathers):
             if need_q is not None:
                 quantize(need_q, stream)
-            K.check(K.lib.mi355_mul_mat_vec_q_group(arr, n, stream), "mi355_mul_mat_vec_q_group")
+            if n == 0:
+                K.check(K.lib.mi355_glu_matvec(arr, stream), "mi355_glu_matvec")
+            else:
+                K.check(K.lib.mi355_mul_mat_vec_q_group(arr, n, stream), "mi355_mul_mat_vec_q_group")
             if world > 1:
                 # rehearsal backends (gloo) gather through host memory; nccl = RCCL gathers device buffers over xGMI
                 if g is not None and backend == "nccl":
@@ -244,21 +273,30 @@ def main():
         step()
     torch.cuda.synchronize()
     K.lib.mi355_timing_enable(0)
-    n_launch, tot_us = K.timing_read("mmvq_q4_K_n1")
-    q4k_bytes = nroof * sum(B.matvec_bytes(mt.type, o.shape[1], mt.k) for mt, o in zip(mats, outs) if mt.type == B.Q4_K)
+    # dominant kernel by time: the fused gate/up launch (mmvq_glu_kernel<q4_K>) when it is in the plan, else the grouped
+    # mat-vec (mmvq_group_kernel<q4_K, 1>).  Algorithmic bytes = SURVEY 8(d)'s M*(K/256)*144 + 4K + 4M per matrix.
+    fused_idx = [i for p in plan if p[2] == 0 for i in p[3]]
+    if fused_idx:
+        tag, kname, roof_idx = "mmvq_glu", "mmvq_glu_kernel<q4_K> (ffn gate + up + GLU + q8_1)", fused_idx
+    else:
+        tag, kname = "mmvq_q4_K_n1", "mmvq_group_kernel<q4_K, ncols=1>"
+        roof_idx = [i for i, mt in enumerate(mats) if mt.type == B.Q4_K]
+    n_launch, tot_us = K.timing_read(tag)
+    q4k_bytes = nroof * sum(B.matvec_bytes(mats[i].type, outs[i].shape[1], mats[i].k) for i in roof_idx)
     avg_us = tot_us / n_launch
     achieved = q4k_bytes / tot_us * 1e-3
-    kernels = {tag: {"launches": n, "avg_us": round(us / n, 3)} for tag, (n, us) in K.timing_report().items() if n}
+    kernels = {t_: {"launches": n, "avg_us": round(us / n, 3)} for t_, (n, us) in K.timing_report().items() if n}
     # HBM bytes per launch of that kernel from the PMC counters: collected in a run of its own (rocprofv3 --pmc cannot be
     # combined with this timed run) by tools/pmc_traffic.sh on this same workload and committed under profiles/.
     traffic = None
     if world == 1 and not args.no_group:
         try:
             tr = json.load(open(os.path.join(ROOT, "profiles", "r01_bench_traffic.json")))
-            traffic = tr["traffic_bytes_per_launch"]
+            if tr["kernel"].startswith("mmvq_glu") == bool(fused_idx):
+                traffic = tr["traffic_bytes_per_launch"]
         except (OSError, KeyError, ValueError):
             traffic = None
-    roofline = {"bound": "hbm", "kernel": "mmvq_group_kernel<q4_K, ncols=1>", "achieved": round(achieved, 1),
+    roofline = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
                 "traffic": traffic, "traffic_source": "profiles/r01_bench_traffic.json (rocprofv3 --pmc FETCH_SIZE x2, separate pass)" if traffic else None,
                 "launches": n_launch, "avg_launch_us": round(avg_us, 3),

@@ -30,6 +30,7 @@
  *   GGML_MI355_NO_FUSE=1     run every graph node with its own kernel, no activation-quantization cache
  *   GGML_MI355_NO_PINNED=1   do not offer the pinned host buffer type
  *   GGML_MI355_NO_SKINNY=1   MUL_MAT with 4..64 columns: mat-vec / bf16 GEMM kernels instead of the skinny int8-MFMA ones
+ *   GGML_MI355_NO_GLU_MATVEC=1  decode ffn: grouped gate+up mat-vec and a separate GLU kernel instead of mi355_glu_matvec
  *   GGML_MI355_MMQ_INT8=1    prefill MUL_MAT on the int8-MFMA tile kernel (the reference's MMQ arithmetic) instead of
  *                            the dequantize-in-LDS bf16 GEMM
  *   GGML_MI355_DUMP_GRAPH=1  print the node list of every graph handed to graph_compute

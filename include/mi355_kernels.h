@@ -170,6 +170,25 @@ typedef struct mi355_qkv_rope_args {
 } mi355_qkv_rope_args;
 MI355_API int mi355_qkv_rope_matvec(const mi355_qkv_rope_args *args, void *stream);
 
+/* Feed-forward input stage of one decode token in ONE launch: g = W_gate x, u = W_up x, dst = act(g) * u, plus the q8_1
+ * form of dst (mi355_quantize_act layout, one row) for the ffn_down mat-vec.  Replaces, for n_tokens == 1, the nodes
+ * MUL_MAT(ffn_up) MUL_MAT(ffn_gate) GLU(split) of build_ffn (src/llama-graph.cpp:470-640), i.e. 2 x mul_mat_vec_q
+ * (ggml-cuda/mmvq.cu:491-561) + the gated activation (ggml-cuda/unary.cu: ggml_cuda_op_swiglu & co) + the q8_1
+ * quantization of the next MUL_MAT (ggml-cuda/quantize.cu).  Bit-identical to those kernels run one by one.  Both matrices
+ * have `type` and m rows (m % 32 == 0: a workgroup owns one q8_1 block of the result); gate_out / up_out (the f32 results
+ * of the two MUL_MAT nodes) may be NULL; out_q / out_ds may both be NULL, and must not overlap act_q / act_ds. */
+typedef struct mi355_glu_matvec_args {
+    int32_t type, glu_op;                                  /* weight type; MI355_GLU_* (0 reglu, 1 geglu, 2 swiglu) */
+    const void *w_gate, *w_up;
+    int64_t gate_row_stride, up_row_stride;                /* bytes */
+    int64_t m, k;
+    const int8_t *act_q; const float *act_ds;              /* activations of the token (mi355_quantize_act) */
+    float *gate_out, *up_out;                              /* f32 [m] each, optional */
+    float *dst;                                            /* f32 [m], 16-byte aligned */
+    int8_t *out_q; float *out_ds;                          /* q8_1 SoA of dst: [m] int8, [m/32][2] f32; optional */
+} mi355_glu_matvec_args;
+MI355_API int mi355_glu_matvec(const mi355_glu_matvec_args *args, void *stream);
+
 /* "Skinny" MUL_MAT, 1 <= n <= 32 activation columns per call, on the int8 matrix cores: same operands and
  * arithmetic contract as mi355_mul_mat_vec_q (one channel), but one v_mfma_i32_32x32x32_i8 covers 32 rows x 32 columns
  * of a 32-block, so the time per weight byte does not grow with n (the mat-vec kernel drops to 9 % of the HBM

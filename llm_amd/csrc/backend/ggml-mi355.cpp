@@ -489,8 +489,11 @@ struct mi355_backend_ctx {
     hipStream_t stream = nullptr;
     // device scratch, grown on demand and reused across ops:
     //   [0] q8_1 activations of the MUL_MAT / MUL_MAT_ID in flight   [1] split-KV partials of FLASH_ATTN_EXT
-    void * scratch[2] = {nullptr, nullptr};
-    size_t scratch_size[2] = {0, 0};
+    //   [2] spare activation buffer: a kernel that reads activations AND emits the next ones (mi355_glu_matvec) writes
+    //       here, then [0] and [2] trade places
+    void * scratch[3] = {nullptr, nullptr, nullptr};
+    size_t scratch_size[3] = {0, 0, 0};
+    void swap_act_scratch() { std::swap(scratch[0], scratch[2]); std::swap(scratch_size[0], scratch_size[2]); }
 
     // the activation tensor whose q8_1 form currently sits in scratch[0]: consecutive MUL_MATs that read
     // the same src1 (wq/wk/wv, gate/up) quantize it once.  Dropped as soon as any node writes into it.
@@ -575,7 +578,7 @@ static void mi355_backend_free(ggml_backend_t backend) {
     mi355_backend_ctx * ctx = (mi355_backend_ctx *)backend->context;
     mi355_set_device(ctx->device);
     HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    for (int i = 0; i < 2; i++) if (ctx->scratch[i]) HIP_CHECK(hipFree(ctx->scratch[i]));
+    for (int i = 0; i < 3; i++) if (ctx->scratch[i]) HIP_CHECK(hipFree(ctx->scratch[i]));
     if (ctx->ev_ready) HIP_CHECK(hipEventDestroy(ctx->ev_ready));
     for (int d = 0; d < MI355_MAX_DEVICES; d++) {
         mi355_backend_ctx::peer_t & p = ctx->peers[d];
@@ -1182,6 +1185,62 @@ static void mi355_mul_mat_group(mi355_backend_ctx * ctx, ggml_cgraph * cgraph, c
     MI_CHECK(mi355_mul_mat_vec_q_group(a, cnt, ctx->stream));
 }
 
+// Feed-forward input of a decode step in one launch.  build_ffn (src/llama-graph.cpp:470-640) spells it as
+//     tmp = MUL_MAT(ffn_up, x)   cur = MUL_MAT(ffn_gate, x)   cur = GLU(cur, tmp)            (split SWIGLU / GEGLU / REGLU)
+// When the two mat-vecs form a group (members[0..1], consecutive nodes, one token) and the GLU is the very next node,
+// mi355_glu_matvec computes all three tensors (bit-identical values) plus the q8_1 form of the GLU result, which
+// ffn_down then finds in the activation cache.  Every tensor of the chain is still written, so no use analysis is
+// needed -- except that a GLU result placed exactly on top of one of its inputs (ggml-alloc's in-place reuse) simply
+// replaces it.  Grids beyond one round of workgroups (m > 16384) stay on the grouped mat-vec, which is faster there.
+static bool mi355_try_fuse_glu_matvec(mi355_backend_ctx * ctx, ggml_cgraph * cgraph, const int * members) {
+    const int n = ggml_graph_n_nodes(cgraph);
+    const int i0 = members[0], i1 = members[1];
+    if (i1 != i0 + 1 || i1 + 1 >= n || getenv("GGML_MI355_NO_GLU_MATVEC")) return false;
+    ggml_tensor * glu = ggml_graph_node(cgraph, i1 + 1);
+    const ggml_tensor * m0 = ggml_graph_node(cgraph, i0), * m1 = ggml_graph_node(cgraph, i1);
+    if (glu->op != GGML_OP_GLU || !glu->src[1] || glu->type != GGML_TYPE_F32) return false;
+    const ggml_tensor * gate = glu->src[0], * up = glu->src[1];
+    if (!((gate == m0 && up == m1) || (gate == m1 && up == m0))) return false;
+    const int op = (int)ggml_get_glu_op(glu);
+    if (op < 0 || op > 2) return false;
+    const ggml_tensor * src1 = m0->src[1];
+    const int64_t K = src1->ne[0], M = gate->ne[0];
+    if (src1->ne[1] != 1 || up->ne[0] != M || M % 32 != 0 || M > 16384 || ggml_nrows(glu) != 1 || glu->ne[0] != M) return false;
+    if (!ggml_is_contiguous(glu) || ((uintptr_t)glu->data & 15)) return false;
+    if ((size_t)K + (size_t)K / 32 * 8 + 16 + 256 > 64 * 1024) return false;
+    // the GLU result may coincide with one of its inputs (then that input is not stored), but not straddle them,
+    // nor touch the activations the mat-vecs were given
+    float * gate_out = (float *)gate->data, * up_out = (float *)up->data;
+    if (glu->data == gate->data) gate_out = nullptr;
+    else if (ranges_overlap(glu->data, ggml_nbytes(glu), gate->data, ggml_nbytes(gate))) return false;
+    if (glu->data == up->data) up_out = nullptr;
+    else if (ranges_overlap(glu->data, ggml_nbytes(glu), up->data, ggml_nbytes(up))) return false;
+    if (ranges_overlap(glu->data, ggml_nbytes(glu), src1->data, ggml_nbytes(src1))) return false;
+
+    const size_t qb = align_up((size_t)mi355_act_q_bytes(K, 1), 256), db = align_up((size_t)mi355_act_ds_bytes(K, 1), 256);
+    const size_t oqb = align_up((size_t)mi355_act_q_bytes(M, 1), 256), odb = align_up((size_t)mi355_act_ds_bytes(M, 1), 256);
+    char * ws = (char *)ctx->get_scratch(0, qb + db);
+    if (!ctx->act_cached(src1)) {
+        MI_CHECK(mi355_quantize_act((const float *)src1->data, (int8_t *)ws, (float *)(ws + qb), K, 1, 1, 1, src1->nb[1], src1->nb[2], src1->nb[3], ctx->stream));
+        ctx->act_remember(src1);
+    }
+    char * os = (char *)ctx->get_scratch(2, oqb + odb);
+    mi355_glu_matvec_args a;
+    memset(&a, 0, sizeof(a));
+    a.type = (int32_t)gate->src[0]->type; a.glu_op = op;
+    a.w_gate = gate->src[0]->data; a.w_up = up->src[0]->data;
+    a.gate_row_stride = (int64_t)gate->src[0]->nb[1]; a.up_row_stride = (int64_t)up->src[0]->nb[1];
+    a.m = M; a.k = K; a.act_q = (const int8_t *)ws; a.act_ds = (const float *)(ws + qb);
+    a.gate_out = gate_out; a.up_out = up_out; a.dst = (float *)glu->data;
+    a.out_q = (int8_t *)os; a.out_ds = (float *)(os + oqb);
+    const int rc = mi355_glu_matvec(&a, ctx->stream);
+    if (rc == MI355_E_UNSUPPORTED || rc == MI355_E_ALIGN) return false;
+    MI_CHECK(rc);
+    ctx->swap_act_scratch();            // scratch[0] now holds the q8_1 form of the GLU result
+    ctx->act_remember(glu);
+    return true;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Fused attention input of a decode step.  llm_build_llama (src/llama-model.cpp:4898-5052) spells it as
 //     Qcur = MUL_MAT(wq, x)  RESHAPE  ROPE      Kcur = MUL_MAT(wk, x)  RESHAPE  ROPE      Vcur = MUL_MAT(wv, x)  RESHAPE
@@ -1409,6 +1468,11 @@ static enum ggml_status mi355_backend_graph_compute(ggml_backend_t backend, ggml
         if (fuse && matvec_groupable(node)) {
             int members[MI355_MMVQ_MAX_GROUP];
             const int cnt = mi355_collect_matvec_group(cgraph, i, done, members);
+            if (cnt == 2 && mi355_try_fuse_glu_matvec(ctx, cgraph, members)) {
+                done[members[1]] = 1;
+                done[members[1] + 1] = 1;
+                continue;
+            }
             if (cnt > 1) {
                 mi355_mul_mat_group(ctx, cgraph, members, cnt);
                 for (int m = 1; m < cnt; m++) done[members[m]] = 1;

@@ -63,6 +63,19 @@ static __device__ __forceinline__ void load8(const char * row, int j, float * ou
     }
 }
 
+// sum over the 16 lanes of a DPP row, result in every lane: four rotate-and-add steps on the VALU (v_add_f32 row_ror)
+// instead of four ds_bpermute round trips through the LDS crossbar
+template <int CTRL> static __device__ __forceinline__ float dpp_rot(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+static __device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_rot<0x128>(v);      // row_ror:8
+    v += dpp_rot<0x124>(v);      // row_ror:4
+    v += dpp_rot<0x122>(v);      // row_ror:2
+    v += dpp_rot<0x121>(v);      // row_ror:1
+    return v;
+}
+
 static __device__ __forceinline__ float alibi_slope(const FArgs & a, uint32_t h) {
     if (!(a.max_bias > 0.0f)) return 1.0f;
     return h < a.n_head_log2 ? powf(a.m0, h + 1) : powf(a.m1, 2 * (h - a.n_head_log2) + 1);
@@ -158,8 +171,11 @@ fattn_vec_kernel(const FArgs a) {
             float s = 0.0f;
 #pragma unroll
             for (int i = 0; i < 8; i++) s += qf[r][i] * kf[i];
+            if constexpr (LPR == 16) s = row16_sum(s);
+            else {
 #pragma unroll
-            for (int o = 1; o < LPR; o <<= 1) s += __shfl_xor(s, o, 64);
+                for (int o = 1; o < LPR; o <<= 1) s += __shfl_xor(s, o, 64);
+            }
             s *= scale;
             if (a.logit_softcap != 0.0f) s = a.logit_softcap * tanhf(s);
             if (mv[r] == -INFINITY) continue;      // masked out (ops.cpp:8105-8108); uniform inside the lane group

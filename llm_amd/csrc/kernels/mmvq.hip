@@ -511,6 +511,102 @@ mmvq_qkv_rope_kernel(const KQkv a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Fused feed-forward input of a decode step: gate and up projections of one token, the gated activation and the
+// q8_1 form of the result for ffn_down -- ONE launch for what the graph spells as 2 MUL_MAT + GLU (2 launches as
+// grouped mat-vec + glu_quant).  512 threads = 8 waves; a workgroup owns 32 consecutive outputs (= one q8_1 block, so
+// the quantization needs no cross-workgroup step), a wave 4 of them, one after the other: for each it streams the
+// gate row and the up row (same activations, shared LDS reads) with the next pair's loads already in flight.
+// Row sums, activation and quantization use the same code as the separate kernels: bit-identical results.
+// ------------------------------------------------------------------------------------------------
+struct KGlu {
+    const uint8_t * wg, * wu; int64_t rsg, rsu;
+    const int8_t * act_q; const float * act_ds; int k, m, op;
+    float * gate_out, * up_out, * dst; int8_t * out_q; float * out_ds;
+};
+
+static __device__ __forceinline__ float glu_act(int op, float x) {
+    switch (op) {
+        case 0: return x > 0.0f ? x : 0.0f;                                  // REGLU
+        case 1: { const float c = 0.044715f, s = 0.79788456080286535587989211986876f; // GEGLU (tanh gelu, ggml_gelu_f32)
+                  return 0.5f * x * (1.0f + tanhf(s * x * (1.0f + c * x * x))); }
+        default: return x / (1.0f + expf(-x));                               // SWIGLU (ggml_silu_f32, vec.h:637-639)
+    }
+}
+
+constexpr int GLU_THREADS = 512;      // 8 waves x GLU_PAIRS (4 or 8) outputs = 32 or 64 outputs per workgroup
+
+template <int TYPE, int GLU_PAIRS>
+__global__ void __launch_bounds__(GLU_THREADS, (TYPE == MI355_TYPE_Q5_K || TYPE == MI355_TYPE_Q6_K) ? 2 : 4)
+mmvq_glu_kernel(const KGlu a) {
+    typedef Unit<TYPE> U;
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int k = a.k;
+    const int row0 = (blockIdx.x * 8 + wave) * GLU_PAIRS;                     // first of this wave's outputs
+    const uint8_t * wg = a.wg + (int64_t)row0 * a.rsg, * wu = a.wu + (int64_t)row0 * a.rsu;
+    const int nunits = k / U::ELEMS;
+    const int niter  = (nunits + 63) >> 6;
+    const int u0 = lane < nunits ? lane : nunits - 1;
+    typename U::Raw c0 = U::load(wg, u0), c1 = U::load(wu, u0);
+    {
+        const int nq = k / 16, nds = k / QK;
+        for (int i = threadIdx.x; i < nq; i += GLU_THREADS) ((v4i *)lds)[i] = ((const v4i *)a.act_q)[i];
+        v2f * lds_ds = (v2f *)(lds + (size_t)k);
+        for (int i = threadIdx.x; i < nds; i += GLU_THREADS) lds_ds[i] = ((const v2f *)a.act_ds)[i];
+        __syncthreads();
+    }
+    const auto lq   = (const __attribute__((address_space(3))) int8_t *)lds;
+    const auto lds_ = (const __attribute__((address_space(3))) float *)(lds + (size_t)k);
+    float sg[GLU_PAIRS], su[GLU_PAIRS];
+#pragma unroll
+    for (int p = 0; p < GLU_PAIRS; p++) {
+        float acc0 = 0.0f, acc1 = 0.0f;
+        for (int it = 0; it < niter; it++) {
+            const int  u_raw = it * 64 + lane;
+            const bool valid = u_raw < nunits;
+            const int  u     = valid ? u_raw : nunits - 1;
+            typename U::Raw n0, n1;
+            const bool more_here = it + 1 < niter;
+            if (more_here || p + 1 < GLU_PAIRS) {
+                const int unr = more_here ? u_raw + 64 : lane;
+                const int un  = unr < nunits ? unr : nunits - 1;
+                const int64_t adv = more_here ? 0 : 1;                       // next unit of this pair, or first of the next
+                n0 = U::load(wg + (p + adv) * a.rsg, un); n1 = U::load(wu + (p + adv) * a.rsu, un);
+            }
+            const typename U::Act av = U::load_act(ActLds{lq, lds_}, u);
+            __builtin_amdgcn_sched_barrier(0);
+            const float v0 = U::dot(U::decode(c0, u), av);
+            const float v1 = U::dot(U::decode(c1, u), av);
+            acc0 += valid ? v0 : 0.0f;
+            acc1 += valid ? v1 : 0.0f;
+            if (more_here || p + 1 < GLU_PAIRS) { c0 = n0; c1 = n1; }
+        }
+        sg[p] = wave_sum(acc0);
+        su[p] = wave_sum(acc1);
+    }
+    // lanes 0..3 finish one output each; the 32 gated values meet in LDS and 8 lanes quantize the block
+    float * hs = (float *)(lds + (((size_t)k + (size_t)k / QK * 8 + 15) & ~(size_t)15));
+    if (lane < GLU_PAIRS) {
+        float g = sg[0], u = su[0];
+#pragma unroll
+        for (int p = 1; p < GLU_PAIRS; p++) if (lane == p) { g = sg[p]; u = su[p]; }
+        if (a.gate_out) a.gate_out[row0 + lane] = g;
+        if (a.up_out)   a.up_out[row0 + lane]   = u;
+        hs[wave * GLU_PAIRS + lane] = glu_act(a.op, g) * u;
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * GLU_PAIRS) {
+        const v4f h = ((const v4f *)hs)[threadIdx.x];
+        const int64_t o0 = (int64_t)blockIdx.x * (8 * GLU_PAIRS) + 4 * threadIdx.x;
+        *(v4f *)(a.dst + o0) = h;
+        if (a.out_q) {
+            const float o[4] = {h.x, h.y, h.z, h.w};
+            quant4_soa(o, a.out_q + o0, a.out_ds + (o0 >> 5) * 2, (threadIdx.x & 7) == 0);
+        }
+    }
+}
+
 static const char * type_name(int t) {
     switch (t) {
         case MI355_TYPE_Q4_0: return "q4_0"; case MI355_TYPE_Q8_0: return "q8_0"; case MI355_TYPE_Q4_K: return "q4_K";
@@ -703,4 +799,50 @@ extern "C" int mi355_qkv_rope_matvec(const mi355_qkv_rope_args * p, void * strea
     if (tq == MI355_TYPE_Q8_0 && tv == MI355_TYPE_Q8_0) return launch_qkv<MI355_TYPE_Q8_0, MI355_TYPE_Q8_0, MI355_TYPE_Q8_0>(a, s);
     if (tq == MI355_TYPE_Q4_0 && tv == MI355_TYPE_Q4_0) return launch_qkv<MI355_TYPE_Q4_0, MI355_TYPE_Q4_0, MI355_TYPE_Q4_0>(a, s);
     return MI355_E_UNSUPPORTED;
+}
+
+template <int TYPE>
+static int launch_glu_mv(const KGlu & a, hipStream_t stream) {
+    const size_t need = (((size_t)a.k + (size_t)a.k / QK * 8 + 15) & ~(size_t)15) + 64 * sizeof(float);
+    if (need > LDS_ACT_LIMIT) return MI355_E_UNSUPPORTED;
+    // 4 outputs per wave.  (8 per wave -- half the workgroups, for grids beyond the 512 workgroups a full chip holds at
+    // once -- measured slower: 2x28672x8192 q4_K 61 us against 56; the plugin keeps such shapes on the grouped mat-vec.)
+    MI355_LAUNCH("mmvq_glu", (mmvq_glu_kernel<TYPE, 4>), dim3((unsigned)(a.m / 32)), dim3(GLU_THREADS), need, stream, a);
+    MI355_CHECK_LAUNCH();
+    return MI355_OK;
+}
+
+extern "C" int mi355_glu_matvec(const mi355_glu_matvec_args * p, void * stream) {
+    if (!p || !p->w_gate || !p->w_up || !p->act_q || !p->act_ds || !p->dst) return MI355_E_NULL;
+    if ((p->out_q == nullptr) != (p->out_ds == nullptr)) return MI355_E_NULL;
+    const int64_t bs = mi355_blck_size(p->type);
+    if (bs == 0 || p->type == MI355_TYPE_F32 || p->type == MI355_TYPE_F16 || p->type == MI355_TYPE_Q8_1) return MI355_E_TYPE;
+    if (p->glu_op < 0 || p->glu_op > 2) return MI355_E_UNSUPPORTED;
+    if (p->m <= 0 || p->m % 32 != 0 || p->m > 0x3fffffff || p->k <= 0 || p->k % bs != 0 || p->k > 0x7fffffff) return MI355_E_SHAPE;
+    if (((uintptr_t)p->act_q & 15) || ((uintptr_t)p->act_ds & 7) || ((uintptr_t)p->dst & 15) || ((uintptr_t)p->gate_out & 3) ||
+        ((uintptr_t)p->up_out & 3) || ((uintptr_t)p->out_q & 3) || ((uintptr_t)p->out_ds & 7)) return MI355_E_ALIGN;
+    if (p->k % QK_K == 0 && ((uintptr_t)p->act_ds & 15)) return MI355_E_ALIGN;
+    const bool a16 = p->type == MI355_TYPE_Q4_K || p->type == MI355_TYPE_Q5_K;
+    const uintptr_t wal = (uintptr_t)p->w_gate | (uintptr_t)p->gate_row_stride | (uintptr_t)p->w_up | (uintptr_t)p->up_row_stride;
+    if (wal & (a16 ? 15 : 1)) return MI355_E_ALIGN;
+    if (p->gate_row_stride < mi355_row_size(p->type, p->k) || p->up_row_stride < mi355_row_size(p->type, p->k)) return MI355_E_SHAPE;
+    // the q8_1 output must not be the buffer the activations are read from: workgroups finish at different times
+    {
+        const char * i0 = (const char *)p->act_q, * i1 = i0 + p->k, * d0 = (const char *)p->act_ds, * d1 = d0 + p->k / QK * 8;
+        const char * o0 = (const char *)p->out_q, * o1 = o0 + p->m, * e0 = (const char *)p->out_ds, * e1 = e0 + p->m / QK * 8;
+        if (p->out_q && ((o0 < i1 && i0 < o1) || (o0 < d1 && d0 < o1) || (e0 < i1 && i0 < e1) || (e0 < d1 && d0 < e1))) return MI355_E_SHAPE;
+    }
+    KGlu a;
+    a.wg = (const uint8_t *)p->w_gate; a.wu = (const uint8_t *)p->w_up; a.rsg = p->gate_row_stride; a.rsu = p->up_row_stride;
+    a.act_q = p->act_q; a.act_ds = p->act_ds; a.k = (int)p->k; a.m = (int)p->m; a.op = p->glu_op;
+    a.gate_out = p->gate_out; a.up_out = p->up_out; a.dst = p->dst; a.out_q = p->out_q; a.out_ds = p->out_ds;
+    hipStream_t s = (hipStream_t)stream;
+    switch (p->type) {
+        case MI355_TYPE_Q4_0: return launch_glu_mv<MI355_TYPE_Q4_0>(a, s);
+        case MI355_TYPE_Q8_0: return launch_glu_mv<MI355_TYPE_Q8_0>(a, s);
+        case MI355_TYPE_Q4_K: return launch_glu_mv<MI355_TYPE_Q4_K>(a, s);
+        case MI355_TYPE_Q5_K: return launch_glu_mv<MI355_TYPE_Q5_K>(a, s);
+        case MI355_TYPE_Q6_K: return launch_glu_mv<MI355_TYPE_Q6_K>(a, s);
+    }
+    return MI355_E_TYPE;
 }

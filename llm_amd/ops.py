@@ -213,6 +213,26 @@ def qkv_rope_matvec(type_qk, type_v, wq, wk, wv, m_q, m_k, m_v, k, aq, ads, pos,
     return q, ko, vo
 
 
+def glu_matvec(t, w_gate, w_up, m, k, aq, ads, glu_op=2, quant=True, keep=True):
+    """Fused decode feed-forward input (mi355_glu_matvec): -> (dst f32 [m], gate f32 [m] | None, up f32 [m] | None,
+    out_q int8 [m] | None, out_ds f32 [m/32, 2] | None)."""
+    _u8(w_gate); _u8(w_up)
+    dev = w_gate.device
+    dst = torch.full((m,), float("nan"), dtype=torch.float32, device=dev)
+    g = torch.full((m,), float("nan"), dtype=torch.float32, device=dev) if keep else None
+    u = torch.full((m,), float("nan"), dtype=torch.float32, device=dev) if keep else None
+    oq = torch.zeros(m, dtype=torch.int8, device=dev) if quant else None
+    ods = torch.zeros((m // 32, 2), dtype=torch.float32, device=dev) if quant else None
+    a = K.GluMatvecArgs()
+    a.type, a.glu_op, a.w_gate, a.w_up = t, glu_op, w_gate.data_ptr(), w_up.data_ptr()
+    a.gate_row_stride = a.up_row_stride = B.row_size(t, k)
+    a.m, a.k, a.act_q, a.act_ds = m, k, aq.data_ptr(), ads.data_ptr()
+    a.gate_out, a.up_out, a.dst = g.data_ptr() if keep else None, u.data_ptr() if keep else None, dst.data_ptr()
+    a.out_q, a.out_ds = oq.data_ptr() if quant else None, ods.data_ptr() if quant else None
+    K.check(K.lib.mi355_glu_matvec(a, _stream()), "mi355_glu_matvec")
+    return dst, g, u, oq, ods
+
+
 def mul_mat_id_dq(t, as_, b, ids, m, n_expert):
     """ggml_mul_mat_id for prefill-sized batches (device-side expert bucketing + one bf16-MFMA GEMM launch):
     as_ = [n_expert][m rows] blocks, b = [n_tokens, b_ne1, k] f32, ids = [n_tokens, n_used] int32 -> [n_tokens, n_used, m] f32."""

@@ -356,6 +356,53 @@ def test_qkv_rope_fused_is_bit_identical_to_separate_kernels(ops, tqk, tv, tk, m
     assert torch.equal(kf.view(it), kr.view(it)) and torch.equal(vf.view(it), vr.view(it))
 
 
+@pytest.mark.parametrize("t", B.WEIGHT_TYPES)
+@pytest.mark.parametrize("m,k,op,keep", [(14336, 4096, 2, True), (96, 512, 2, False), (352, 8192, 1, True), (64, 1024, 0, True), (28672, 2048, 2, True)])
+def test_glu_matvec_fused_is_bit_identical_to_separate_kernels(ops, t, m, k, op, keep):
+    """mi355_glu_matvec == grouped gate/up mat-vec + glu_quant (act(gate) * up and its q8_1 form), to the bit
+    (Llama-3-8B ffn shape, a ragged number of 32-blocks, K = 8192 with two units per lane, all three activations)."""
+    import llm_amd.kernels as K
+    rng = np.random.default_rng(m + k + op)
+    x = dev(rng.standard_normal((1, k)).astype(np.float32))
+    aq, ads = ops.quantize_act(x)
+    wg, wu = dev(B.random_blocks(t, m, k, seed=11)), dev(B.random_blocks(t, m, k, seed=12))
+    g0, u0 = ops.mul_mat_vec_q_group(t, [wg, wu], [m, m], k, aq, ads, 1)
+    d0 = torch.empty(1, m, device="cuda")
+    q0 = torch.empty((1, m), dtype=torch.int8, device="cuda")
+    s0 = torch.empty((1, m // 32, 2), dtype=torch.float32, device="cuda")
+    T = K.Tensor.of
+    K.check(K.lib.mi355_glu_quant_f32(op, T(g0.view(1, m)), T(u0.view(1, m)), T(d0), 0, q0.data_ptr(), s0.data_ptr(),
+                                      torch.cuda.current_stream().cuda_stream), "glu_quant")
+    d1, g1, u1, q1, s1 = ops.glu_matvec(t, wg, wu, m, k, aq, ads, glu_op=op, quant=True, keep=keep)
+    assert torch.isfinite(d1).all() and float(d1.abs().max()) > 0
+    assert torch.equal(d1.view(torch.int32), d0.view(-1).view(torch.int32))
+    assert torch.equal(q1, q0.view(-1)) and torch.equal(s1.view(torch.int32), s0.view(-1, 2).view(torch.int32))
+    if keep:
+        assert torch.equal(g1.view(torch.int32), g0.view(-1).view(torch.int32)) and torch.equal(u1.view(torch.int32), u0.view(-1).view(torch.int32))
+    d2 = ops.glu_matvec(t, wg, wu, m, k, aq, ads, glu_op=op, quant=False, keep=False)[0]
+    assert torch.equal(d2.view(torch.int32), d1.view(torch.int32))
+
+
+def test_glu_matvec_argument_errors(ops):
+    import llm_amd.kernels as K
+    a = K.GluMatvecArgs()
+    assert K.lib.mi355_glu_matvec(a, None) == -4                       # NULL pointers
+    x = dev(np.zeros((1, 512), np.float32))
+    aq, ads = ops.quantize_act(x)
+    w = dev(B.random_blocks(B.Q4_K, 64, 512, seed=1))
+    d = dev(np.zeros(64, np.float32))
+    a.type, a.glu_op, a.w_gate, a.w_up = B.Q4_K, 2, w.data_ptr(), w.data_ptr()
+    a.gate_row_stride = a.up_row_stride = B.row_size(B.Q4_K, 512)
+    a.m, a.k, a.act_q, a.act_ds, a.dst = 48, 512, aq.data_ptr(), ads.data_ptr(), d.data_ptr()
+    assert K.lib.mi355_glu_matvec(a, None) == -2                       # m not a multiple of 32
+    a.m, a.out_q, a.out_ds = 64, aq.data_ptr(), ads.data_ptr()
+    assert K.lib.mi355_glu_matvec(a, None) == -2                       # q8_1 output on top of the activations being read
+    a.out_ds = None
+    assert K.lib.mi355_glu_matvec(a, None) == -4                       # out_q without out_ds
+    a.out_q, a.glu_op = None, 7
+    assert K.lib.mi355_glu_matvec(a, None) == -6                       # unknown activation
+
+
 @pytest.mark.parametrize("rows,n", [(1, 4096), (3, 1024), (8, 8192), (2, 96), (1, 4128)])
 @pytest.mark.parametrize("with_add", [False, True])
 def test_fused_norm_matches_separate_ops(ops, rows, n, with_add):
