@@ -134,6 +134,10 @@ typedef struct mi355_mmvq_args {
     int32_t        ids_nused;      /* expert slots per token */
     int32_t        act_ne1;        /* b->ne[1] of MUL_MAT_ID (1 or ids_nused) */
     int32_t        n_expert;       /* bound for ids values (out-of-range ids are skipped) */
+    const float   *residual;       /* optional (nchannels == 1, no ids): f32 laid out like dst; then sum = dst + residual is */
+    float         *sum;            /* stored too -- the ADD node after wo / ffn_down (ggml-cuda/binbcast.cu), bit-identical
+                                    * to a separate add.  sum == dst: only the sum is stored (ADD in place on the result);
+                                    * sum == residual is allowed.  Both NULL or both set. */
 } mi355_mmvq_args;
 
 MI355_API int mi355_mul_mat_vec_q(const mi355_mmvq_args *args, void *stream);
@@ -167,6 +171,10 @@ typedef struct mi355_qkv_rope_args {
     float freq_base, freq_scale, ext_factor, attn_factor, beta_fast, beta_slow;
     int32_t type_k;                                        /* type of wk when it differs from wq's (8-expert Q4_K_M: wq Q4_K, wk/wv
                                                             * Q8_0); 0 = same as type_qk */
+    /* optional RMS_NORM -> MUL(weight) prologue, as in mi355_glu_matvec_args (k <= 4096 here): the activations are
+     * q8_1((norm_x * rsqrt(mean(norm_x^2) + norm_eps)) * norm_w), act_q / act_ds are not read, norm_out receives the f32
+     * result.  norm_x, norm_w and every output of the launch must not overlap. */
+    const float *norm_x, *norm_w; float *norm_out; float norm_eps;
 } mi355_qkv_rope_args;
 MI355_API int mi355_qkv_rope_matvec(const mi355_qkv_rope_args *args, void *stream);
 
@@ -186,6 +194,12 @@ typedef struct mi355_glu_matvec_args {
     float *gate_out, *up_out;                              /* f32 [m] each, optional */
     float *dst;                                            /* f32 [m], 16-byte aligned */
     int8_t *out_q; float *out_ds;                          /* q8_1 SoA of dst: [m] int8, [m/32][2] f32; optional */
+    /* optional RMS_NORM -> MUL(weight) prologue (build_norm, src/llama-graph.cpp; ggml-cuda/norm.cu rms_norm_f32 + the
+     * weight MUL): when norm_x is set the activations are q8_1((norm_x * rsqrt(mean(norm_x^2) + norm_eps)) * norm_w),
+     * computed by every workgroup for itself, bit-identical to mi355_rms_norm_mul_quant_f32; act_q / act_ds are not
+     * read, norm_out receives the f32 result (k floats).  k <= 8192; the three pointers 16-byte aligned.  norm_x,
+     * norm_w and every output of the launch must not overlap (workgroups finish at different times). */
+    const float *norm_x, *norm_w; float *norm_out; float norm_eps;
 } mi355_glu_matvec_args;
 MI355_API int mi355_glu_matvec(const mi355_glu_matvec_args *args, void *stream);
 

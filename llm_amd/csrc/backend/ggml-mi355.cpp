@@ -1160,7 +1160,8 @@ static int mi355_collect_matvec_group(ggml_cgraph * cgraph, int i, const std::ve
     return cnt;
 }
 
-static void mi355_mul_mat_group(mi355_backend_ctx * ctx, ggml_cgraph * cgraph, const int * members, int cnt) {
+static void mi355_mul_mat_group(mi355_backend_ctx * ctx, ggml_cgraph * cgraph, const int * members, int cnt,
+                                const float * residual = nullptr, float * sum = nullptr) {
     const ggml_tensor * first = ggml_graph_node(cgraph, members[0]);
     const ggml_tensor * src1 = first->src[1];
     const int64_t K = src1->ne[0], N = src1->ne[1];
@@ -1182,7 +1183,70 @@ static void mi355_mul_mat_group(mi355_backend_ctx * ctx, ggml_cgraph * cgraph, c
         a[m].dst = (float *)node->data; a[m].dst_col_stride = (int64_t)(node->nb[1] / sizeof(float));
         a[m].m = w->ne[1]; a[m].k = K; a[m].ncols = (int32_t)N; a[m].nchannels = 1; a[m].ch_ratio = 1;
     }
+    a[0].residual = residual; a[0].sum = sum;      // mat-vec + ADD (cnt == 1)
     MI_CHECK(mi355_mul_mat_vec_q_group(a, cnt, ctx->stream));
+}
+
+// Decode mat-vec followed by the residual ADD (wo / ffn_down of every layer: cur = MUL_MAT(w, x); out = ADD(cur, inp)) in
+// one launch: the lane that stores a result element also stores result + residual.  Per-element, so the ADD may be in
+// place on either operand; both tensors are written unless the sum takes the result's place.  With the ADD gone from
+// it, the norm that follows needs no residual input -- which is what lets it move into the next mat-vec's prologue
+// (mi355_try_fuse_norm_glu_matvec): there every workgroup reads the row, so nothing may update it in that launch.
+static bool mi355_try_fuse_matvec_add(mi355_backend_ctx * ctx, ggml_cgraph * cgraph, int i) {
+    const int n = ggml_graph_n_nodes(cgraph);
+    if (i + 1 >= n || getenv("GGML_MI355_NO_MATVEC_ADD")) return false;
+    ggml_tensor * mm = ggml_graph_node(cgraph, i), * add = ggml_graph_node(cgraph, i + 1);
+    if (add->op != GGML_OP_ADD || add->type != GGML_TYPE_F32) return false;
+    const ggml_tensor * r = add->src[0] == mm ? add->src[1] : (add->src[1] == mm ? add->src[0] : nullptr);
+    if (!r || r == mm || r->type != GGML_TYPE_F32) return false;
+    if (!ggml_are_same_shape(mm, add) || !ggml_are_same_shape(r, add) || !ggml_is_contiguous(add) || !ggml_is_contiguous(r)) return false;
+    const size_t nb = ggml_nbytes(add);
+    if (ranges_overlap(r->data, nb, mm->data, nb)) return false;
+    if (add->data != mm->data && ranges_overlap(add->data, nb, mm->data, nb)) return false;
+    if (add->data != r->data && ranges_overlap(add->data, nb, r->data, nb)) return false;
+    // neither output may land on the activations this mat-vec is about to be given
+    const ggml_tensor * src1 = mm->src[1];
+    if (ranges_overlap(add->data, nb, src1->data, ggml_nbytes(src1))) return false;
+    const int members[1] = {i};
+    mi355_mul_mat_group(ctx, cgraph, members, 1, (const float *)r->data, (float *)add->data);
+    ctx->act_invalidate_if_written(add);
+    return true;
+}
+
+// ---- norm prologue of the fused decode kernels (mi355_glu_matvec / mi355_qkv_rope_matvec with norm_x set) ----------
+// RMS_NORM at node i followed by MUL with the per-feature norm weight at i+1, one token, nothing else reading the bare
+// norm (the checks of mi355_try_fuse_rms_norm_mul): returns the weight tensor, or NULL.
+static const ggml_tensor * decode_norm_pattern(ggml_cgraph * cgraph, int i, const std::vector<char> & done) {
+    const int n = ggml_graph_n_nodes(cgraph);
+    if (i + 1 >= n || done[i] || done[i + 1]) return nullptr;
+    const ggml_tensor * norm = ggml_graph_node(cgraph, i), * mul = ggml_graph_node(cgraph, i + 1);
+    if (norm->op != GGML_OP_RMS_NORM || mul->op != GGML_OP_MUL) return nullptr;
+    const ggml_tensor * w = mul->src[0] == norm ? mul->src[1] : (mul->src[1] == norm ? mul->src[0] : nullptr);
+    if (!w || w == norm) return nullptr;
+    if (w->type != GGML_TYPE_F32 || mul->type != GGML_TYPE_F32 || norm->type != GGML_TYPE_F32 || norm->src[0]->type != GGML_TYPE_F32) return nullptr;
+    if (w->ne[0] != norm->ne[0] || ggml_nrows(w) != 1 || w->nb[0] != sizeof(float)) return nullptr;
+    if (!ggml_are_same_shape(norm, mul) || ggml_nrows(mul) != 1 || !ggml_is_contiguous(mul) || (norm->flags & GGML_TENSOR_FLAG_OUTPUT)) return nullptr;
+    if (norm->src[0]->nb[0] != sizeof(float)) return nullptr;
+    for (int j = i + 2; j < n; j++) {           // any other reader of the un-multiplied norm?
+        const ggml_tensor * t = ggml_graph_node(cgraph, j);
+        for (int s2 = 0; s2 < GGML_MAX_SRC; s2++) if (t->src[s2] == norm || (t->src[s2] && t->src[s2]->view_src == norm)) return nullptr;
+    }
+    return w;
+}
+
+// In such a launch every workgroup reads the norm input x and the weight w while workgroup 0 stores the MUL result and
+// all of them store their share of the other outputs: x, w and the outputs must be pairwise apart (outs[0] is the MUL
+// result), K within the prologue's reach and the three rows 16-byte aligned.
+static bool norm_prologue_ok(const ggml_tensor * x, const ggml_tensor * w, int64_t K, int64_t max_k, const ggml_tensor * const * outs,
+                             const size_t * out_bytes, int n_outs) {
+    if (K > max_k || K % 32 != 0) return false;
+    if (((uintptr_t)x->data | (uintptr_t)w->data | (uintptr_t)outs[0]->data) & 15) return false;
+    const size_t xb = (size_t)K * sizeof(float);
+    for (int o = 0; o < n_outs; o++) {
+        if (ranges_overlap(outs[o]->data, out_bytes[o], x->data, xb) || ranges_overlap(outs[o]->data, out_bytes[o], w->data, xb)) return false;
+        for (int q = 0; q < o; q++) if (ranges_overlap(outs[o]->data, out_bytes[o], outs[q]->data, out_bytes[q])) return false;
+    }
+    return true;
 }
 
 // Feed-forward input of a decode step in one launch.  build_ffn (src/llama-graph.cpp:470-640) spells it as
@@ -1192,7 +1256,7 @@ static void mi355_mul_mat_group(mi355_backend_ctx * ctx, ggml_cgraph * cgraph, c
 // ffn_down then finds in the activation cache.  Every tensor of the chain is still written, so no use analysis is
 // needed -- except that a GLU result placed exactly on top of one of its inputs (ggml-alloc's in-place reuse) simply
 // replaces it.  Grids beyond one round of workgroups (m > 16384) stay on the grouped mat-vec, which is faster there.
-static bool mi355_try_fuse_glu_matvec(mi355_backend_ctx * ctx, ggml_cgraph * cgraph, const int * members) {
+static bool mi355_try_fuse_glu_matvec(mi355_backend_ctx * ctx, ggml_cgraph * cgraph, const int * members, int norm_idx = -1) {
     const int n = ggml_graph_n_nodes(cgraph);
     const int i0 = members[0], i1 = members[1];
     if (i1 != i0 + 1 || i1 + 1 >= n || getenv("GGML_MI355_NO_GLU_MATVEC")) return false;
@@ -1219,26 +1283,64 @@ static bool mi355_try_fuse_glu_matvec(mi355_backend_ctx * ctx, ggml_cgraph * cgr
 
     const size_t qb = align_up((size_t)mi355_act_q_bytes(K, 1), 256), db = align_up((size_t)mi355_act_ds_bytes(K, 1), 256);
     const size_t oqb = align_up((size_t)mi355_act_q_bytes(M, 1), 256), odb = align_up((size_t)mi355_act_ds_bytes(M, 1), 256);
-    char * ws = (char *)ctx->get_scratch(0, qb + db);
-    if (!ctx->act_cached(src1)) {
-        MI_CHECK(mi355_quantize_act((const float *)src1->data, (int8_t *)ws, (float *)(ws + qb), K, 1, 1, 1, src1->nb[1], src1->nb[2], src1->nb[3], ctx->stream));
-        ctx->act_remember(src1);
-    }
-    char * os = (char *)ctx->get_scratch(2, oqb + odb);
     mi355_glu_matvec_args a;
     memset(&a, 0, sizeof(a));
+    char * ws = nullptr, * os;
+    if (norm_idx >= 0) {
+        // RMS_NORM (norm_idx) -> MUL by the norm weight (norm_idx + 1 == src1) in the prologue: every workgroup reads the
+        // norm input, workgroup 0 stores src1 -- so src1, the norm input and the weight must be pairwise apart, and none
+        // of the launch's other outputs may touch the two inputs
+        const ggml_tensor * norm = ggml_graph_node(cgraph, norm_idx);
+        const ggml_tensor * x = norm->src[0];
+        const ggml_tensor * w = src1->src[0] == norm ? src1->src[1] : src1->src[0];
+        // outputs that coincide (a GLU result in place on gate / up) were already reduced to one above
+        const ggml_tensor * outs[4] = {src1, glu, nullptr, nullptr};
+        size_t ob[4] = {ggml_nbytes(src1), ggml_nbytes(glu), 0, 0};
+        int no = 2;
+        if (gate_out) { outs[no] = gate; ob[no++] = ggml_nbytes(gate); }
+        if (up_out)   { outs[no] = up;   ob[no++] = ggml_nbytes(up); }
+        if (!norm_prologue_ok(x, w, K, 8192, outs, ob, no)) return false;
+        a.norm_x = (const float *)x->data; a.norm_w = (const float *)w->data; a.norm_out = (float *)src1->data;
+        memcpy(&a.norm_eps, norm->op_params, sizeof(float));
+        os = (char *)ctx->get_scratch(0, oqb + odb);      // scratch[0] is not read by this launch: the result goes straight in
+    } else {
+        ws = (char *)ctx->get_scratch(0, qb + db);
+        if (!ctx->act_cached(src1)) {
+            MI_CHECK(mi355_quantize_act((const float *)src1->data, (int8_t *)ws, (float *)(ws + qb), K, 1, 1, 1, src1->nb[1], src1->nb[2], src1->nb[3], ctx->stream));
+            ctx->act_remember(src1);
+        }
+        os = (char *)ctx->get_scratch(2, oqb + odb);
+    }
     a.type = (int32_t)gate->src[0]->type; a.glu_op = op;
     a.w_gate = gate->src[0]->data; a.w_up = up->src[0]->data;
     a.gate_row_stride = (int64_t)gate->src[0]->nb[1]; a.up_row_stride = (int64_t)up->src[0]->nb[1];
-    a.m = M; a.k = K; a.act_q = (const int8_t *)ws; a.act_ds = (const float *)(ws + qb);
+    a.m = M; a.k = K;
+    if (ws) { a.act_q = (const int8_t *)ws; a.act_ds = (const float *)(ws + qb); }
     a.gate_out = gate_out; a.up_out = up_out; a.dst = (float *)glu->data;
     a.out_q = (int8_t *)os; a.out_ds = (float *)(os + oqb);
     const int rc = mi355_glu_matvec(&a, ctx->stream);
     if (rc == MI355_E_UNSUPPORTED || rc == MI355_E_ALIGN) return false;
     MI_CHECK(rc);
-    ctx->swap_act_scratch();            // scratch[0] now holds the q8_1 form of the GLU result
+    if (norm_idx < 0) ctx->swap_act_scratch();            // scratch[0] now holds the q8_1 form of the GLU result
     ctx->act_remember(glu);
     return true;
+}
+
+// RMS_NORM -> MUL(norm weight) -> MUL_MAT(ffn_up) MUL_MAT(ffn_gate) -> GLU of a decode token: five nodes, one launch
+// (the norm runs in the prologue of mi355_glu_matvec).  The norm checks are those of mi355_try_fuse_rms_norm_mul.
+static int mi355_collect_matvec_group(ggml_cgraph * cgraph, int i, const std::vector<char> & done, int * members);
+static bool matvec_groupable(const ggml_tensor * node);
+static bool mi355_try_fuse_norm_glu_matvec(mi355_backend_ctx * ctx, ggml_cgraph * cgraph, int i, const std::vector<char> & done) {
+    const int n = ggml_graph_n_nodes(cgraph);
+    if (i + 4 >= n || getenv("GGML_MI355_NO_NORM_GLU")) return false;
+    for (int j = i; j <= i + 4; j++) if (done[j]) return false;
+    if (!decode_norm_pattern(cgraph, i, done)) return false;
+    const ggml_tensor * mul = ggml_graph_node(cgraph, i + 1);
+    const ggml_tensor * m0 = ggml_graph_node(cgraph, i + 2);
+    if (!matvec_groupable(m0) || m0->src[1] != mul) return false;
+    int members[MI355_MMVQ_MAX_GROUP];
+    if (mi355_collect_matvec_group(cgraph, i + 2, done, members) != 2 || members[1] != i + 3) return false;
+    return mi355_try_fuse_glu_matvec(ctx, cgraph, members, i);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1331,7 +1433,9 @@ static bool mi355_try_fuse_moe_router(mi355_backend_ctx * ctx, ggml_cgraph * cgr
     return true;
 }
 
-static bool mi355_try_fuse_qkv_rope(mi355_backend_ctx * ctx, ggml_cgraph * cgraph, int i, std::vector<char> & done) {
+// norm_idx >= 0: nodes norm_idx (RMS_NORM) and norm_idx + 1 (MUL by the norm weight, == x) come right before node i and
+// run in the launch's prologue (attn_norm of every layer): 9 nodes, one launch.
+static bool mi355_try_fuse_qkv_rope(mi355_backend_ctx * ctx, ggml_cgraph * cgraph, int i, std::vector<char> & done, int norm_idx = -1) {
     const int n = ggml_graph_n_nodes(cgraph);
     ggml_tensor * mq = ggml_graph_node(cgraph, i);
     if (!matvec_groupable(mq) || mq->src[1]->ne[1] != 1) return false;
@@ -1403,6 +1507,15 @@ static bool mi355_try_fuse_qkv_rope(mi355_backend_ctx * ctx, ggml_cgraph * cgrap
     char * ws = (char *)ctx->get_scratch(0, qb + db);
     mi355_qkv_rope_args a;
     memset(&a, 0, sizeof(a));
+    if (norm_idx >= 0) {
+        const ggml_tensor * norm = ggml_graph_node(cgraph, norm_idx);
+        const ggml_tensor * w = x->src[0] == norm ? x->src[1] : x->src[0];
+        const ggml_tensor * outs[4] = {x, rq, ck, cv};
+        const size_t ob[4] = {ggml_nbytes(x), ggml_nbytes(rq), ggml_nbytes(ck), ggml_nbytes(cv)};
+        if (!norm_prologue_ok(norm->src[0], w, K, 4096, outs, ob, 4)) return false;
+        a.norm_x = (const float *)norm->src[0]->data; a.norm_w = (const float *)w->data; a.norm_out = (float *)x->data;
+        memcpy(&a.norm_eps, norm->op_params, sizeof(float));
+    }
     a.type_qk = (int32_t)wq->type; a.type_v = (int32_t)wv->type;
     a.type_k = wk->type != wq->type ? (int32_t)wk->type : 0;
     a.wq = wq->data; a.wk = wk->data; a.wv = wv->data;
@@ -1417,7 +1530,7 @@ static bool mi355_try_fuse_qkv_rope(mi355_backend_ctx * ctx, ggml_cgraph * cgrap
     memcpy(&a.attn_factor, rp + 8, 4); memcpy(&a.beta_fast, rp + 9, 4); memcpy(&a.beta_slow, rp + 10, 4);
     // dry validation first (argument errors are reported before anything is launched): an unsupported type pair or
     // shape leaves the graph to the unfused path
-    const bool need_quant = !ctx->act_cached(x);
+    const bool need_quant = norm_idx < 0 && !ctx->act_cached(x);
     if (need_quant) {
         MI_CHECK(mi355_quantize_act((const float *)x->data, (int8_t *)ws, (float *)(ws + qb), K, 1, 1, 1, x->nb[1], x->nb[2], x->nb[3], ctx->stream));
         ctx->act_remember(x);
@@ -1427,6 +1540,7 @@ static bool mi355_try_fuse_qkv_rope(mi355_backend_ctx * ctx, ggml_cgraph * cgrap
     MI_CHECK(rc);
     for (int m = 1; m < 7; m++) done[idx[m]] = 1;
     ctx->act_invalidate_if_written(rq);
+    if (norm_idx >= 0) ctx->act_invalidate_if_written(x);
     return true;
 }
 
@@ -1478,9 +1592,23 @@ static enum ggml_status mi355_backend_graph_compute(ggml_backend_t backend, ggml
                 for (int m = 1; m < cnt; m++) done[members[m]] = 1;
                 continue;
             }
+            if (mi355_try_fuse_matvec_add(ctx, cgraph, i)) {
+                done[i + 1] = 1;
+                continue;
+            }
         }
         // fusion: RMS_NORM followed by MUL with the per-feature norm weight (every llama layer), when the
         // norm result has no other reader in this graph
+        if (fuse && node->op == GGML_OP_RMS_NORM && mi355_try_fuse_norm_glu_matvec(ctx, cgraph, i, done)) {
+            i += 4;
+            continue;
+        }
+        if (fuse && node->op == GGML_OP_RMS_NORM && i + 2 < n && !getenv("GGML_MI355_NO_NORM_QKV") && decode_norm_pattern(cgraph, i, done) &&
+            ggml_graph_node(cgraph, i + 2)->op == GGML_OP_MUL_MAT && ggml_graph_node(cgraph, i + 2)->src[1] == ggml_graph_node(cgraph, i + 1) &&
+            mi355_try_fuse_qkv_rope(ctx, cgraph, i + 2, done, i)) {
+            i += 2;      // the norm, its MUL and wq; the other six nodes are marked done
+            continue;
+        }
         if (node->op == GGML_OP_RMS_NORM && i + 1 < n && mi355_try_fuse_rms_norm_mul(ctx, cgraph, i)) {
             i++;
             continue;

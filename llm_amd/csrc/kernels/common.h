@@ -41,6 +41,20 @@ static __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// sum over the NW waves of a block (sh: NW floats of LDS): wave butterflies, then the wave sums added in wave order
+template <int NW>
+static __device__ __forceinline__ float block_sum_n(float v, float * sh) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sh[wave] = v;
+    __syncthreads();
+    float r = sh[0];
+#pragma unroll
+    for (int i = 1; i < NW; i++) r += sh[i];
+    return r;
+}
+
 // per-byte (x - c) for bytes x in [0,127], c in [0,127]: no borrow can cross a byte
 static __device__ __forceinline__ int sub_bytes(int x, int c4) { return ((x | 0x80808080) - c4) ^ 0x80808080; }
 

@@ -47,18 +47,6 @@ static __device__ __forceinline__ float block_sum(float v, float * sh) {
     __syncthreads();
     return sh[0] + sh[1] + sh[2] + sh[3];
 }
-template <int NW>
-static __device__ __forceinline__ float block_sum_n(float v, float * sh) {
-    v = wave_sum(v);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    __syncthreads();
-    if (lane == 0) sh[wave] = v;
-    __syncthreads();
-    float r = sh[0];
-#pragma unroll
-    for (int i = 1; i < NW; i++) r += sh[i];      // NW = 4: ((sh0 + sh1) + sh2) + sh3, as block_sum
-    return r;
-}
 static __device__ __forceinline__ float block_max(float v, float * sh) {
     v = wave_max(v);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

@@ -300,7 +300,8 @@ struct ActLds { const __attribute__((address_space(3))) int8_t * q; const __attr
 //   wmat: first row of the matrix; row: this wave's row (rows >= m compute on the last row and store nothing)
 template <int TYPE, int NCOLS, bool LDSACT>
 static __device__ __forceinline__ void mmvq_row(const uint8_t * wmat, int64_t w_row_stride, int m, int row, const int8_t * gq,
-                                                const float * gds, int k, float * dch, int64_t dst_col_stride, uint8_t * lds) {
+                                                const float * gds, int k, float * dch, int64_t dst_col_stride, uint8_t * lds,
+                                                const float * res = nullptr, float * sum = nullptr) {
     typedef Unit<TYPE> U;
     const int lane = threadIdx.x & 63;
     const int rowc = row < m ? row : m - 1;           // tail waves re-read the last row, never store
@@ -312,6 +313,10 @@ static __device__ __forceinline__ void mmvq_row(const uint8_t * wmat, int64_t w_
     const int nunits = k / U::ELEMS;
     const int niter  = (nunits + 63) >> 6;
     typename U::Raw cur = U::load(wrow, lane < nunits ? lane : nunits - 1);
+    // residual epilogue (sum = result + res, the ADD node that follows wo / ffn_down): requested now, used at the end
+    float rv[NCOLS];
+#pragma unroll
+    for (int c = 0; c < NCOLS; c++) rv[c] = (res && lane == 0 && row < m) ? res[(int64_t)c * dst_col_stride + row] : 0.0f;
 
     if (LDSACT) {
         // activations -> LDS: [NCOLS][k] int8, then [NCOLS][k/32][2] f32 (columns are contiguous rows of act)
@@ -358,7 +363,11 @@ static __device__ __forceinline__ void mmvq_row(const uint8_t * wmat, int64_t w_
 #pragma unroll
     for (int c = 0; c < NCOLS; c++) {
         const float v = wave_sum(acc[c]);
-        if (lane == 0 && row < m) dch[(int64_t)c * dst_col_stride + row] = v;
+        if (lane == 0 && row < m) {
+            const int64_t o = (int64_t)c * dst_col_stride + row;
+            if (sum != dch) dch[o] = v;             // sum == dch: the ADD is in place on the mat-vec result
+            if (res) sum[o] = v + rv[c];
+        }
     }
 }
 
@@ -394,6 +403,7 @@ struct KGroup {
     int m[MI355_MMVQ_MAX_GROUP], blk_end[MI355_MMVQ_MAX_GROUP];
     const int8_t * act_q; const float * act_ds;
     int k, n;
+    const float * res[MI355_MMVQ_MAX_GROUP]; float * sum[MI355_MMVQ_MAX_GROUP];   // optional residual epilogue per matrix
 };
 
 template <int TYPE, int NCOLS, bool LDSACT>
@@ -407,7 +417,7 @@ mmvq_group_kernel(const KGroup a) {
         if (i + 1 < a.n && (int)blockIdx.x >= a.blk_end[i]) { mi = i + 1; blk0 = a.blk_end[i]; }
     }
     mmvq_row<TYPE, NCOLS, LDSACT>(a.W[mi], a.w_row_stride[mi], a.m[mi], ((int)blockIdx.x - blk0) * 4 + wave, a.act_q, a.act_ds,
-                                  a.k, a.dst[mi], a.dst_col_stride[mi], lds);
+                                  a.k, a.dst[mi], a.dst_col_stride[mi], lds, a.res[mi], a.sum[mi]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -418,16 +428,55 @@ mmvq_group_kernel(const KGroup a) {
 // f16 (or f32) straight into the cache rows.  Row sums, rotation and conversion use the same code as the
 // separate kernels, so the results are bit-identical to the unfused graph.
 // ------------------------------------------------------------------------------------------------
+// RMS_NORM -> MUL(weight) -> q8_1 of one token's row, written straight into the activation area of LDS ([k] int8, then
+// [k/32] {d, sum}): the prologue of the fused decode kernels.  Every workgroup normalises the row for itself (k floats
+// out of L2, hidden behind the first weight loads) with the arithmetic of rms_norm_kernel -- one 16-value chunk per
+// thread, wave butterflies, wave sums added in wave order -- so the values are bit-identical to the separate norm launch
+// (NT = 256 covers rows up to 4096 like its 256-thread form, NT = 512 rows up to 8192 like its 512-thread form; waves
+// without a chunk add 0).  `store`: this workgroup also writes the f32 result (the graph's MUL node).
+template <int NT>
+static __device__ __forceinline__ void norm_to_lds(const float * nx, const float * nw, float * nout, float eps, int k, uint8_t * lds, bool store) {
+    __shared__ float sh[NT / 64];
+    const int nc = k >> 4, c = threadIdx.x;
+    v4f v[4], wv[4];
+    float s = 0.0f;
+    if (c < nc) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            v[q]  = ((const v4f *)nx)[4 * c + q];
+            wv[q] = ((const v4f *)nw)[4 * c + q];
+            s += v[q].x * v[q].x + v[q].y * v[q].y + v[q].z * v[q].z + v[q].w * v[q].w;
+        }
+    }
+    s = block_sum_n<NT / 64>(s, sh);
+    const float scale = 1.0f / sqrtf(s / (float)k + eps);
+    if (c < nc) {
+        float o[16];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            v4f t = v[q] * scale;
+            t = t * wv[q];
+            if (store) ((v4f *)nout)[4 * c + q] = t;
+            o[4 * q] = t.x; o[4 * q + 1] = t.y; o[4 * q + 2] = t.z; o[4 * q + 3] = t.w;
+        }
+        quant16_soa(o, (int8_t *)lds + 16 * c, (float *)(lds + (size_t)k) + (c >> 1) * 2, (c & 1) == 0);
+    }
+    __syncthreads();
+}
+
 template <int TYPE, bool LDSACT>
 static __device__ __forceinline__ void mmvq_row2(const uint8_t * w0, const uint8_t * w1, const int8_t * gq, const float * gds,
-                                                 int k, uint8_t * lds, float & s0, float & s1) {
+                                                 int k, uint8_t * lds, float & s0, float & s1, const float * nx = nullptr,
+                                                 const float * nw = nullptr, float * nout = nullptr, float eps = 0.0f) {
     typedef Unit<TYPE> U;
     const int lane = threadIdx.x & 63;
     const int nunits = k / U::ELEMS;
     const int niter  = (nunits + 63) >> 6;
     const int u0 = lane < nunits ? lane : nunits - 1;
     typename U::Raw c0 = U::load(w0, u0), c1 = U::load(w1, u0);
-    if (LDSACT) {
+    if (LDSACT && nx) {
+        norm_to_lds<256>(nx, nw, nout, eps, k, lds, blockIdx.x == 0);
+    } else if (LDSACT) {
         const int nq = k / 16, nds = k / QK;
         for (int i = threadIdx.x; i < nq; i += 256) ((v4i *)lds)[i] = ((const v4i *)gq)[i];
         v2f * lds_ds = (v2f *)(lds + (size_t)k);
@@ -469,6 +518,7 @@ struct KQkv {
     const int8_t * act_q; const float * act_ds; int k;
     float * q_out; void * k_out; void * v_out; int k_f16, v_f16;
     const int32_t * pos; const float * ff; RopeP rp;
+    const float * nx, * nw; float * nout; float eps;    // optional rms-norm prologue (see norm_to_lds)
 };
 
 template <int TQ, int TK, int TV>
@@ -496,9 +546,9 @@ mmvq_qkv_rope_kernel(const KQkv a) {
     const uint8_t * w = a.W[mat];
     const int64_t rs = a.w_row_stride[mat];
     float s0, s1;
-    if (mat == 0)      mmvq_row2<TQ, true>(w + r0 * rs, w + r1 * rs, a.act_q, a.act_ds, a.k, lds, s0, s1);
-    else if (mat == 1) mmvq_row2<TK, true>(w + r0 * rs, w + r1 * rs, a.act_q, a.act_ds, a.k, lds, s0, s1);
-    else               mmvq_row2<TV, true>(w + r0 * rs, w + r1 * rs, a.act_q, a.act_ds, a.k, lds, s0, s1);
+    if (mat == 0)      mmvq_row2<TQ, true>(w + r0 * rs, w + r1 * rs, a.act_q, a.act_ds, a.k, lds, s0, s1, a.nx, a.nw, a.nout, a.eps);
+    else if (mat == 1) mmvq_row2<TK, true>(w + r0 * rs, w + r1 * rs, a.act_q, a.act_ds, a.k, lds, s0, s1, a.nx, a.nw, a.nout, a.eps);
+    else               mmvq_row2<TV, true>(w + r0 * rs, w + r1 * rs, a.act_q, a.act_ds, a.k, lds, s0, s1, a.nx, a.nw, a.nout, a.eps);
     if (lane == 0) {
         float y0 = s0, y1 = s1;
         if (rot) { y0 = s0 * c - s1 * sn; y1 = s0 * sn + s1 * c; }
@@ -523,6 +573,7 @@ struct KGlu {
     const uint8_t * wg, * wu; int64_t rsg, rsu;
     const int8_t * act_q; const float * act_ds; int k, m, op;
     float * gate_out, * up_out, * dst; int8_t * out_q; float * out_ds;
+    const float * nx, * nw; float * nout; float eps;    // optional rms-norm prologue: activations = q8_1((nx * scale) * nw)
 };
 
 static __device__ __forceinline__ float glu_act(int op, float x) {
@@ -549,7 +600,9 @@ mmvq_glu_kernel(const KGlu a) {
     const int niter  = (nunits + 63) >> 6;
     const int u0 = lane < nunits ? lane : nunits - 1;
     typename U::Raw c0 = U::load(wg, u0), c1 = U::load(wu, u0);
-    {
+    if (a.nx) {
+        norm_to_lds<GLU_THREADS>(a.nx, a.nw, a.nout, a.eps, k, lds, blockIdx.x == 0);
+    } else {
         const int nq = k / 16, nds = k / QK;
         for (int i = threadIdx.x; i < nq; i += GLU_THREADS) ((v4i *)lds)[i] = ((const v4i *)a.act_q)[i];
         v2f * lds_ds = (v2f *)(lds + (size_t)k);
@@ -694,6 +747,7 @@ extern "C" int mi355_mul_mat_vec_q(const mi355_mmvq_args * p, void * stream) {
     if (rc != MI355_OK) return rc;
     if (p->m == 0) return MI355_OK;
     if (p->nchannels == 1 && !p->ids) return mi355_mul_mat_vec_q_group(p, 1, stream);   // one kernel for the plain case
+    if (p->residual || p->sum) return MI355_E_UNSUPPORTED;     // the residual epilogue exists for the plain case only
 
     KArgs a;
     a.W = (const uint8_t *)p->W; a.w_row_stride = p->w_row_stride; a.w_ch_stride = p->w_ch_stride;
@@ -728,6 +782,9 @@ extern "C" int mi355_mul_mat_vec_q_group(const mi355_mmvq_args * p, int n_mats, 
         if (p[i].m == 0) continue;
         a.W[n] = (const uint8_t *)p[i].W; a.w_row_stride[n] = p[i].w_row_stride;
         a.dst[n] = p[i].dst; a.dst_col_stride[n] = p[i].dst_col_stride; a.m[n] = (int)p[i].m;
+        if ((p[i].residual == nullptr) != (p[i].sum == nullptr)) return MI355_E_NULL;
+        if (((uintptr_t)p[i].residual | (uintptr_t)p[i].sum) & 3) return MI355_E_ALIGN;
+        a.res[n] = p[i].residual; a.sum[n] = p[i].sum;
         blocks += (p[i].m + 3) / 4;
         if (blocks > 0x7fffffff) return MI355_E_SHAPE;
         a.blk_end[n] = (int)blocks;
@@ -756,7 +813,10 @@ static int launch_qkv(const KQkv & a, hipStream_t stream) {
 }
 
 extern "C" int mi355_qkv_rope_matvec(const mi355_qkv_rope_args * p, void * stream) {
-    if (!p || !p->wq || !p->wk || !p->wv || !p->act_q || !p->act_ds || !p->q_out || !p->k_out || !p->v_out || !p->pos) return MI355_E_NULL;
+    if (!p || !p->wq || !p->wk || !p->wv || !p->q_out || !p->k_out || !p->v_out || !p->pos) return MI355_E_NULL;
+    if (p->norm_x ? (!p->norm_w || !p->norm_out) : (!p->act_q || !p->act_ds)) return MI355_E_NULL;
+    if (p->norm_x && (p->k > 4096 || p->k % 32 != 0)) return MI355_E_UNSUPPORTED;   // 256-thread workgroups: one 16-value chunk per thread
+    if (p->norm_x && (((uintptr_t)p->norm_x | (uintptr_t)p->norm_w | (uintptr_t)p->norm_out) & 15)) return MI355_E_ALIGN;
     const int type_k = p->type_k ? p->type_k : p->type_qk;      // 0: wk has wq's type
     const int64_t bsa = mi355_blck_size(p->type_qk), bsb = mi355_blck_size(p->type_v), bsk = mi355_blck_size(type_k);
     auto weight = [](int t) { return t == MI355_TYPE_Q4_0 || t == MI355_TYPE_Q8_0 || t == MI355_TYPE_Q4_K || t == MI355_TYPE_Q5_K || t == MI355_TYPE_Q6_K; };
@@ -766,8 +826,9 @@ extern "C" int mi355_qkv_rope_matvec(const mi355_qkv_rope_args * p, void * strea
     if (p->m_q <= 0 || p->m_k <= 0 || p->m_v <= 0 || p->m_q % 8 || p->m_k % 8 || p->m_v % 8 || p->m_q + p->m_k + p->m_v > 0x3fffffff) return MI355_E_SHAPE;
     if (p->head_dim < 2 || (p->head_dim & 1) || p->m_q % p->head_dim || p->m_k % p->head_dim || p->n_dims < 2 || (p->n_dims & 1) || p->n_dims > p->head_dim) return MI355_E_SHAPE;
     if (p->mode != 0 && p->mode != 2) return MI355_E_UNSUPPORTED;
-    if (((uintptr_t)p->act_q & 15) || ((uintptr_t)p->act_ds & 7) || ((uintptr_t)p->q_out & 3) || ((uintptr_t)p->k_out & 3) || ((uintptr_t)p->v_out & 3)) return MI355_E_ALIGN;
-    if (p->k % QK_K == 0 && ((uintptr_t)p->act_ds & 15)) return MI355_E_ALIGN;
+    if (((uintptr_t)p->q_out & 3) || ((uintptr_t)p->k_out & 3) || ((uintptr_t)p->v_out & 3)) return MI355_E_ALIGN;
+    if (!p->norm_x && (((uintptr_t)p->act_q & 15) || ((uintptr_t)p->act_ds & 7))) return MI355_E_ALIGN;
+    if (!p->norm_x && p->k % QK_K == 0 && ((uintptr_t)p->act_ds & 15)) return MI355_E_ALIGN;
     const bool a16 = p->type_qk == MI355_TYPE_Q4_K || p->type_qk == MI355_TYPE_Q5_K, b16 = p->type_v == MI355_TYPE_Q4_K || p->type_v == MI355_TYPE_Q5_K;
     const bool k16 = type_k == MI355_TYPE_Q4_K || type_k == MI355_TYPE_Q5_K;
     if (((uintptr_t)p->wq | (uintptr_t)p->wq_row_stride) & (a16 ? 15 : 1)) return MI355_E_ALIGN;
@@ -783,6 +844,7 @@ extern "C" int mi355_qkv_rope_matvec(const mi355_qkv_rope_args * p, void * strea
     a.q_out = p->q_out; a.k_out = p->k_out; a.v_out = p->v_out;
     a.k_f16 = p->k_out_type == MI355_TYPE_F16; a.v_f16 = p->v_out_type == MI355_TYPE_F16;
     a.pos = p->pos; a.ff = p->freq_factors;
+    a.nx = p->norm_x; a.nw = p->norm_w; a.nout = p->norm_out; a.eps = p->norm_eps;
     a.rp = rope_params(p->n_dims, p->mode, p->head_dim, p->n_ctx_orig, p->freq_base, p->freq_scale, p->ext_factor, p->attn_factor,
                        p->beta_fast, p->beta_slow);
     hipStream_t s = (hipStream_t)stream;
@@ -813,15 +875,22 @@ static int launch_glu_mv(const KGlu & a, hipStream_t stream) {
 }
 
 extern "C" int mi355_glu_matvec(const mi355_glu_matvec_args * p, void * stream) {
-    if (!p || !p->w_gate || !p->w_up || !p->act_q || !p->act_ds || !p->dst) return MI355_E_NULL;
+    if (!p || !p->w_gate || !p->w_up || !p->dst) return MI355_E_NULL;
+    if (p->norm_x ? (!p->norm_w || !p->norm_out) : (!p->act_q || !p->act_ds)) return MI355_E_NULL;
     if ((p->out_q == nullptr) != (p->out_ds == nullptr)) return MI355_E_NULL;
     const int64_t bs = mi355_blck_size(p->type);
     if (bs == 0 || p->type == MI355_TYPE_F32 || p->type == MI355_TYPE_F16 || p->type == MI355_TYPE_Q8_1) return MI355_E_TYPE;
     if (p->glu_op < 0 || p->glu_op > 2) return MI355_E_UNSUPPORTED;
     if (p->m <= 0 || p->m % 32 != 0 || p->m > 0x3fffffff || p->k <= 0 || p->k % bs != 0 || p->k > 0x7fffffff) return MI355_E_SHAPE;
-    if (((uintptr_t)p->act_q & 15) || ((uintptr_t)p->act_ds & 7) || ((uintptr_t)p->dst & 15) || ((uintptr_t)p->gate_out & 3) ||
-        ((uintptr_t)p->up_out & 3) || ((uintptr_t)p->out_q & 3) || ((uintptr_t)p->out_ds & 7)) return MI355_E_ALIGN;
-    if (p->k % QK_K == 0 && ((uintptr_t)p->act_ds & 15)) return MI355_E_ALIGN;
+    if (((uintptr_t)p->dst & 15) || ((uintptr_t)p->gate_out & 3) || ((uintptr_t)p->up_out & 3) || ((uintptr_t)p->out_q & 3) ||
+        ((uintptr_t)p->out_ds & 7)) return MI355_E_ALIGN;
+    if (p->norm_x) {
+        if (p->k > 8192 || p->k % 32 != 0) return MI355_E_UNSUPPORTED;        // one 16-value chunk per thread
+        if (((uintptr_t)p->norm_x | (uintptr_t)p->norm_w | (uintptr_t)p->norm_out) & 15) return MI355_E_ALIGN;
+    } else {
+        if (((uintptr_t)p->act_q & 15) || ((uintptr_t)p->act_ds & 7)) return MI355_E_ALIGN;
+        if (p->k % QK_K == 0 && ((uintptr_t)p->act_ds & 15)) return MI355_E_ALIGN;
+    }
     const bool a16 = p->type == MI355_TYPE_Q4_K || p->type == MI355_TYPE_Q5_K;
     const uintptr_t wal = (uintptr_t)p->w_gate | (uintptr_t)p->gate_row_stride | (uintptr_t)p->w_up | (uintptr_t)p->up_row_stride;
     if (wal & (a16 ? 15 : 1)) return MI355_E_ALIGN;
@@ -830,12 +899,13 @@ extern "C" int mi355_glu_matvec(const mi355_glu_matvec_args * p, void * stream) 
     {
         const char * i0 = (const char *)p->act_q, * i1 = i0 + p->k, * d0 = (const char *)p->act_ds, * d1 = d0 + p->k / QK * 8;
         const char * o0 = (const char *)p->out_q, * o1 = o0 + p->m, * e0 = (const char *)p->out_ds, * e1 = e0 + p->m / QK * 8;
-        if (p->out_q && ((o0 < i1 && i0 < o1) || (o0 < d1 && d0 < o1) || (e0 < i1 && i0 < e1) || (e0 < d1 && d0 < e1))) return MI355_E_SHAPE;
+        if (p->out_q && !p->norm_x && ((o0 < i1 && i0 < o1) || (o0 < d1 && d0 < o1) || (e0 < i1 && i0 < e1) || (e0 < d1 && d0 < e1))) return MI355_E_SHAPE;
     }
     KGlu a;
     a.wg = (const uint8_t *)p->w_gate; a.wu = (const uint8_t *)p->w_up; a.rsg = p->gate_row_stride; a.rsu = p->up_row_stride;
     a.act_q = p->act_q; a.act_ds = p->act_ds; a.k = (int)p->k; a.m = (int)p->m; a.op = p->glu_op;
     a.gate_out = p->gate_out; a.up_out = p->up_out; a.dst = p->dst; a.out_q = p->out_q; a.out_ds = p->out_ds;
+    a.nx = p->norm_x; a.nw = p->norm_w; a.nout = p->norm_out; a.eps = p->norm_eps;
     hipStream_t s = (hipStream_t)stream;
     switch (p->type) {
         case MI355_TYPE_Q4_0: return launch_glu_mv<MI355_TYPE_Q4_0>(a, s);

@@ -34,6 +34,7 @@ class MmvqArgs(C.Structure):
         ("dst", _vp), ("dst_col_stride", _i64), ("dst_ch_stride", _i64),
         ("m", _i64), ("k", _i64), ("ncols", _i32), ("nchannels", _i32), ("ch_ratio", _i32),
         ("ids", _vp), ("ids_stride", _i32), ("ids_nused", _i32), ("act_ne1", _i32), ("n_expert", _i32),
+        ("residual", _vp), ("sum", _vp),
     ]
 
 
@@ -65,6 +66,7 @@ class QkvRopeArgs(C.Structure):
         ("head_dim", _i32), ("n_dims", _i32), ("mode", _i32), ("n_ctx_orig", _i32),
         ("freq_base", C.c_float), ("freq_scale", C.c_float), ("ext_factor", C.c_float), ("attn_factor", C.c_float),
         ("beta_fast", C.c_float), ("beta_slow", C.c_float), ("type_k", C.c_int32),
+        ("norm_x", _vp), ("norm_w", _vp), ("norm_out", _vp), ("norm_eps", C.c_float),
     ]
 
 
@@ -73,7 +75,7 @@ class GluMatvecArgs(C.Structure):
     _fields_ = [
         ("type", _i32), ("glu_op", _i32), ("w_gate", _vp), ("w_up", _vp), ("gate_row_stride", _i64), ("up_row_stride", _i64),
         ("m", _i64), ("k", _i64), ("act_q", _vp), ("act_ds", _vp), ("gate_out", _vp), ("up_out", _vp), ("dst", _vp),
-        ("out_q", _vp), ("out_ds", _vp),
+        ("out_q", _vp), ("out_ds", _vp), ("norm_x", _vp), ("norm_w", _vp), ("norm_out", _vp), ("norm_eps", C.c_float),
     ]
 
 

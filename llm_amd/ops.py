@@ -60,8 +60,9 @@ def dequantize(t, blocks, n):
     return y
 
 
-def mul_mat_vec_q(t, w, m, k, aq, ads, ncols, dst=None, w_row_stride=None):
-    """Decode mat-vec on pre-quantized activations (act rows 0..ncols-1)."""
+def mul_mat_vec_q(t, w, m, k, aq, ads, ncols, dst=None, w_row_stride=None, residual=None, sum_out=None):
+    """Decode mat-vec on pre-quantized activations (act rows 0..ncols-1).  residual ([ncols, m] f32): also store
+    sum_out = result + residual (sum_out may be dst -> only the sum is stored, or residual itself)."""
     _u8(w)
     if dst is None:
         dst = torch.empty((ncols, m), dtype=torch.float32, device=w.device)
@@ -70,6 +71,8 @@ def mul_mat_vec_q(t, w, m, k, aq, ads, ncols, dst=None, w_row_stride=None):
     a.act_q, a.act_ds, a.act_ch_stride = aq.data_ptr(), ads.data_ptr(), 0
     a.dst, a.dst_col_stride, a.dst_ch_stride = dst.data_ptr(), dst.stride(0), 0
     a.m, a.k, a.ncols, a.nchannels, a.ch_ratio = m, k, ncols, 1, 1
+    if residual is not None:
+        a.residual, a.sum = residual.data_ptr(), sum_out.data_ptr()
     K.check(K.lib.mi355_mul_mat_vec_q(a, _stream()), "mi355_mul_mat_vec_q")
     return dst
 
@@ -191,7 +194,7 @@ def rope(x, pos, n_dims, mode, n_ctx_orig=8192, freq_base=10000.0, freq_scale=1.
 
 def qkv_rope_matvec(type_qk, type_v, wq, wk, wv, m_q, m_k, m_v, k, aq, ads, pos, head_dim, n_dims, mode, kv_dtype=torch.float16,
                     n_ctx_orig=8192, freq_base=10000.0, freq_scale=1.0, ext_factor=0.0, attn_factor=1.0, beta_fast=32.0,
-                    beta_slow=1.0, freq_factors=None, type_k=None):
+                    beta_slow=1.0, freq_factors=None, type_k=None, norm=None):
     """Fused decode attention input (mi355_qkv_rope_matvec): -> (q f32 [m_q], k [m_k], v [m_v] of kv_dtype).
     type_k: type of wk when it differs from wq's (type_qk)."""
     q = torch.empty(m_q, dtype=torch.float32, device=wq.device)
@@ -204,7 +207,11 @@ def qkv_rope_matvec(type_qk, type_v, wq, wk, wv, m_q, m_k, m_v, k, aq, ads, pos,
     a.type_k = type_k if type_k is not None and type_k != type_qk else 0
     a.wv_row_stride = B.row_size(type_v, k)
     a.m_q, a.m_k, a.m_v, a.k = m_q, m_k, m_v, k
-    a.act_q, a.act_ds, a.q_out, a.k_out, a.v_out = aq.data_ptr(), ads.data_ptr(), q.data_ptr(), ko.data_ptr(), vo.data_ptr()
+    a.q_out, a.k_out, a.v_out = q.data_ptr(), ko.data_ptr(), vo.data_ptr()
+    if norm is not None:     # (x [k], w [k], eps, out [k]): rms_norm(x) * w computed inside the launch, aq / ads unused
+        a.norm_x, a.norm_w, a.norm_eps, a.norm_out = norm[0].data_ptr(), norm[1].data_ptr(), norm[2], norm[3].data_ptr()
+    else:
+        a.act_q, a.act_ds = aq.data_ptr(), ads.data_ptr()
     a.k_out_type = a.v_out_type = B.F16 if kv_dtype == torch.float16 else B.F32
     a.pos, a.freq_factors = pos.data_ptr(), freq_factors.data_ptr() if freq_factors is not None else None
     a.head_dim, a.n_dims, a.mode, a.n_ctx_orig = head_dim, n_dims, mode, n_ctx_orig
@@ -213,9 +220,10 @@ def qkv_rope_matvec(type_qk, type_v, wq, wk, wv, m_q, m_k, m_v, k, aq, ads, pos,
     return q, ko, vo
 
 
-def glu_matvec(t, w_gate, w_up, m, k, aq, ads, glu_op=2, quant=True, keep=True):
+def glu_matvec(t, w_gate, w_up, m, k, aq, ads, glu_op=2, quant=True, keep=True, norm=None):
     """Fused decode feed-forward input (mi355_glu_matvec): -> (dst f32 [m], gate f32 [m] | None, up f32 [m] | None,
-    out_q int8 [m] | None, out_ds f32 [m/32, 2] | None)."""
+    out_q int8 [m] | None, out_ds f32 [m/32, 2] | None).  norm = (x [k] f32, w [k] f32, eps, out [k] f32): the
+    activations are rms_norm(x) * w, computed inside the launch (aq / ads unused, may be None)."""
     _u8(w_gate); _u8(w_up)
     dev = w_gate.device
     dst = torch.full((m,), float("nan"), dtype=torch.float32, device=dev)
@@ -226,7 +234,11 @@ def glu_matvec(t, w_gate, w_up, m, k, aq, ads, glu_op=2, quant=True, keep=True):
     a = K.GluMatvecArgs()
     a.type, a.glu_op, a.w_gate, a.w_up = t, glu_op, w_gate.data_ptr(), w_up.data_ptr()
     a.gate_row_stride = a.up_row_stride = B.row_size(t, k)
-    a.m, a.k, a.act_q, a.act_ds = m, k, aq.data_ptr(), ads.data_ptr()
+    a.m, a.k = m, k
+    if norm is not None:
+        a.norm_x, a.norm_w, a.norm_eps, a.norm_out = norm[0].data_ptr(), norm[1].data_ptr(), norm[2], norm[3].data_ptr()
+    else:
+        a.act_q, a.act_ds = aq.data_ptr(), ads.data_ptr()
     a.gate_out, a.up_out, a.dst = g.data_ptr() if keep else None, u.data_ptr() if keep else None, dst.data_ptr()
     a.out_q, a.out_ds = oq.data_ptr() if quant else None, ods.data_ptr() if quant else None
     K.check(K.lib.mi355_glu_matvec(a, _stream()), "mi355_glu_matvec")

@@ -356,6 +356,33 @@ def test_qkv_rope_fused_is_bit_identical_to_separate_kernels(ops, tqk, tv, tk, m
     assert torch.equal(kf.view(it), kr.view(it)) and torch.equal(vf.view(it), vr.view(it))
 
 
+@pytest.mark.parametrize("tqk,tv", [(B.Q4_K, B.Q4_K), (B.Q4_K, B.Q6_K), (B.Q8_0, B.Q8_0)])
+@pytest.mark.parametrize("k", [4096, 1024, 96])
+def test_qkv_rope_norm_prologue_equals_separate_norm(ops, tqk, tv, k):
+    """mi355_qkv_rope_matvec with the RMS_NORM -> MUL(weight) prologue == mi355_rms_norm_mul_quant_f32 followed by the
+    plain fused launch, to the bit."""
+    import llm_amd.kernels as K
+    if k % B.BLCK_SIZE[tqk] != 0 or k % B.BLCK_SIZE[tv] != 0:
+        pytest.skip("k not a multiple of the block size")
+    hd, nh, nkv = 128, 8, 2
+    rng = np.random.default_rng(k)
+    x, nw = (dev(rng.standard_normal(sh).astype(np.float32)) for sh in ((1, k), (k,)))
+    wq, wk, wv = (dev(B.random_blocks(t, m, k, seed=s_)) for t, m, s_ in ((tqk, nh * hd, 1), (tqk, nkv * hd, 2), (tv, nkv * hd, 3)))
+    pos = torch.tensor([11], dtype=torch.int32, device="cuda")
+    T, s = K.Tensor.of, torch.cuda.current_stream().cuda_stream
+    n0 = torch.empty_like(x)
+    aq = torch.empty((1, k), dtype=torch.int8, device="cuda")
+    ads = torch.empty((1, k // 32, 2), dtype=torch.float32, device="cuda")
+    K.check(K.lib.mi355_rms_norm_mul_quant_f32(T(x), nw.data_ptr(), T(n0), 1e-5, aq.data_ptr(), ads.data_ptr(), s), "rms_norm_mul_quant")
+    q0, k0, v0 = ops.qkv_rope_matvec(tqk, tv, wq, wk, wv, nh * hd, nkv * hd, nkv * hd, k, aq, ads, pos, hd, 128, 0, freq_base=500000.0)
+    n1 = torch.full_like(x, float("nan"))
+    q1, k1, v1 = ops.qkv_rope_matvec(tqk, tv, wq, wk, wv, nh * hd, nkv * hd, nkv * hd, k, None, None, pos, hd, 128, 0, freq_base=500000.0,
+                                     norm=(x, nw, 1e-5, n1))
+    assert torch.isfinite(q1).all() and float(q1.abs().max()) > 0
+    assert torch.equal(n1.view(torch.int32), n0.view(torch.int32)) and torch.equal(q1.view(torch.int32), q0.view(torch.int32))
+    assert torch.equal(k1.view(torch.int16), k0.view(torch.int16)) and torch.equal(v1.view(torch.int16), v0.view(torch.int16))
+
+
 @pytest.mark.parametrize("t", B.WEIGHT_TYPES)
 @pytest.mark.parametrize("m,k,op,keep", [(14336, 4096, 2, True), (96, 512, 2, False), (352, 8192, 1, True), (64, 1024, 0, True), (28672, 2048, 2, True)])
 def test_glu_matvec_fused_is_bit_identical_to_separate_kernels(ops, t, m, k, op, keep):
@@ -401,6 +428,59 @@ def test_glu_matvec_argument_errors(ops):
     assert K.lib.mi355_glu_matvec(a, None) == -4                       # out_q without out_ds
     a.out_q, a.glu_op = None, 7
     assert K.lib.mi355_glu_matvec(a, None) == -6                       # unknown activation
+
+
+@pytest.mark.parametrize("t", B.WEIGHT_TYPES)
+@pytest.mark.parametrize("m,k,n,mode", [(4096, 4096, 1, "separate"), (4096, 14336, 1, "in_place"), (130, 512, 3, "on_residual"), (7, 1024, 8, "separate")])
+def test_mmvq_residual_epilogue_equals_separate_add(ops, t, m, k, n, mode):
+    """mat-vec + ADD in one launch (mi355_mmvq_args.residual / .sum): the sum equals result + residual to the bit, the
+    result itself is still stored unless the sum takes its place (ADD in place on the mat-vec result)."""
+    rng = np.random.default_rng(m + k + n)
+    x = dev(rng.standard_normal((n, k)).astype(np.float32))
+    aq, ads = ops.quantize_act(x)
+    w = dev(B.random_blocks(t, m, k, seed=21))
+    res = dev(rng.standard_normal((n, m)).astype(np.float32))
+    ref = ops.mul_mat_vec_q(t, w, m, k, aq, ads, n)
+    exp = ref + res
+    dst = torch.full((n, m), float("nan"), device="cuda")
+    if mode == "separate":
+        out = torch.full((n, m), float("nan"), device="cuda")
+        ops.mul_mat_vec_q(t, w, m, k, aq, ads, n, dst=dst, residual=res, sum_out=out)
+        assert torch.equal(dst.view(torch.int32), ref.view(torch.int32))
+    elif mode == "in_place":
+        ops.mul_mat_vec_q(t, w, m, k, aq, ads, n, dst=dst, residual=res, sum_out=dst)
+        out = dst
+    else:
+        out = res.clone()
+        ops.mul_mat_vec_q(t, w, m, k, aq, ads, n, dst=dst, residual=out, sum_out=out)
+        assert torch.equal(dst.view(torch.int32), ref.view(torch.int32))
+    assert torch.isfinite(out).all() and torch.equal(out.view(torch.int32), exp.view(torch.int32))
+
+
+@pytest.mark.parametrize("t", [B.Q4_K, B.Q6_K, B.Q8_0])
+@pytest.mark.parametrize("m,k", [(14336, 4096), (96, 1024), (2816, 8192), (64, 96)])
+def test_glu_matvec_norm_prologue_equals_separate_norm(ops, t, m, k):
+    """mi355_glu_matvec with the RMS_NORM -> MUL(weight) prologue == mi355_rms_norm_mul_quant_f32 followed by the plain
+    mi355_glu_matvec, to the bit (rows of 4096 and fewer: the 256-thread norm kernel; 8192: its 512-thread form)."""
+    import llm_amd.kernels as K
+    if k % B.BLCK_SIZE[t] != 0:
+        pytest.skip("k not a multiple of the block size")
+    rng = np.random.default_rng(m + k)
+    x, nw = (dev(rng.standard_normal(sh).astype(np.float32)) for sh in ((1, k), (k,)))
+    wg, wu = dev(B.random_blocks(t, m, k, seed=31)), dev(B.random_blocks(t, m, k, seed=32))
+    T, s = K.Tensor.of, torch.cuda.current_stream().cuda_stream
+    n0 = torch.empty_like(x)
+    aq = torch.empty((1, k), dtype=torch.int8, device="cuda")
+    ads = torch.empty((1, k // 32, 2), dtype=torch.float32, device="cuda")
+    K.check(K.lib.mi355_rms_norm_mul_quant_f32(T(x), nw.data_ptr(), T(n0), 1e-5, aq.data_ptr(), ads.data_ptr(), s), "rms_norm_mul_quant")
+    d0, g0, u0, q0, s0 = ops.glu_matvec(t, wg, wu, m, k, aq, ads)
+    n1 = torch.full_like(x, float("nan"))
+    d1, g1, u1, q1, s1 = ops.glu_matvec(t, wg, wu, m, k, None, None, norm=(x, nw, 1e-5, n1))
+    assert torch.isfinite(d1).all() and float(d1.abs().max()) > 0
+    assert torch.equal(n1.view(torch.int32), n0.view(torch.int32))
+    for a, b in ((d0, d1), (g0, g1), (u0, u1), (s0, s1)):
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+    assert torch.equal(q0, q1)
 
 
 @pytest.mark.parametrize("rows,n", [(1, 4096), (3, 1024), (8, 8192), (2, 96), (1, 4128)])
