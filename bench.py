@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--no-group", action="store_true", help="one launch per matrix instead of grouped QKV / gate+up launches")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
     ap.add_argument("--no-glu-fuse", action="store_true", help="grouped gate+up mat-vec and a separate quantization instead of mi355_glu_matvec")
+    ap.add_argument("--no-norm-fuse", action="store_true", help="pre-quantized activations instead of the rms-norm prologue / residual epilogue launches")
     return ap.parse_args()
 
 
@@ -156,6 +157,20 @@ def main():
     # is not a launch of its own.  Row-split ranks (N > 1) hold slices of both matrices and keep the grouped mat-vec.
     fuse_glu = world == 1 and not args.no_group and not args.no_glu_fuse
     hidden = torch.empty((1, dims.n_ff), dtype=torch.float32, device="cuda")
+    # ... and, as in the plugin's decode graph, the RMS_NORM -> MUL(weight) -> q8_1 of the layer input runs
+    # in the prologue of the launch that consumes it (wq/wk/wv with rope and the KV-cache store: mi355_qkv_rope_matvec;
+    # gate/up: mi355_glu_matvec) and wo / ffn_down add the residual in their epilogue, so the only activation
+    # quantizations left as launches are the attention output's (attention itself is not part of this bench) and the
+    # final norm's.
+    fuse_norm = fuse_glu and not args.no_norm_fuse and dims.n_embd <= 4096
+    norm_w = torch.rand(dims.n_embd, device="cuda", generator=gen) + 0.5
+    normed = torch.empty((1, dims.n_embd), dtype=torch.float32, device="cuda")
+    resid = torch.randn((1, dims.n_embd), device="cuda", generator=gen)
+    resid_out = torch.empty((1, dims.n_embd), dtype=torch.float32, device="cuda")
+    kv_dim = dims.n_head_kv * dims.head_dim
+    k_row = torch.empty(kv_dim, dtype=torch.float16, device="cuda")
+    v_row = torch.empty(kv_dim, dtype=torch.float16, device="cuda")
+    pos = torch.tensor([127], dtype=torch.int32, device="cuda")
 
     def glu_arg(ig, iu):
         mg = mats[ig]
@@ -167,6 +182,25 @@ def main():
         a.m, a.k, a.act_q, a.act_ds = mg.m, mg.k, aq.data_ptr(), ads.data_ptr()
         a.gate_out, a.up_out, a.dst = outs[ig].data_ptr(), outs[iu].data_ptr(), hidden.data_ptr()
         a.out_q, a.out_ds = oq.data_ptr(), ods.data_ptr()
+        if fuse_norm:
+            a.act_q = a.act_ds = None
+            a.norm_x, a.norm_w, a.norm_out, a.norm_eps = xs[mg.k].data_ptr(), norm_w.data_ptr(), normed.data_ptr(), 1e-5
+        return a
+
+    def qkv_arg(iq, ik, iv):
+        mq, mk, mv = mats[iq], mats[ik], mats[iv]
+        a = K.QkvRopeArgs()
+        a.type_qk, a.type_v, a.type_k = mq.type, mv.type, 0
+        a.wq, a.wk, a.wv = weights[iq].data_ptr(), weights[ik].data_ptr(), weights[iv].data_ptr()
+        a.wq_row_stride = a.wk_row_stride = B.row_size(mq.type, mq.k)
+        a.wv_row_stride = B.row_size(mv.type, mv.k)
+        a.m_q, a.m_k, a.m_v, a.k = mq.m, mk.m, mv.m, mq.k
+        a.q_out, a.k_out, a.v_out = outs[iq].data_ptr(), k_row.data_ptr(), v_row.data_ptr()
+        a.k_out_type = a.v_out_type = B.F16
+        a.pos, a.freq_factors = pos.data_ptr(), None
+        a.head_dim, a.n_dims, a.mode, a.n_ctx_orig = dims.head_dim, dims.head_dim, 0, 8192
+        a.freq_base, a.freq_scale, a.ext_factor, a.attn_factor, a.beta_fast, a.beta_slow = 500000.0, 1.0, 0.0, 1.0, 32.0, 1.0
+        a.norm_x, a.norm_w, a.norm_out, a.norm_eps = xs[mq.k].data_ptr(), norm_w.data_ptr(), normed.data_ptr(), 1e-5
         return a
 
     plan = []      # (quantize_k or None, ctypes array of MmvqArgs | GluMatvecArgs, n (0 = fused glu), [matrix indices])
@@ -175,6 +209,9 @@ def main():
         need_q = mt.k if mt.src != last_src else None   # one q8_1 quantization per distinct activation, as in the graph
         last_src = mt.src
         prev = plan[-1] if plan else None
+        if fuse_norm and mt.src == "attn_norm" and prev and mats[prev[3][0]].src == "attn_norm" and need_q is None:
+            prev[3].append(i)        # wq, wk, wv of a layer: one mi355_qkv_rope_matvec launch, whatever wv's type
+            continue
         if (not args.no_group and need_q is None and prev and len(prev[3]) < 4 and mats[prev[3][0]].type == mt.type
                 and mats[prev[3][0]].k == mt.k and mats[prev[3][0]].src == mt.src):
             prev[3].append(i)
@@ -201,8 +238,14 @@ def main():
         names = [mats[i].name.split(".")[-1] for i in p[3]]
         if fuse_glu and names == ["ffn_gate", "ffn_up"] and mats[p[3][0]].m % 32 == 0 and mats[p[3][0]].m <= 16384:
             p[1], p[2] = glu_arg(*p[3]), 0
+            if fuse_norm:
+                p[0] = None
+        elif fuse_norm and names == ["attn_q", "attn_k", "attn_v"]:
+            p[0], p[1], p[2] = None, qkv_arg(*p[3]), -1
         else:
             arr = (K.MmvqArgs * len(p[3]))(*[mm_arg(mats[i], weights[i], outs[i]) for i in p[3]])
+            if fuse_norm and names in (["attn_output"], ["ffn_down"]):       # + residual ADD in the epilogue
+                arr[0].residual, arr[0].sum = resid.data_ptr(), resid_out.data_ptr()
             p[1], p[2] = arr, len(p[3])
     for prev, p in zip(plan, plan[1:]):
         if prev[2] == 0 and mats[p[3][0]].src == "ffn_act":
@@ -216,6 +259,8 @@ def main():
                 quantize(need_q, stream)
             if n == 0:
                 K.check(K.lib.mi355_glu_matvec(arr, stream), "mi355_glu_matvec")
+            elif n < 0:
+                K.check(K.lib.mi355_qkv_rope_matvec(arr, stream), "mi355_qkv_rope_matvec")
             else:
                 K.check(K.lib.mi355_mul_mat_vec_q_group(arr, n, stream), "mi355_mul_mat_vec_q_group")
             if world > 1:
@@ -311,7 +356,8 @@ def main():
             "dtype": "int8", "data": "synthetic",
             "config": {"workload": f"{dims.name} Q4_K_M decode mat-vec sweep: 225 weight matrices "
                                    f"({MS.decode_weight_bytes(dims) / 1e9:.3f} GB, Q4_K + Q6_K per llama.cpp's recipe) streamed once per "
-                                   "step + q8_1 activation quantization, random-init GGUF blocks",
+                                   "step, in the launches the plugin uses for a decode token (rms-norm + q8_1 in the prologue of the fused "
+                                   "QKV+rope and gate/up+GLU launches, residual add in the wo / down epilogue), random-init GGUF blocks",
                        "parallelism": "single GPU" if world == 1 else f"row split x{world} + RCCL all-gather",
                        "launch": "hipGraph replay" if use_graph else "eager",
                        "launches_per_step": n_launches, "grouped": not args.no_group,

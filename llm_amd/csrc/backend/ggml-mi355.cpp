@@ -18,6 +18,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -1560,6 +1561,23 @@ static enum ggml_status mi355_backend_graph_compute(ggml_backend_t backend, ggml
         }
     }
     std::vector<char> done(n, 0);    // nodes already computed by a hoisting fusion
+    static const bool time_graph = getenv("GGML_MI355_TIME_GRAPH") != nullptr;   // diagnostics: host time spent issuing a graph
+    struct host_timer {
+        bool on; int n; std::chrono::steady_clock::time_point t0;
+        ~host_timer() {
+            if (!on) return;
+            static double tot = 0, between = 0; static long calls = 0;
+            static std::chrono::steady_clock::time_point last_end;
+            const auto now = std::chrono::steady_clock::now();
+            tot += std::chrono::duration<double, std::micro>(now - t0).count();
+            if (calls) between += std::chrono::duration<double, std::micro>(t0 - last_end).count();
+            last_end = now; calls++;
+            if (calls % 64 == 0) {
+                fprintf(stderr, "[mi355] graph_compute host time: %.1f us avg over 64 calls (%d nodes), %.1f us between calls\n", tot / 64, n, between / 64);
+                tot = between = 0;
+            }
+        }
+    } timer{time_graph, n, std::chrono::steady_clock::now()};
     for (int i = 0; i < n; i++) {
         ggml_tensor * node = ggml_graph_node(cgraph, i);
         if (done[i]) continue;
