@@ -76,6 +76,50 @@ static __device__ __forceinline__ float row16_sum(float v) {
     return v;
 }
 
+// One lane's 8 consecutive features of a K or V row.  f16 rows stay packed (4 VGPRs): the K dot product then runs on
+// v_dot2_f32_f16 against the query rounded to f16 -- which is what the CPU oracle does too (it converts Q to the K
+// type's vec_dot type, ops.cpp:8061-8066) -- and V feeds the mixed-precision FMA (f16 operand, f32 accumulate) with no
+// conversion instruction.  Quantized rows are dequantized to f32 when loaded.
+typedef _Float16 fa_half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 fa_half2 __attribute__((ext_vector_type(2)));
+template <int TYPE> struct FaRow {
+    float f[8];
+    __device__ __forceinline__ void load(const char * row, int j) { load8<TYPE>(row, j, f); }
+    __device__ __forceinline__ float get(int i) const { return f[i]; }
+};
+template <> struct FaRow<MI355_TYPE_F16> {
+    fa_half8 h;
+    __device__ __forceinline__ void load(const char * row, int j) { h = *(const fa_half8 *)(row + j * 16); }
+    __device__ __forceinline__ float get(int i) const { return (float)h[i]; }
+};
+// the query features of one head in the form the K type's dot product wants
+template <int TK> struct FaQ {
+    float f[8];
+    __device__ __forceinline__ void set(const v4f q0, const v4f q1) { f[0] = q0.x; f[1] = q0.y; f[2] = q0.z; f[3] = q0.w; f[4] = q1.x; f[5] = q1.y; f[6] = q1.z; f[7] = q1.w; }
+    __device__ __forceinline__ float dot(const FaRow<TK> & k) const {
+        float t = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 8; i++) t += f[i] * k.f[i];
+        return t;
+    }
+};
+template <> struct FaQ<MI355_TYPE_F16> {
+    fa_half8 h;
+    __device__ __forceinline__ void set(const v4f q0, const v4f q1) {
+        h[0] = (_Float16)q0.x; h[1] = (_Float16)q0.y; h[2] = (_Float16)q0.z; h[3] = (_Float16)q0.w;
+        h[4] = (_Float16)q1.x; h[5] = (_Float16)q1.y; h[6] = (_Float16)q1.z; h[7] = (_Float16)q1.w;
+    }
+    __device__ __forceinline__ float dot(const FaRow<MI355_TYPE_F16> & k) const {
+        float t = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const fa_half2 a = {h[2 * i], h[2 * i + 1]}, b = {k.h[2 * i], k.h[2 * i + 1]};
+            t = __builtin_amdgcn_fdot2(a, b, t, false);
+        }
+        return t;
+    }
+};
+
 static __device__ __forceinline__ float alibi_slope(const FArgs & a, uint32_t h) {
     if (!(a.max_bias > 0.0f)) return 1.0f;
     return h < a.n_head_log2 ? powf(a.m0, h + 1) : powf(a.m1, 2 * (h - a.n_head_log2) + 1);
@@ -124,7 +168,7 @@ fattn_vec_kernel(const FArgs a) {
     const int i3 = blockIdx.z / a.nsplit, split = blockIdx.z % a.nsplit;
 
     // this lane's 8 query features for each of the R heads
-    float qf[R][8];
+    FaQ<TK> qf[R];
     float slope[R];
     const char * mrow[R];
 #pragma unroll
@@ -132,8 +176,7 @@ fattn_vec_kernel(const FArgs a) {
         const int h = h0 + r < hk * ratio + ratio ? h0 + r : hk * ratio + ratio - 1; // clamp (ratio % R != 0)
         const float * qp = (const float *)(a.q + iq * a.q_nb1 + h * a.q_nb2 + i3 * a.q_nb3) + j * 8;
         const v4f q0 = *(const v4f *)qp, q1 = *(const v4f *)(qp + 4);
-        qf[r][0] = q0.x; qf[r][1] = q0.y; qf[r][2] = q0.z; qf[r][3] = q0.w;
-        qf[r][4] = q1.x; qf[r][5] = q1.y; qf[r][6] = q1.z; qf[r][7] = q1.w;
+        qf[r].set(q0, q1);
         slope[r] = alibi_slope(a, (uint32_t)h);
         mrow[r] = a.mask ? a.mask + iq * a.m_nb1 + (h % a.m_ne2) * a.m_nb2 + (i3 % a.m_ne3) * a.m_nb3 : nullptr;
     }
@@ -152,43 +195,74 @@ fattn_vec_kernel(const FArgs a) {
     const int kv0 = split * per, kv1 = kv0 + per < a.n_kv ? kv0 + per : a.n_kv;
     const float scale = a.logit_softcap != 0.0f ? a.scale / a.logit_softcap : a.scale;
 
-    // software pipeline: the K/V rows of step i+1 are requested before step i is consumed
-    float kf[8], vf[8], kn[8], vn[8];
+    // software pipeline: the K/V rows of step i+1 are requested before step i is consumed.  A step is U = 2 rows per lane
+    // group (rows ic and ic + G): twice the loads in flight per round trip, and one rescale of the running sums per two rows.
+    constexpr int U = 2;
+    FaRow<TK> kf[U], kn[U];
+    FaRow<TV> vf[U], vn[U];
     int ic = kv0 + g;
     if (ic < kv1) {
-        load8<TK>(kbase + (int64_t)ic * a.k_nb1, j, kf);
-        load8<TV>(vbase + (int64_t)ic * a.v_nb1, j, vf);
-    }
-    for (; ic < kv1; ic += G) {
-        const int in = ic + G < kv1 ? ic + G : ic;   // the last step re-reads its own row
-        load8<TK>(kbase + (int64_t)in * a.k_nb1, j, kn);
-        load8<TV>(vbase + (int64_t)in * a.v_nb1, j, vn);
-        float mv[R];
 #pragma unroll
-        for (int r = 0; r < R; r++) mv[r] = mrow[r] ? slope[r] * __half2float(((const __half *)mrow[r])[ic]) : 0.0f;
+        for (int u = 0; u < U; u++) {
+            const int iu = ic + u * G < kv1 ? ic + u * G : ic;     // past the end: re-read a valid row, ignored below
+            kf[u].load(kbase + (int64_t)iu * a.k_nb1, j);
+            vf[u].load(vbase + (int64_t)iu * a.v_nb1, j);
+        }
+    }
+    for (; ic < kv1; ic += U * G) {
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int in = ic + (U + u) * G < kv1 ? ic + (U + u) * G : ic;   // the last step re-reads its own row
+            kn[u].load(kbase + (int64_t)in * a.k_nb1, j);
+            vn[u].load(vbase + (int64_t)in * a.v_nb1, j);
+        }
+        float mv[R][U];
 #pragma unroll
         for (int r = 0; r < R; r++) {
-            float s = 0.0f;
 #pragma unroll
-            for (int i = 0; i < 8; i++) s += qf[r][i] * kf[i];
-            if constexpr (LPR == 16) s = row16_sum(s);
-            else {
-#pragma unroll
-                for (int o = 1; o < LPR; o <<= 1) s += __shfl_xor(s, o, 64);
+            for (int u = 0; u < U; u++) {
+                const int iu = ic + u * G;
+                mv[r][u] = iu >= kv1 ? -INFINITY : (mrow[r] ? slope[r] * __half2float(((const __half *)mrow[r])[iu]) : 0.0f);
             }
-            s *= scale;
-            if (a.logit_softcap != 0.0f) s = a.logit_softcap * tanhf(s);
-            if (mv[r] == -INFINITY) continue;      // masked out (ops.cpp:8105-8108); uniform inside the lane group
-            s += mv[r];
-            const float mn = fmaxf(m[r], s);
-            const float corr = expf(m[r] - mn), p = expf(s - mn);
-            m[r] = mn;
-            l[r] = l[r] * corr + p;
-#pragma unroll
-            for (int i = 0; i < 8; i++) acc[r][i] = acc[r][i] * corr + p * vf[i];
         }
 #pragma unroll
-        for (int i = 0; i < 8; i++) { kf[i] = kn[i]; vf[i] = vn[i]; }
+        for (int r = 0; r < R; r++) {
+            float s[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                float t = qf[r].dot(kf[u]);
+                if constexpr (LPR == 16) t = row16_sum(t);
+                else {
+#pragma unroll
+                    for (int o = 1; o < LPR; o <<= 1) t += __shfl_xor(t, o, 64);
+                }
+                t *= scale;
+                if (a.logit_softcap != 0.0f) t = a.logit_softcap * tanhf(t);
+                s[u] = mv[r][u] == -INFINITY ? -INFINITY : t + mv[r][u];   // masked out (ops.cpp:8105-8108) or past the end
+            }
+            float mn = m[r];
+#pragma unroll
+            for (int u = 0; u < U; u++) mn = fmaxf(mn, s[u]);
+            if (mn == -INFINITY) continue;          // nothing seen yet and both rows masked; uniform inside the lane group
+            const float corr = __expf(m[r] - mn);   // m == -inf: 0.  (v_exp_f32: relative error ~1e-6, far inside the op's budget)
+            float p[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) p[u] = __expf(s[u] - mn);
+            m[r] = mn;
+            float ls = l[r] * corr;
+#pragma unroll
+            for (int u = 0; u < U; u++) ls += p[u];
+            l[r] = ls;
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                float t = acc[r][i] * corr;
+#pragma unroll
+                for (int u = 0; u < U; u++) t = __builtin_fmaf(p[u], vf[u].get(i), t);
+                acc[r][i] = t;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) { kf[u] = kn[u]; vf[u] = vn[u]; }
     }
 
     // merge: first the lane groups of each wave (xor-shuffles), then the waves through LDS
@@ -247,9 +321,13 @@ fattn_vec_kernel(const FArgs a) {
     __syncthreads();
     if (tid == 0) {
         int * cnt = a.counters + ((size_t)i3 * a.n_q + iq) * gridDim.x + blockIdx.x;
-        const int old = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        // release only: the acquire half (cache invalidation) is paid by the one workgroup that goes on to merge
+        const int old = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         last_flag = old == a.nsplit - 1;
-        if (last_flag) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-armed for the next launch
+        if (last_flag) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-armed for the next launch
+        }
     }
     __syncthreads();
     if (!last_flag) return;
@@ -497,8 +575,12 @@ static int launch_vec(const FArgs & a, hipStream_t s) {
 // chain: Llama-3-8B decode at n_kv 256 (GQA 4) 390.9 t/s with 4, 405.7 with 2, 394.6 with 1; Llama-3-70B (GQA 8) 78.9
 // with 8, 82.7 with 4.
 static int fa_heads_per_wg(int64_t ratio, int64_t d, int64_t n_kv) {
+    // GQA 4, f16, 8 KV heads (tools/bench_fattn.py), 2 / 4 heads per workgroup: n_kv 4096 17.5 / 20.1 us, 16384 29.7 / 28.5,
+    // 65536 83.4 / 60.7 (4.4 TB/s): with 2 every K/V row is fetched by two workgroups, which long contexts cannot afford
     if (n_kv < 2048) return ratio >= 2 ? 2 : 1;
-    return ratio >= 8 && d <= 128 ? 8 : ratio >= 4 ? 4 : ratio >= 2 ? 2 : 1;
+    if (ratio >= 8) return d <= 128 ? 8 : 4;
+    if (ratio >= 4) return n_kv >= 16384 ? 4 : 2;
+    return ratio >= 2 ? 2 : 1;
 }
 
 template <int D, int TK, int TV>
@@ -583,9 +665,18 @@ int mi355_flash_attn_ext_quant(const mi355_fattn_args * p, void * workspace, int
     const int64_t n_counters = (int64_t)p->ne3 * p->n_q * p->n_head_kv * ((ratio + rr - 1) / rr);
     if (workspace && workspace_bytes > WS_HEADER && ((uintptr_t)workspace & 15) == 0 && n_counters * 4 <= WS_HEADER &&
         base_wgs < 512 && p->n_kv >= 4 * G) {
+        // Every slice costs a partial store, a device-scope arrival and a share of the merge, so more slices only pay
+        // while they shorten the chain of round trips: one round trip (G rows) per slice up to 8 slices, then slices of
+        // >= 4 round trips, and never more than one workgroup per CU in total.  Measured, 8 KV heads x GQA 4, f16
+        // (tools/bench_fattn.py; us with the former "one round trip per slice, up to 64 slices" rule -> now):
+        // n_kv 1024 21.0 -> 12.6, 4096 31.2 -> 19.3, 16384 51.2 -> 36.3, 65536 104.8 -> 103; twice the workgroups (two per
+        // CU) is slower at every length, also with the cheaper inner loop (65536, 4 heads per workgroup: 60.7 -> 75.8).
         int64_t want = (p->n_kv + G - 1) / G;
-        const int64_t fill = 2048 / (base_wgs > 0 ? base_wgs : 1);   // no point beyond ~8 workgroups per CU
-        if (want > fill) want = fill;
+        const int64_t hgroups = (ratio + rr - 1) / rr;
+        const int64_t fill = 256 / (base_wgs * hgroups > 0 ? base_wgs * hgroups : 1);
+        const int64_t chain4 = (p->n_kv + 4 * G - 1) / (4 * G);
+        if (want > 8) want = chain4 > 8 ? chain4 : 8;
+        if (want > fill) want = fill > 8 ? fill : 8;
         if (want > 64) want = 64;
         const int64_t per = (int64_t)p->ne3 * p->n_q * p->n_head * (p->d + 2) * (int64_t)sizeof(float);
         if (per > 0 && want * per > workspace_bytes - WS_HEADER) want = (workspace_bytes - WS_HEADER) / per;
