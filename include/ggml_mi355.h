@@ -37,6 +37,7 @@
  *   GGML_MI355_MMQ_INT8=1    prefill MUL_MAT on the int8-MFMA tile kernel (the reference's MMQ arithmetic) instead of
  *                            the dequantize-in-LDS bf16 GEMM
  *   GGML_MI355_DUMP_GRAPH=1  print the node list of every graph handed to graph_compute
+ *   GGML_MI355_TIME_GRAPH=1  every 64 calls, print the host time spent inside graph_compute and between calls
  *   GGML_MI355_VIRTUAL_DEVICES=n   expose n ggml devices mapped round-robin onto the physical GPUs (tests the row-split
  *                            path on a one-GPU machine)
  */
