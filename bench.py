@@ -356,8 +356,9 @@ def main():
             "dtype": "int8", "data": "synthetic",
             "config": {"workload": f"{dims.name} Q4_K_M decode mat-vec sweep: 225 weight matrices "
                                    f"({MS.decode_weight_bytes(dims) / 1e9:.3f} GB, Q4_K + Q6_K per llama.cpp's recipe) streamed once per "
-                                   "step, in the launches the plugin uses for a decode token (rms-norm + q8_1 in the prologue of the fused "
-                                   "QKV+rope and gate/up+GLU launches, residual add in the wo / down epilogue), random-init GGUF blocks",
+                                   "step" + (", in the launches the plugin uses for a decode token (rms-norm + q8_1 in the prologue of the fused "
+                                             "QKV+rope and gate/up+GLU launches, residual add in the wo / down epilogue)" if fuse_norm else
+                                             " + q8_1 activation quantization") + ", random-init GGUF blocks",
                        "parallelism": "single GPU" if world == 1 else f"row split x{world} + RCCL all-gather",
                        "launch": "hipGraph replay" if use_graph else "eager",
                        "launches_per_step": n_launches, "grouped": not args.no_group,
