@@ -31,7 +31,19 @@ struct FArgs {
     float * part; // [ne3][n_q][n_head][nsplit][D + 2] when nsplit > 1
     int * counters; // [ne3][n_q][gridDim.x] arrival counters of the KV slices (all zero between launches)
     int8_t * act_q; float * act_ds; // optional: q8_1 form of dst (token row = all heads), written with the result
+#ifdef FA_STAMPS
+    long long * stamps;             // diagnostic build only (lab/fattn_stamps.hip): [workgroup][8] s_memtime / s_memrealtime
+#endif
 };
+
+#ifdef FA_STAMPS
+#define FA_STAMP(i) do { if (threadIdx.x == 0) st_[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#define FA_STAMP_FLUSH() do { if (threadIdx.x == 0 && a.stamps) { st_[6] = __builtin_amdgcn_s_memrealtime(); \
+        long long * o_ = a.stamps + ((int64_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8; for (int i_ = 0; i_ < 8; i_++) o_[i_] = st_[i_]; } } while (0)
+#else
+#define FA_STAMP(i) do { } while (0)
+#define FA_STAMP_FLUSH() do { } while (0)
+#endif
 
 // 8 consecutive features of a K/V row as f32
 template <int TYPE>
@@ -157,8 +169,13 @@ fattn_vec_kernel(const FArgs a) {
     constexpr int LPR = D / 8;               // lanes per KV row
     constexpr int G   = FA_THREADS / LPR;    // row groups per workgroup
     constexpr int NW  = FA_THREADS / 64;     // waves
-    extern __shared__ __attribute__((aligned(16))) float sm[]; // [R][NW][D + 2]
+    extern __shared__ __attribute__((aligned(16))) float sm[]; // [R][G][D + 2], [R][G], [R][2]
     const int tid = threadIdx.x;
+#ifdef FA_STAMPS
+    long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    st_[7] = __builtin_amdgcn_s_memrealtime();
+#endif
+    FA_STAMP(0);
     const int j = tid % LPR, g = tid / LPR;
     const int ratio = a.n_head / a.n_head_kv;
     const int hgroups = (ratio + R - 1) / R;      // workgroups per kv head
@@ -209,6 +226,7 @@ fattn_vec_kernel(const FArgs a) {
             vf[u].load(vbase + (int64_t)iu * a.v_nb1, j);
         }
     }
+    FA_STAMP(1);
     for (; ic < kv1; ic += U * G) {
 #pragma unroll
         for (int u = 0; u < U; u++) {
@@ -265,26 +283,33 @@ fattn_vec_kernel(const FArgs a) {
         for (int u = 0; u < U; u++) { kf[u] = kn[u]; vf[u] = vn[u]; }
     }
 
-    // merge: first the lane groups of each wave (xor-shuffles), then the waves through LDS
-    const int wave = tid >> 6;
+    FA_STAMP(2);
+    // merge of the G lane groups through LDS: every group stores its (acc, m, l); one wave per head turns the G maxima
+    // into weights exp(m_g - M) and the total L; then one thread per (head, feature) adds up the weighted accumulators.
+    // (A butterfly of xor-shuffles over the groups of a wave followed by a merge of the waves cost 2.2 us here -- 40
+    // ds_bpermute and 16 expf in dependent chains; this is two barriers and 2 x G LDS reads per output.)
+    float * wsm = sm + (size_t)R * G * (D + 2);          // [R][G] weights, then [R][2] {M, L}
+    float * mlsm = wsm + R * G;
 #pragma unroll
     for (int r = 0; r < R; r++) {
+        float * slot = sm + ((size_t)r * G + g) * (D + 2);
+        *(v4f *)(slot + j * 8)     = v4f{acc[r][0], acc[r][1], acc[r][2], acc[r][3]};
+        *(v4f *)(slot + j * 8 + 4) = v4f{acc[r][4], acc[r][5], acc[r][6], acc[r][7]};
+        if (j == 0) { slot[D] = m[r]; slot[D + 1] = l[r]; }
+    }
+    __syncthreads();
+    {
+        const int wave = tid >> 6, lane = tid & 63;
+        for (int r = wave; r < R; r += NW) {
+            const float * slot = sm + ((size_t)r * G + (lane < G ? lane : 0)) * (D + 2);
+            const float mg = lane < G ? slot[D] : -INFINITY, lg = lane < G ? slot[D + 1] : 0.0f;
+            float M = mg;
 #pragma unroll
-        for (int o = LPR; o < 64; o <<= 1) {
-            const float mo = __shfl_xor(m[r], o, 64), lo = __shfl_xor(l[r], o, 64);
-            const float mn = fmaxf(m[r], mo);
-            const float w0 = m[r] == -INFINITY ? 0.0f : expf(m[r] - mn);
-            const float w1 = mo == -INFINITY ? 0.0f : expf(mo - mn);
-            l[r] = l[r] * w0 + lo * w1;
-#pragma unroll
-            for (int i = 0; i < 8; i++) acc[r][i] = acc[r][i] * w0 + __shfl_xor(acc[r][i], o, 64) * w1;
-            m[r] = mn;
-        }
-        if ((tid & 63) < LPR) {
-            float * slot = sm + ((size_t)r * NW + wave) * (D + 2);
-#pragma unroll
-            for (int i = 0; i < 8; i++) slot[j * 8 + i] = acc[r][i];
-            if (j == 0) { slot[D] = m[r]; slot[D + 1] = l[r]; }
+            for (int o = 32; o > 0; o >>= 1) M = fmaxf(M, __shfl_xor(M, o, 64));
+            const float w = mg == -INFINITY ? 0.0f : __expf(mg - M);
+            const float L = wave_sum(lg * w);
+            if (lane < G) wsm[r * G + lane] = w;
+            if (lane == 0) { mlsm[2 * r] = M; mlsm[2 * r + 1] = L; }
         }
     }
     __syncthreads();
@@ -292,16 +317,12 @@ fattn_vec_kernel(const FArgs a) {
         const int r = idx / D, d = idx % D;
         const int h = h0 + r;
         if (h >= hk * ratio + ratio) continue;
-        const float * base = sm + (size_t)r * NW * (D + 2);
-        float M = -INFINITY;
-        for (int gg = 0; gg < NW; gg++) M = fmaxf(M, base[gg * (D + 2) + D]);
-        float L = 0.0f, O = 0.0f;
-        for (int gg = 0; gg < NW; gg++) {
-            const float mg = base[gg * (D + 2) + D];
-            const float w = mg == -INFINITY ? 0.0f : expf(mg - M);
-            L += base[gg * (D + 2) + D + 1] * w;
-            O += base[gg * (D + 2) + d] * w;
-        }
+        const float * base = sm + (size_t)r * G * (D + 2) + d;
+        const float * wr = wsm + r * G;
+        float O = 0.0f;
+#pragma unroll 8
+        for (int gg = 0; gg < G; gg++) O = __builtin_fmaf(base[(size_t)gg * (D + 2)], wr[gg], O);
+        const float M = mlsm[2 * r], L = mlsm[2 * r + 1];
         if (a.nsplit == 1) {
             fattn_store<D>(a, h, iq, i3, d, O / L);
         } else {
@@ -310,7 +331,8 @@ fattn_vec_kernel(const FArgs a) {
             if (d == 0) { p[D] = M; p[D + 1] = L; }
         }
     }
-    if (a.nsplit == 1) return;
+    FA_STAMP(3);
+    if (a.nsplit == 1) { FA_STAMP_FLUSH(); return; }
 
     // The slices of one (kv-head group, token) meet at an arrival counter; whoever arrives last merges all partials
     // and writes the result, so there is no second launch.  Hand-off (one release and one acquire per workgroup, not
@@ -330,7 +352,8 @@ fattn_vec_kernel(const FArgs a) {
         }
     }
     __syncthreads();
-    if (!last_flag) return;
+    FA_STAMP(4);
+    if (!last_flag) { FA_STAMP_FLUSH(); return; }
     for (int idx = tid; idx < R * D; idx += FA_THREADS) {
         const int r = idx / D, d = idx % D;
         const int h = h0 + r;
@@ -360,6 +383,8 @@ fattn_vec_kernel(const FArgs a) {
         }
         fattn_store<D>(a, h, iq, i3, d, O / L);
     }
+    FA_STAMP(5);
+    FA_STAMP_FLUSH();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -555,11 +580,11 @@ static int launch_mma(const FArgs & a, int tkv, hipStream_t s) {
 
 template <int D, int R, int TK, int TV>
 static int launch_vec(const FArgs & a, hipStream_t s) {
-    constexpr int NW = FA_THREADS / 64;
     const int ratio = a.n_head / a.n_head_kv;
     const int hgroups = (ratio + R - 1) / R;
     const dim3 grid((unsigned)(a.n_head_kv * hgroups), (unsigned)a.n_q, (unsigned)(a.ne3 * a.nsplit));
-    const size_t sh = (size_t)R * NW * (D + 2) * sizeof(float);
+    constexpr int G = FA_THREADS / (D / 8);
+    const size_t sh = ((size_t)R * G * (D + 2) + (size_t)R * G + 2 * R) * sizeof(float);
     if (sh > 48 * 1024) { // raise the dynamic-LDS cap once per instantiation
         static const hipError_t attr = hipFuncSetAttribute((const void *)fattn_vec_kernel<D, R, TK, TV>,
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
