@@ -562,7 +562,11 @@ def test_flash_attn_golden(ops, tag):
 
 
 @pytest.mark.parametrize("d,nh,nhkv,nq,nkv,causal", [(128, 8, 2, 96, 200, True), (128, 4, 4, 33, 64, False), (64, 8, 1, 130, 333, True),
-                                                      (128, 32, 8, 512, 512, True), (128, 8, 2, 1, 300, False), (128, 8, 2, 4, 4096, False)])
+                                                      (128, 32, 8, 512, 512, True), (128, 8, 2, 1, 300, False), (128, 8, 2, 4, 4096, False),
+                                                      # long decode contexts: ragged slice ends, 4 heads per workgroup from n_kv 16384
+                                                      # (GQA 4), 8 per workgroup (GQA 8), no GQA, two tokens
+                                                      (128, 32, 8, 1, 20000, False), (128, 8, 2, 2, 16411, False), (128, 64, 8, 1, 5000, False),
+                                                      (64, 8, 8, 1, 9000, False), (128, 32, 8, 1, 1000, True)])
 def test_flash_attn_f16_vs_f64_oracle(ops, d, nh, nhkv, nq, nkv, causal):
     """prefill shapes take the matrix-core tile kernel (n_q >= 32), decode shapes the split-KV vec kernel; both
     against the oracle's double-precision evaluation of the op on the same f16 K/V."""
@@ -584,7 +588,7 @@ def test_flash_attn_f16_vs_f64_oracle(ops, d, nh, nhkv, nq, nkv, causal):
 
 
 @pytest.mark.parametrize("tkv", [B.Q8_0, B.Q4_0])
-@pytest.mark.parametrize("d,nh,nhkv,nq,nkv", [(128, 8, 2, 96, 200), (64, 4, 4, 33, 130), (128, 8, 2, 3, 300)])
+@pytest.mark.parametrize("d,nh,nhkv,nq,nkv", [(128, 8, 2, 96, 200), (64, 4, 4, 33, 130), (128, 8, 2, 3, 300), (128, 32, 8, 1, 17000)])
 def test_flash_attn_quantized_kv_vs_f64_oracle(ops, tkv, d, nh, nhkv, nq, nkv):
     """q8_0 / q4_0 KV cache: the tile kernel dequantizes K/V blocks to f16 while staging (n_q >= 32), the vec
     kernel in registers (decode); both vs the oracle's f64 evaluation on the same quantized rows."""
