@@ -200,6 +200,13 @@ typedef struct mi355_glu_matvec_args {
      * read, norm_out receives the f32 result (k floats).  k <= 8192; the three pointers 16-byte aligned.  norm_x,
      * norm_w and every output of the launch must not overlap (workgroups finish at different times). */
     const float *norm_x, *norm_w; float *norm_out; float norm_eps;
+    /* optional expert routing -- the MUL_MAT_ID(ffn_up_exps) MUL_MAT_ID(ffn_gate_exps) GLU nodes of one decode token
+     * (build_moe_ffn, src/llama-graph.cpp:660-760; ggml_cuda_mul_mat_id, ggml-cuda.cu:2065-2206): ids = the token's
+     * n_slots expert ids (device, int32); slot s uses the matrices at w_gate + ids[s] * gate_expert_stride (bytes) and
+     * w_up + ids[s] * up_expert_stride, reads the same activations, and writes its m outputs at index s * m of gate_out /
+     * up_out / dst / out_q (out_ds: s * m / 32 pairs).  Out-of-range ids leave the slot's outputs untouched.  Not
+     * combinable with the norm prologue. */
+    const int32_t *ids; int32_t n_slots, n_expert; int64_t gate_expert_stride, up_expert_stride;
 } mi355_glu_matvec_args;
 MI355_API int mi355_glu_matvec(const mi355_glu_matvec_args *args, void *stream);
 

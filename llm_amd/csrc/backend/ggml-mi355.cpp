@@ -1344,6 +1344,67 @@ static bool mi355_try_fuse_norm_glu_matvec(mi355_backend_ctx * ctx, ggml_cgraph 
     return mi355_try_fuse_glu_matvec(ctx, cgraph, members, i);
 }
 
+// Expert feed-forward input of one decode token in one launch (build_moe_ffn, src/llama-graph.cpp:660-760):
+//     up = MUL_MAT_ID(ffn_up_exps, x, ids)   gate = MUL_MAT_ID(ffn_gate_exps, x, ids)   cur = GLU(gate, up)
+// three consecutive nodes, one token, x broadcast over the slots -> mi355_glu_matvec with ids: all three tensors are
+// written (bit-identical values) plus the q8_1 form of the GLU result, which MUL_MAT_ID(ffn_down_exps) finds in the
+// activation cache.  A GLU result exactly on top of one of its inputs replaces it.
+static bool mi355_try_fuse_moe_glu_matvec(mi355_backend_ctx * ctx, ggml_cgraph * cgraph, int i, const std::vector<char> & done) {
+    const int n = ggml_graph_n_nodes(cgraph);
+    if (i + 2 >= n || done[i + 1] || done[i + 2] || getenv("GGML_MI355_NO_GLU_MATVEC")) return false;
+    const ggml_tensor * m0 = ggml_graph_node(cgraph, i), * m1 = ggml_graph_node(cgraph, i + 1);
+    ggml_tensor * glu = ggml_graph_node(cgraph, i + 2);
+    if (m1->op != GGML_OP_MUL_MAT_ID || glu->op != GGML_OP_GLU || !glu->src[1] || glu->type != GGML_TYPE_F32) return false;
+    const ggml_tensor * gate = glu->src[0], * up = glu->src[1];
+    if (!((gate == m0 && up == m1) || (gate == m1 && up == m0))) return false;
+    const int op = (int)ggml_get_glu_op(glu);
+    if (op < 0 || op > 2) return false;
+    const ggml_tensor * b = m0->src[1], * ids = m0->src[2];
+    if (m1->src[1] != b || m1->src[2] != ids) return false;
+    const ggml_tensor * wg = gate->src[0], * wu = up->src[0];
+    if (!is_weight_type(wg->type) || wg->type != wu->type || tensor_is_split(wg) || tensor_is_split(wu)) return false;
+    const int64_t K = wg->ne[0], M = wg->ne[1], n_expert = wg->ne[2], n_used = ids->ne[0];
+    if (wu->ne[0] != K || wu->ne[1] != M || wu->ne[2] != n_expert || wg->ne[3] != 1 || wu->ne[3] != 1) return false;
+    if (b->ne[1] != 1 || b->ne[2] != 1 || b->ne[3] != 1 || ids->ne[1] != 1 || ids->type != GGML_TYPE_I32 || ids->nb[0] != sizeof(int32_t)) return false;
+    if (n_used < 1 || n_used > 64 || M % 32 != 0 || K % ggml_blck_size(wg->type) != 0 || b->type != GGML_TYPE_F32 || b->nb[0] != sizeof(float)) return false;
+    if ((size_t)K + (size_t)K / 32 * 8 + 16 + 256 > 64 * 1024) return false;
+    const ggml_tensor * outs[3] = {gate, up, glu};
+    for (const ggml_tensor * o : outs) {
+        if (o->type != GGML_TYPE_F32 || o->ne[0] != M || o->ne[1] != n_used || ggml_nrows(o) != n_used || !ggml_is_contiguous(o)) return false;
+        if (ranges_overlap(o->data, ggml_nbytes(o), b->data, ggml_nbytes(b)) || ranges_overlap(o->data, ggml_nbytes(o), ids->data, ggml_nbytes(ids))) return false;
+    }
+    if (ranges_overlap(gate->data, ggml_nbytes(gate), up->data, ggml_nbytes(up)) || ((uintptr_t)glu->data & 15)) return false;
+    float * gate_out = (float *)gate->data, * up_out = (float *)up->data;
+    if (glu->data == gate->data) gate_out = nullptr;
+    else if (ranges_overlap(glu->data, ggml_nbytes(glu), gate->data, ggml_nbytes(gate))) return false;
+    if (glu->data == up->data) up_out = nullptr;
+    else if (ranges_overlap(glu->data, ggml_nbytes(glu), up->data, ggml_nbytes(up))) return false;
+
+    const size_t qb = align_up((size_t)mi355_act_q_bytes(K, 1), 256), db = align_up((size_t)mi355_act_ds_bytes(K, 1), 256);
+    const size_t oqb = align_up((size_t)mi355_act_q_bytes(M, n_used), 256), odb = align_up((size_t)mi355_act_ds_bytes(M, n_used), 256);
+    char * ws = (char *)ctx->get_scratch(0, qb + db);
+    if (!ctx->act_cached(b)) {
+        MI_CHECK(mi355_quantize_act((const float *)b->data, (int8_t *)ws, (float *)(ws + qb), K, 1, 1, 1, b->nb[1], b->nb[2], b->nb[3], ctx->stream));
+        ctx->act_remember(b);
+    }
+    char * os = (char *)ctx->get_scratch(2, oqb + odb);
+    mi355_glu_matvec_args a;
+    memset(&a, 0, sizeof(a));
+    a.type = (int32_t)wg->type; a.glu_op = op;
+    a.w_gate = wg->data; a.w_up = wu->data; a.gate_row_stride = (int64_t)wg->nb[1]; a.up_row_stride = (int64_t)wu->nb[1];
+    a.m = M; a.k = K; a.act_q = (const int8_t *)ws; a.act_ds = (const float *)(ws + qb);
+    a.gate_out = gate_out; a.up_out = up_out; a.dst = (float *)glu->data;
+    a.out_q = (int8_t *)os; a.out_ds = (float *)(os + oqb);
+    a.ids = (const int32_t *)ids->data; a.n_slots = (int32_t)n_used; a.n_expert = (int32_t)n_expert;
+    a.gate_expert_stride = (int64_t)wg->nb[2]; a.up_expert_stride = (int64_t)wu->nb[2];
+    const int rc = mi355_glu_matvec(&a, ctx->stream);
+    if (rc == MI355_E_UNSUPPORTED || rc == MI355_E_ALIGN) return false;
+    MI_CHECK(rc);
+    ctx->swap_act_scratch();            // scratch[0] now holds the q8_1 form of the GLU result ([n_used][M], the layout of a [M, n_used] src1)
+    ctx->act_remember(glu);
+    return true;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Fused attention input of a decode step.  llm_build_llama (src/llama-model.cpp:4898-5052) spells it as
 //     Qcur = MUL_MAT(wq, x)  RESHAPE  ROPE      Kcur = MUL_MAT(wk, x)  RESHAPE  ROPE      Vcur = MUL_MAT(wv, x)  RESHAPE
@@ -1596,6 +1657,11 @@ static enum ggml_status mi355_backend_graph_compute(ggml_backend_t backend, ggml
         // fusion: Q/K/V projections + rope + KV-cache store of one token in one launch
         if (fuse && node->op == GGML_OP_MUL_MAT && node->src[0]->type == GGML_TYPE_F32 && mi355_try_fuse_moe_router(ctx, cgraph, i, done)) continue;
         if (fuse && node->op == GGML_OP_MUL_MAT && mi355_try_fuse_qkv_rope(ctx, cgraph, i, done)) continue;
+        if (fuse && node->op == GGML_OP_MUL_MAT_ID && mi355_try_fuse_moe_glu_matvec(ctx, cgraph, i, done)) {
+            done[i + 1] = 1;
+            done[i + 2] = 1;
+            continue;
+        }
         // fusion: decode mat-vecs that share their activation run as one grouped launch
         if (fuse && matvec_groupable(node)) {
             int members[MI355_MMVQ_MAX_GROUP];

@@ -574,6 +574,9 @@ struct KGlu {
     const int8_t * act_q; const float * act_ds; int k, m, op;
     float * gate_out, * up_out, * dst; int8_t * out_q; float * out_ds;
     const float * nx, * nw; float * nout; float eps;    // optional rms-norm prologue: activations = q8_1((nx * scale) * nw)
+    // optional expert routing (MUL_MAT_ID pair of a decode token): blockIdx.y = slot, matrices of expert ids[slot], all slots read
+    // the same activations, outputs of slot s at [s * m]
+    const int32_t * ids; int n_expert, n_slots; int64_t wg_ex_stride, wu_ex_stride;
 };
 
 static __device__ __forceinline__ float glu_act(int op, float x) {
@@ -595,7 +598,13 @@ mmvq_glu_kernel(const KGlu a) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int k = a.k;
     const int row0 = (blockIdx.x * 8 + wave) * GLU_PAIRS;                     // first of this wave's outputs
-    const uint8_t * wg = a.wg + (int64_t)row0 * a.rsg, * wu = a.wu + (int64_t)row0 * a.rsu;
+    int64_t ex = 0;
+    if (a.ids) {
+        ex = a.ids[blockIdx.y];
+        if (ex < 0 || ex >= a.n_expert) return;      // out-of-range expert id (uniform per workgroup): outputs untouched
+    }
+    const int64_t so = (int64_t)blockIdx.y * a.m;     // this slot's outputs
+    const uint8_t * wg = a.wg + ex * a.wg_ex_stride + (int64_t)row0 * a.rsg, * wu = a.wu + ex * a.wu_ex_stride + (int64_t)row0 * a.rsu;
     const int nunits = k / U::ELEMS;
     const int niter  = (nunits + 63) >> 6;
     const int u0 = lane < nunits ? lane : nunits - 1;
@@ -644,14 +653,14 @@ mmvq_glu_kernel(const KGlu a) {
         float g = sg[0], u = su[0];
 #pragma unroll
         for (int p = 1; p < GLU_PAIRS; p++) if (lane == p) { g = sg[p]; u = su[p]; }
-        if (a.gate_out) a.gate_out[row0 + lane] = g;
-        if (a.up_out)   a.up_out[row0 + lane]   = u;
+        if (a.gate_out) a.gate_out[so + row0 + lane] = g;
+        if (a.up_out)   a.up_out[so + row0 + lane]   = u;
         hs[wave * GLU_PAIRS + lane] = glu_act(a.op, g) * u;
     }
     __syncthreads();
     if (threadIdx.x < 2 * GLU_PAIRS) {
         const v4f h = ((const v4f *)hs)[threadIdx.x];
-        const int64_t o0 = (int64_t)blockIdx.x * (8 * GLU_PAIRS) + 4 * threadIdx.x;
+        const int64_t o0 = so + (int64_t)blockIdx.x * (8 * GLU_PAIRS) + 4 * threadIdx.x;
         *(v4f *)(a.dst + o0) = h;
         if (a.out_q) {
             const float o[4] = {h.x, h.y, h.z, h.w};
@@ -869,7 +878,7 @@ static int launch_glu_mv(const KGlu & a, hipStream_t stream) {
     if (need > LDS_ACT_LIMIT) return MI355_E_UNSUPPORTED;
     // 4 outputs per wave.  (8 per wave -- half the workgroups, for grids beyond the 512 workgroups a full chip holds at
     // once -- measured slower: 2x28672x8192 q4_K 61 us against 56; the plugin keeps such shapes on the grouped mat-vec.)
-    MI355_LAUNCH("mmvq_glu", (mmvq_glu_kernel<TYPE, 4>), dim3((unsigned)(a.m / 32)), dim3(GLU_THREADS), need, stream, a);
+    MI355_LAUNCH("mmvq_glu", (mmvq_glu_kernel<TYPE, 4>), dim3((unsigned)(a.m / 32), (unsigned)(a.ids ? a.n_slots : 1)), dim3(GLU_THREADS), need, stream, a);
     MI355_CHECK_LAUNCH();
     return MI355_OK;
 }
@@ -881,6 +890,7 @@ extern "C" int mi355_glu_matvec(const mi355_glu_matvec_args * p, void * stream) 
     const int64_t bs = mi355_blck_size(p->type);
     if (bs == 0 || p->type == MI355_TYPE_F32 || p->type == MI355_TYPE_F16 || p->type == MI355_TYPE_Q8_1) return MI355_E_TYPE;
     if (p->glu_op < 0 || p->glu_op > 2) return MI355_E_UNSUPPORTED;
+    if (p->ids && (p->n_slots < 1 || p->n_slots > 64 || p->n_expert < 1 || p->norm_x)) return MI355_E_SHAPE;
     if (p->m <= 0 || p->m % 32 != 0 || p->m > 0x3fffffff || p->k <= 0 || p->k % bs != 0 || p->k > 0x7fffffff) return MI355_E_SHAPE;
     if (((uintptr_t)p->dst & 15) || ((uintptr_t)p->gate_out & 3) || ((uintptr_t)p->up_out & 3) || ((uintptr_t)p->out_q & 3) ||
         ((uintptr_t)p->out_ds & 7)) return MI355_E_ALIGN;
@@ -906,6 +916,8 @@ extern "C" int mi355_glu_matvec(const mi355_glu_matvec_args * p, void * stream) 
     a.act_q = p->act_q; a.act_ds = p->act_ds; a.k = (int)p->k; a.m = (int)p->m; a.op = p->glu_op;
     a.gate_out = p->gate_out; a.up_out = p->up_out; a.dst = p->dst; a.out_q = p->out_q; a.out_ds = p->out_ds;
     a.nx = p->norm_x; a.nw = p->norm_w; a.nout = p->norm_out; a.eps = p->norm_eps;
+    a.ids = p->ids; a.n_expert = p->n_expert; a.n_slots = p->n_slots; a.wg_ex_stride = p->gate_expert_stride; a.wu_ex_stride = p->up_expert_stride;
+    if (p->ids && ((p->gate_expert_stride | p->up_expert_stride) & (a16 ? 15 : 1))) return MI355_E_ALIGN;
     hipStream_t s = (hipStream_t)stream;
     switch (p->type) {
         case MI355_TYPE_Q4_0: return launch_glu_mv<MI355_TYPE_Q4_0>(a, s);

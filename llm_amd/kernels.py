@@ -76,6 +76,7 @@ class GluMatvecArgs(C.Structure):
         ("type", _i32), ("glu_op", _i32), ("w_gate", _vp), ("w_up", _vp), ("gate_row_stride", _i64), ("up_row_stride", _i64),
         ("m", _i64), ("k", _i64), ("act_q", _vp), ("act_ds", _vp), ("gate_out", _vp), ("up_out", _vp), ("dst", _vp),
         ("out_q", _vp), ("out_ds", _vp), ("norm_x", _vp), ("norm_w", _vp), ("norm_out", _vp), ("norm_eps", C.c_float),
+        ("ids", _vp), ("n_slots", _i32), ("n_expert", _i32), ("gate_expert_stride", _i64), ("up_expert_stride", _i64),
     ]
 
 

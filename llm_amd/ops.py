@@ -220,17 +220,18 @@ def qkv_rope_matvec(type_qk, type_v, wq, wk, wv, m_q, m_k, m_v, k, aq, ads, pos,
     return q, ko, vo
 
 
-def glu_matvec(t, w_gate, w_up, m, k, aq, ads, glu_op=2, quant=True, keep=True, norm=None):
+def glu_matvec(t, w_gate, w_up, m, k, aq, ads, glu_op=2, quant=True, keep=True, norm=None, ids=None, n_expert=0):
     """Fused decode feed-forward input (mi355_glu_matvec): -> (dst f32 [m], gate f32 [m] | None, up f32 [m] | None,
     out_q int8 [m] | None, out_ds f32 [m/32, 2] | None).  norm = (x [k] f32, w [k] f32, eps, out [k] f32): the
     activations are rms_norm(x) * w, computed inside the launch (aq / ads unused, may be None)."""
     _u8(w_gate); _u8(w_up)
     dev = w_gate.device
-    dst = torch.full((m,), float("nan"), dtype=torch.float32, device=dev)
-    g = torch.full((m,), float("nan"), dtype=torch.float32, device=dev) if keep else None
-    u = torch.full((m,), float("nan"), dtype=torch.float32, device=dev) if keep else None
-    oq = torch.zeros(m, dtype=torch.int8, device=dev) if quant else None
-    ods = torch.zeros((m // 32, 2), dtype=torch.float32, device=dev) if quant else None
+    ns = 1 if ids is None else ids.numel()       # ids: int32 [n_slots] expert of each slot; w_gate / w_up then hold n_expert matrices
+    dst = torch.full((ns * m,), float("nan"), dtype=torch.float32, device=dev)
+    g = torch.full((ns * m,), float("nan"), dtype=torch.float32, device=dev) if keep else None
+    u = torch.full((ns * m,), float("nan"), dtype=torch.float32, device=dev) if keep else None
+    oq = torch.zeros(ns * m, dtype=torch.int8, device=dev) if quant else None
+    ods = torch.zeros((ns * m // 32, 2), dtype=torch.float32, device=dev) if quant else None
     a = K.GluMatvecArgs()
     a.type, a.glu_op, a.w_gate, a.w_up = t, glu_op, w_gate.data_ptr(), w_up.data_ptr()
     a.gate_row_stride = a.up_row_stride = B.row_size(t, k)
@@ -241,6 +242,9 @@ def glu_matvec(t, w_gate, w_up, m, k, aq, ads, glu_op=2, quant=True, keep=True, 
         a.act_q, a.act_ds = aq.data_ptr(), ads.data_ptr()
     a.gate_out, a.up_out, a.dst = g.data_ptr() if keep else None, u.data_ptr() if keep else None, dst.data_ptr()
     a.out_q, a.out_ds = oq.data_ptr() if quant else None, ods.data_ptr() if quant else None
+    if ids is not None:
+        a.ids, a.n_slots, a.n_expert = ids.data_ptr(), ns, n_expert
+        a.gate_expert_stride = a.up_expert_stride = B.row_size(t, k) * m
     K.check(K.lib.mi355_glu_matvec(a, _stream()), "mi355_glu_matvec")
     return dst, g, u, oq, ods
 

@@ -410,6 +410,30 @@ def test_glu_matvec_fused_is_bit_identical_to_separate_kernels(ops, t, m, k, op,
     assert torch.equal(d2.view(torch.int32), d1.view(torch.int32))
 
 
+@pytest.mark.parametrize("t", [B.Q4_K, B.Q6_K, B.Q8_0])
+@pytest.mark.parametrize("m,k,n_exp,ids", [(14336, 4096, 8, (5, 2)), (96, 512, 4, (3, 3, 0)), (64, 1024, 8, (7, 9))])
+def test_glu_matvec_expert_routing(ops, t, m, k, n_exp, ids):
+    """mi355_glu_matvec with ids (MUL_MAT_ID gate / up of one decode token + GLU): every slot equals the plain launch on
+    its expert's matrices, to the bit; an out-of-range id leaves its slot untouched."""
+    rng = np.random.default_rng(m + k)
+    x = dev(rng.standard_normal((1, k)).astype(np.float32))
+    aq, ads = ops.quantize_act(x)
+    rs = B.row_size(t, k)
+    wg, wu = dev(B.random_blocks(t, n_exp * m, k, seed=41)), dev(B.random_blocks(t, n_exp * m, k, seed=42))
+    idt = torch.tensor(ids, dtype=torch.int32, device="cuda")
+    d1, g1, u1, q1, s1 = ops.glu_matvec(t, wg, wu, m, k, aq, ads, ids=idt, n_expert=n_exp)
+    for s_, e in enumerate(ids):
+        sl = slice(s_ * m, (s_ + 1) * m)
+        if e >= n_exp:
+            assert torch.isnan(d1[sl]).all() and int(q1[sl].abs().max()) == 0
+            continue
+        d0, g0, u0, q0, s0 = ops.glu_matvec(t, wg.view(n_exp, m * rs)[e], wu.view(n_exp, m * rs)[e], m, k, aq, ads)
+        assert torch.isfinite(d0).all() and float(d0.abs().max()) > 0
+        for a, b in ((d0, d1[sl]), (g0, g1[sl]), (u0, u1[sl]), (s0, s1[s_ * m // 32:(s_ + 1) * m // 32])):
+            assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+        assert torch.equal(q0, q1[sl])
+
+
 def test_glu_matvec_argument_errors(ops):
     import llm_amd.kernels as K
     a = K.GluMatvecArgs()

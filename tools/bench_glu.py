@@ -37,3 +37,28 @@ for t, m, k in ((B.Q4_K, 14336, 4096), (B.Q4_K, 28672, 8192), (B.Q6_K, 14336, 40
     wb = 2 * m * rs
     print(f"{name} 2x{m}x{k}: grouped {a['mmvq_%s_n1' % name]:.2f} + glu {a['glu_quant']:.2f} us   fused {b['mmvq_glu']:.2f} us ({wb / b['mmvq_glu'] / 1e3:.0f} GB/s)", flush=True)
     del pool
+
+# expert-routed form (Mixtral-8x7B decode: 8 experts, 2 used): two MUL_MAT_ID mat-vecs + glu_quant against one launch
+t, m, k, n_exp = B.Q4_K, 14336, 4096, 8
+rs = B.row_size(t, k)
+pool = [(torch.randint(0, 255, (n_exp * m * rs,), dtype=torch.uint8, device="cuda"), torch.randint(0, 255, (n_exp * m * rs,), dtype=torch.uint8, device="cuda")) for _ in range(2)]
+x = torch.randn(1, 1, k, device="cuda")
+aq, ads = ops.quantize_act(x.view(1, k))
+d0 = torch.empty(2, m, device="cuda"); q0 = torch.empty((2, m), dtype=torch.int8, device="cuda"); s0 = torch.empty((2, m // 32, 2), device="cuda")
+def sep(i):
+    wg, wu = pool[i % 2]
+    ids = torch.tensor([[(i * 3) % 8, (i * 3 + 5) % 8]], dtype=torch.int32, device="cuda")
+    g = ops.mul_mat_id(t, wg, x, ids, m, n_exp)
+    u = ops.mul_mat_id(t, wu, x, ids, m, n_exp)
+    K.check(K.lib.mi355_glu_quant_f32(2, T(g.view(2, m)), T(u.view(2, m)), T(d0), 0, q0.data_ptr(), s0.data_ptr(), s), "glu")
+def fused(i):
+    wg, wu = pool[i % 2]
+    ids = torch.tensor([(i * 3) % 8, (i * 3 + 5) % 8], dtype=torch.int32, device="cuda")
+    ops.glu_matvec(t, wg, wu, m, k, aq, ads, ids=ids, n_expert=n_exp)
+K.lib.mi355_timing_reset()
+a = timed(sep, [])
+rep = {tg: (n, us) for tg, (n, us) in K.timing_report().items() if n}
+print("MoE separate:", {tg: round(us / n, 2) for tg, (n, us) in rep.items()}, flush=True)
+K.lib.mi355_timing_reset()
+b = timed(fused, ["mmvq_glu"])
+print(f"MoE fused: {b['mmvq_glu']:.2f} us", flush=True)
