@@ -31,6 +31,7 @@
  *   GGML_MI355_NO_PINNED=1   do not offer the pinned host buffer type
  *   GGML_MI355_NO_SKINNY=1   MUL_MAT with 4..64 columns: mat-vec / bf16 GEMM kernels instead of the skinny int8-MFMA ones
  *   GGML_MI355_NO_GLU_MATVEC=1  decode ffn: grouped gate+up mat-vec and a separate GLU kernel instead of mi355_glu_matvec
+ *   GGML_MI355_NO_MOE_DOWN=1    MoE decode: MUL_MAT_ID(down_exps), the weight MUL and the expert / residual ADDs as separate nodes
  *   GGML_MI355_NO_MATVEC_ADD=1  decode: wo / ffn_down mat-vec and the residual ADD as separate nodes
  *   GGML_MI355_NO_NORM_GLU=1, GGML_MI355_NO_NORM_QKV=1  decode: ffn_norm / attn_norm as a launch of its own instead of the
  *                            prologue of mi355_glu_matvec / mi355_qkv_rope_matvec

@@ -210,6 +210,25 @@ typedef struct mi355_glu_matvec_args {
 } mi355_glu_matvec_args;
 MI355_API int mi355_glu_matvec(const mi355_glu_matvec_args *args, void *stream);
 
+/* Expert feed-forward output of one decode token in ONE launch: y[s] = W[ids[s]] h[s] (MUL_MAT_ID(ffn_down_exps)), y[s] *=
+ * weights[s] (the MUL by the normalised router weights), sum_out = (y[0] + y[1]) + ... (the ADD chain over the slot views),
+ * residual_out = sum_out + residual (the layer's residual ADD) -- build_moe_ffn, src/llama-graph.cpp:760-795; replaces
+ * ggml_cuda_mul_mat_id (ggml-cuda.cu:2065-2206) + 3 binbcast launches.  Bit-identical to those kernels run one by one.
+ * act_q / act_ds: q8_1 SoA of the n_slots activation rows (mi355_quantize_act layout, slot s = row s); out (optional):
+ * unweighted y [n_slots][m]; weighted_out: [n_slots][m] (may equal out: MUL in place); sum_out [m]; residual /
+ * residual_out [m] optional (both or neither; residual_out may equal sum_out or residual).  n_slots <= 8.  Slots with an
+ * out-of-range id contribute nothing and are not stored. */
+typedef struct mi355_moe_down_args {
+    int32_t type, n_slots, n_expert;
+    const void *W; int64_t w_row_stride, w_expert_stride;  /* bytes */
+    int64_t m, k;
+    const int8_t *act_q; const float *act_ds;
+    const int32_t *ids; const float *weights;              /* device, n_slots each */
+    float *out, *weighted_out, *sum_out;
+    const float *residual; float *residual_out;
+} mi355_moe_down_args;
+MI355_API int mi355_moe_down_matvec(const mi355_moe_down_args *args, void *stream);
+
 /* "Skinny" MUL_MAT, 1 <= n <= 32 activation columns per call, on the int8 matrix cores: same operands and
  * arithmetic contract as mi355_mul_mat_vec_q (one channel), but one v_mfma_i32_32x32x32_i8 covers 32 rows x 32 columns
  * of a 32-block, so the time per weight byte does not grow with n (the mat-vec kernel drops to 9 % of the HBM

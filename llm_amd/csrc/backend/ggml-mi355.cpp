@@ -1115,6 +1115,8 @@ static bool is_view_op(const ggml_tensor * t) {
     return t->op == GGML_OP_NONE || t->op == GGML_OP_RESHAPE || t->op == GGML_OP_VIEW || t->op == GGML_OP_PERMUTE || t->op == GGML_OP_TRANSPOSE;
 }
 
+static const ggml_tensor * view_root(const ggml_tensor * t) { return t->view_src ? t->view_src : t; }
+
 static bool matvec_groupable(const ggml_tensor * node) {
     if (node->op != GGML_OP_MUL_MAT) return false;
     const ggml_tensor * a = node->src[0], * b = node->src[1];
@@ -1405,6 +1407,103 @@ static bool mi355_try_fuse_moe_glu_matvec(mi355_backend_ctx * ctx, ggml_cgraph *
     return true;
 }
 
+// Expert feed-forward output of one decode token in one launch (build_moe_ffn, src/llama-graph.cpp:760-795):
+//     y = MUL_MAT_ID(ffn_down_exps, h, ids)  [router nodes, views]  y = MUL(y, weights)  out = ADD(view(y, 0), view(y, 1))
+//     [l_out = ADD(out, residual)]
+// for two used experts (Mixtral).  The nodes after the MUL_MAT_ID must be the next ones still to run (the router's
+// GET_ROWS / SUM_ROWS / DIV that llama.cpp places in between were already computed by mi355_try_fuse_moe_router, so the
+// weights exist); every tensor of the chain is written with bit-identical values.  Outputs may coincide exactly where
+// the graph computes in place (MUL on y, l_out on out or on the residual) and must be apart otherwise.
+static int next_active_node(ggml_cgraph * cgraph, int j, const std::vector<char> & done) {
+    const int n = ggml_graph_n_nodes(cgraph);
+    for (j++; j < n; j++) {
+        const ggml_tensor * t = ggml_graph_node(cgraph, j);
+        if (done[j] || ggml_is_empty(t) || is_view_op(t)) continue;
+        return j;
+    }
+    return -1;
+}
+
+static bool same_or_apart(const ggml_tensor * a, const ggml_tensor * b) {
+    return a->data == b->data ? ggml_nbytes(a) == ggml_nbytes(b) : !ranges_overlap(a->data, ggml_nbytes(a), b->data, ggml_nbytes(b));
+}
+
+static bool mi355_try_fuse_moe_down(mi355_backend_ctx * ctx, ggml_cgraph * cgraph, int i, std::vector<char> & done) {
+    if (getenv("GGML_MI355_NO_MOE_DOWN")) return false;
+    const ggml_tensor * down = ggml_graph_node(cgraph, i);
+    const ggml_tensor * as = down->src[0], * b = down->src[1], * ids = down->src[2];
+    const int64_t K = as->ne[0], M = as->ne[1], n_expert = as->ne[2], n_used = ids->ne[0];
+    if (n_used != 2 || !is_weight_type(as->type) || tensor_is_split(as) || as->ne[3] != 1) return false;
+    if (ids->ne[1] != 1 || ids->type != GGML_TYPE_I32 || ids->nb[0] != sizeof(int32_t)) return false;
+    if (b->type != GGML_TYPE_F32 || b->ne[0] != K || b->ne[1] != n_used || b->ne[2] != 1 || b->ne[3] != 1 || !ggml_is_contiguous(b)) return false;
+    if (down->type != GGML_TYPE_F32 || down->ne[0] != M || down->ne[1] != n_used || ggml_nrows(down) != n_used || !ggml_is_contiguous(down)) return false;
+    if (K % ggml_blck_size(as->type) != 0 || K % 32 != 0) return false;
+    const int jm = next_active_node(cgraph, i, done);
+    if (jm < 0) return false;
+    const ggml_tensor * mul = ggml_graph_node(cgraph, jm);
+    if (mul->op != GGML_OP_MUL || mul->src[0] != down || mul->type != GGML_TYPE_F32 || !ggml_are_same_shape(mul, down) || !ggml_is_contiguous(mul)) return false;
+    const ggml_tensor * w = mul->src[1];
+    if (w->type != GGML_TYPE_F32 || w->ne[0] != 1 || w->ne[1] != n_used || ggml_nelements(w) != n_used || w->nb[1] != sizeof(float)) return false;
+    const int ja = next_active_node(cgraph, jm, done);
+    if (ja < 0) return false;
+    const ggml_tensor * add = ggml_graph_node(cgraph, ja);
+    if (add->op != GGML_OP_ADD || add->type != GGML_TYPE_F32 || add->ne[0] != M || ggml_nrows(add) != 1 || !ggml_is_contiguous(add)) return false;
+    for (int s2 = 0; s2 < 2; s2++) {
+        const ggml_tensor * v = add->src[s2];
+        if (!v || view_root(v) != mul || v->type != GGML_TYPE_F32 || v->ne[0] != M || ggml_nrows(v) != 1 || v->nb[0] != sizeof(float)) return false;
+        if (v->data != (const char *)mul->data + s2 * mul->nb[1]) return false;
+    }
+    // optional residual ADD right behind
+    const ggml_tensor * radd = nullptr, * r = nullptr;
+    const int jr = next_active_node(cgraph, ja, done);
+    if (jr >= 0) {
+        const ggml_tensor * t = ggml_graph_node(cgraph, jr);
+        if (t->op == GGML_OP_ADD && t->type == GGML_TYPE_F32 && (t->src[0] == add || t->src[1] == add)) {
+            const ggml_tensor * o = t->src[0] == add ? t->src[1] : t->src[0];
+            if (o != add && o->type == GGML_TYPE_F32 && ggml_are_same_shape(o, add) && ggml_are_same_shape(t, add) && ggml_is_contiguous(o) &&
+                ggml_is_contiguous(t)) { radd = t; r = o; }
+        }
+    }
+    // placement
+    if (!same_or_apart(mul, down)) return false;
+    const ggml_tensor * big[2] = {down, mul};
+    const ggml_tensor * small[3] = {add, radd, r};
+    for (const ggml_tensor * sm : small) {
+        if (!sm) continue;
+        for (const ggml_tensor * bg : big) if (ranges_overlap(sm->data, ggml_nbytes(sm), bg->data, ggml_nbytes(bg))) return false;
+    }
+    if (radd && (!same_or_apart(radd, add) || !same_or_apart(radd, r) || !same_or_apart(add, r))) return false;
+    if (radd && add->data == r->data) return false;      // the sum would overwrite the residual before it is read back
+    const ggml_tensor * outs[4] = {down, mul, add, radd};
+    for (const ggml_tensor * o : outs) {
+        if (!o) continue;
+        if (ranges_overlap(o->data, ggml_nbytes(o), ids->data, ggml_nbytes(ids)) || ranges_overlap(o->data, ggml_nbytes(o), w->data, ggml_nbytes(w)) ||
+            ranges_overlap(o->data, ggml_nbytes(o), b->data, ggml_nbytes(b))) return false;
+    }
+    const size_t qb = align_up((size_t)mi355_act_q_bytes(K, n_used), 256), db = align_up((size_t)mi355_act_ds_bytes(K, n_used), 256);
+    char * ws = (char *)ctx->get_scratch(0, qb + db);
+    if (!ctx->act_cached(b)) {
+        MI_CHECK(mi355_quantize_act((const float *)b->data, (int8_t *)ws, (float *)(ws + qb), K, n_used, 1, 1, b->nb[1], b->nb[2], b->nb[3], ctx->stream));
+        ctx->act_remember(b);
+    }
+    mi355_moe_down_args a;
+    memset(&a, 0, sizeof(a));
+    a.type = (int32_t)as->type; a.n_slots = (int32_t)n_used; a.n_expert = (int32_t)n_expert;
+    a.W = as->data; a.w_row_stride = (int64_t)as->nb[1]; a.w_expert_stride = (int64_t)as->nb[2];
+    a.m = M; a.k = K; a.act_q = (const int8_t *)ws; a.act_ds = (const float *)(ws + qb);
+    a.ids = (const int32_t *)ids->data; a.weights = (const float *)w->data;
+    a.out = mul->data == down->data ? nullptr : (float *)down->data;
+    a.weighted_out = (float *)mul->data; a.sum_out = (float *)add->data;
+    if (radd) { a.residual = (const float *)r->data; a.residual_out = (float *)radd->data; }
+    const int rc = mi355_moe_down_matvec(&a, ctx->stream);
+    if (rc == MI355_E_UNSUPPORTED || rc == MI355_E_ALIGN) return false;
+    MI_CHECK(rc);
+    done[jm] = 1; done[ja] = 1;
+    if (radd) done[jr] = 1;
+    for (const ggml_tensor * o : outs) if (o) ctx->act_invalidate_if_written(o);
+    return true;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Fused attention input of a decode step.  llm_build_llama (src/llama-model.cpp:4898-5052) spells it as
 //     Qcur = MUL_MAT(wq, x)  RESHAPE  ROPE      Kcur = MUL_MAT(wk, x)  RESHAPE  ROPE      Vcur = MUL_MAT(wv, x)  RESHAPE
@@ -1413,7 +1512,6 @@ static bool mi355_try_fuse_moe_glu_matvec(mi355_backend_ctx * ctx, ggml_cgraph *
 // is found for a single token, with f16/f32 cache rows and no other reader of the intermediates, one launch of
 // mi355_qkv_rope_matvec produces rope(Qcur) and both cache rows; Qcur, Kcur, Vcur and rope(Kcur) are never stored.
 // ------------------------------------------------------------------------------------------------
-static const ggml_tensor * view_root(const ggml_tensor * t) { return t->view_src ? t->view_src : t; }
 
 // MoE router of a decode-sized batch in one launch: MUL_MAT(f32 gate_inp, x) SOFT_MAX ARGSORT(desc) [top-k view] GET_ROWS
 // SUM_ROWS DIV (build_moe_ffn, src/llama-graph.cpp:660-720) -> mi355_moe_router_f32.  Every tensor of the chain is written,
@@ -1662,6 +1760,7 @@ static enum ggml_status mi355_backend_graph_compute(ggml_backend_t backend, ggml
             done[i + 2] = 1;
             continue;
         }
+        if (fuse && node->op == GGML_OP_MUL_MAT_ID && mi355_try_fuse_moe_down(ctx, cgraph, i, done)) continue;
         // fusion: decode mat-vecs that share their activation run as one grouped launch
         if (fuse && matvec_groupable(node)) {
             int members[MI355_MMVQ_MAX_GROUP];

@@ -669,6 +669,97 @@ mmvq_glu_kernel(const KGlu a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Expert feed-forward output of one decode token in one launch (build_moe_ffn, src/llama-graph.cpp:760-795):
+//     y = MUL_MAT_ID(ffn_down_exps, h, ids) [m, n_slots]   y = MUL(y, weights [1, n_slots])   out = ADD(ADD(y_0, y_1), ...)
+//     [l_out = ADD(out, residual)]
+// A wave owns one output row and walks the slots: row `r` of expert ids[s] against slot s's activations (all slots'
+// activations staged in LDS), weighted, summed in slot order, plus the residual.  Every graph tensor is written.
+// ------------------------------------------------------------------------------------------------
+constexpr int MOE_DOWN_MAX_SLOTS = 8;
+struct KMoeDown {
+    const uint8_t * W; int64_t w_row_stride, w_ex_stride;
+    const int8_t * act_q; const float * act_ds;         // [n_slots][k], [n_slots][k/32][2]
+    const int32_t * ids; const float * wts;             // [n_slots] each
+    float * y_out, * yw_out, * sum_out;                 // [n_slots][m] unweighted (optional), [n_slots][m] weighted, [m]
+    const float * res; float * res_out;                 // optional residual and its sum
+    int m, k, n_slots, n_expert;
+};
+
+template <int TYPE, bool LDSACT>
+__global__ void __launch_bounds__(256)
+mmvq_moe_down_kernel(const KMoeDown a) {
+    typedef Unit<TYPE> U;
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int k = a.k, row = blockIdx.x * 4 + wave;
+    const int rowc = row < a.m ? row : a.m - 1;
+    const int nunits = k / U::ELEMS, niter = (nunits + 63) >> 6;
+    const size_t slot_q = (size_t)k, slot_ds = (size_t)k / QK * 8;
+    int ex[MOE_DOWN_MAX_SLOTS];
+#pragma unroll
+    for (int s = 0; s < MOE_DOWN_MAX_SLOTS; s++) {
+        const int e = s < a.n_slots ? a.ids[s] : 0;
+        ex[s] = (e < 0 || e >= a.n_expert) ? -1 : e;     // out-of-range id: the slot contributes nothing and is not stored
+    }
+    const uint8_t * wrow0 = a.W + (int64_t)(ex[0] < 0 ? 0 : ex[0]) * a.w_ex_stride + (int64_t)rowc * a.w_row_stride;
+    typename U::Raw cur = U::load(wrow0, lane < nunits ? lane : nunits - 1);
+    const float rv = (a.res && lane == 0 && row < a.m) ? a.res[row] : 0.0f;
+    if (LDSACT) {
+        const int nq = a.n_slots * k / 16, nds = a.n_slots * (k / QK);
+        for (int i = threadIdx.x; i < nq; i += 256) ((v4i *)lds)[i] = ((const v4i *)a.act_q)[i];
+        v2f * lds_ds = (v2f *)(lds + (size_t)a.n_slots * slot_q);
+        for (int i = threadIdx.x; i < nds; i += 256) lds_ds[i] = ((const v2f *)a.act_ds)[i];
+        __syncthreads();
+    }
+    float total = 0.0f;
+    for (int s = 0; s < a.n_slots; s++) {
+        int e = 0, en = 0;
+#pragma unroll
+        for (int t = 0; t < MOE_DOWN_MAX_SLOTS; t++) { if (t == s) e = ex[t]; if (t == s + 1) en = ex[t]; }
+        const uint8_t * wrow  = a.W + (int64_t)(e < 0 ? 0 : e) * a.w_ex_stride + (int64_t)rowc * a.w_row_stride;
+        const uint8_t * wnext = a.W + (int64_t)(en < 0 ? 0 : en) * a.w_ex_stride + (int64_t)rowc * a.w_row_stride;
+        float acc = 0.0f;
+        for (int it = 0; it < niter; it++) {
+            const int  u_raw = it * 64 + lane;
+            const bool valid = u_raw < nunits;
+            const int  u     = valid ? u_raw : nunits - 1;
+            typename U::Raw nxt;
+            const bool more_here = it + 1 < niter;
+            if (more_here || s + 1 < a.n_slots) {
+                const int unr = more_here ? u_raw + 64 : lane;
+                nxt = U::load(more_here ? wrow : wnext, unr < nunits ? unr : nunits - 1);
+            }
+            typename U::Act av;
+            if (LDSACT) {
+                const auto lq  = (const __attribute__((address_space(3))) int8_t *)lds + (size_t)s * slot_q;
+                const auto lds_ = (const __attribute__((address_space(3))) float *)(lds + (size_t)a.n_slots * slot_q + (size_t)s * slot_ds);
+                av = U::load_act(ActLds{lq, lds_}, u);
+            } else {
+                av = U::load_act(ActPtr{a.act_q + (int64_t)s * k, a.act_ds + (int64_t)s * (k / QK) * 2}, u);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const float v = U::dot(U::decode(cur, u), av);
+            acc += valid ? v : 0.0f;
+            if (more_here || s + 1 < a.n_slots) cur = nxt;
+        }
+        const float y = wave_sum(acc);
+        if (e >= 0) {
+            const float yw = y * a.wts[s];
+            if (lane == 0 && row < a.m) {
+                if (a.y_out) a.y_out[(int64_t)s * a.m + row] = y;
+                a.yw_out[(int64_t)s * a.m + row] = yw;
+            }
+            total = s == 0 ? yw : total + yw;
+        }
+    }
+    if (lane == 0 && row < a.m) {
+        if (a.sum_out != a.res_out) a.sum_out[row] = total;      // in place: only the residual sum survives
+        if (a.res) a.res_out[row] = total + rv;
+    }
+}
+
+
 static const char * type_name(int t) {
     switch (t) {
         case MI355_TYPE_Q4_0: return "q4_0"; case MI355_TYPE_Q8_0: return "q8_0"; case MI355_TYPE_Q4_K: return "q4_K";
@@ -925,6 +1016,47 @@ extern "C" int mi355_glu_matvec(const mi355_glu_matvec_args * p, void * stream) 
         case MI355_TYPE_Q4_K: return launch_glu_mv<MI355_TYPE_Q4_K>(a, s);
         case MI355_TYPE_Q5_K: return launch_glu_mv<MI355_TYPE_Q5_K>(a, s);
         case MI355_TYPE_Q6_K: return launch_glu_mv<MI355_TYPE_Q6_K>(a, s);
+    }
+    return MI355_E_TYPE;
+}
+
+template <int TYPE>
+static int launch_moe_down(const KMoeDown & a, hipStream_t stream) {
+    const size_t need = (size_t)a.n_slots * ((size_t)a.k + (size_t)a.k / QK * 8);
+    const dim3 grid((unsigned)((a.m + 3) / 4));
+    if (need <= LDS_ACT_LIMIT) MI355_LAUNCH("mmvq_moe_down", (mmvq_moe_down_kernel<TYPE, true>), grid, dim3(256), need, stream, a);
+    else                       MI355_LAUNCH("mmvq_moe_down", (mmvq_moe_down_kernel<TYPE, false>), grid, dim3(256), 0, stream, a);
+    MI355_CHECK_LAUNCH();
+    return MI355_OK;
+}
+
+extern "C" int mi355_moe_down_matvec(const mi355_moe_down_args * p, void * stream) {
+    if (!p || !p->W || !p->act_q || !p->act_ds || !p->ids || !p->weights || !p->weighted_out || !p->sum_out) return MI355_E_NULL;
+    if ((p->residual == nullptr) != (p->residual_out == nullptr)) return MI355_E_NULL;
+    const int64_t bs = mi355_blck_size(p->type);
+    if (bs == 0 || p->type == MI355_TYPE_F32 || p->type == MI355_TYPE_F16 || p->type == MI355_TYPE_Q8_1) return MI355_E_TYPE;
+    if (p->m <= 0 || p->m > 0x7fffffff || p->k <= 0 || p->k % bs != 0 || p->k > 0x7fffffff || p->n_expert < 1) return MI355_E_SHAPE;
+    if (p->n_slots < 1 || p->n_slots > MOE_DOWN_MAX_SLOTS) return MI355_E_UNSUPPORTED;
+    if (((uintptr_t)p->act_q & 15) || ((uintptr_t)p->act_ds & 7) || (p->k & 15)) return MI355_E_ALIGN;
+    if (p->k % QK_K == 0 && ((uintptr_t)p->act_ds & 15)) return MI355_E_ALIGN;
+    const bool a16 = p->type == MI355_TYPE_Q4_K || p->type == MI355_TYPE_Q5_K;
+    if (((uintptr_t)p->W | (uintptr_t)p->w_row_stride | (uintptr_t)p->w_expert_stride) & (a16 ? 15 : 1)) return MI355_E_ALIGN;
+    if (p->w_row_stride < mi355_row_size(p->type, p->k)) return MI355_E_SHAPE;
+    if (((uintptr_t)p->out | (uintptr_t)p->weighted_out | (uintptr_t)p->sum_out | (uintptr_t)p->residual | (uintptr_t)p->residual_out |
+         (uintptr_t)p->weights | (uintptr_t)p->ids) & 3) return MI355_E_ALIGN;
+    KMoeDown a;
+    a.W = (const uint8_t *)p->W; a.w_row_stride = p->w_row_stride; a.w_ex_stride = p->w_expert_stride;
+    a.act_q = p->act_q; a.act_ds = p->act_ds; a.ids = p->ids; a.wts = p->weights;
+    a.y_out = p->out; a.yw_out = p->weighted_out; a.sum_out = p->sum_out; a.res = p->residual;
+    a.res_out = p->residual ? p->residual_out : nullptr;
+    a.m = (int)p->m; a.k = (int)p->k; a.n_slots = p->n_slots; a.n_expert = p->n_expert;
+    hipStream_t s = (hipStream_t)stream;
+    switch (p->type) {
+        case MI355_TYPE_Q4_0: return launch_moe_down<MI355_TYPE_Q4_0>(a, s);
+        case MI355_TYPE_Q8_0: return launch_moe_down<MI355_TYPE_Q8_0>(a, s);
+        case MI355_TYPE_Q4_K: return launch_moe_down<MI355_TYPE_Q4_K>(a, s);
+        case MI355_TYPE_Q5_K: return launch_moe_down<MI355_TYPE_Q5_K>(a, s);
+        case MI355_TYPE_Q6_K: return launch_moe_down<MI355_TYPE_Q6_K>(a, s);
     }
     return MI355_E_TYPE;
 }

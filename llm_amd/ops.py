@@ -249,6 +249,28 @@ def glu_matvec(t, w_gate, w_up, m, k, aq, ads, glu_op=2, quant=True, keep=True, 
     return dst, g, u, oq, ods
 
 
+def moe_down_matvec(t, w, m, k, n_expert, aq, ads, ids, weights, residual=None, in_place=False):
+    """Fused expert feed-forward output of one decode token (mi355_moe_down_matvec): w = [n_expert][m rows] blocks, aq / ads =
+    q8_1 of the [n_slots, k] activations, ids int32 [n_slots], weights f32 [n_slots]
+    -> (y [n_slots, m] | None when in_place, weighted [n_slots, m], sum [m], sum + residual [m] | None)."""
+    _u8(w)
+    ns, dev = ids.numel(), w.device
+    y = None if in_place else torch.full((ns, m), float("nan"), dtype=torch.float32, device=dev)
+    yw = torch.full((ns, m), float("nan"), dtype=torch.float32, device=dev)
+    sm = torch.full((m,), float("nan"), dtype=torch.float32, device=dev)
+    ro = torch.full((m,), float("nan"), dtype=torch.float32, device=dev) if residual is not None else None
+    a = K.MoeDownArgs()
+    a.type, a.n_slots, a.n_expert, a.W = t, ns, n_expert, w.data_ptr()
+    a.w_row_stride = B.row_size(t, k)
+    a.w_expert_stride = a.w_row_stride * m
+    a.m, a.k, a.act_q, a.act_ds, a.ids, a.weights = m, k, aq.data_ptr(), ads.data_ptr(), ids.data_ptr(), weights.data_ptr()
+    a.out, a.weighted_out, a.sum_out = None if in_place else y.data_ptr(), yw.data_ptr(), sm.data_ptr()
+    if residual is not None:
+        a.residual, a.residual_out = residual.data_ptr(), ro.data_ptr()
+    K.check(K.lib.mi355_moe_down_matvec(a, _stream()), "mi355_moe_down_matvec")
+    return y, yw, sm, ro
+
+
 def mul_mat_id_dq(t, as_, b, ids, m, n_expert):
     """ggml_mul_mat_id for prefill-sized batches (device-side expert bucketing + one bf16-MFMA GEMM launch):
     as_ = [n_expert][m rows] blocks, b = [n_tokens, b_ne1, k] f32, ids = [n_tokens, n_used] int32 -> [n_tokens, n_used, m] f32."""

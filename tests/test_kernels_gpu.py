@@ -434,6 +434,37 @@ def test_glu_matvec_expert_routing(ops, t, m, k, n_exp, ids):
         assert torch.equal(q0, q1[sl])
 
 
+@pytest.mark.parametrize("t", [B.Q4_K, B.Q6_K, B.Q8_0, B.Q4_0])
+@pytest.mark.parametrize("m,k,n_exp,ids,res", [(4096, 14336, 8, (5, 2), True), (130, 512, 4, (3, 3, 0), False), (64, 1024, 8, (7, 1), True),
+                                                (7, 32768, 3, (2, 0), True)])
+def test_moe_down_matvec_equals_separate_ops(ops, t, m, k, n_exp, ids, res):
+    """mi355_moe_down_matvec == MUL_MAT_ID (per-pair mat-vec) + MUL by the router weights + ADD over the slots + residual
+    ADD, every tensor to the bit (Mixtral ffn_down shape, three slots, a K too long for the LDS activation copy)."""
+    if k % B.BLCK_SIZE[t]:
+        pytest.skip("k not a multiple of the block size")
+    rng = np.random.default_rng(m + k)
+    ns = len(ids)
+    h = dev(rng.standard_normal((1, ns, k)).astype(np.float32))
+    w = dev(B.random_blocks(t, n_exp * m, k, seed=51))
+    idt = torch.tensor([ids], dtype=torch.int32, device="cuda")
+    wts = dev(rng.random(ns).astype(np.float32))
+    r = dev(rng.standard_normal(m).astype(np.float32)) if res else None
+    y0 = ops.mul_mat_id(t, w, h, idt, m, n_exp)[0]                 # [ns, m]
+    yw0 = y0 * wts[:, None]
+    sm0 = yw0[0] + yw0[1]
+    for s_ in range(2, ns):
+        sm0 = sm0 + yw0[s_]
+    aq, ads = ops.quantize_act(h.view(ns, k))
+    for in_place in (False, True):
+        y1, yw1, sm1, r1 = ops.moe_down_matvec(t, w, m, k, n_exp, aq, ads, idt.view(-1), wts, residual=r, in_place=in_place)
+        assert torch.isfinite(sm1).all() and float(sm1.abs().max()) > 0
+        if not in_place:
+            assert torch.equal(y1.view(torch.int32), y0.view(torch.int32))
+        assert torch.equal(yw1.view(torch.int32), yw0.view(torch.int32)) and torch.equal(sm1.view(torch.int32), sm0.view(torch.int32))
+        if res:
+            assert torch.equal(r1.view(torch.int32), (sm0 + r).view(torch.int32))
+
+
 def test_glu_matvec_argument_errors(ops):
     import llm_amd.kernels as K
     a = K.GluMatvecArgs()
