@@ -481,6 +481,9 @@ static ggml_backend_buffer_type_t mi355_split_buffer_type(int main_device, const
     return b;
 }
 
+// environment switches are read once per process (graph_compute consults them per node)
+#define MI355_ENV_SET(name) ([]() -> bool { static const bool v_ = getenv(name) != nullptr; return v_; }())
+
 // ------------------------------------------------------------------------------------------------
 // backend (stream)
 // ------------------------------------------------------------------------------------------------
@@ -671,8 +674,8 @@ enum mi355_mm_path { MM_VEC = 0, MM_DQ = 1, MM_SKINNY_K = 2, MM_SKINNY = 3, MM_Q
 static int mm_path_fmt(int path) { return path == MM_DQ ? 1 : path == MM_SKINNY_K ? 2 : 0; }
 
 static int mi355_mul_mat_path(const ggml_tensor * src0, const ggml_tensor * src1) {
-    static const bool int8_mmq = getenv("GGML_MI355_MMQ_INT8") != nullptr;
-    static const bool no_skinny = getenv("GGML_MI355_NO_SKINNY") != nullptr;
+    static const bool int8_mmq = MI355_ENV_SET("GGML_MI355_MMQ_INT8");
+    static const bool no_skinny = MI355_ENV_SET("GGML_MI355_NO_SKINNY");
     const int64_t K = src0->ne[0], N = src1->ne[1];
     const bool aligned = (((uintptr_t)src1->data | src1->nb[1] | src1->nb[2] | src1->nb[3]) & 15) == 0;
     if (!no_skinny && K % 256 == 0 && aligned && !(N > 8 && int8_mmq)) {
@@ -783,7 +786,7 @@ static void mi355_mul_mat(mi355_backend_ctx * ctx, ggml_tensor * dst) {
     const mi355_act_layout L = mi355_act_planes(path, K, rows);
     const size_t qb = L.total(), db = 0;
     char * ws = (char *)ctx->get_scratch(0, qb);
-    if (!ctx->act_cached(src1, fmt) || getenv("GGML_MI355_NO_FUSE")) {
+    if (!ctx->act_cached(src1, fmt) || MI355_ENV_SET("GGML_MI355_NO_FUSE")) {
         const float * x = (const float *)src1->data;
         if (fmt == 1)      MI_CHECK(mi355_act_bf16(x, (uint16_t *)ws, K, N, ne12, ne13, src1->nb[1], src1->nb[2], src1->nb[3], ctx->stream));
         else if (fmt == 2) MI_CHECK(mi355_quantize_act_q8k(x, (int8_t *)ws, (float *)(ws + L.b0), (int16_t *)(ws + L.b0 + L.b1), K, N, ne12, ne13,
@@ -857,7 +860,7 @@ static void mi355_mul_mat_id(mi355_backend_ctx * ctx, ggml_tensor * dst) {
                            ((((uintptr_t)b->data) | b->nb[1] | b->nb[2]) & 15) == 0;
     // (measured on 8x7B Q4_K_M: below ~20 pairs the per-pair mat-vec wins -- 16 pairs: 548 vs 521 t/s -- above 256 the GEMM)
     if (n_tokens * n_used >= 20 && n_tokens * n_used <= sk_max && K % 256 == 0 && n_expert <= 256 && dense_dst &&
-        getenv("GGML_MI355_NO_SKINNY") == nullptr) {
+        !MI355_ENV_SET("GGML_MI355_NO_SKINNY")) {
         const int64_t need = mi355_mul_mat_id_skinny_workspace_bytes((int)as->type, K, n_tokens, b_ne1, n_used, n_expert);
         void * ws = ctx->get_scratch(0, (size_t)need);
         ctx->act_cache.valid = false;
@@ -871,7 +874,7 @@ static void mi355_mul_mat_id(mi355_backend_ctx * ctx, ggml_tensor * dst) {
     // prefill-sized batches: bucket the (token, slot) pairs by expert on the device and run one bf16-MFMA GEMM over all
     // experts, so every touched expert matrix is read once.  Below ~64 pairs the per-pair mat-vec (each pair streams
     // its expert's rows, mostly from the Infinity Cache) is faster than dequantizing whole tiles for a few columns.
-    if (n_tokens * n_used >= 64 && K % 64 == 0 && n_expert <= 256 && dense_dst && getenv("GGML_MI355_MMQ_INT8") == nullptr) {
+    if (n_tokens * n_used >= 64 && K % 64 == 0 && n_expert <= 256 && dense_dst && !MI355_ENV_SET("GGML_MI355_MMQ_INT8")) {
         const int64_t need = mi355_mul_mat_id_dq_workspace_bytes(K, n_tokens, b_ne1, n_used, n_expert);
         void * ws = ctx->get_scratch(0, (size_t)need);
         ctx->act_cache.valid = false;     // the workspace replaces whatever activations were cached in scratch[0]
@@ -966,7 +969,7 @@ static void mi355_flash_attn(mi355_backend_ctx * ctx, ggml_tensor * dst) {
     // decode: the result (all heads of a token = one activation row) feeds the attention-output MUL_MAT; emit its
     // q8_1 form from the same kernel
     const int64_t K = a.d * a.n_head, rows = a.n_q * a.ne3;
-    if (rows <= 8 && ggml_is_contiguous(dst) && getenv("GGML_MI355_NO_FUSE") == nullptr) {
+    if (rows <= 8 && ggml_is_contiguous(dst) && !MI355_ENV_SET("GGML_MI355_NO_FUSE")) {
         const size_t qb = align_up((size_t)mi355_act_q_bytes(K, rows), 256), db = align_up((size_t)mi355_act_ds_bytes(K, rows), 256);
         char * act = (char *)ctx->get_scratch(0, qb + db);
         const int rc = mi355_flash_attn_ext_quant(&a, ws, ws_bytes, (int8_t *)act, (float *)(act + qb), ctx->stream);
@@ -1020,7 +1023,7 @@ static mi355_tensor to_mi355_tensor(const ggml_tensor * t) {
 static bool mi355_try_fuse_rms_norm_mul(mi355_backend_ctx * ctx, ggml_cgraph * cgraph, int i, ggml_tensor * add = nullptr) {
     ggml_tensor * norm = ggml_graph_node(cgraph, i);
     ggml_tensor * mul  = ggml_graph_node(cgraph, i + 1);
-    if (mul->op != GGML_OP_MUL || getenv("GGML_MI355_NO_FUSE")) return false;
+    if (mul->op != GGML_OP_MUL || MI355_ENV_SET("GGML_MI355_NO_FUSE")) return false;
     const ggml_tensor * w = mul->src[0] == norm ? mul->src[1] : (mul->src[1] == norm ? mul->src[0] : nullptr);
     if (!w || w == norm) return false;
     if (w->type != GGML_TYPE_F32 || mul->type != GGML_TYPE_F32 || norm->type != GGML_TYPE_F32) return false;
@@ -1084,7 +1087,7 @@ static bool mi355_try_fuse_rms_norm_mul(mi355_backend_ctx * ctx, ggml_cgraph * c
 static bool mi355_glu_with_quant(mi355_backend_ctx * ctx, ggml_tensor * node) {
     const ggml_tensor * a = node->src[0], * b = node->src[1];
     const int64_t rows = ggml_nrows(node), K = node->ne[0];
-    if (rows > 8 || K % 32 != 0 || !ggml_is_contiguous(node) || getenv("GGML_MI355_NO_FUSE")) return false;
+    if (rows > 8 || K % 32 != 0 || !ggml_is_contiguous(node) || MI355_ENV_SET("GGML_MI355_NO_FUSE")) return false;
     auto T = [](const ggml_tensor * t) { mi355_tensor r; r.data = t->data; r.type = (int32_t)t->type;
                                          for (int d = 0; d < 4; d++) { r.ne[d] = t->ne[d]; r.nb[d] = (int64_t)t->nb[d]; } return r; };
     mi355_tensor ta = T(a), tb, td = T(node);
@@ -1197,7 +1200,7 @@ static void mi355_mul_mat_group(mi355_backend_ctx * ctx, ggml_cgraph * cgraph, c
 // (mi355_try_fuse_norm_glu_matvec): there every workgroup reads the row, so nothing may update it in that launch.
 static bool mi355_try_fuse_matvec_add(mi355_backend_ctx * ctx, ggml_cgraph * cgraph, int i) {
     const int n = ggml_graph_n_nodes(cgraph);
-    if (i + 1 >= n || getenv("GGML_MI355_NO_MATVEC_ADD")) return false;
+    if (i + 1 >= n || MI355_ENV_SET("GGML_MI355_NO_MATVEC_ADD")) return false;
     ggml_tensor * mm = ggml_graph_node(cgraph, i), * add = ggml_graph_node(cgraph, i + 1);
     if (add->op != GGML_OP_ADD || add->type != GGML_TYPE_F32) return false;
     const ggml_tensor * r = add->src[0] == mm ? add->src[1] : (add->src[1] == mm ? add->src[0] : nullptr);
@@ -1262,7 +1265,7 @@ static bool norm_prologue_ok(const ggml_tensor * x, const ggml_tensor * w, int64
 static bool mi355_try_fuse_glu_matvec(mi355_backend_ctx * ctx, ggml_cgraph * cgraph, const int * members, int norm_idx = -1) {
     const int n = ggml_graph_n_nodes(cgraph);
     const int i0 = members[0], i1 = members[1];
-    if (i1 != i0 + 1 || i1 + 1 >= n || getenv("GGML_MI355_NO_GLU_MATVEC")) return false;
+    if (i1 != i0 + 1 || i1 + 1 >= n || MI355_ENV_SET("GGML_MI355_NO_GLU_MATVEC")) return false;
     ggml_tensor * glu = ggml_graph_node(cgraph, i1 + 1);
     const ggml_tensor * m0 = ggml_graph_node(cgraph, i0), * m1 = ggml_graph_node(cgraph, i1);
     if (glu->op != GGML_OP_GLU || !glu->src[1] || glu->type != GGML_TYPE_F32) return false;
@@ -1335,7 +1338,7 @@ static int mi355_collect_matvec_group(ggml_cgraph * cgraph, int i, const std::ve
 static bool matvec_groupable(const ggml_tensor * node);
 static bool mi355_try_fuse_norm_glu_matvec(mi355_backend_ctx * ctx, ggml_cgraph * cgraph, int i, const std::vector<char> & done) {
     const int n = ggml_graph_n_nodes(cgraph);
-    if (i + 4 >= n || getenv("GGML_MI355_NO_NORM_GLU")) return false;
+    if (i + 4 >= n || MI355_ENV_SET("GGML_MI355_NO_NORM_GLU")) return false;
     for (int j = i; j <= i + 4; j++) if (done[j]) return false;
     if (!decode_norm_pattern(cgraph, i, done)) return false;
     const ggml_tensor * mul = ggml_graph_node(cgraph, i + 1);
@@ -1353,7 +1356,7 @@ static bool mi355_try_fuse_norm_glu_matvec(mi355_backend_ctx * ctx, ggml_cgraph 
 // activation cache.  A GLU result exactly on top of one of its inputs replaces it.
 static bool mi355_try_fuse_moe_glu_matvec(mi355_backend_ctx * ctx, ggml_cgraph * cgraph, int i, const std::vector<char> & done) {
     const int n = ggml_graph_n_nodes(cgraph);
-    if (i + 2 >= n || done[i + 1] || done[i + 2] || getenv("GGML_MI355_NO_GLU_MATVEC")) return false;
+    if (i + 2 >= n || done[i + 1] || done[i + 2] || MI355_ENV_SET("GGML_MI355_NO_GLU_MATVEC")) return false;
     const ggml_tensor * m0 = ggml_graph_node(cgraph, i), * m1 = ggml_graph_node(cgraph, i + 1);
     ggml_tensor * glu = ggml_graph_node(cgraph, i + 2);
     if (m1->op != GGML_OP_MUL_MAT_ID || glu->op != GGML_OP_GLU || !glu->src[1] || glu->type != GGML_TYPE_F32) return false;
@@ -1429,7 +1432,7 @@ static bool same_or_apart(const ggml_tensor * a, const ggml_tensor * b) {
 }
 
 static bool mi355_try_fuse_moe_down(mi355_backend_ctx * ctx, ggml_cgraph * cgraph, int i, std::vector<char> & done) {
-    if (getenv("GGML_MI355_NO_MOE_DOWN")) return false;
+    if (MI355_ENV_SET("GGML_MI355_NO_MOE_DOWN")) return false;
     const ggml_tensor * down = ggml_graph_node(cgraph, i);
     const ggml_tensor * as = down->src[0], * b = down->src[1], * ids = down->src[2];
     const int64_t K = as->ne[0], M = as->ne[1], n_expert = as->ne[2], n_used = ids->ne[0];
@@ -1709,8 +1712,8 @@ static enum ggml_status mi355_backend_graph_compute(ggml_backend_t backend, ggml
     mi355_set_device(ctx->device);
     ctx->act_cache.valid = false; // tensors may have been rewritten through set_tensor / copies between calls
     const int n = ggml_graph_n_nodes(cgraph);
-    const bool fuse = getenv("GGML_MI355_NO_FUSE") == nullptr;
-    if (getenv("GGML_MI355_DUMP_GRAPH")) {   // diagnostics: the node list this backend was handed
+    const bool fuse = !MI355_ENV_SET("GGML_MI355_NO_FUSE");
+    if (MI355_ENV_SET("GGML_MI355_DUMP_GRAPH")) {   // diagnostics: the node list this backend was handed
         for (int i = 0; i < n; i++) {
             const ggml_tensor * t = ggml_graph_node(cgraph, i);
             fprintf(stderr, "[mi355] %4d %-14s %-28s [%lld,%lld,%lld,%lld] %p", i, ggml_op_name(t->op), t->name, (long long)t->ne[0],
@@ -1786,7 +1789,7 @@ static enum ggml_status mi355_backend_graph_compute(ggml_backend_t backend, ggml
             i += 4;
             continue;
         }
-        if (fuse && node->op == GGML_OP_RMS_NORM && i + 2 < n && !getenv("GGML_MI355_NO_NORM_QKV") && decode_norm_pattern(cgraph, i, done) &&
+        if (fuse && node->op == GGML_OP_RMS_NORM && i + 2 < n && !MI355_ENV_SET("GGML_MI355_NO_NORM_QKV") && decode_norm_pattern(cgraph, i, done) &&
             ggml_graph_node(cgraph, i + 2)->op == GGML_OP_MUL_MAT && ggml_graph_node(cgraph, i + 2)->src[1] == ggml_graph_node(cgraph, i + 1) &&
             mi355_try_fuse_qkv_rope(ctx, cgraph, i + 2, done, i)) {
             i += 2;      // the norm, its MUL and wq; the other six nodes are marked done
