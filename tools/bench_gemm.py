@@ -11,7 +11,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 which = sys.argv[2] if len(sys.argv) > 2 else "dq"
 only = tuple(int(v) for v in sys.argv[3].split(",")) if len(sys.argv) > 3 else None      # "type,m,k": one shape only
 s = torch.cuda.current_stream().cuda_stream
-for t, m, k in ((B.Q4_K, 4096, 4096), (B.Q4_K, 14336, 4096), (B.Q4_K, 4096, 14336), (B.Q6_K, 4096, 14336), (B.Q6_K, 128256, 4096),
+for t, m, k in ((B.Q4_K, 1024, 4096), (B.Q4_K, 4096, 4096), (B.Q4_K, 14336, 4096), (B.Q4_K, 4096, 14336), (B.Q6_K, 4096, 14336), (B.Q6_K, 128256, 4096),
                 (B.Q8_0, 14336, 4096), (B.Q4_0, 14336, 4096), (B.Q5_K, 1024, 8192)):
     if only and (t, m, k) != only: continue
     w = torch.from_numpy(B.random_blocks(t, min(m, 16384), k, seed=1)).cuda()
