@@ -365,6 +365,14 @@ MI355_API int mi355_glu_f32(int glu_op, const mi355_tensor *a, const mi355_tenso
 /* same, plus the q8_1 form of dst (see mi355_rms_norm_mul_quant_f32); nc % 32 == 0, 16-byte aligned rows */
 MI355_API int mi355_glu_quant_f32(int glu_op, const mi355_tensor *a, const mi355_tensor *b, const mi355_tensor *dst, int swapped,
                                   int8_t *act_q, float *act_ds, void *stream);
+/* Prefill forms of the two fused producers: the f32 result plus its bf16 rows ([rows][ne0] uint16, the rounding of
+ * mi355_act_bf16) for the dequantize-in-LDS GEMM that reads it -- what ggml-cuda does with a separate convert kernel
+ * before cuBLAS (ggml-cuda.cu:1200-1260).  b / sum NULL: no residual add.  ne0 % 16 == 0 (norm) / % 4 == 0 (glu),
+ * rows 16-byte aligned, else MI355_E_UNSUPPORTED. */
+MI355_API int mi355_rms_norm_mul_bf16_f32(const mi355_tensor *a, const mi355_tensor *b, const mi355_tensor *sum, const float *w,
+                                          const mi355_tensor *dst, float eps, uint16_t *act_bf16, void *stream);
+MI355_API int mi355_glu_bf16_f32(int glu_op, const mi355_tensor *a, const mi355_tensor *b, const mi355_tensor *dst, int swapped,
+                                 uint16_t *act_bf16, void *stream);
 
 /* copy / convert with arbitrary strides and equal element counts (ggml_cpy, ggml_cont, ggml_dup):
  * f32 -> f32 | f16 | q8_0, f16 -> f16 | f32.  The q8_0 destination follows quantize_row_q8_0_ref

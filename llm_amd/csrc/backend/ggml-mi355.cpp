@@ -1059,6 +1059,21 @@ static bool mi355_try_fuse_rms_norm_mul(mi355_backend_ctx * ctx, ggml_cgraph * c
         char * ws = (char *)ctx->get_scratch(0, qb + db);
         aq = (int8_t *)ws; ads = (float *)(ws + qb);
     }
+    // prefill-sized rows (every MUL_MAT that reads them takes the bf16 GEMM): also emit the bf16 rows, so those MUL_MATs
+    // need no conversion launch
+    if (rows > 128 && K % 16 == 0 && K <= 8192 && ggml_is_contiguous(mul) && !MI355_ENV_SET("GGML_MI355_MMQ_INT8")) {
+        uint16_t * abf = (uint16_t *)ctx->get_scratch(0, align_up((size_t)rows * K * 2, 256));
+        mi355_tensor ta = to_mi355_tensor(add ? add->src[0] : x), tb, ts;
+        if (add) { tb = to_mi355_tensor(add->src[1]); ts = to_mi355_tensor(add); }
+        const int rc = mi355_rms_norm_mul_bf16_f32(&ta, add ? &tb : nullptr, add ? &ts : nullptr, (const float *)w->data, &td, eps, abf, ctx->stream);
+        if (rc == MI355_OK) {
+            if (add) ctx->act_invalidate_if_written(add);
+            ctx->act_invalidate_if_written(mul);
+            ctx->act_remember(mul, 1);
+            return true;
+        }
+        if (rc != MI355_E_UNSUPPORTED) MI_CHECK(rc);
+    }
     if (add) {
         mi355_tensor ta = to_mi355_tensor(add->src[0]), tb = to_mi355_tensor(add->src[1]), ts = to_mi355_tensor(add);
         int rc = mi355_add_rms_norm_mul_f32(&ta, &tb, &ts, (const float *)w->data, &td, eps, aq, ads, ctx->stream);
@@ -1087,11 +1102,20 @@ static bool mi355_try_fuse_rms_norm_mul(mi355_backend_ctx * ctx, ggml_cgraph * c
 static bool mi355_glu_with_quant(mi355_backend_ctx * ctx, ggml_tensor * node) {
     const ggml_tensor * a = node->src[0], * b = node->src[1];
     const int64_t rows = ggml_nrows(node), K = node->ne[0];
-    if (rows > 8 || K % 32 != 0 || !ggml_is_contiguous(node) || MI355_ENV_SET("GGML_MI355_NO_FUSE")) return false;
+    if (!ggml_is_contiguous(node) || MI355_ENV_SET("GGML_MI355_NO_FUSE")) return false;
     auto T = [](const ggml_tensor * t) { mi355_tensor r; r.data = t->data; r.type = (int32_t)t->type;
                                          for (int d = 0; d < 4; d++) { r.ne[d] = t->ne[d]; r.nb[d] = (int64_t)t->nb[d]; } return r; };
     mi355_tensor ta = T(a), tb, td = T(node);
     if (b) tb = T(b);
+    if (rows > 128 && b && K % 4 == 0 && !MI355_ENV_SET("GGML_MI355_MMQ_INT8")) {   // prefill: bf16 rows for the ffn_down GEMM
+        uint16_t * abf = (uint16_t *)ctx->get_scratch(0, align_up((size_t)rows * K * 2, 256));
+        const int rc = mi355_glu_bf16_f32((int)ggml_get_glu_op(node), &ta, &tb, &td, ((const int32_t *)node->op_params)[1], abf, ctx->stream);
+        if (rc == MI355_E_UNSUPPORTED) return false;
+        MI_CHECK(rc);
+        ctx->act_remember(node, 1);
+        return true;
+    }
+    if (rows > 8 || K % 32 != 0) return false;
     const size_t qb = align_up((size_t)mi355_act_q_bytes(K, rows), 256), db = align_up((size_t)mi355_act_ds_bytes(K, rows), 256);
     char * ws = (char *)ctx->get_scratch(0, qb + db);
     const int rc = mi355_glu_quant_f32((int)ggml_get_glu_op(node), &ta, b ? &tb : nullptr, &td, ((const int32_t *)node->op_params)[1],

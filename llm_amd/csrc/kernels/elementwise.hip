@@ -83,7 +83,7 @@ binary_kernel(const T4 a, const T4 b, const T4 d, int64_t n) {
 template <bool HAS_W, bool HAS_ADD, int NT>
 __global__ void __launch_bounds__(NT)
 rms_norm_kernel(const T4 x, const T4 y, const T4 sum, const float * __restrict__ w, const T4 d, float eps, bool vec,
-                int8_t * __restrict__ aq, float * __restrict__ ads) {
+                int8_t * __restrict__ aq, float * __restrict__ ads, uint16_t * __restrict__ abf) {
     __shared__ float sh[NT / 64];
     const int row = blockIdx.x;
     const int ne1 = (int)x.ne[1], ne2 = (int)x.ne[2];
@@ -131,6 +131,14 @@ rms_norm_kernel(const T4 x, const T4 y, const T4 sum, const float * __restrict__
                     o[4 * q] = t.x; o[4 * q + 1] = t.y; o[4 * q + 2] = t.z; o[4 * q + 3] = t.w;
                 }
                 if (aq) quant16_soa(o, aq + (int64_t)row * n + 16 * c, ads + ((int64_t)row * (n / QK) + (c >> 1)) * 2, (c & 1) == 0);
+                if (abf) {      // bf16 form of the row for the prefill GEMM (the rounding of mi355_act_bf16)
+                    typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+                    bf8 b0, b1;
+#pragma unroll
+                    for (int i = 0; i < 8; i++) { b0[i] = (__bf16)o[i]; b1[i] = (__bf16)o[8 + i]; }
+                    bf8 * bo = (bf8 *)(abf + (int64_t)row * n + 16 * c);
+                    bo[0] = b0; bo[1] = b1;
+                }
             }
         }
         return;
@@ -229,6 +237,20 @@ glu_kernel(int op, const char * a, const char * b, int64_t a_row, int64_t b_row,
         const float g = ((const float *)(b + r * b_row))[c];
         ((float *)(d + r * d_row))[c] = act_glu(op, x) * g;
     }
+}
+
+// vectorized split-GLU that also stores the bf16 form of the result (prefill: the result feeds the ffn_down GEMM)
+__global__ void __launch_bounds__(256)
+glu_bf16_kernel(int op, const char * a, const char * b, int64_t a_row, int64_t b_row, char * d, int64_t d_row, int nc, uint16_t * __restrict__ abf) {
+    const int i = blockIdx.y * 256 + threadIdx.x;    // float4 index inside the row
+    if (i * 4 >= nc) return;
+    const int64_t r = blockIdx.x;
+    const v4f x = ((const v4f *)(a + r * a_row))[i], g = ((const v4f *)(b + r * b_row))[i];
+    const v4f ov = {act_glu(op, x.x) * g.x, act_glu(op, x.y) * g.y, act_glu(op, x.z) * g.z, act_glu(op, x.w) * g.w};
+    ((v4f *)(d + r * d_row))[i] = ov;
+    typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
+    const bf4 bv = {(__bf16)ov.x, (__bf16)ov.y, (__bf16)ov.z, (__bf16)ov.w};
+    *(bf4 *)(abf + r * nc + 4 * i) = bv;
 }
 
 // vectorized split-GLU with fused q8_1 quantization of the result (decode: the result feeds ffn_down)
@@ -369,7 +391,7 @@ int mi355_binary_f32(int op, const mi355_tensor * a, const mi355_tensor * b, con
 }
 
 static int launch_rms_norm(const mi355_tensor * x, const mi355_tensor * y, const mi355_tensor * sum, const float * w,
-                           const mi355_tensor * dst, float eps, int8_t * aq, float * ads, void * stream) {
+                           const mi355_tensor * dst, float eps, int8_t * aq, float * ads, void * stream, uint16_t * abf = nullptr) {
     CHECK_T(x); CHECK_T(dst);
     if (x->type != MI355_TYPE_F32 || dst->type != MI355_TYPE_F32) return MI355_E_TYPE;
     if (!same_shape(x, dst) || x->nb[0] != 4 || dst->nb[0] != 4) return MI355_E_SHAPE;
@@ -387,19 +409,20 @@ static int launch_rms_norm(const mi355_tensor * x, const mi355_tensor * y, const
     }
     const bool vec = (al & 15) == 0 && x->ne[0] % 4 == 0 && x->ne[0] <= 8192;
     if (aq && (!vec || x->ne[0] % QK != 0 || !ads)) return MI355_E_UNSUPPORTED;
+    if (abf && (!vec || x->ne[0] % 16 != 0 || ((uintptr_t)abf & 15))) return MI355_E_UNSUPPORTED;
     if (y && (!vec || !w)) return MI355_E_UNSUPPORTED;
     const dim3 grid((unsigned)rows);
     hipStream_t s = (hipStream_t)stream;
     if (x->ne[0] > 4096) {
         const dim3 block(512);
-        if (y)      MI355_LAUNCH("add_rms_norm_mul", (rms_norm_kernel<true, true, 512>), grid, block, 0, s, t4(x), t4(y), t4(sum), w, t4(dst), eps, vec, aq, ads);
-        else if (w) MI355_LAUNCH("rms_norm_mul", (rms_norm_kernel<true, false, 512>), grid, block, 0, s, t4(x), t4(x), t4(x), w, t4(dst), eps, vec, aq, ads);
-        else        MI355_LAUNCH("rms_norm", (rms_norm_kernel<false, false, 512>), grid, block, 0, s, t4(x), t4(x), t4(x), w, t4(dst), eps, vec, aq, ads);
+        if (y)      MI355_LAUNCH("add_rms_norm_mul", (rms_norm_kernel<true, true, 512>), grid, block, 0, s, t4(x), t4(y), t4(sum), w, t4(dst), eps, vec, aq, ads, abf);
+        else if (w) MI355_LAUNCH("rms_norm_mul", (rms_norm_kernel<true, false, 512>), grid, block, 0, s, t4(x), t4(x), t4(x), w, t4(dst), eps, vec, aq, ads, abf);
+        else        MI355_LAUNCH("rms_norm", (rms_norm_kernel<false, false, 512>), grid, block, 0, s, t4(x), t4(x), t4(x), w, t4(dst), eps, vec, aq, ads, abf);
     } else {
         const dim3 block(256);
-        if (y)      MI355_LAUNCH("add_rms_norm_mul", (rms_norm_kernel<true, true, 256>), grid, block, 0, s, t4(x), t4(y), t4(sum), w, t4(dst), eps, vec, aq, ads);
-        else if (w) MI355_LAUNCH("rms_norm_mul", (rms_norm_kernel<true, false, 256>), grid, block, 0, s, t4(x), t4(x), t4(x), w, t4(dst), eps, vec, aq, ads);
-        else        MI355_LAUNCH("rms_norm", (rms_norm_kernel<false, false, 256>), grid, block, 0, s, t4(x), t4(x), t4(x), w, t4(dst), eps, vec, aq, ads);
+        if (y)      MI355_LAUNCH("add_rms_norm_mul", (rms_norm_kernel<true, true, 256>), grid, block, 0, s, t4(x), t4(y), t4(sum), w, t4(dst), eps, vec, aq, ads, abf);
+        else if (w) MI355_LAUNCH("rms_norm_mul", (rms_norm_kernel<true, false, 256>), grid, block, 0, s, t4(x), t4(x), t4(x), w, t4(dst), eps, vec, aq, ads, abf);
+        else        MI355_LAUNCH("rms_norm", (rms_norm_kernel<false, false, 256>), grid, block, 0, s, t4(x), t4(x), t4(x), w, t4(dst), eps, vec, aq, ads, abf);
     }
     MI355_CHECK_LAUNCH();
     return MI355_OK;
@@ -427,6 +450,12 @@ int mi355_add_rms_norm_mul_f32(const mi355_tensor * a, const mi355_tensor * b, c
     return launch_rms_norm(a, b, sum, w, dst, eps, act_q, act_ds, stream);
 }
 
+int mi355_rms_norm_mul_bf16_f32(const mi355_tensor * a, const mi355_tensor * b, const mi355_tensor * sum, const float * w,
+                                const mi355_tensor * dst, float eps, uint16_t * act_bf16, void * stream) {
+    if (!w || !act_bf16 || ((b == nullptr) != (sum == nullptr))) return MI355_E_NULL;
+    return launch_rms_norm(a, b, sum, w, dst, eps, nullptr, nullptr, stream, act_bf16);
+}
+
 int mi355_rope_f32(const mi355_tensor * x, const int32_t * pos, const float * freq_factors, const mi355_tensor * dst,
                    int n_dims, int mode, int n_ctx_orig, float freq_base, float freq_scale, float ext_factor,
                    float attn_factor, float beta_fast, float beta_slow, void * stream) {
@@ -444,7 +473,13 @@ int mi355_rope_f32(const mi355_tensor * x, const int32_t * pos, const float * fr
 }
 
 static int launch_glu(int glu_op, const mi355_tensor * a, const mi355_tensor * b, const mi355_tensor * dst, int swapped,
-                      int8_t * aq, float * ads, void * stream);
+                      int8_t * aq, float * ads, void * stream, uint16_t * abf = nullptr);
+
+int mi355_glu_bf16_f32(int glu_op, const mi355_tensor * a, const mi355_tensor * b, const mi355_tensor * dst, int swapped,
+                       uint16_t * act_bf16, void * stream) {
+    if (!act_bf16) return MI355_E_NULL;
+    return launch_glu(glu_op, a, b, dst, swapped, nullptr, nullptr, stream, act_bf16);
+}
 
 int mi355_glu_f32(int glu_op, const mi355_tensor * a, const mi355_tensor * b, const mi355_tensor * dst, int swapped, void * stream) {
     return launch_glu(glu_op, a, b, dst, swapped, nullptr, nullptr, stream);
@@ -457,7 +492,7 @@ int mi355_glu_quant_f32(int glu_op, const mi355_tensor * a, const mi355_tensor *
 }
 
 static int launch_glu(int glu_op, const mi355_tensor * a, const mi355_tensor * b, const mi355_tensor * dst, int swapped,
-                      int8_t * aq, float * ads, void * stream) {
+                      int8_t * aq, float * ads, void * stream, uint16_t * abf) {
     CHECK_T(a); CHECK_T(dst);
     if (b && !b->data) return MI355_E_NULL;
     if (a->type != MI355_TYPE_F32 || dst->type != MI355_TYPE_F32 || (b && b->type != MI355_TYPE_F32)) return MI355_E_TYPE;
@@ -471,6 +506,15 @@ static int launch_glu(int glu_op, const mi355_tensor * a, const mi355_tensor * b
     if (n == 0) return MI355_OK;
     const char * ap = (const char *)a->data, * bp = b ? (const char *)b->data : (const char *)a->data;
     if (!b) { ap += swapped ? nc * 4 : 0; bp += swapped ? 0 : nc * 4; }
+    if (abf) {
+        const uintptr_t al = (uintptr_t)ap | (uintptr_t)bp | (uintptr_t)dst->data | (uintptr_t)a->nb[1] | (uintptr_t)(b ? b->nb[1] : a->nb[1]) | (uintptr_t)dst->nb[1];
+        if ((al & 15) || ((uintptr_t)abf & 7) || nc % 4 != 0 || nrows(dst) > 0x7fffffff) return MI355_E_UNSUPPORTED;
+        const dim3 grid((unsigned)nrows(dst), (unsigned)((nc / 4 + 255) / 256));
+        MI355_LAUNCH("glu_bf16", glu_bf16_kernel, grid, dim3(256), 0, (hipStream_t)stream, glu_op, ap, bp, a->nb[1],
+                     b ? b->nb[1] : a->nb[1], (char *)dst->data, dst->nb[1], (int)nc, abf);
+        MI355_CHECK_LAUNCH();
+        return MI355_OK;
+    }
     if (aq) {
         const uintptr_t al = (uintptr_t)ap | (uintptr_t)bp | (uintptr_t)dst->data | (uintptr_t)a->nb[1] | (uintptr_t)(b ? b->nb[1] : a->nb[1]) | (uintptr_t)dst->nb[1];
         if ((al & 15) || nc % QK != 0 || nrows(dst) > 0x7fffffff) return MI355_E_UNSUPPORTED;

@@ -62,7 +62,7 @@ def test_mixtral_style_graph_runs_entirely_on_the_device(tmp_path):
         path = str(tmp_path / f"moe_logits_{name}.bin")
         r = subprocess.run([tool, "tinymoe", "Q4_K_M", "-ngl", ngl, "--dump-logits", path], capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-3000:]
-        outs[name] = np.fromfile(path, dtype=np.float32).reshape(9, -1)
+        outs[name] = np.fromfile(path, dtype=np.float32).reshape(10, -1)
     a, b = outs["cpu"], outs["gpu"]
     assert np.isfinite(b).all()
     nmse = float(((a - b) ** 2).sum() / (a ** 2).sum())
@@ -81,7 +81,7 @@ def test_llama_logits_match_ggml_cpu(ftype, ctk, tmp_path):
         r = subprocess.run([tool, "tiny", ftype, "-ngl", ngl, "-ctk", ctk, "-ctv", ctk, "--dump-logits", path],
                            capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-3000:]
-        outs[name] = np.fromfile(path, dtype=np.float32).reshape(9, -1)
+        outs[name] = np.fromfile(path, dtype=np.float32).reshape(10, -1)
     a, b = outs["cpu"], outs["gpu"]
     assert np.isfinite(b).all()
     nmse = float(((a - b) ** 2).sum() / (a ** 2).sum())

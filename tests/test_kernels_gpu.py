@@ -538,6 +538,31 @@ def test_glu_matvec_norm_prologue_equals_separate_norm(ops, t, m, k):
     assert torch.equal(q0, q1)
 
 
+@pytest.mark.parametrize("rows,n,with_add", [(130, 4096, True), (200, 1024, False), (129, 8192, True), (3, 96, False)])
+def test_norm_and_glu_bf16_forms(ops, rows, n, with_add):
+    """prefill producers: mi355_rms_norm_mul_bf16_f32 / mi355_glu_bf16_f32 == the plain kernels bit for bit, and their bf16
+    rows == mi355_act_bf16 of that f32 result."""
+    import llm_amd.kernels as K
+    rng = np.random.default_rng(rows + n)
+    x, y, w = (dev(rng.standard_normal(sh).astype(np.float32)) for sh in ((rows, n), (rows, n), (n,)))
+    T, s = K.Tensor.of, torch.cuda.current_stream().cuda_stream
+    su0, d0, su1, d1 = (torch.empty_like(x) for _ in range(4))
+    bf = torch.empty((rows, n), dtype=torch.int16, device="cuda")
+    if with_add:
+        K.check(K.lib.mi355_add_rms_norm_mul_f32(T(x), T(y), T(su0), w.data_ptr(), T(d0), 1e-5, None, None, s), "add_rms_norm_mul")
+        K.check(K.lib.mi355_rms_norm_mul_bf16_f32(T(x), T(y), T(su1), w.data_ptr(), T(d1), 1e-5, bf.data_ptr(), s), "rms_norm_mul_bf16")
+        assert torch.equal(su0.view(torch.int32), su1.view(torch.int32))
+    else:
+        K.check(K.lib.mi355_rms_norm_mul_f32(T(x), w.data_ptr(), T(d0), 1e-5, s), "rms_norm_mul")
+        K.check(K.lib.mi355_rms_norm_mul_bf16_f32(T(x), None, None, w.data_ptr(), T(d1), 1e-5, bf.data_ptr(), s), "rms_norm_mul_bf16")
+    assert torch.isfinite(d1).all() and torch.equal(d0.view(torch.int32), d1.view(torch.int32))
+    assert torch.equal(bf, ops.act_bf16(d1))
+    g0, g1 = torch.empty_like(x), torch.empty_like(x)
+    K.check(K.lib.mi355_glu_f32(2, T(x), T(y), T(g0), 0, s), "glu")
+    K.check(K.lib.mi355_glu_bf16_f32(2, T(x), T(y), T(g1), 0, bf.data_ptr(), s), "glu_bf16")
+    assert torch.equal(g0.view(torch.int32), g1.view(torch.int32)) and torch.equal(bf, ops.act_bf16(g1))
+
+
 @pytest.mark.parametrize("rows,n", [(1, 4096), (3, 1024), (8, 8192), (2, 96), (1, 4128)])
 @pytest.mark.parametrize("with_add", [False, True])
 def test_fused_norm_matches_separate_ops(ops, rows, n, with_add):
