@@ -404,7 +404,7 @@ fattn_vec_kernel(const FArgs a) {
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float v16f __attribute__((ext_vector_type(16)));
 
-constexpr int MMA_BQ = 64, MMA_BKV = 64, MMA_THREADS = 128;
+constexpr int MMA_BKV = 64, MMA_WAVES = 4, MMA_THREADS = 64 * MMA_WAVES;
 
 // 8 consecutive features of a K/V row as f16 (16 bytes): f16 rows are copied, q8_0 / q4_0 rows are dequantized
 // (d * q in f32, as the vec kernel does) and rounded to f16
@@ -423,15 +423,21 @@ template <int D, int TKV>
 __global__ void __launch_bounds__(MMA_THREADS)
 fattn_mma_kernel(const FArgs a) {
     constexpr int KP = D * 2 + 16;          // K tile row pitch (bytes)
-    constexpr int VP = MMA_BKV * 2 + 16;    // V^T tile row pitch (bytes)
+    constexpr int VP = D * 2 + 64;          // V tile row pitch (bytes): 4 consecutive rows land on 4 disjoint groups of 16 banks, so
+                                            // the transposed reads below (4 rows x 64 B per 32-lane half) are conflict-free
     constexpr int DT = D / 32, KS = D / 16;
     __shared__ __attribute__((aligned(16))) uint8_t Ks[MMA_BKV * KP];
-    __shared__ __attribute__((aligned(16))) uint8_t Vt[D * VP];
+    __shared__ __attribute__((aligned(16))) uint8_t Vs[MMA_BKV * VP];   // row-major like K; consumed column-wise with ds_read_b64_tr_b16
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 31, lh = lane >> 5;
-    const int h = blockIdx.y, i3 = blockIdx.z;
-    const int hk = h / (a.n_head / a.n_head_kv);
-    const int q = blockIdx.x * MMA_BQ + wave * 32 + lr;
+    // The 4 waves share every K/V tile: they take up to 4 heads of one KV head (GQA) and, if that leaves waves over, further
+    // 32-query blocks -- so a tile is staged once for 4 x 32 (head, query) rows and the causal skip works on 32-query blocks.
+    const int ratio = a.n_head / a.n_head_kv;
+    const int hpw = ratio % 4 == 0 ? 4 : ratio % 2 == 0 ? 2 : 1;               // heads per workgroup (divides the GQA ratio)
+    const int qpw = MMA_WAVES / hpw;                                          // 32-query blocks per workgroup
+    const int h = (int)blockIdx.y * hpw + wave % hpw, i3 = blockIdx.z;
+    const int hk = h / ratio;
+    const int q = ((int)blockIdx.x * qpw + wave / hpw) * 32 + lr;
     const int qc = q < a.n_q ? q : a.n_q - 1;
 
     // Q^T operand: this lane's query row, features 16 ks + 8 lh .. + 8, pre-scaled, f16
@@ -460,31 +466,11 @@ fattn_mma_kernel(const FArgs a) {
     float m = -INFINITY, l = 0.0f;
 
     constexpr int CH = MMA_BKV * D * 2 / 16 / MMA_THREADS;   // 16-byte chunks per thread per tile
+    const bool mvec = mrow && (((uintptr_t)a.mask | (uintptr_t)a.m_nb1 | (uintptr_t)a.m_nb2 | (uintptr_t)a.m_nb3) & 7) == 0;   // 4 mask values per load
     for (int kv0 = 0; kv0 < a.n_kv; kv0 += MMA_BKV) {
-        __syncthreads();                                     // previous block fully consumed
-        // ---- stage K (row-major) and V (transposed + permuted)
-#pragma unroll
-        for (int i = 0; i < CH; i++) {
-            const int c = tid + MMA_THREADS * i;
-            {
-                const int row = c / (D / 8), cc = c % (D / 8);
-                const int kv = kv0 + row < a.n_kv ? kv0 + row : a.n_kv - 1;
-                *(v4i *)(Ks + row * KP + cc * 16) = load8h<TKV>(kbase + (int64_t)kv * a.k_nb1, cc);
-            }
-            {
-                const int row = c % MMA_BKV, cc = c / MMA_BKV;   // consecutive lanes: consecutive kv rows, same features
-                const int kv = kv0 + row < a.n_kv ? kv0 + row : a.n_kv - 1;
-                const v4i raw = load8h<TKV>(vbase + (int64_t)kv * a.v_nb1, cc);
-                const int kv32 = row & 31;
-                const int pos = (row & 32) + (kv32 >> 4) * 16 + ((kv32 >> 2) & 1) * 8 + ((kv32 & 3) | (((kv32 >> 3) & 1) << 2));
-                const uint16_t * hv = (const uint16_t *)&raw;
-#pragma unroll
-                for (int e = 0; e < 8; e++) *(uint16_t *)(Vt + (cc * 8 + e) * VP + pos * 2) = hv[e];
-            }
-        }
-        __syncthreads();
-
-        // ---- mask tile of this wave: 2 S^T tiles x 16 kv rows per lane
+        // ---- mask tile of this wave: 2 S^T tiles x 16 kv rows per lane.  Read before anything is staged: a block that is
+        // masked out for every query of the workgroup (the upper triangle of causal prefill: almost half of all blocks)
+        // costs these loads and one barrier, no K/V traffic.
         float mv[2][16];
         bool any = false;
 #pragma unroll
@@ -492,17 +478,36 @@ fattn_mma_kernel(const FArgs a) {
 #pragma unroll
             for (int g = 0; g < 4; g++) {
                 const int kvl = kv0 + 32 * t + 8 * g + 4 * lh;     // 4 consecutive kv rows
+                if (mvec && kvl + 4 <= a.n_kv) {
+                    typedef _Float16 mh4 __attribute__((ext_vector_type(4)));
+                    const mh4 raw = *(const mh4 *)(mrow + kvl);
 #pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    const int kv = kvl + e;
-                    float v = kv < a.n_kv ? 0.0f : -INFINITY;
-                    if (mrow && kv < a.n_kv) v = __half2float(mrow[kv]);
-                    mv[t][4 * g + e] = v;
-                    any |= v != -INFINITY;
+                    for (int e = 0; e < 4; e++) mv[t][4 * g + e] = (float)raw[e];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const int kv = kvl + e;
+                        float v = kv < a.n_kv ? 0.0f : -INFINITY;
+                        if (mrow && kv < a.n_kv) v = __half2float(mrow[kv]);
+                        mv[t][4 * g + e] = v;
+                    }
                 }
+#pragma unroll
+                for (int e = 0; e < 4; e++) any |= mv[t][4 * g + e] != -INFINITY;
             }
+        if (!__syncthreads_or(any)) continue;                // (also: previous block fully consumed)
+        // ---- stage K and V, both row-major: coalesced 16-byte loads, 16-byte LDS stores
+#pragma unroll
+        for (int i = 0; i < CH; i++) {
+            const int c = tid + MMA_THREADS * i;
+            const int row = c / (D / 8), cc = c % (D / 8);
+            const int kv = kv0 + row < a.n_kv ? kv0 + row : a.n_kv - 1;
+            *(v4i *)(Ks + row * KP + cc * 16) = load8h<TKV>(kbase + (int64_t)kv * a.k_nb1, cc);
+            *(v4i *)(Vs + row * VP + cc * 16) = load8h<TKV>(vbase + (int64_t)kv * a.v_nb1, cc);
+        }
+        __syncthreads();
         if (!__any(any)) continue;     // whole tile masked out for every query of this wave (uniform per wave; the
-                                       // barriers sit at the top of the loop, which every wave still reaches)
+                                       // barrier at the top of the loop is still reached by every wave)
 
         // ---- S^T = K Q^T
         v16f sacc[2];
@@ -543,16 +548,30 @@ fattn_mma_kernel(const FArgs a) {
         for (int i = 0; i < DT; i++)
 #pragma unroll
             for (int r = 0; r < 16; r++) o[i][r] *= corr;
-        // ---- O^T += V^T P^T
+        // ---- O^T += V^T P^T.  A operand: lane (lr, lh) needs V[kv][d = 32 i + lr] for the 8 kv of its k slots, in the order
+        // the S^T accumulators gave P: kv = 32 t + 16 s2 + 8 (j >> 2) + 4 lh + (j & 3).  ds_read_b64_tr_b16 hands every lane of
+        // a 16-lane group one COLUMN of a 4-row x 16-column block (lane 4q + p supplies the address of row q, columns 4p..4p+3),
+        // so two reads -- rows base + 4 lh + 0..3 and base + 8 + 4 lh + 0..3, columns 16 (lr >> 4) .. + 15 of d tile i -- are the
+        // operand, straight from the row-major tile.
+        {
+            typedef short tr4 __attribute__((ext_vector_type(4)));
+            const int q4 = (lane & 15) >> 2, p4 = lane & 3;
+            const uint8_t * vb = Vs + (4 * lh + q4) * VP + (16 * ((lane >> 4) & 1) + 4 * p4) * 2;
 #pragma unroll
-        for (int i = 0; i < DT; i++)
+            for (int i = 0; i < DT; i++)
 #pragma unroll
-            for (int t = 0; t < 2; t++)
+                for (int t = 0; t < 2; t++)
 #pragma unroll
-                for (int s2 = 0; s2 < 2; s2++) {
-                    const half8 vf = *(const half8 *)(Vt + (32 * i + lr) * VP + (32 * t + 16 * s2 + 8 * lh) * 2);
-                    o[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[t][s2], o[i], 0, 0, 0);
-                }
+                    for (int s2 = 0; s2 < 2; s2++) {
+                        const uint8_t * pb = vb + (32 * t + 16 * s2) * VP + 64 * i;
+                        const tr4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tr4 *)pb);
+                        const tr4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tr4 *)(pb + 8 * VP));
+                        half8 vf;
+                        __builtin_memcpy(&vf, &lo, 8);
+                        __builtin_memcpy((char *)&vf + 8, &hi, 8);
+                        o[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[t][s2], o[i], 0, 0, 0);
+                    }
+        }
     }
 
     if (q < a.n_q) {
@@ -570,7 +589,9 @@ fattn_mma_kernel(const FArgs a) {
 
 template <int D>
 static int launch_mma(const FArgs & a, int tkv, hipStream_t s) {
-    const dim3 grid((unsigned)((a.n_q + MMA_BQ - 1) / MMA_BQ), (unsigned)a.n_head, (unsigned)a.ne3);
+    const int ratio = a.n_head / a.n_head_kv;
+    const int hpw = ratio % 4 == 0 ? 4 : ratio % 2 == 0 ? 2 : 1, qpw = MMA_WAVES / hpw, bq = 32 * qpw;
+    const dim3 grid((unsigned)((a.n_q + bq - 1) / bq), (unsigned)(a.n_head / hpw), (unsigned)a.ne3);
     if (tkv == MI355_TYPE_F16)       MI355_LAUNCH("fattn_mma", (fattn_mma_kernel<D, MI355_TYPE_F16>), grid, dim3(MMA_THREADS), 0, s, a);
     else if (tkv == MI355_TYPE_Q8_0) MI355_LAUNCH("fattn_mma", (fattn_mma_kernel<D, MI355_TYPE_Q8_0>), grid, dim3(MMA_THREADS), 0, s, a);
     else                             MI355_LAUNCH("fattn_mma", (fattn_mma_kernel<D, MI355_TYPE_Q4_0>), grid, dim3(MMA_THREADS), 0, s, a);
