@@ -420,7 +420,7 @@ static __device__ __forceinline__ v4i load8h(const char * row, int j) {
 }
 
 template <int D, int TKV>
-__global__ void __launch_bounds__(MMA_THREADS)
+__global__ void __launch_bounds__(MMA_THREADS, 2)
 fattn_mma_kernel(const FArgs a) {
     constexpr int KP = D * 2 + 16;          // K tile row pitch (bytes)
     constexpr int VP = D * 2 + 64;          // V tile row pitch (bytes): 4 consecutive rows land on 4 disjoint groups of 16 banks, so
