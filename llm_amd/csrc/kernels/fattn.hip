@@ -467,47 +467,80 @@ fattn_mma_kernel(const FArgs a) {
 
     constexpr int CH = MMA_BKV * D * 2 / 16 / MMA_THREADS;   // 16-byte chunks per thread per tile
     const bool mvec = mrow && (((uintptr_t)a.mask | (uintptr_t)a.m_nb1 | (uintptr_t)a.m_nb2 | (uintptr_t)a.m_nb3) & 7) == 0;   // 4 mask values per load
-    for (int kv0 = 0; kv0 < a.n_kv; kv0 += MMA_BKV) {
-        // ---- mask tile of this wave: 2 S^T tiles x 16 kv rows per lane.  Read before anything is staged: a block that is
-        // masked out for every query of the workgroup (the upper triangle of causal prefill: almost half of all blocks)
-        // costs these loads and one barrier, no K/V traffic.
-        float mv[2][16];
+    typedef _Float16 mh4 __attribute__((ext_vector_type(4)));
+    // mask tile of this wave for the block at kv0: 2 S^T tiles x 16 kv rows per lane, kept packed (f16)
+    auto load_mask = [&](int kv0, mh4 (&mp)[2][4]) -> bool {
         bool any = false;
 #pragma unroll
         for (int t = 0; t < 2; t++)
 #pragma unroll
             for (int g = 0; g < 4; g++) {
                 const int kvl = kv0 + 32 * t + 8 * g + 4 * lh;     // 4 consecutive kv rows
+                mh4 v;
                 if (mvec && kvl + 4 <= a.n_kv) {
-                    typedef _Float16 mh4 __attribute__((ext_vector_type(4)));
-                    const mh4 raw = *(const mh4 *)(mrow + kvl);
-#pragma unroll
-                    for (int e = 0; e < 4; e++) mv[t][4 * g + e] = (float)raw[e];
+                    v = *(const mh4 *)(mrow + kvl);
                 } else {
 #pragma unroll
                     for (int e = 0; e < 4; e++) {
                         const int kv = kvl + e;
-                        float v = kv < a.n_kv ? 0.0f : -INFINITY;
-                        if (mrow && kv < a.n_kv) v = __half2float(mrow[kv]);
-                        mv[t][4 * g + e] = v;
+                        v[e] = kv < a.n_kv ? (mrow ? *(const _Float16 *)(mrow + kv) : (_Float16)0.0f) : (_Float16)(-INFINITY);
                     }
                 }
+                mp[t][g] = v;
 #pragma unroll
-                for (int e = 0; e < 4; e++) any |= mv[t][4 * g + e] != -INFINITY;
+                for (int e = 0; e < 4; e++) any |= (float)v[e] != -INFINITY;
             }
-        if (!__syncthreads_or(any)) continue;                // (also: previous block fully consumed)
-        // ---- stage K and V, both row-major: coalesced 16-byte loads, 16-byte LDS stores
+        return any;
+    };
+    // K/V rows of one block: global -> registers (issue) -> LDS (commit).  The loads of block j+1 are issued before block j is
+    // computed, so their latency hides behind its MFMAs.
+    v4i kreg[CH], vreg[CH];
+    auto issue = [&](int kv0) {
 #pragma unroll
         for (int i = 0; i < CH; i++) {
             const int c = tid + MMA_THREADS * i;
             const int row = c / (D / 8), cc = c % (D / 8);
             const int kv = kv0 + row < a.n_kv ? kv0 + row : a.n_kv - 1;
-            *(v4i *)(Ks + row * KP + cc * 16) = load8h<TKV>(kbase + (int64_t)kv * a.k_nb1, cc);
-            *(v4i *)(Vs + row * VP + cc * 16) = load8h<TKV>(vbase + (int64_t)kv * a.v_nb1, cc);
+            kreg[i] = load8h<TKV>(kbase + (int64_t)kv * a.k_nb1, cc);
+            vreg[i] = load8h<TKV>(vbase + (int64_t)kv * a.v_nb1, cc);
         }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int i = 0; i < CH; i++) {
+            const int c = tid + MMA_THREADS * i;
+            const int row = c / (D / 8), cc = c % (D / 8);
+            *(v4i *)(Ks + row * KP + cc * 16) = kreg[i];
+            *(v4i *)(Vs + row * VP + cc * 16) = vreg[i];
+        }
+    };
+    // A block that is masked out for every query of the workgroup (the upper triangle of causal prefill: almost half of all
+    // blocks) costs its mask loads and one barrier, no K/V traffic: the mask of block j+1 is read, and voted on, during block j.
+    mh4 mcur[2][4], mnxt[2][4];
+    bool any_n = load_mask(0, mnxt);
+    bool wg_n = __syncthreads_or(any_n);
+    if (wg_n) issue(0);
+    for (int kv0 = 0; kv0 < a.n_kv; kv0 += MMA_BKV) {
+        const bool wg = wg_n, any = any_n;
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+#pragma unroll
+            for (int g = 0; g < 4; g++) mcur[t][g] = mnxt[t][g];
+        any_n = kv0 + MMA_BKV < a.n_kv ? load_mask(kv0 + MMA_BKV, mnxt) : false;
+        wg_n = __syncthreads_or(any_n);                     // (also: the previous block is fully consumed, the tiles are free)
+        if (wg) commit();
+        if (wg_n) issue(kv0 + MMA_BKV);
+        if (!wg) continue;
         __syncthreads();
-        if (!__any(any)) continue;     // whole tile masked out for every query of this wave (uniform per wave; the
-                                       // barrier at the top of the loop is still reached by every wave)
+        if (!__any(any)) continue;     // whole tile masked out for every query of this wave (uniform per wave; every wave still
+                                       // reaches the two barriers of the next iteration)
+        float mv[2][16];
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+#pragma unroll
+            for (int g = 0; g < 4; g++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) mv[t][4 * g + e] = (float)mcur[t][g][e];
 
         // ---- S^T = K Q^T
         v16f sacc[2];
