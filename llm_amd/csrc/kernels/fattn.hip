@@ -390,16 +390,17 @@ fattn_vec_kernel(const FArgs a) {
 // ------------------------------------------------------------------------------------------------
 // Prefill: tile kernel on the f16 matrix cores (v_mfma_f32_32x32x16_f16); f16 K/V, or q8_0 / q4_0 K/V dequantized
 // to f16 while a block is staged; no ALiBi / softcap.
-//   workgroup = 128 threads = 2 waves; a wave owns 32 query rows of one head, the workgroup walks the KV
-//   range in blocks of 64 rows staged in LDS (K row-major; V transposed and permuted so that both MFMA
-//   operands are single ds_read_b128).
+//   workgroup = 256 threads = 4 waves; a wave owns 32 query rows of one head and the 4 waves take up to 4 heads of one KV
+//   head (or further 32-query blocks), so the KV blocks of 64 rows the workgroup walks are staged in LDS once for all of
+//   them; K and V both row-major (coalesced 16-byte loads, 16-byte LDS stores).
 //   S^T[kv][q] = K Q^T is computed transposed on purpose: the accumulator layout then puts one query per
 //   lane (column) and 16 kv rows in its registers, so the online-softmax row reductions are in-register
 //   plus one cross-half shuffle, and exp(S^T) packed to f16 is already the B operand of O^T = V^T P^T.
 //   The kv order inside a 16-wide MFMA step is whatever the accumulator layout delivers,
 //       kv(t, s, half, j) = 32 t + (j & 3) + 8 (2 s + (j >> 2)) + 4 half,
-//   and V^T is stored in LDS in exactly that order.  Blocks whose mask tile is entirely -inf (the upper
-//   triangle of causal prefill) skip all MFMA work.
+//   and the V^T operand is gathered from the row-major tile in exactly that order with ds_read_b64_tr_b16.  A block whose
+//   mask tile is entirely -inf for the workgroup (the upper triangle of causal prefill) is not even staged: masks are read
+//   and voted on one block ahead, and the K/V loads of the next block fly during the MFMAs of the current one.
 // ------------------------------------------------------------------------------------------------
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float v16f __attribute__((ext_vector_type(16)));
