@@ -646,7 +646,10 @@ def test_flash_attn_golden(ops, tag):
                                                       # long decode contexts: ragged slice ends, 4 heads per workgroup from n_kv 16384
                                                       # (GQA 4), 8 per workgroup (GQA 8), no GQA, two tokens
                                                       (128, 32, 8, 1, 20000, False), (128, 8, 2, 2, 16411, False), (128, 64, 8, 1, 5000, False),
-                                                      (64, 8, 8, 1, 9000, False), (128, 32, 8, 1, 1000, True)])
+                                                      (64, 8, 8, 1, 9000, False), (128, 32, 8, 1, 1000, True),
+                                                      # prefill tile kernel: GQA 2 (two heads x two query blocks per workgroup), GQA 3 (one head x four),
+                                                      # a long causal prompt whose upper-triangle blocks are never staged
+                                                      (128, 4, 2, 70, 130, True), (128, 6, 2, 50, 90, True), (128, 8, 2, 700, 700, True)])
 def test_flash_attn_f16_vs_f64_oracle(ops, d, nh, nhkv, nq, nkv, causal):
     """prefill shapes take the matrix-core tile kernel (n_q >= 32), decode shapes the split-KV vec kernel; both
     against the oracle's double-precision evaluation of the op on the same f16 K/V."""
