@@ -407,18 +407,54 @@ typedef float v16f __attribute__((ext_vector_type(16)));
 
 constexpr int MMA_BKV = 64, MMA_WAVES = 4, MMA_THREADS = 64 * MMA_WAVES;
 
-// 8 consecutive features of a K/V row as f16 (16 bytes): f16 rows are copied, q8_0 / q4_0 rows are dequantized
-// (d * q in f32, as the vec kernel does) and rounded to f16
-template <int TYPE>
-static __device__ __forceinline__ v4i load8h(const char * row, int j) {
-    if (TYPE == MI355_TYPE_F16) return *(const v4i *)(row + j * 16);
-    float f[8];
-    load8<TYPE>(row, j, f);
-    half8 h;
+// 8 consecutive features of a K/V row on their way into the LDS tile: `load` only requests the bytes (so the loads of the
+// next block can fly during the current one), `f16` turns them into 8 halfs when the tile is written -- f16 rows are
+// copied, q8_0 / q4_0 rows are dequantized (d * q in f32, as the vec kernel does) and rounded to f16.
+template <int TYPE> struct MmaChunk {
+    v4i raw;
+    __device__ __forceinline__ void load(const char * row, int j) { raw = *(const v4i *)(row + j * 16); }
+    __device__ __forceinline__ v4i f16() const { return raw; }
+};
+template <> struct MmaChunk<MI355_TYPE_Q8_0> {
+    int w0, w1; uint16_t d;
+    __device__ __forceinline__ void load(const char * row, int j) {
+        const char * blk = row + (j >> 2) * 34;
+        d = *(const uint16_t *)blk;
+        const int8_t * qs = (const int8_t *)(blk + 2 + (j & 3) * 8);
+        __builtin_memcpy(&w0, qs, 4); __builtin_memcpy(&w1, qs + 4, 4);
+    }
+    __device__ __forceinline__ v4i f16() const {
+        const float dd = h2f(d);
+        half8 h;
 #pragma unroll
-    for (int i = 0; i < 8; i++) h[i] = (_Float16)f[i];
-    return *(const v4i *)&h;
-}
+        for (int i = 0; i < 4; i++) {
+            h[i]     = (_Float16)__fmul_rn((float)(int8_t)(w0 >> (8 * i)), dd);
+            h[4 + i] = (_Float16)__fmul_rn((float)(int8_t)(w1 >> (8 * i)), dd);
+        }
+        return *(const v4i *)&h;
+    }
+};
+template <> struct MmaChunk<MI355_TYPE_Q4_0> {
+    int w0, w1; uint16_t d; int sh;
+    __device__ __forceinline__ void load(const char * row, int j) {
+        const char * blk = row + (j >> 2) * 18;
+        d = *(const uint16_t *)blk;
+        const int e0 = (j & 3) * 8;
+        const uint8_t * qs = (const uint8_t *)(blk + 2 + (e0 & 15));
+        sh = e0 >= 16 ? 4 : 0;
+        __builtin_memcpy(&w0, qs, 4); __builtin_memcpy(&w1, qs + 4, 4);
+    }
+    __device__ __forceinline__ v4i f16() const {
+        const float dd = h2f(d);
+        half8 h;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            h[i]     = (_Float16)__fmul_rn((float)((((uint32_t)w0 >> (8 * i + sh)) & 0xF) - 8.0f), dd);
+            h[4 + i] = (_Float16)__fmul_rn((float)((((uint32_t)w1 >> (8 * i + sh)) & 0xF) - 8.0f), dd);
+        }
+        return *(const v4i *)&h;
+    }
+};
 
 template <int D, int TKV>
 __global__ void __launch_bounds__(MMA_THREADS, 2)
@@ -495,15 +531,15 @@ fattn_mma_kernel(const FArgs a) {
     };
     // K/V rows of one block: global -> registers (issue) -> LDS (commit).  The loads of block j+1 are issued before block j is
     // computed, so their latency hides behind its MFMAs.
-    v4i kreg[CH], vreg[CH];
+    MmaChunk<TKV> kreg[CH], vreg[CH];
     auto issue = [&](int kv0) {
 #pragma unroll
         for (int i = 0; i < CH; i++) {
             const int c = tid + MMA_THREADS * i;
             const int row = c / (D / 8), cc = c % (D / 8);
             const int kv = kv0 + row < a.n_kv ? kv0 + row : a.n_kv - 1;
-            kreg[i] = load8h<TKV>(kbase + (int64_t)kv * a.k_nb1, cc);
-            vreg[i] = load8h<TKV>(vbase + (int64_t)kv * a.v_nb1, cc);
+            kreg[i].load(kbase + (int64_t)kv * a.k_nb1, cc);
+            vreg[i].load(vbase + (int64_t)kv * a.v_nb1, cc);
         }
     };
     auto commit = [&]() {
@@ -511,8 +547,8 @@ fattn_mma_kernel(const FArgs a) {
         for (int i = 0; i < CH; i++) {
             const int c = tid + MMA_THREADS * i;
             const int row = c / (D / 8), cc = c % (D / 8);
-            *(v4i *)(Ks + row * KP + cc * 16) = kreg[i];
-            *(v4i *)(Vs + row * VP + cc * 16) = vreg[i];
+            *(v4i *)(Ks + row * KP + cc * 16) = kreg[i].f16();
+            *(v4i *)(Vs + row * VP + cc * 16) = vreg[i].f16();
         }
     };
     // A block that is masked out for every query of the workgroup (the upper triangle of causal prefill: almost half of all
