@@ -614,10 +614,12 @@ fattn_mma_kernel(const FArgs a) {
         ps += __shfl_xor(ps, 32, 64);
         l = l * corr + ps;
         m = mn;
+        if (__any(corr != 1.0f)) {      // the running maxima settle after a few blocks: most blocks need no rescale at all
 #pragma unroll
-        for (int i = 0; i < DT; i++)
+            for (int i = 0; i < DT; i++)
 #pragma unroll
-            for (int r = 0; r < 16; r++) o[i][r] *= corr;
+                for (int r = 0; r < 16; r++) o[i][r] *= corr;
+        }
         // ---- O^T += V^T P^T.  A operand: lane (lr, lh) needs V[kv][d = 32 i + lr] for the 8 kv of its k slots, in the order
         // the S^T accumulators gave P: kv = 32 t + 16 s2 + 8 (j >> 2) + 4 lh + (j & 3).  ds_read_b64_tr_b16 hands every lane of
         // a 16-lane group one COLUMN of a 4-row x 16-column block (lane 4q + p supplies the address of row q, columns 4p..4p+3),
