@@ -478,16 +478,20 @@ fattn_mma_kernel(const FArgs a) {
     const int qc = q < a.n_q ? q : a.n_q - 1;
 
     // Q^T operand: this lane's query row, features 16 ks + 8 lh .. + 8, pre-scaled, f16
+    // (the scores live in the log2 domain: Q carries scale * log2(e), the mask is multiplied by log2(e) when it is added, and
+    // the exponentials are bare v_exp_f32)
+    constexpr float LOG2E = 1.4426950408889634f;
+    const float qs = a.scale * LOG2E;
     half8 qf[KS];
     {
         const float * qp = (const float *)(a.q + (int64_t)qc * a.q_nb1 + (int64_t)h * a.q_nb2 + (int64_t)i3 * a.q_nb3);
 #pragma unroll
         for (int ks = 0; ks < KS; ks++) {
             const v4f x0 = *(const v4f *)(qp + 16 * ks + 8 * lh), x1 = *(const v4f *)(qp + 16 * ks + 8 * lh + 4);
-            qf[ks][0] = (_Float16)(x0.x * a.scale); qf[ks][1] = (_Float16)(x0.y * a.scale);
-            qf[ks][2] = (_Float16)(x0.z * a.scale); qf[ks][3] = (_Float16)(x0.w * a.scale);
-            qf[ks][4] = (_Float16)(x1.x * a.scale); qf[ks][5] = (_Float16)(x1.y * a.scale);
-            qf[ks][6] = (_Float16)(x1.z * a.scale); qf[ks][7] = (_Float16)(x1.w * a.scale);
+            qf[ks][0] = (_Float16)(x0.x * qs); qf[ks][1] = (_Float16)(x0.y * qs);
+            qf[ks][2] = (_Float16)(x0.z * qs); qf[ks][3] = (_Float16)(x0.w * qs);
+            qf[ks][4] = (_Float16)(x1.x * qs); qf[ks][5] = (_Float16)(x1.y * qs);
+            qf[ks][6] = (_Float16)(x1.z * qs); qf[ks][7] = (_Float16)(x1.w * qs);
         }
     }
     const __half * mrow = a.mask ? (const __half *)(a.mask + (int64_t)qc * a.m_nb1 + (int64_t)(h % a.m_ne2) * a.m_nb2 +
@@ -596,18 +600,18 @@ fattn_mma_kernel(const FArgs a) {
 #pragma unroll
         for (int t = 0; t < 2; t++)
 #pragma unroll
-            for (int r = 0; r < 16; r++) { sacc[t][r] += mv[t][r]; mx = fmaxf(mx, sacc[t][r]); }
+            for (int r = 0; r < 16; r++) { sacc[t][r] = __builtin_fmaf(mv[t][r], LOG2E, sacc[t][r]); mx = fmaxf(mx, sacc[t][r]); }
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float mn = fmaxf(m, mx);
         const float msafe = mn == -INFINITY ? 0.0f : mn;          // fully masked so far: every p below is exp(-inf) = 0
-        const float corr = __expf(m - msafe);                      // m = -inf -> 0
+        const float corr = __builtin_amdgcn_exp2f(m - msafe);      // m = -inf -> 0
         float ps = 0.0f;
         half8 pf[2][2];
 #pragma unroll
         for (int t = 0; t < 2; t++)
 #pragma unroll
             for (int r = 0; r < 16; r++) {
-                const float p = __expf(sacc[t][r] - msafe);
+                const float p = __builtin_amdgcn_exp2f(sacc[t][r] - msafe);
                 ps += p;
                 pf[t][r >> 3][r & 7] = (_Float16)p;
             }
