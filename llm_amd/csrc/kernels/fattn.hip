@@ -510,8 +510,7 @@ fattn_mma_kernel(const FArgs a) {
     const bool mvec = mrow && (((uintptr_t)a.mask | (uintptr_t)a.m_nb1 | (uintptr_t)a.m_nb2 | (uintptr_t)a.m_nb3) & 7) == 0;   // 4 mask values per load
     typedef _Float16 mh4 __attribute__((ext_vector_type(4)));
     // mask tile of this wave for the block at kv0: 2 S^T tiles x 16 kv rows per lane, kept packed (f16)
-    auto load_mask = [&](int kv0, mh4 (&mp)[2][4]) -> bool {
-        bool any = false;
+    auto issue_mask = [&](int kv0, mh4 (&mp)[2][4]) {
 #pragma unroll
         for (int t = 0; t < 2; t++)
 #pragma unroll
@@ -528,9 +527,16 @@ fattn_mma_kernel(const FArgs a) {
                     }
                 }
                 mp[t][g] = v;
-#pragma unroll
-                for (int e = 0; e < 4; e++) any |= (float)v[e] != -INFINITY;
             }
+    };
+    auto mask_any = [&](const mh4 (&mp)[2][4]) -> bool {
+        bool any = false;
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+#pragma unroll
+            for (int g = 0; g < 4; g++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) any |= (float)mp[t][g][e] != -INFINITY;
         return any;
     };
     // K/V rows of one block: global -> registers (issue) -> LDS (commit).  The loads of block j+1 are issued before block j is
@@ -557,20 +563,25 @@ fattn_mma_kernel(const FArgs a) {
     };
     // A block that is masked out for every query of the workgroup (the upper triangle of causal prefill: almost half of all
     // blocks) costs its mask loads and one barrier, no K/V traffic: the mask of block j+1 is read, and voted on, during block j.
-    mh4 mcur[2][4], mnxt[2][4];
-    bool any_n = load_mask(0, mnxt);
+    // The mask loads run two blocks ahead (requested during block j-1, voted on at the top of block j for block j+1), so the
+    // vote does not wait on memory either.
+    mh4 mcur[2][4], mnxt[2][4], mnx2[2][4];
+    issue_mask(0, mnxt);
+    bool any_n = mask_any(mnxt);
     bool wg_n = __syncthreads_or(any_n);
     if (wg_n) issue(0);
+    issue_mask(MMA_BKV, mnx2);                              // (rows past n_kv read as -inf without touching memory)
     for (int kv0 = 0; kv0 < a.n_kv; kv0 += MMA_BKV) {
         const bool wg = wg_n, any = any_n;
 #pragma unroll
         for (int t = 0; t < 2; t++)
 #pragma unroll
-            for (int g = 0; g < 4; g++) mcur[t][g] = mnxt[t][g];
-        any_n = kv0 + MMA_BKV < a.n_kv ? load_mask(kv0 + MMA_BKV, mnxt) : false;
+            for (int g = 0; g < 4; g++) { mcur[t][g] = mnxt[t][g]; mnxt[t][g] = mnx2[t][g]; }
+        any_n = kv0 + MMA_BKV < a.n_kv ? mask_any(mnxt) : false;
         wg_n = __syncthreads_or(any_n);                     // (also: the previous block is fully consumed, the tiles are free)
         if (wg) commit();
         if (wg_n) issue(kv0 + MMA_BKV);
+        issue_mask(kv0 + 2 * MMA_BKV, mnx2);
         if (!wg) continue;
         __syncthreads();
         if (!__any(any)) continue;     // whole tile masked out for every query of this wave (uniform per wave; every wave still
