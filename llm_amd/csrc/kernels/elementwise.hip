@@ -218,6 +218,42 @@ rope_kernel(const T4 x, const int32_t * __restrict__ pos, const float * __restri
     }
 }
 
+// prefill form: one lane per (rotated pair, token) that walks the heads, so cos / sin (a powf and a sincosf) are computed once per
+// (pair, token) instead of once per head -- the arithmetic per element is unchanged (bit-identical to rope_kernel)
+__global__ void __launch_bounds__(256)
+rope_heads_kernel(const T4 x, const int32_t * __restrict__ pos, const float * __restrict__ ff, const T4 d, const RopeP p, int64_t npt) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int half = p.ne0 / 2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < npt; i += stride) {
+        const int ic = (int)(i % half);          // pair index inside the row
+        const int64_t r = i / half;
+        const int64_t i2 = r % x.ne[2], i3 = r / x.ne[2];
+        const int i0 = 2 * ic;
+        const bool pass = i0 >= p.n_dims;        // dims beyond n_dims are copied through (ops.cpp: tail loops)
+        float c = 1.0f, s = 0.0f;
+        if (!pass) rope_cos_sin(p, pos[i2], ff, ic, c, s);
+        const int e0 = pass ? i0 : (p.mode & 2) ? ic : i0, e1 = pass ? i0 + 1 : (p.mode & 2) ? ic + p.n_dims / 2 : i0 + 1;
+        // 8 heads at a time, all loads before the first store (x and d may be the same memory, which keeps the compiler from
+        // overlapping the iterations on its own; a lane only ever touches its own two elements of each head)
+        for (int64_t h0 = 0; h0 < x.ne[1]; h0 += 8) {
+            float x0[8], x1[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int64_t i1 = h0 + u < x.ne[1] ? h0 + u : x.ne[1] - 1;
+                const float * xs = (const float *)(x.data + i1 * x.nb[1] + i2 * x.nb[2] + i3 * x.nb[3]);
+                x0[u] = xs[e0]; x1[u] = xs[e1];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                if (h0 + u >= x.ne[1]) break;
+                float * ds = (float *)(d.data + (h0 + u) * d.nb[1] + i2 * d.nb[2] + i3 * d.nb[3]);
+                if (pass) { ds[e0] = x0[u]; ds[e1] = x1[u]; }
+                else      { ds[e0] = x0[u] * c - x1[u] * s; ds[e1] = x0[u] * s + x1[u] * c; }
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------- glu
 static __device__ __forceinline__ float act_glu(int op, float x) {
     switch (op) {
@@ -467,7 +503,12 @@ int mi355_rope_f32(const mi355_tensor * x, const int32_t * pos, const float * fr
     const RopeP p = rope_params(n_dims, mode, (int)x->ne[0], n_ctx_orig, freq_base, freq_scale, ext_factor, attn_factor, beta_fast, beta_slow);
     const int64_t npairs = nelem(x) / 2;
     if (npairs == 0) return MI355_OK;
-    MI355_LAUNCH("rope", rope_kernel, dim3(grid_for(npairs)), dim3(256), 0, (hipStream_t)stream, t4(x), pos, freq_factors, t4(dst), p, npairs);
+    // many heads and enough (pair, token) work to fill the chip: compute cos / sin once per (pair, token), walk the heads
+    const int64_t npt = npairs / (x->ne[1] > 0 ? x->ne[1] : 1);
+    if (x->ne[1] >= 4 && npt >= 16384)
+        MI355_LAUNCH("rope", rope_heads_kernel, dim3(grid_for(npt)), dim3(256), 0, (hipStream_t)stream, t4(x), pos, freq_factors, t4(dst), p, npt);
+    else
+        MI355_LAUNCH("rope", rope_kernel, dim3(grid_for(npairs)), dim3(256), 0, (hipStream_t)stream, t4(x), pos, freq_factors, t4(dst), p, npairs);
     MI355_CHECK_LAUNCH();
     return MI355_OK;
 }

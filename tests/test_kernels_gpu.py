@@ -538,6 +538,20 @@ def test_glu_matvec_norm_prologue_equals_separate_norm(ops, t, m, k):
     assert torch.equal(q0, q1)
 
 
+@pytest.mark.parametrize("mode,n_dims,nh", [(0, 128, 32), (2, 128, 8), (0, 96, 8), (2, 64, 32)])
+def test_rope_head_walking_kernel_is_bit_identical(ops, mode, n_dims, nh):
+    """prefill-sized ROPE (cos / sin computed once per (pair, token), heads walked by the lane) == the per-pair kernel that small
+    launches take, to the bit: 512 tokens in one call vs the same tokens 64 at a time."""
+    hd, nt = 128, 512
+    rng = np.random.default_rng(mode + n_dims + nh)
+    x = dev(rng.standard_normal((nt, nh, hd)).astype(np.float32))
+    pos = torch.arange(1000, 1000 + nt, dtype=torch.int32, device="cuda")
+    kw = dict(freq_base=500000.0, freq_scale=0.5 if n_dims == 96 else 1.0, ext_factor=1.0 if n_dims == 96 else 0.0, n_ctx_orig=4096)
+    big = ops.rope(x, pos, n_dims, mode, **kw)
+    small = torch.cat([ops.rope(x[i:i + 64].contiguous(), pos[i:i + 64].contiguous(), n_dims, mode, **kw) for i in range(0, nt, 64)])
+    assert torch.isfinite(big).all() and torch.equal(big.view(torch.int32), small.view(torch.int32))
+
+
 @pytest.mark.parametrize("rows,n,with_add", [(130, 4096, True), (200, 1024, False), (129, 8192, True), (3, 96, False)])
 def test_norm_and_glu_bf16_forms(ops, rows, n, with_add):
     """prefill producers: mi355_rms_norm_mul_bf16_f32 / mi355_glu_bf16_f32 == the plain kernels bit for bit, and their bf16
