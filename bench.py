@@ -246,6 +246,16 @@ def main():
             arr = (K.MmvqArgs * len(p[3]))(*[mm_arg(mats[i], weights[i], outs[i]) for i in p[3]])
             if fuse_norm and names in (["attn_output"], ["ffn_down"]):       # + residual ADD in the epilogue
                 arr[0].residual, arr[0].sum = resid.data_ptr(), resid_out.data_ptr()
+            if fuse_norm and names == ["attn_output"]:
+                # the attention output arrives as f32 (attention is not part of this bench): wo quantizes it in its prologue
+                arr[0].act_q = arr[0].act_ds = None
+                arr[0].src_f32 = xs[mats[p[3][0]].k].data_ptr()
+                p[0] = None
+            if fuse_norm and names == ["output"]:
+                # final norm in the prologue of the output mat-vec
+                arr[0].act_q = arr[0].act_ds = None
+                arr[0].src_f32, arr[0].norm_w, arr[0].norm_out, arr[0].norm_eps = xs[mats[p[3][0]].k].data_ptr(), norm_w.data_ptr(), normed.data_ptr(), 1e-5
+                p[0] = None
             p[1], p[2] = arr, len(p[3])
     for prev, p in zip(plan, plan[1:]):
         if prev[2] == 0 and mats[p[3][0]].src == "ffn_act":

@@ -49,7 +49,11 @@ enum mi355_error {
 };
 
 /* library / device introspection */
-MI355_API int         mi355_abi_version(void);          /* bumps on any signature change */
+#define MI355_ABI_VERSION 2                             /* bumped on any signature or struct change */
+MI355_API int         mi355_abi_version(void);          /* == MI355_ABI_VERSION of the header the library was built from;
+                                                         * the plugin and the Python binding refuse a library that differs */
+MI355_API int64_t     mi355_args_sizeof(int which);     /* sizeof of 0 mi355_mmvq_args, 1 qkv_rope, 2 glu_matvec, 3 moe_down,
+                                                         * 4 fattn_args, 5 mi355_tensor; -1 otherwise */
 MI355_API const char *mi355_error_string(int err);      /* MI355_E_* or hipGetErrorString */
 MI355_API int64_t     mi355_blck_size(int type);        /* elements per block, 0 if unknown */
 MI355_API int64_t     mi355_type_size(int type);        /* bytes per block, 0 if unknown */
@@ -138,6 +142,16 @@ typedef struct mi355_mmvq_args {
     float         *sum;            /* stored too -- the ADD node after wo / ffn_down (ggml-cuda/binbcast.cu), bit-identical
                                     * to a separate add.  sum == dst: only the sum is stored (ADD in place on the result);
                                     * sum == residual is allowed.  Both NULL or both set. */
+    /* optional (ncols == 1, nchannels == 1, no ids; k <= 16384, k % 32 == 0; 16-byte aligned): the activations given as
+     * the f32 row src_f32[k] instead of act_q / act_ds (which are then not read).  Every workgroup quantizes the row for
+     * itself in its prologue, bit-identical to mi355_quantize_act -- the reference's separate quantize_q8_1 launch
+     * (ggml-cuda/quantize.cu:4-48) disappears.  With norm_w set the row is first normalised: q8_1((x * rsqrt(mean(x^2) +
+     * norm_eps)) * norm_w), bit-identical to mi355_rms_norm_mul_quant_f32, and norm_out[k] receives the f32 result
+     * (RMS_NORM + MUL nodes, ggml-cuda/norm.cu).  src_f32, norm_w and every output must not overlap. */
+    const float   *src_f32;
+    const float   *norm_w;
+    float         *norm_out;
+    float          norm_eps;
 } mi355_mmvq_args;
 
 MI355_API int mi355_mul_mat_vec_q(const mi355_mmvq_args *args, void *stream);

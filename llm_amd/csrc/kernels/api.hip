@@ -3,7 +3,20 @@
 
 extern "C" {
 
-int mi355_abi_version(void) { return 1; }
+int mi355_abi_version(void) { return MI355_ABI_VERSION; }
+
+// sizeof() of the argument structs, so that a binding built against another header is caught at load time
+int64_t mi355_args_sizeof(int which) {
+    switch (which) {
+        case 0: return (int64_t)sizeof(mi355_mmvq_args);
+        case 1: return (int64_t)sizeof(mi355_qkv_rope_args);
+        case 2: return (int64_t)sizeof(mi355_glu_matvec_args);
+        case 3: return (int64_t)sizeof(mi355_moe_down_args);
+        case 4: return (int64_t)sizeof(mi355_fattn_args);
+        case 5: return (int64_t)sizeof(mi355_tensor);
+    }
+    return -1;
+}
 
 const char * mi355_error_string(int err) {
     switch (err) {

@@ -35,10 +35,24 @@ static __device__ __forceinline__ v4i ld16_a2(const void * p) {
 }
 static __device__ __forceinline__ uint16_t ld_u16(const void * p) { return *(const uint16_t *)p; }
 
+// Sum over the 64 lanes of a wave, the same value in every lane.  Four DPP steps inside each row of 16 lanes (xor 1,
+// xor 2, mirror within 8, mirror within 16: a few cycles each, against ~100 for the ds_bpermute behind __shfl_xor), then
+// the four row sums are read with v_readlane and added in row order.  Every reduction in this library goes through
+// here, so fused and unfused forms of an op add in the same order.
+template <int CTRL>
+static __device__ __forceinline__ float dpp_f32(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
 static __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += dpp_f32<0xB1>(v);      // quad_perm [1,0,3,2]
+    v += dpp_f32<0x4E>(v);      // quad_perm [2,3,0,1]
+    v += dpp_f32<0x141>(v);     // row_half_mirror
+    v += dpp_f32<0x140>(v);     // row_mirror
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+    const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+    const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return (r0 + r1) + (r2 + r3);
 }
 
 // sum over the NW waves of a block (sh: NW floats of LDS): wave butterflies, then the wave sums added in wave order
@@ -52,6 +66,18 @@ static __device__ __forceinline__ float block_sum_n(float v, float * sh) {
     float r = sh[0];
 #pragma unroll
     for (int i = 1; i < NW; i++) r += sh[i];
+    return r;
+}
+
+// the same with the wave count known at run time (nw <= 16; sh: 16 floats)
+static __device__ __forceinline__ float block_sum_rt(float v, float * sh, int nw) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sh[wave] = v;
+    __syncthreads();
+    float r = sh[0];
+    for (int i = 1; i < nw; i++) r += sh[i];
     return r;
 }
 
@@ -107,5 +133,25 @@ static __device__ __forceinline__ void quant16_soa(const float v[16], int8_t * q
     *(v4i *)q_dst = packed;
     if (leader) { v2f ds; ds.x = __half2float(__float2half_rn(d)); ds.y = (float)sum; *(v2f *)ds_dst = ds; }
 }
+
+// Optional in-kernel timeline stamps (lab builds only: -DMI355_STAMPS, llm_amd/csrc/lab/timeline.cpp).  Up to eight 100 MHz
+// s_memrealtime stamps per wave: 0 entry, 1 activations staged, 2 weight loop done, 3 results stored, 4 activations fetched.
+#ifdef MI355_STAMPS
+extern unsigned long long * mi355_stamp_host_ptr;
+#define STAMP_FIELD unsigned long long * stamps;
+#define STAMP_SET(a) ((a).stamps = mi355_stamp_host_ptr)
+#define STAMP_PTR(a) ((a).stamps)
+#define STAMP_AT(p, i)                                                                                                         \
+    do {                                                                                                                       \
+        if ((p) && (threadIdx.x & 63) == 0)                                                                                    \
+            ((unsigned long long *)(p))[((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 8 + (i)] = \
+                __builtin_amdgcn_s_memrealtime();                                                                              \
+    } while (0)
+#else
+#define STAMP_FIELD
+#define STAMP_SET(a) ((void)0)
+#define STAMP_PTR(a) nullptr
+#define STAMP_AT(p, i) ((void)0)
+#endif
 
 #define MI355_CHECK_LAUNCH() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)

@@ -283,6 +283,190 @@ template <> struct Unit<MI355_TYPE_Q4_0> {
     }
 };
 
+// ================================================================================================
+// Single-column streaming core (decode: ncols == 1).
+//
+// Where a decode launch's time went (llm_amd/csrc/lab/timeline.cpp, stamps inside the kernels): the marginal rate of the
+// weight stream is ~6.7 TB/s, but every launch paid 4-5 us that had nothing to do with bytes -- the activation loads
+// were issued behind the first weight loads and vmcnt retires in order, so staging (or the norm prologue) waited for a
+// whole round of weights (2.5-4 us) while only one unit per lane was in flight; then the loop had one round trip per
+// iteration.  Here:
+//   * a wave owns `nrows` rows (any function of the row index gives the row pointer: consecutive rows, rotated pairs,
+//     gate/up alternation) and walks them as one flat sequence of (row, unit-iteration) steps;
+//   * PF steps of raw weights are requested before anything else is waited for and stay PF steps ahead in a register
+//     ring of PF + 1 slots (the slot refilled at a step is the one the previous step finished with);
+//   * the activation / norm-input loads are issued BEFORE the first weight loads (they are L2 hits and come back while
+//     the weights are still in flight), the staging arithmetic runs under the weight latency;
+//   * row sums end in lane (row index within the wave), so a wave stores / post-processes all its rows at once.
+// The per-lane accumulation order (units lane, lane + 64, ...) and wave_sum are those of mmvq_row, so results are
+// bit-identical to the multi-column kernel's.
+// ================================================================================================
+static __device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+
+template <int TYPE, int PF, class RowPtr>
+struct WStream {
+    typedef Unit<TYPE> U;
+    static constexpr int NB = PF + 1;
+    typename U::Raw ring[NB];
+    RowPtr rowp;
+    int nrows, nunits, niter, lane;
+    int lr, lit;                 // next (row, iteration) to request
+
+    __device__ __forceinline__ WStream(RowPtr rp, int nrows_, int k) : rowp(rp), nrows(nrows_) {
+#ifdef MI355_NO_WEIGHTS   // lab: the staging alone
+        nrows = 0;
+#endif
+        nunits = k / U::ELEMS; niter = (nunits + 63) >> 6; lane = threadIdx.x & 63; lr = 0; lit = 0;
+    }
+    __device__ __forceinline__ void request(typename U::Raw & dst) {
+        if (lr < nrows) {                                   // wave-uniform
+            const int u_raw = lit * 64 + lane;
+            dst = U::load(rowp(lr), u_raw < nunits ? u_raw : nunits - 1);   // lanes past the end re-read the last unit, contribute 0
+            if (++lit == niter) { lit = 0; ++lr; }
+        }
+    }
+    __device__ __forceinline__ void begin() {
+#pragma unroll
+        for (int p = 0; p < PF; p++) request(ring[p]);
+    }
+    // returns, in lane r, the sum of the wave's r-th row (nrows <= 64)
+    template <class AP>
+    __device__ __forceinline__ float run(const AP act) {
+        float out = 0.0f, acc = 0.0f;
+        int r = 0, it = 0;
+        while (r < nrows) {
+#pragma unroll
+            for (int p = 0; p < NB; p++) {
+                if (r < nrows) {
+                    request(ring[(p + PF) % NB]);
+                    const int  u_raw = it * 64 + lane;
+                    const bool valid = u_raw < nunits;
+                    const int  u     = valid ? u_raw : nunits - 1;
+                    const typename U::Act av = U::load_act(act, u);
+                    __builtin_amdgcn_sched_barrier(0);
+                    const float v = U::dot(U::decode(ring[p], u), av);
+                    acc += valid ? v : 0.0f;
+                    if (++it == niter) {
+                        const float s = wave_sum(acc);
+                        out = lane == r ? s : out;
+                        acc = 0.0f; it = 0; ++r;
+                    }
+                }
+            }
+        }
+        return out;
+    }
+};
+
+// Activations of one token into LDS ([k] int8, then [k/32] {d, sum}), in two phases so that the global loads go out before
+// the weight stream's and the arithmetic runs under its latency.  Three sources:
+//   quantized (act_q / act_ds from mi355_quantize_act): a copy;
+//   f32 row x: q8_1(x), the arithmetic of quantize_kernel / quant16_soa;
+//   f32 row x with a norm weight: q8_1((x * rsqrt(mean(x^2) + eps)) * w), the arithmetic of rms_norm_kernel -- one 16-value
+//   chunk per thread, wave sums added in wave order -- so the values are bit-identical to the separate launches (the
+//   stand-alone kernel runs 256 threads up to k = 4096 and 512 up to 8192: chunks sit in the same waves here, the
+//   remaining waves add 0).  `store`: this workgroup also writes the f32 result (the graph's MUL node).
+struct ActSrc {
+    const int8_t * q; const float * ds;                 // quantized source, or
+    const float * x, * nw; float * nout; float eps;     // f32 source (nw == nullptr: no norm)
+};
+
+// How the staging is ordered against the weight stream (llm_amd/csrc/lab/timeline.cpp, stamps inside the kernels):
+//   * a CU keeps about 48 KB of loads in flight; a wave that issues a load beyond that stalls AT THE ISSUE until older
+//     loads return.  Sixteen waves requesting their first weights fill that at once, so a wave that has started its
+//     weight stream reaches a workgroup barrier microseconds late -- the staging must not end in a barrier that the
+//     streaming waves take part in after their first request;
+//   * vmcnt retires in order: anything a wave loads after its weight requests returns behind them.
+// So: the waves that hold a piece of the activations ("staging waves": one 16-value chunk per lane for an f32 source, a
+// slice of the copy for a quantized one) fetch and finish it BEFORE their first weight request and meet each other only
+// through counters in LDS; the other waves request weights at once; everybody polls the "image complete" counter just
+// before the first LDS read, long after it has been reached.
+template <int NT_>                                      // threads per workgroup; 0: blockDim.x (a multiple of 64, <= 1024)
+struct ActStage {
+    int  k, NT, n_stage;            // n_stage: waves that signal `done`
+
+    typedef __attribute__((address_space(3))) unsigned lds_u32;     // explicit LDS pointers: a generic one would poll with flat
+    typedef __attribute__((address_space(3))) float    lds_f32;     // loads, which wait on vmcnt -- behind the weight stream
+    static __device__ __forceinline__ lds_u32 * ctr()  { __shared__ unsigned c[4]; return (lds_u32 *)c; }
+    static __device__ __forceinline__ lds_f32 * sums() { __shared__ float sh[16]; return (lds_f32 *)sh; }
+    static __device__ __forceinline__ void lds_wait(volatile lds_u32 * c, unsigned need) {
+        while (*c < need) __builtin_amdgcn_s_sleep(1);
+        asm volatile("" ::: "memory");
+    }
+    static __device__ __forceinline__ void lds_signal(lds_u32 * c) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // this wave's LDS writes are done (LDS ops of a wave run in order)
+        if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+
+    // Stage the activations of one token into LDS ([k] int8, then [k/32] {d, sum}).  Call before the wave's first weight
+    // request.  f32 source: the arithmetic of rms_norm_kernel / quantize_kernel (see ActSrc), wave sums added in wave order.
+    // The only workgroup barrier (counters zeroed) sits behind the activation requests, before anything else is in flight.
+    __device__ __forceinline__ void stage(const ActSrc & a, int k_, uint8_t * lds, bool store, void * stamps = nullptr) {
+        k = k_; NT = NT_ ? NT_ : (int)blockDim.x;
+        const int t = threadIdx.x, wave = wave_id();
+        if (t < 4) ctr()[t] = 0;
+        if (a.x) {
+            const int nc = k >> 4, nsw = (nc + 63) >> 6;
+            n_stage = nsw;
+            const bool has = t < nc;
+            v4f v[4], wv[4];
+            if (has) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    v[q] = ((const v4f *)a.x)[4 * t + q];
+                    if (a.nw) wv[q] = ((const v4f *)a.nw)[4 * t + q];
+                }
+            }
+            __syncthreads();
+            if (wave >= nsw) return;
+            float s = 0.0f;
+            if (has) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) s += v[q].x * v[q].x + v[q].y * v[q].y + v[q].z * v[q].z + v[q].w * v[q].w;
+            }
+#ifdef MI355_STAMPS
+            asm volatile("" : "+v"(s));
+            STAMP_AT(stamps, 5);
+#endif
+            float scale = 1.0f;
+            if (a.nw) {
+                lds_f32 * sh = sums();
+                const float wsum = wave_sum(s);
+                if ((t & 63) == 0) sh[wave] = wsum;
+                lds_signal(&ctr()[0]);
+                lds_wait(&ctr()[0], (unsigned)nsw);
+                float tot = ((volatile lds_f32 *)sh)[0];
+                for (int i = 1; i < nsw; i++) tot += ((volatile lds_f32 *)sh)[i];
+                scale = 1.0f / sqrtf(tot / (float)k + a.eps);
+            }
+#ifdef MI355_STAMPS
+            asm volatile("" : "+v"(scale));
+            STAMP_AT(stamps, 6);
+#endif
+            if (has) {
+                float o[16];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    v4f x = v[q];
+                    if (a.nw) { x = x * scale; x = x * wv[q]; if (store) ((v4f *)a.nout)[4 * t + q] = x; }
+                    o[4 * q] = x.x; o[4 * q + 1] = x.y; o[4 * q + 2] = x.z; o[4 * q + 3] = x.w;
+                }
+                quant16_soa(o, (int8_t *)lds + 16 * t, (float *)(lds + (size_t)k) + (t >> 1) * 2, (t & 1) == 0);
+            }
+        } else {
+            n_stage = NT >> 6;
+            const int nq = k >> 4, nds = k / QK;
+            v2f * lds_ds = (v2f *)(lds + (size_t)k);
+            for (int i = t; i < nq; i += NT) ((v4i *)lds)[i] = ((const v4i *)a.q)[i];
+            for (int i = t; i < nds; i += NT) lds_ds[i] = ((const v2f *)a.ds)[i];
+            __syncthreads();
+        }
+        lds_signal(&ctr()[1]);
+    }
+    // before the first LDS read of the activations
+    __device__ __forceinline__ void wait() { lds_wait(&ctr()[1], (unsigned)n_stage); }
+};
+
 // ------------------------------------------------------------------------------------------------
 struct KArgs {
     const uint8_t * W; int64_t w_row_stride, w_ch_stride;
@@ -301,8 +485,9 @@ struct ActLds { const __attribute__((address_space(3))) int8_t * q; const __attr
 template <int TYPE, int NCOLS, bool LDSACT>
 static __device__ __forceinline__ void mmvq_row(const uint8_t * wmat, int64_t w_row_stride, int m, int row, const int8_t * gq,
                                                 const float * gds, int k, float * dch, int64_t dst_col_stride, uint8_t * lds,
-                                                const float * res = nullptr, float * sum = nullptr) {
+                                                const float * res = nullptr, float * sum = nullptr, void * stamps = nullptr) {
     typedef Unit<TYPE> U;
+    STAMP_AT(stamps, 0);
     const int lane = threadIdx.x & 63;
     const int rowc = row < m ? row : m - 1;           // tail waves re-read the last row, never store
     const uint8_t * wrow = wmat + (int64_t)rowc * w_row_stride;
@@ -326,6 +511,7 @@ static __device__ __forceinline__ void mmvq_row(const uint8_t * wmat, int64_t w_
         for (int i = threadIdx.x; i < nds; i += 256) lds_ds[i] = ((const v2f *)gds)[i];
         __syncthreads();
     }
+    STAMP_AT(stamps, 1);
 
     float acc[NCOLS];
 #pragma unroll
@@ -359,6 +545,7 @@ static __device__ __forceinline__ void mmvq_row(const uint8_t * wmat, int64_t w_
         }
         if (it + 1 < niter) cur = nxt;
     }
+    STAMP_AT(stamps, 2);
 
 #pragma unroll
     for (int c = 0; c < NCOLS; c++) {
@@ -369,6 +556,7 @@ static __device__ __forceinline__ void mmvq_row(const uint8_t * wmat, int64_t w_
             if (res) sum[o] = v + rv[c];
         }
     }
+    STAMP_AT(stamps, 3);
 }
 
 template <int TYPE, int NCOLS, bool LDSACT>
@@ -404,6 +592,7 @@ struct KGroup {
     const int8_t * act_q; const float * act_ds;
     int k, n;
     const float * res[MI355_MMVQ_MAX_GROUP]; float * sum[MI355_MMVQ_MAX_GROUP];   // optional residual epilogue per matrix
+    STAMP_FIELD
 };
 
 template <int TYPE, int NCOLS, bool LDSACT>
@@ -417,7 +606,75 @@ mmvq_group_kernel(const KGroup a) {
         if (i + 1 < a.n && (int)blockIdx.x >= a.blk_end[i]) { mi = i + 1; blk0 = a.blk_end[i]; }
     }
     mmvq_row<TYPE, NCOLS, LDSACT>(a.W[mi], a.w_row_stride[mi], a.m[mi], ((int)blockIdx.x - blk0) * 4 + wave, a.act_q, a.act_ds,
-                                  a.k, a.dst[mi], a.dst_col_stride[mi], lds, a.res[mi], a.sum[mi]);
+                                  a.k, a.dst[mi], a.dst_col_stride[mi], lds, a.res[mi], a.sum[mi], STAMP_PTR(a));
+}
+
+// Single-column form of the grouped launch (decode): 1024 threads = 16 waves per workgroup, one workgroup per CU's
+// worth of rows, `rpw` consecutive rows per wave (1 for a 4096-row matrix: 256 workgroups).  Optional residual epilogue
+// per matrix; the activations come quantized, as an f32 row to quantize, or as an f32 row to normalise and quantize.
+constexpr int MV1_THREADS = 1024;
+struct KStream {
+    const uint8_t * W[MI355_MMVQ_MAX_GROUP]; int64_t w_row_stride[MI355_MMVQ_MAX_GROUP];
+    float * dst[MI355_MMVQ_MAX_GROUP];
+    const float * res[MI355_MMVQ_MAX_GROUP]; float * sum[MI355_MMVQ_MAX_GROUP];
+    int m[MI355_MMVQ_MAX_GROUP], blk_end[MI355_MMVQ_MAX_GROUP];
+    int n, k, rpw;
+    ActSrc act;
+    STAMP_FIELD
+};
+
+template <int TYPE, bool LDSACT>
+__global__ void __launch_bounds__(MV1_THREADS)
+mmvq1_kernel(const KStream a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    STAMP_AT(STAMP_PTR(a), 0);
+#ifndef MV_PF
+#define MV_PF 1        // steps requested ahead; 2 and 3 measured 3-4 % slower over a layer (timeline.cpp: the staging waves slow down)
+#endif
+    constexpr int PF = MV_PF;
+    const int wave = wave_id(), lane = threadIdx.x & 63;
+    int mi = 0, blk0 = 0;
+#pragma unroll
+    for (int i = 0; i + 1 < MI355_MMVQ_MAX_GROUP; i++) {
+        if (i + 1 < a.n && (int)blockIdx.x >= a.blk_end[i]) { mi = i + 1; blk0 = a.blk_end[i]; }
+    }
+    const int row0 = (((int)blockIdx.x - blk0) * (MV1_THREADS / 64) + wave) * a.rpw;
+    int nrows = a.m[mi] - row0;
+    nrows = nrows < 0 ? 0 : (nrows > a.rpw ? a.rpw : nrows);
+    ActStage<MV1_THREADS> st;
+    if (LDSACT) st.stage(a.act, a.k, lds, blockIdx.x == 0, STAMP_PTR(a));
+    STAMP_AT(STAMP_PTR(a), 4);
+    const float * res = a.res[mi];
+    const float rv = (res && lane < nrows) ? res[row0 + lane] : 0.0f;
+#ifdef MI355_SAME_ROW      // lab: every wave reads row 0 (cache hits): the loop's compute rate
+    const uint8_t * wmat = a.W[mi];
+    const int64_t rs = 0;
+#else
+    const uint8_t * wmat = a.W[mi] + (int64_t)row0 * a.w_row_stride[mi];
+    const int64_t rs = a.w_row_stride[mi];
+#endif
+    auto rowp = [=](int r) { return wmat + (int64_t)r * rs; };
+    WStream<TYPE, PF, decltype(rowp)> ws(rowp, nrows, a.k);
+    ws.begin();
+    float out;
+    if (LDSACT) {
+        st.wait();
+        STAMP_AT(STAMP_PTR(a), 1);
+        const auto lq  = (const __attribute__((address_space(3))) int8_t *)lds;
+        const auto lds_ = (const __attribute__((address_space(3))) float *)(lds + (size_t)a.k);
+        out = ws.run(ActLds{lq, lds_});
+    } else {
+        STAMP_AT(STAMP_PTR(a), 1);
+        out = ws.run(ActPtr{a.act.q, a.act.ds});
+    }
+    STAMP_AT(STAMP_PTR(a), 2);
+    if (lane < nrows) {
+        const int64_t o = row0 + lane;
+        float * dst = a.dst[mi], * sum = a.sum[mi];
+        if (sum != dst) dst[o] = out;               // sum == dst: the ADD is in place on the mat-vec result
+        if (res) sum[o] = out + rv;
+    }
+    STAMP_AT(STAMP_PTR(a), 3);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -428,136 +685,89 @@ mmvq_group_kernel(const KGroup a) {
 // f16 (or f32) straight into the cache rows.  Row sums, rotation and conversion use the same code as the
 // separate kernels, so the results are bit-identical to the unfused graph.
 // ------------------------------------------------------------------------------------------------
-// RMS_NORM -> MUL(weight) -> q8_1 of one token's row, written straight into the activation area of LDS ([k] int8, then
-// [k/32] {d, sum}): the prologue of the fused decode kernels.  Every workgroup normalises the row for itself (k floats
-// out of L2, hidden behind the first weight loads) with the arithmetic of rms_norm_kernel -- one 16-value chunk per
-// thread, wave butterflies, wave sums added in wave order -- so the values are bit-identical to the separate norm launch
-// (NT = 256 covers rows up to 4096 like its 256-thread form, NT = 512 rows up to 8192 like its 512-thread form; waves
-// without a chunk add 0).  `store`: this workgroup also writes the f32 result (the graph's MUL node).
-template <int NT>
-static __device__ __forceinline__ void norm_to_lds(const float * nx, const float * nw, float * nout, float eps, int k, uint8_t * lds, bool store) {
-    __shared__ float sh[NT / 64];
-    const int nc = k >> 4, c = threadIdx.x;
-    v4f v[4], wv[4];
-    float s = 0.0f;
-    if (c < nc) {
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            v[q]  = ((const v4f *)nx)[4 * c + q];
-            wv[q] = ((const v4f *)nw)[4 * c + q];
-            s += v[q].x * v[q].x + v[q].y * v[q].y + v[q].z * v[q].z + v[q].w * v[q].w;
-        }
-    }
-    s = block_sum_n<NT / 64>(s, sh);
-    const float scale = 1.0f / sqrtf(s / (float)k + eps);
-    if (c < nc) {
-        float o[16];
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            v4f t = v[q] * scale;
-            t = t * wv[q];
-            if (store) ((v4f *)nout)[4 * c + q] = t;
-            o[4 * q] = t.x; o[4 * q + 1] = t.y; o[4 * q + 2] = t.z; o[4 * q + 3] = t.w;
-        }
-        quant16_soa(o, (int8_t *)lds + 16 * c, (float *)(lds + (size_t)k) + (c >> 1) * 2, (c & 1) == 0);
-    }
-    __syncthreads();
-}
-
-template <int TYPE, bool LDSACT>
-static __device__ __forceinline__ void mmvq_row2(const uint8_t * w0, const uint8_t * w1, const int8_t * gq, const float * gds,
-                                                 int k, uint8_t * lds, float & s0, float & s1, const float * nx = nullptr,
-                                                 const float * nw = nullptr, float * nout = nullptr, float eps = 0.0f) {
-    typedef Unit<TYPE> U;
-    const int lane = threadIdx.x & 63;
-    const int nunits = k / U::ELEMS;
-    const int niter  = (nunits + 63) >> 6;
-    const int u0 = lane < nunits ? lane : nunits - 1;
-    typename U::Raw c0 = U::load(w0, u0), c1 = U::load(w1, u0);
-    if (LDSACT && nx) {
-        norm_to_lds<256>(nx, nw, nout, eps, k, lds, blockIdx.x == 0);
-    } else if (LDSACT) {
-        const int nq = k / 16, nds = k / QK;
-        for (int i = threadIdx.x; i < nq; i += 256) ((v4i *)lds)[i] = ((const v4i *)gq)[i];
-        v2f * lds_ds = (v2f *)(lds + (size_t)k);
-        for (int i = threadIdx.x; i < nds; i += 256) lds_ds[i] = ((const v2f *)gds)[i];
-        __syncthreads();
-    }
-    float acc0 = 0.0f, acc1 = 0.0f;
-    for (int it = 0; it < niter; it++) {
-        const int  u_raw = it * 64 + lane;
-        const bool valid = u_raw < nunits;
-        const int  u     = valid ? u_raw : nunits - 1;
-        typename U::Raw n0, n1;
-        if (it + 1 < niter) {
-            const int un = u_raw + 64 < nunits ? u_raw + 64 : nunits - 1;
-            n0 = U::load(w0, un); n1 = U::load(w1, un);
-        }
-        typename U::Act av;
-        if (LDSACT) {
-            const auto lq  = (const __attribute__((address_space(3))) int8_t *)lds;
-            const auto lds_ = (const __attribute__((address_space(3))) float *)(lds + (size_t)k);
-            av = U::load_act(ActLds{lq, lds_}, u);
-        } else {
-            av = U::load_act(ActPtr{gq, gds}, u);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        const float v0 = U::dot(U::decode(c0, u), av);
-        const float v1 = U::dot(U::decode(c1, u), av);
-        acc0 += valid ? v0 : 0.0f;
-        acc1 += valid ? v1 : 0.0f;
-        if (it + 1 < niter) { c0 = n0; c1 = n1; }
-    }
-    s0 = wave_sum(acc0);
-    s1 = wave_sum(acc1);
-}
-
 struct KQkv {
     const uint8_t * W[3]; int64_t w_row_stride[3];
-    int blk_end[3];                      // workgroups [blk_end[i-1], blk_end[i]) belong to matrix i (0 Q, 1 K, 2 V)
-    const int8_t * act_q; const float * act_ds; int k;
+    int pair_end[3];                     // rotated pairs [pair_end[i-1], pair_end[i]) belong to matrix i (0 Q, 1 K, 2 V)
+    int ppw;                             // consecutive pairs per wave (1, 2 or 4: divides every matrix's pair count)
+    ActSrc act; int k;
     float * q_out; void * k_out; void * v_out; int k_f16, v_f16;
     const int32_t * pos; const float * ff; RopeP rp;
-    const float * nx, * nw; float * nout; float eps;    // optional rms-norm prologue (see norm_to_lds)
+    STAMP_FIELD
 };
 
-template <int TQ, int TK, int TV>
-__global__ void __launch_bounds__(256)
-mmvq_qkv_rope_kernel(const KQkv a) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    int mat = 0, blk0 = 0;
-#pragma unroll
-    for (int i = 0; i < 2; i++) if ((int)blockIdx.x >= a.blk_end[i]) { mat = i + 1; blk0 = a.blk_end[i]; }
-    const int pair = ((int)blockIdx.x - blk0) * 4 + wave;
-    int r0, r1, ic = 0;
-    bool rot = false;
+// Up to 1024 threads; the Q | K | V pair list is dealt to the waves of the grid in order, `ppw` consecutive pairs per wave
+// (3072 pairs of an 8B token = 256 workgroups x 12 waves x 1 pair), so a wave's matrix is its own (wave-uniform) while a
+// workgroup may straddle two matrices.  The two rows of pair j end in lanes 2j, 2j + 1; lane 2j rotates and stores.
+constexpr int QKV_MAX_PPW = 4;
+
+template <int TYPE>
+static __device__ __forceinline__ void qkv_body(const KQkv & a, ActStage<0> & st, uint8_t * lds, int mat, int pair0, int np) {
+    const int lane = threadIdx.x & 63;
+    // rows of pair j of this wave: r0 = base + j * step, r1 = r0 + delta (wave-uniform; a wave's pairs sit in one head)
+    int base, step, delta, ic0 = -1;
     if (mat < 2) {
-        const int half = a.rp.ne0 / 2, h = pair / half;
-        ic = pair % half;
-        if (2 * ic >= a.rp.n_dims) { r0 = h * a.rp.ne0 + 2 * ic; r1 = r0 + 1; }                      // passed through
-        else if (a.rp.mode & 2)    { r0 = h * a.rp.ne0 + ic; r1 = r0 + a.rp.n_dims / 2; rot = true; } // NEOX
-        else                       { r0 = h * a.rp.ne0 + 2 * ic; r1 = r0 + 1; rot = true; }           // NORMAL
+        const int half = a.rp.ne0 / 2, h = pair0 / half, ic = pair0 % half;
+        if (2 * ic >= a.rp.n_dims) { base = h * a.rp.ne0 + 2 * ic; step = 2; delta = 1; }                           // passed through
+        else if (a.rp.mode & 2)    { base = h * a.rp.ne0 + ic; step = 1; delta = a.rp.n_dims / 2; ic0 = ic; }      // NEOX
+        else                       { base = h * a.rp.ne0 + 2 * ic; step = 2; delta = 1; ic0 = ic; }                // NORMAL
     } else {
-        r0 = 2 * pair; r1 = r0 + 1;
+        base = 2 * pair0; step = 2; delta = 1;
     }
-    float c = 1.0f, sn = 0.0f;
-    if (rot) rope_cos_sin(a.rp, a.pos[0], a.ff, ic, c, sn);
-    const uint8_t * w = a.W[mat];
+    const uint8_t * w = a.W[mat] + (int64_t)base * a.w_row_stride[mat];
     const int64_t rs = a.w_row_stride[mat];
-    float s0, s1;
-    if (mat == 0)      mmvq_row2<TQ, true>(w + r0 * rs, w + r1 * rs, a.act_q, a.act_ds, a.k, lds, s0, s1, a.nx, a.nw, a.nout, a.eps);
-    else if (mat == 1) mmvq_row2<TK, true>(w + r0 * rs, w + r1 * rs, a.act_q, a.act_ds, a.k, lds, s0, s1, a.nx, a.nw, a.nout, a.eps);
-    else               mmvq_row2<TV, true>(w + r0 * rs, w + r1 * rs, a.act_q, a.act_ds, a.k, lds, s0, s1, a.nx, a.nw, a.nout, a.eps);
-    if (lane == 0) {
-        float y0 = s0, y1 = s1;
-        if (rot) { y0 = s0 * c - s1 * sn; y1 = s0 * sn + s1 * c; }
+    auto rowp = [=](int r) { return w + (int64_t)((r >> 1) * step + (r & 1) * delta) * rs; };
+    constexpr int PF = 2;        // a wave has 2 * ppw * (k / 4096) steps in all: both rows of an 8B pair are in flight at once
+    WStream<TYPE, PF, decltype(rowp)> ws(rowp, 2 * np, a.k);
+    ws.begin();
+    // the rotation of pair j (lane 2j) while the weights are in flight: a powf and a sincosf, ~1 us if left to the end
+    float rc = 1.0f, rsn = 0.0f;
+    if (ic0 >= 0 && lane < 2 * np && !(lane & 1)) rope_cos_sin(a.rp, a.pos[0], a.ff, ic0 + (lane >> 1), rc, rsn);
+    st.wait();
+    STAMP_AT(STAMP_PTR(a), 1);
+    const auto lq  = (const __attribute__((address_space(3))) int8_t *)lds;
+    const auto lds_ = (const __attribute__((address_space(3))) float *)(lds + (size_t)a.k);
+    const float out = ws.run(ActLds{lq, lds_});
+    STAMP_AT(STAMP_PTR(a), 2);
+    const float other = dpp_f32<0xB1>(out);          // lane 2j: the sum of row 2j + 1
+    if (lane < 2 * np && !(lane & 1)) {
+        const int j = lane >> 1;
+        const int r0 = base + j * step, r1 = r0 + delta;
+        float y0 = out, y1 = other;
+        if (ic0 >= 0) { y0 = out * rc - other * rsn; y1 = out * rsn + other * rc; }
         if (mat == 0) { a.q_out[r0] = y0; a.q_out[r1] = y1; }
         else {
             void * o = mat == 1 ? a.k_out : a.v_out;
             if (mat == 1 ? a.k_f16 : a.v_f16) { ((__half *)o)[r0] = __float2half_rn(y0); ((__half *)o)[r1] = __float2half_rn(y1); }
             else                              { ((float *)o)[r0] = y0; ((float *)o)[r1] = y1; }
         }
+    }
+    STAMP_AT(STAMP_PTR(a), 3);
+}
+
+constexpr int QKV_MAX_WAVES = 12;      // 768 threads: 3 waves per SIMD, 168 VGPRs (the three type bodies of a mixed launch need ~140)
+
+template <int TQ, int TK, int TV>
+__global__ void __launch_bounds__(QKV_MAX_WAVES * 64)
+mmvq_qkv_rope_kernel(const KQkv a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    STAMP_AT(STAMP_PTR(a), 0);
+    ActStage<0> st;
+    st.stage(a.act, a.k, lds, blockIdx.x == 0, STAMP_PTR(a));
+    STAMP_AT(STAMP_PTR(a), 4);
+    const int gw = (int)blockIdx.x * (int)(blockDim.x >> 6) + wave_id();
+    const int p_first = gw * a.ppw;
+    int np = a.pair_end[2] - p_first;
+    np = np < 0 ? 0 : (np > a.ppw ? a.ppw : np);
+    const int pf  = np ? p_first : 0;                        // idle tail waves: matrix 0, no rows
+    const int mat = pf < a.pair_end[0] ? 0 : (pf < a.pair_end[1] ? 1 : 2);
+    const int pair0 = pf - (mat == 0 ? 0 : a.pair_end[mat - 1]);
+    if (TQ == TK && TK == TV) {
+        qkv_body<TQ>(a, st, lds, mat, pair0, np);
+    } else {
+        // one barrier sequence per branch: every wave of the workgroup executes exactly one of them
+        if (mat == 0)      qkv_body<TQ>(a, st, lds, 0, pair0, np);
+        else if (mat == 1) qkv_body<TK>(a, st, lds, 1, pair0, np);
+        else               qkv_body<TV>(a, st, lds, 2, pair0, np);
     }
 }
 
@@ -571,12 +781,12 @@ mmvq_qkv_rope_kernel(const KQkv a) {
 // ------------------------------------------------------------------------------------------------
 struct KGlu {
     const uint8_t * wg, * wu; int64_t rsg, rsu;
-    const int8_t * act_q; const float * act_ds; int k, m, op;
+    ActSrc act; int k, m, op;
     float * gate_out, * up_out, * dst; int8_t * out_q; float * out_ds;
-    const float * nx, * nw; float * nout; float eps;    // optional rms-norm prologue: activations = q8_1((nx * scale) * nw)
     // optional expert routing (MUL_MAT_ID pair of a decode token): blockIdx.y = slot, matrices of expert ids[slot], all slots read
     // the same activations, outputs of slot s at [s * m]
     const int32_t * ids; int n_expert, n_slots; int64_t wg_ex_stride, wu_ex_stride;
+    STAMP_FIELD
 };
 
 static __device__ __forceinline__ float glu_act(int op, float x) {
@@ -588,85 +798,68 @@ static __device__ __forceinline__ float glu_act(int op, float x) {
     }
 }
 
-constexpr int GLU_THREADS = 512;      // 8 waves x GLU_PAIRS (4 or 8) outputs = 32 or 64 outputs per workgroup
+constexpr int GLU_PAIRS   = 4;        // outputs per wave: NT / 64 waves x 4 = 32 (512 threads) or 64 (1024) outputs per workgroup,
+                                      // whole q8_1 blocks of the result
+#ifndef GLU_PF
+#define GLU_PF 1
+#endif
 
-template <int TYPE, int GLU_PAIRS>
-__global__ void __launch_bounds__(GLU_THREADS, (TYPE == MI355_TYPE_Q5_K || TYPE == MI355_TYPE_Q6_K) ? 2 : 4)
+template <int TYPE, int GLU_THREADS>
+__global__ void __launch_bounds__(GLU_THREADS)
 mmvq_glu_kernel(const KGlu a) {
-    typedef Unit<TYPE> U;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    STAMP_AT(STAMP_PTR(a), 0);
+    const int wave = wave_id(), lane = threadIdx.x & 63;
     const int k = a.k;
-    const int row0 = (blockIdx.x * 8 + wave) * GLU_PAIRS;                     // first of this wave's outputs
+    constexpr int NW = GLU_THREADS / 64;
+    const int row0 = (blockIdx.x * NW + wave) * GLU_PAIRS;                    // first of this wave's outputs
     int64_t ex = 0;
     if (a.ids) {
         ex = a.ids[blockIdx.y];
         if (ex < 0 || ex >= a.n_expert) return;      // out-of-range expert id (uniform per workgroup): outputs untouched
     }
+    ActStage<GLU_THREADS> st;
+    st.stage(a.act, k, lds, blockIdx.x == 0 && blockIdx.y == 0, STAMP_PTR(a));
+    STAMP_AT(STAMP_PTR(a), 4);
     const int64_t so = (int64_t)blockIdx.y * a.m;     // this slot's outputs
     const uint8_t * wg = a.wg + ex * a.wg_ex_stride + (int64_t)row0 * a.rsg, * wu = a.wu + ex * a.wu_ex_stride + (int64_t)row0 * a.rsu;
-    const int nunits = k / U::ELEMS;
-    const int niter  = (nunits + 63) >> 6;
-    const int u0 = lane < nunits ? lane : nunits - 1;
-    typename U::Raw c0 = U::load(wg, u0), c1 = U::load(wu, u0);
-    if (a.nx) {
-        norm_to_lds<GLU_THREADS>(a.nx, a.nw, a.nout, a.eps, k, lds, blockIdx.x == 0);
-    } else {
-        const int nq = k / 16, nds = k / QK;
-        for (int i = threadIdx.x; i < nq; i += GLU_THREADS) ((v4i *)lds)[i] = ((const v4i *)a.act_q)[i];
-        v2f * lds_ds = (v2f *)(lds + (size_t)k);
-        for (int i = threadIdx.x; i < nds; i += GLU_THREADS) lds_ds[i] = ((const v2f *)a.act_ds)[i];
-        __syncthreads();
-    }
+#ifdef MI355_SAME_ROW
+    wg = a.wg; wu = a.wu;
+    const int64_t rsg = 0, rsu = 0;
+#else
+    const int64_t rsg = a.rsg, rsu = a.rsu;
+#endif
+    // the wave's 8 rows in the order gate 0, up 0, gate 1, up 1, ...: output j ends in lanes 2j (gate) and 2j + 1 (up)
+    auto rowp = [=](int r) { return (r & 1) ? wu + (int64_t)(r >> 1) * rsu : wg + (int64_t)(r >> 1) * rsg; };
+    constexpr int PF = GLU_PF;
+    WStream<TYPE, PF, decltype(rowp)> ws(rowp, 2 * GLU_PAIRS, k);
+    ws.begin();
+    st.wait();
+    STAMP_AT(STAMP_PTR(a), 1);
     const auto lq   = (const __attribute__((address_space(3))) int8_t *)lds;
     const auto lds_ = (const __attribute__((address_space(3))) float *)(lds + (size_t)k);
-    float sg[GLU_PAIRS], su[GLU_PAIRS];
-#pragma unroll
-    for (int p = 0; p < GLU_PAIRS; p++) {
-        float acc0 = 0.0f, acc1 = 0.0f;
-        for (int it = 0; it < niter; it++) {
-            const int  u_raw = it * 64 + lane;
-            const bool valid = u_raw < nunits;
-            const int  u     = valid ? u_raw : nunits - 1;
-            typename U::Raw n0, n1;
-            const bool more_here = it + 1 < niter;
-            if (more_here || p + 1 < GLU_PAIRS) {
-                const int unr = more_here ? u_raw + 64 : lane;
-                const int un  = unr < nunits ? unr : nunits - 1;
-                const int64_t adv = more_here ? 0 : 1;                       // next unit of this pair, or first of the next
-                n0 = U::load(wg + (p + adv) * a.rsg, un); n1 = U::load(wu + (p + adv) * a.rsu, un);
-            }
-            const typename U::Act av = U::load_act(ActLds{lq, lds_}, u);
-            __builtin_amdgcn_sched_barrier(0);
-            const float v0 = U::dot(U::decode(c0, u), av);
-            const float v1 = U::dot(U::decode(c1, u), av);
-            acc0 += valid ? v0 : 0.0f;
-            acc1 += valid ? v1 : 0.0f;
-            if (more_here || p + 1 < GLU_PAIRS) { c0 = n0; c1 = n1; }
-        }
-        sg[p] = wave_sum(acc0);
-        su[p] = wave_sum(acc1);
-    }
-    // lanes 0..3 finish one output each; the 32 gated values meet in LDS and 8 lanes quantize the block
+    const float out = ws.run(ActLds{lq, lds_});
+    STAMP_AT(STAMP_PTR(a), 2);
+    // even lanes 0..6 finish one output each; the 32 gated values meet in LDS and 8 lanes quantize the block
+    const float up = dpp_f32<0xB1>(out);
     float * hs = (float *)(lds + (((size_t)k + (size_t)k / QK * 8 + 15) & ~(size_t)15));
-    if (lane < GLU_PAIRS) {
-        float g = sg[0], u = su[0];
-#pragma unroll
-        for (int p = 1; p < GLU_PAIRS; p++) if (lane == p) { g = sg[p]; u = su[p]; }
-        if (a.gate_out) a.gate_out[so + row0 + lane] = g;
-        if (a.up_out)   a.up_out[so + row0 + lane]   = u;
-        hs[wave * GLU_PAIRS + lane] = glu_act(a.op, g) * u;
+    if (lane < 2 * GLU_PAIRS && !(lane & 1)) {
+        const int j = lane >> 1;
+        if (a.gate_out) a.gate_out[so + row0 + j] = out;
+        if (a.up_out)   a.up_out[so + row0 + j]   = up;
+        hs[wave * GLU_PAIRS + j] = glu_act(a.op, out) * up;
     }
     __syncthreads();
-    if (threadIdx.x < 2 * GLU_PAIRS) {
+    if (threadIdx.x < NW * GLU_PAIRS / 4) {
         const v4f h = ((const v4f *)hs)[threadIdx.x];
-        const int64_t o0 = so + (int64_t)blockIdx.x * (8 * GLU_PAIRS) + 4 * threadIdx.x;
+        const int64_t o0 = so + (int64_t)blockIdx.x * (NW * GLU_PAIRS) + 4 * threadIdx.x;
         *(v4f *)(a.dst + o0) = h;
         if (a.out_q) {
             const float o[4] = {h.x, h.y, h.z, h.w};
             quant4_soa(o, a.out_q + o0, a.out_ds + (o0 >> 5) * 2, (threadIdx.x & 7) == 0);
         }
     }
+    STAMP_AT(STAMP_PTR(a), 3);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -793,6 +986,18 @@ static int launch_group(const KGroup & a, hipStream_t stream) {
 }
 
 template <int TYPE>
+static int launch_stream(const KStream & a, hipStream_t stream) {
+    const dim3 grid((unsigned)a.blk_end[a.n - 1]);
+    const size_t need = (size_t)a.k + (size_t)a.k / QK * 8;
+    static const std::string tag = std::string("mmvq_") + type_name(TYPE) + "_n1";
+    if (need <= LDS_ACT_LIMIT)  MI355_LAUNCH(tag.c_str(), (mmvq1_kernel<TYPE, true>), grid, dim3(MV1_THREADS), need, stream, a);
+    else if (a.act.x)           return MI355_E_UNSUPPORTED;
+    else                        MI355_LAUNCH(tag.c_str(), (mmvq1_kernel<TYPE, false>), grid, dim3(MV1_THREADS), 0, stream, a);
+    MI355_CHECK_LAUNCH();
+    return MI355_OK;
+}
+
+template <int TYPE>
 static int dispatch_group_cols(const KGroup & a, int ncols, hipStream_t s) {
     switch (ncols) {
         case 1: return launch_group<TYPE, 1>(a, s);
@@ -825,7 +1030,14 @@ static int dispatch_cols(const KArgs & a, int ncols, int nchannels, hipStream_t 
 } // namespace
 
 static int validate(const mi355_mmvq_args * p) {
-    if (!p || !p->W || !p->act_q || !p->act_ds || !p->dst) return MI355_E_NULL;
+    if (!p || !p->W || !p->dst) return MI355_E_NULL;
+    if (p->src_f32) {
+        // activations given as an f32 row, quantized (and optionally normalised first) by every workgroup for itself
+        if (p->ncols != 1 || p->nchannels != 1 || p->ids) return MI355_E_UNSUPPORTED;
+        if (p->k > 16384 || p->k % 32 != 0) return MI355_E_UNSUPPORTED;          // one 16-value chunk per thread, 1024 threads
+        if ((p->norm_w == nullptr) != (p->norm_out == nullptr)) return MI355_E_NULL;
+        if (((uintptr_t)p->src_f32 | (uintptr_t)p->norm_w | (uintptr_t)p->norm_out) & 15) return MI355_E_ALIGN;
+    } else if (!p->act_q || !p->act_ds) return MI355_E_NULL;
     const int64_t bs = mi355_blck_size(p->type);
     if (bs == 0 || p->type == MI355_TYPE_F32 || p->type == MI355_TYPE_F16 || p->type == MI355_TYPE_Q8_1) return MI355_E_TYPE;
     if (p->m < 0 || p->k <= 0 || p->k % bs != 0 || p->ncols < 1 || p->ncols > 8 || p->nchannels < 1 ||
@@ -833,8 +1045,9 @@ static int validate(const mi355_mmvq_args * p) {
     if (p->ids && (p->ids_nused < 1 || p->act_ne1 < 1 || p->n_expert < 1)) return MI355_E_SHAPE;
     // alignment the loads rely on: activations 16 B; q4_K/q5_K blocks 16 B; the 2-byte-aligned
     // types (q4_0, q8_0, q6_K) only need their natural 2 B
-    if (((uintptr_t)p->act_q & 15) || ((uintptr_t)p->act_ds & 7) || ((uintptr_t)p->dst & 3)) return MI355_E_ALIGN;
-    if (p->k % QK_K == 0 && ((uintptr_t)p->act_ds & 15)) return MI355_E_ALIGN;
+    if ((uintptr_t)p->dst & 3) return MI355_E_ALIGN;
+    if (!p->src_f32 && (((uintptr_t)p->act_q & 15) || ((uintptr_t)p->act_ds & 7))) return MI355_E_ALIGN;
+    if (!p->src_f32 && p->k % QK_K == 0 && ((uintptr_t)p->act_ds & 15)) return MI355_E_ALIGN;
     const bool a16 = p->type == MI355_TYPE_Q4_K || p->type == MI355_TYPE_Q5_K;
     const uintptr_t wal = (uintptr_t)p->W | (uintptr_t)p->w_row_stride | (uintptr_t)p->w_ch_stride;
     if (wal & (a16 ? 15 : 1)) return MI355_E_ALIGN;
@@ -878,7 +1091,7 @@ extern "C" int mi355_mul_mat_vec_q_group(const mi355_mmvq_args * p, int n_mats, 
         if (rc != MI355_OK) return rc;
         if (p[i].nchannels != 1 || p[i].ids) return MI355_E_UNSUPPORTED;
         if (p[i].type != p[0].type || p[i].k != p[0].k || p[i].ncols != p[0].ncols || p[i].act_q != p[0].act_q ||
-            p[i].act_ds != p[0].act_ds) return MI355_E_SHAPE;
+            p[i].act_ds != p[0].act_ds || p[i].src_f32 != p[0].src_f32 || p[i].norm_w != p[0].norm_w) return MI355_E_SHAPE;
         if (p[i].m == 0) continue;
         a.W[n] = (const uint8_t *)p[i].W; a.w_row_stride[n] = p[i].w_row_stride;
         a.dst[n] = p[i].dst; a.dst_col_stride[n] = p[i].dst_col_stride; a.m[n] = (int)p[i].m;
@@ -892,7 +1105,37 @@ extern "C" int mi355_mul_mat_vec_q_group(const mi355_mmvq_args * p, int n_mats, 
     }
     if (n == 0) return MI355_OK;
     a.n = n; a.k = (int)p[0].k; a.act_q = p[0].act_q; a.act_ds = p[0].act_ds;
+    STAMP_SET(a);
     hipStream_t s = (hipStream_t)stream;
+    if (p[0].ncols == 1) {
+        KStream b;
+        memset(&b, 0, sizeof(b));
+        int64_t rows = 0;
+        for (int i = 0; i < n; i++) rows += a.m[i];
+        // one workgroup of 16 waves per CU: rows per wave so that the grid is about 256 workgroups (a wave's sums end
+        // in its lanes, hence at most 64 rows)
+        int64_t rpw = (rows + 4095) / 4096;
+        if (rpw > 64) rpw = 64;
+        int64_t blk = 0;
+        for (int i = 0; i < n; i++) {
+            b.W[i] = a.W[i]; b.w_row_stride[i] = a.w_row_stride[i]; b.dst[i] = a.dst[i]; b.res[i] = a.res[i]; b.sum[i] = a.sum[i];
+            b.m[i] = a.m[i];
+            blk += (a.m[i] + 16 * rpw - 1) / (16 * rpw);
+            b.blk_end[i] = (int)blk;
+        }
+        b.n = n; b.k = a.k; b.rpw = (int)rpw;
+        b.act = ActSrc{p[0].act_q, p[0].act_ds, p[0].src_f32, p[0].norm_w, p[0].norm_out, p[0].norm_eps};
+        STAMP_SET(b);
+        switch (p[0].type) {
+            case MI355_TYPE_Q4_0: return launch_stream<MI355_TYPE_Q4_0>(b, s);
+            case MI355_TYPE_Q8_0: return launch_stream<MI355_TYPE_Q8_0>(b, s);
+            case MI355_TYPE_Q4_K: return launch_stream<MI355_TYPE_Q4_K>(b, s);
+            case MI355_TYPE_Q5_K: return launch_stream<MI355_TYPE_Q5_K>(b, s);
+            case MI355_TYPE_Q6_K: return launch_stream<MI355_TYPE_Q6_K>(b, s);
+        }
+        return MI355_E_TYPE;
+    }
+    if (p[0].src_f32) return MI355_E_UNSUPPORTED;          // the f32 prologue exists for one column only
     switch (p[0].type) {
         case MI355_TYPE_Q4_0: return dispatch_group_cols<MI355_TYPE_Q4_0>(a, p[0].ncols, s);
         case MI355_TYPE_Q8_0: return dispatch_group_cols<MI355_TYPE_Q8_0>(a, p[0].ncols, s);
@@ -904,10 +1147,23 @@ extern "C" int mi355_mul_mat_vec_q_group(const mi355_mmvq_args * p, int n_mats, 
 }
 
 template <int TQ, int TK, int TV>
-static int launch_qkv(const KQkv & a, hipStream_t stream) {
+static int launch_qkv(KQkv & a, hipStream_t stream) {
     const size_t need = (size_t)a.k + (size_t)a.k / QK * 8;
     if (need > LDS_ACT_LIMIT) return MI355_E_UNSUPPORTED;
-    MI355_LAUNCH("mmvq_qkv_rope", (mmvq_qkv_rope_kernel<TQ, TK, TV>), dim3((unsigned)a.blk_end[2]), dim3(256), need, stream, a);
+    // deal the pairs to one workgroup per CU: waves per workgroup x pairs per wave >= pairs per CU, with as few idle
+    // wave slots as possible (8B: 3072 pairs = 256 x 12 waves x 1 pair; 70B: 5120 = 256 x 10 x 2)
+    const int total = a.pair_end[2], per_cu = (total + 255) / 256;
+    int ppw = 1;
+    while (ppw < QKV_MAX_PPW && per_cu > QKV_MAX_WAVES * ppw) ppw *= 2;
+    // a wave's pairs must not straddle a matrix, a head or the rotated / passed-through boundary
+    while (ppw > 1 && (a.pair_end[0] % ppw || a.pair_end[1] % ppw || (a.rp.ne0 / 2) % ppw || (a.rp.n_dims / 2) % ppw)) ppw /= 2;
+    int nw = (per_cu + ppw - 1) / ppw;
+    nw = nw < 4 ? 4 : (nw > QKV_MAX_WAVES ? QKV_MAX_WAVES : nw);
+    if (a.act.x && (a.k >> 4) > nw * 64) nw = ((a.k >> 4) + 63) / 64;     // the f32 prologue: one 16-value chunk per thread
+    if (nw > QKV_MAX_WAVES) return MI355_E_UNSUPPORTED;
+    a.ppw = ppw;
+    const int grid = (total + nw * ppw - 1) / (nw * ppw);
+    MI355_LAUNCH("mmvq_qkv_rope", (mmvq_qkv_rope_kernel<TQ, TK, TV>), dim3((unsigned)grid), dim3((unsigned)(nw * 64)), need, stream, a);
     MI355_CHECK_LAUNCH();
     return MI355_OK;
 }
@@ -915,7 +1171,7 @@ static int launch_qkv(const KQkv & a, hipStream_t stream) {
 extern "C" int mi355_qkv_rope_matvec(const mi355_qkv_rope_args * p, void * stream) {
     if (!p || !p->wq || !p->wk || !p->wv || !p->q_out || !p->k_out || !p->v_out || !p->pos) return MI355_E_NULL;
     if (p->norm_x ? (!p->norm_w || !p->norm_out) : (!p->act_q || !p->act_ds)) return MI355_E_NULL;
-    if (p->norm_x && (p->k > 4096 || p->k % 32 != 0)) return MI355_E_UNSUPPORTED;   // 256-thread workgroups: one 16-value chunk per thread
+    if (p->norm_x && (p->k > 16 * 64 * QKV_MAX_WAVES || p->k % 32 != 0)) return MI355_E_UNSUPPORTED;  // one 16-value chunk per thread
     if (p->norm_x && (((uintptr_t)p->norm_x | (uintptr_t)p->norm_w | (uintptr_t)p->norm_out) & 15)) return MI355_E_ALIGN;
     const int type_k = p->type_k ? p->type_k : p->type_qk;      // 0: wk has wq's type
     const int64_t bsa = mi355_blck_size(p->type_qk), bsb = mi355_blck_size(p->type_v), bsk = mi355_blck_size(type_k);
@@ -939,12 +1195,12 @@ extern "C" int mi355_qkv_rope_matvec(const mi355_qkv_rope_args * p, void * strea
     KQkv a;
     a.W[0] = (const uint8_t *)p->wq; a.W[1] = (const uint8_t *)p->wk; a.W[2] = (const uint8_t *)p->wv;
     a.w_row_stride[0] = p->wq_row_stride; a.w_row_stride[1] = p->wk_row_stride; a.w_row_stride[2] = p->wv_row_stride;
-    a.blk_end[0] = (int)(p->m_q / 8); a.blk_end[1] = a.blk_end[0] + (int)(p->m_k / 8); a.blk_end[2] = a.blk_end[1] + (int)(p->m_v / 8);
-    a.act_q = p->act_q; a.act_ds = p->act_ds; a.k = (int)p->k;
+    a.pair_end[0] = (int)(p->m_q / 2); a.pair_end[1] = a.pair_end[0] + (int)(p->m_k / 2); a.pair_end[2] = a.pair_end[1] + (int)(p->m_v / 2);
+    a.act = ActSrc{p->act_q, p->act_ds, p->norm_x, p->norm_w, p->norm_out, p->norm_eps}; a.k = (int)p->k;
     a.q_out = p->q_out; a.k_out = p->k_out; a.v_out = p->v_out;
     a.k_f16 = p->k_out_type == MI355_TYPE_F16; a.v_f16 = p->v_out_type == MI355_TYPE_F16;
     a.pos = p->pos; a.ff = p->freq_factors;
-    a.nx = p->norm_x; a.nw = p->norm_w; a.nout = p->norm_out; a.eps = p->norm_eps;
+    STAMP_SET(a);
     a.rp = rope_params(p->n_dims, p->mode, p->head_dim, p->n_ctx_orig, p->freq_base, p->freq_scale, p->ext_factor, p->attn_factor,
                        p->beta_fast, p->beta_slow);
     hipStream_t s = (hipStream_t)stream;
@@ -969,7 +1225,13 @@ static int launch_glu_mv(const KGlu & a, hipStream_t stream) {
     if (need > LDS_ACT_LIMIT) return MI355_E_UNSUPPORTED;
     // 4 outputs per wave.  (8 per wave -- half the workgroups, for grids beyond the 512 workgroups a full chip holds at
     // once -- measured slower: 2x28672x8192 q4_K 61 us against 56; the plugin keeps such shapes on the grouped mat-vec.)
-    MI355_LAUNCH("mmvq_glu", (mmvq_glu_kernel<TYPE, 4>), dim3((unsigned)(a.m / 32), (unsigned)(a.ids ? a.n_slots : 1)), dim3(GLU_THREADS), need, stream, a);
+#ifndef GLU_WIDE
+#define GLU_WIDE 0      // 1024-thread workgroups (64 outputs): no faster than two 512-thread workgroups per CU
+#endif
+    if (GLU_WIDE && a.m % 64 == 0)
+        MI355_LAUNCH("mmvq_glu", (mmvq_glu_kernel<TYPE, 1024>), dim3((unsigned)(a.m / 64), (unsigned)(a.ids ? a.n_slots : 1)), dim3(1024), need, stream, a);
+    else
+        MI355_LAUNCH("mmvq_glu", (mmvq_glu_kernel<TYPE, 512>), dim3((unsigned)(a.m / 32), (unsigned)(a.ids ? a.n_slots : 1)), dim3(512), need, stream, a);
     MI355_CHECK_LAUNCH();
     return MI355_OK;
 }
@@ -1004,9 +1266,10 @@ extern "C" int mi355_glu_matvec(const mi355_glu_matvec_args * p, void * stream) 
     }
     KGlu a;
     a.wg = (const uint8_t *)p->w_gate; a.wu = (const uint8_t *)p->w_up; a.rsg = p->gate_row_stride; a.rsu = p->up_row_stride;
-    a.act_q = p->act_q; a.act_ds = p->act_ds; a.k = (int)p->k; a.m = (int)p->m; a.op = p->glu_op;
+    a.act = ActSrc{p->act_q, p->act_ds, p->norm_x, p->norm_w, p->norm_out, p->norm_eps};
+    a.k = (int)p->k; a.m = (int)p->m; a.op = p->glu_op;
     a.gate_out = p->gate_out; a.up_out = p->up_out; a.dst = p->dst; a.out_q = p->out_q; a.out_ds = p->out_ds;
-    a.nx = p->norm_x; a.nw = p->norm_w; a.nout = p->norm_out; a.eps = p->norm_eps;
+    STAMP_SET(a);
     a.ids = p->ids; a.n_expert = p->n_expert; a.n_slots = p->n_slots; a.wg_ex_stride = p->gate_expert_stride; a.wu_ex_stride = p->up_expert_stride;
     if (p->ids && ((p->gate_expert_stride | p->up_expert_stride) & (a16 ? 15 : 1))) return MI355_E_ALIGN;
     hipStream_t s = (hipStream_t)stream;

@@ -17,8 +17,10 @@ lib = C.CDLL(LIB_PATH)
 
 _vp, _i64, _i32 = C.c_void_p, C.c_int64, C.c_int32
 
+ABI_VERSION = 2          # MI355_ABI_VERSION of include/mi355_kernels.h this binding mirrors
+
 EXPORTS = [
-    "mi355_abi_version", "mi355_error_string", "mi355_blck_size", "mi355_type_size", "mi355_row_size",
+    "mi355_abi_version", "mi355_args_sizeof", "mi355_error_string", "mi355_blck_size", "mi355_type_size", "mi355_row_size",
     "mi355_quantize_row_q8_1", "mi355_act_q_bytes", "mi355_act_ds_bytes", "mi355_quantize_act",
     "mi355_timing_enable", "mi355_timing_reset", "mi355_timing_read", "mi355_timing_report",
     "mi355_binary_f32", "mi355_rms_norm_f32", "mi355_rms_norm_mul_f32", "mi355_rms_norm_mul_quant_f32", "mi355_glu_quant_f32", "mi355_rms_norm_mul_bf16_f32", "mi355_glu_bf16_f32", "mi355_add_rms_norm_mul_f32", "mi355_mul_mat_vec_q_group", "mi355_qkv_rope_matvec", "mi355_glu_matvec", "mi355_moe_down_matvec", "mi355_rope_f32", "mi355_glu_f32", "mi355_cpy", "mi355_get_rows",
@@ -35,6 +37,7 @@ class MmvqArgs(C.Structure):
         ("m", _i64), ("k", _i64), ("ncols", _i32), ("nchannels", _i32), ("ch_ratio", _i32),
         ("ids", _vp), ("ids_stride", _i32), ("ids_nused", _i32), ("act_ne1", _i32), ("n_expert", _i32),
         ("residual", _vp), ("sum", _vp),
+        ("src_f32", _vp), ("norm_w", _vp), ("norm_out", _vp), ("norm_eps", C.c_float),
     ]
 
 
@@ -103,6 +106,10 @@ class FattnArgs(C.Structure):
 
 
 lib.mi355_abi_version.restype = C.c_int
+lib.mi355_args_sizeof.restype = _i64
+lib.mi355_args_sizeof.argtypes = [C.c_int]
+if lib.mi355_abi_version() != ABI_VERSION:
+    raise ImportError(f"{LIB_PATH} has ABI version {lib.mi355_abi_version()}, this binding mirrors version {ABI_VERSION}: rebuild")
 lib.mi355_error_string.restype = C.c_char_p
 lib.mi355_error_string.argtypes = [C.c_int]
 for _n in ("mi355_blck_size", "mi355_type_size"):
@@ -189,3 +196,9 @@ class Mi355Error(RuntimeError):
 def check(code, where):
     if code != 0:
         raise Mi355Error(code, where)
+
+
+# the hand-kept ctypes mirrors must have the C structs' sizes (a stale library or binding would read struct tails as garbage)
+for _which, _cls in enumerate((MmvqArgs, QkvRopeArgs, GluMatvecArgs, MoeDownArgs, FattnArgs, Tensor)):
+    if lib.mi355_args_sizeof(_which) != C.sizeof(_cls):
+        raise ImportError(f"{_cls.__name__}: ctypes mirror is {C.sizeof(_cls)} bytes, the library's struct {lib.mi355_args_sizeof(_which)}")
