@@ -460,6 +460,17 @@ MI355_API int     mi355_flash_attn_ext(const mi355_fattn_args *args, void *works
 MI355_API int     mi355_flash_attn_ext_quant(const mi355_fattn_args *args, void *workspace, int64_t workspace_bytes,
                                              int8_t *act_q, float *act_ds, void *stream);
 
+/* FLASH_ATTN_EXT for callers that cannot allocate (HIP graph capture, tight serving loops, harnesses that forbid
+ * hipMalloc).  NO COUNTERPART IN THE REFERENCE (ggml-cuda takes its split-KV buffer from the backend's pool).  Same
+ * arguments, arithmetic and results as mi355_flash_attn_ext called with a zeroed workspace of
+ * mi355_flash_attn_ext_noalloc_max_bytes() bytes, but the split-KV scratch (arrival counters + partials) is a fixed
+ * array inside the library: 64 KiB + 4 MiB per GPU, held until the process ends.  Calls no hipMalloc / hipFree or any
+ * allocating routine.  MI355_E_WORKSPACE when mi355_flash_attn_ext_workspace_bytes(args) exceeds the array (e.g.
+ * n_q * n_head * (d + 2) * 256 B > 4 MiB: use the workspace form).  All calls on one GPU share the array: calls that
+ * overlap on one GPU (two streams) race; order them on one stream. */
+MI355_API int64_t mi355_flash_attn_ext_noalloc_max_bytes(void);
+MI355_API int     mi355_flash_attn_ext_noalloc(const mi355_fattn_args *args, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -15,6 +15,7 @@
 //     at an arrival counter; the workgroup that arrives last merges them (same rescaling rule) -- one launch.
 // All accumulation is f32 (the CPU oracle accumulates f16 V in fp16; NMSE budget 5e-4).
 #include "common.h"
+#include <mutex>
 
 namespace {
 
@@ -825,6 +826,57 @@ int mi355_flash_attn_ext_quant(const mi355_fattn_args * p, void * workspace, int
         case 256: return dispatch_types<256>(a, p->type_k, p->type_v, s);
     }
     return MI355_E_UNSUPPORTED;
+}
+
+// ---- the entry point that allocates nothing --------------------------------------------------------------------------
+// Callers under HIP graph capture, tight serving loops and harnesses that forbid hipMalloc cannot bring a workspace.  The
+// split-KV scratch (arrival counters + (m, l, acc) partials) then lives in a file-scope device array of fixed size; every
+// GPU the library runs on holds its own copy until the process ends.  In host code the array's NAME is only a stand-in
+// for the symbol (passing it to a kernel compiles and faults), so the device address is fetched once per device with
+// hipGetSymbolAddress, with that device current, and only that pointer is used afterwards.
+#define MI355_FATTN_SCRATCH_BYTES (65536 + (4 << 20))
+static __device__ __align__(256) unsigned char scratch[MI355_FATTN_SCRATCH_BYTES];
+
+namespace {
+constexpr int MAX_DEVICES = 64;
+std::mutex g_scratch_mu;
+void * g_scratch_ptr[MAX_DEVICES] = {};
+
+int scratch_for_current_device(void ** out) {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    if (dev < 0 || dev >= MAX_DEVICES) return MI355_E_UNSUPPORTED;
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    if (!g_scratch_ptr[dev]) {
+        void * ptr = nullptr;
+        e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));      // this device's copy of the array
+        if (e != hipSuccess) return (int)e;
+        if (!ptr || ((uintptr_t)ptr & 255)) return MI355_E_ALIGN;
+        g_scratch_ptr[dev] = ptr;
+    }
+    *out = g_scratch_ptr[dev];
+    return MI355_OK;
+}
+} // namespace
+
+int64_t mi355_flash_attn_ext_noalloc_max_bytes(void) { return MI355_FATTN_SCRATCH_BYTES; }
+
+int mi355_flash_attn_ext_noalloc(const mi355_fattn_args * p, void * stream) {
+    if (!p) return MI355_E_NULL;
+    // the scratch must hold what the launcher would ask a caller's workspace for; larger problems (long prefill batches,
+    // many heads x many slices) are refused, never silently run with fewer slices
+    const int64_t need = mi355_flash_attn_ext_workspace_bytes(p);
+    if (need < 0 || need > MI355_FATTN_SCRATCH_BYTES) return MI355_E_WORKSPACE;
+    void * ws = nullptr;
+    const int rc = scratch_for_current_device(&ws);
+    if (rc != MI355_OK) return rc;
+    // The array keeps the last call's contents.  The partials are written before they are read; the arrival counters
+    // must start at zero: every call leaves them at zero again, and they are cleared here as well (a memset node under
+    // capture) so that a call cut short by an error cannot poison the next one.
+    hipError_t e = hipMemsetAsync(ws, 0, (size_t)WS_HEADER, (hipStream_t)stream);
+    if (e != hipSuccess) return (int)e;
+    return mi355_flash_attn_ext_quant(p, ws, MI355_FATTN_SCRATCH_BYTES, nullptr, nullptr, stream);
 }
 
 } // extern "C"

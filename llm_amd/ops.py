@@ -148,7 +148,8 @@ def mul_mat_id(t, as_, b, ids, m, n_expert):
     return dst
 
 
-def flash_attn_ext(q, k, v, mask, type_kv, n_kv, scale, max_bias=0.0, logit_softcap=0.0, use_workspace=True, quant=False):
+def flash_attn_ext(q, k, v, mask, type_kv, n_kv, scale, max_bias=0.0, logit_softcap=0.0, use_workspace=True, quant=False,
+                   workspace_bytes=None, noalloc=False):
     """ggml_flash_attn_ext, batch 1.  q: [n_head, n_q, d] f32; k, v: [n_head_kv, n_kv, row_bytes] uint8 rows of
     type_kv (F16 / Q8_0 / Q4_0); mask: [n_q_pad, n_kv] f16 bits (int16) or None -> [n_q, n_head, d] f32."""
     assert q.is_cuda and q.dtype == torch.float32 and q.is_contiguous() and k.is_contiguous() and v.is_contiguous()
@@ -167,8 +168,11 @@ def flash_attn_ext(q, k, v, mask, type_kv, n_kv, scale, max_bias=0.0, logit_soft
     a.d, a.n_q, a.n_kv, a.n_head, a.n_head_kv, a.ne3 = d, n_q, n_kv, n_head, n_head_kv, 1
     a.scale, a.max_bias, a.logit_softcap = scale, max_bias, logit_softcap
     ws, wsb = None, 0
+    if noalloc:      # the entry point that allocates nothing: the split-KV scratch is a fixed array inside the library
+        K.check(K.lib.mi355_flash_attn_ext_noalloc(a, _stream()), "mi355_flash_attn_ext_noalloc")
+        return dst
     if use_workspace:
-        wsb = K.lib.mi355_flash_attn_ext_workspace_bytes(a)
+        wsb = workspace_bytes if workspace_bytes is not None else K.lib.mi355_flash_attn_ext_workspace_bytes(a)
         ws = torch.zeros(max(wsb, 16), dtype=torch.uint8, device=q.device)   # arrival counters must start at zero
     if quant:
         aq = torch.empty((n_q, n_head * d), dtype=torch.int8, device=q.device)
