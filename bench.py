@@ -35,6 +35,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--model", default="llama3-8b")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the llama-bench style tg128 / pp512 leg")
     ap.add_argument("--no-group", action="store_true", help="one launch per matrix instead of grouped QKV / gate+up launches")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
     ap.add_argument("--no-glu-fuse", action="store_true", help="grouped gate+up mat-vec and a separate quantization instead of mi355_glu_matvec")
@@ -54,19 +55,38 @@ def make_weights(torch, B, t, m, k, gen):
     return w.view(m, rs)
 
 
-def cpu_baseline(threads):
-    """ggml-cpu (the reference itself, oracle/_ref built from its sources) on the same mat-vec, host cores."""
+def _ref_bench(args, timeout):
     exe = os.path.join(ROOT, "oracle", "_ref", "ref_bench")
-    if os.path.exists(exe):
+    if not os.path.exists(exe):
+        raise FileNotFoundError("oracle/_ref/ref_bench is not built (make -C oracle ref)")
+    env = dict(os.environ, OMP_NUM_THREADS=str(args[4]), OMP_WAIT_POLICY="active")
+    out = subprocess.run([exe] + [str(a) for a in args], capture_output=True, text=True, timeout=timeout, check=True, env=env)
+    return json.loads(out.stdout.strip().splitlines()[-1])
+
+
+def cpu_baseline(threads):
+    """ggml-cpu (the reference itself, oracle/_ref built from its sources) on the host cores, timed BEFORE this process
+    touches the GPU: the bench's dominant shape (q4_K 14336x4096, cold: rotating over 2.1 GB) and BASELINE.json's
+    config 1 (q4_0 4096x4096 n=1).  If the reference binary is missing or fails, the 1-core scalar oracle port is timed
+    instead and the record says so loudly ("degraded": true, with the reason)."""
+    try:
+        r = _ref_bench(["q4_K", 14336, 4096, 1, threads, 8, 64], 240)
+        base = {"value": round(r["gbps"], 2), "unit": "GB/s", "cores": threads, "kind": "reference", "degraded": False,
+                "sample": f"ggml-cpu MUL_MAT q4_K 14336x4096 n=1 rotating over 64 matrices (2.1 GB, cold), "
+                          f"{r['runs']} runs in ~8 s, {r['us_per_run']:.1f} us/run"}
         try:
-            out = subprocess.run([exe, "q4_K", "14336", "4096", "1", str(threads), "10", "64"], capture_output=True,
-                                 text=True, timeout=120, check=True).stdout.strip().splitlines()[-1]
-            r = json.loads(out)
-            return {"value": round(r["gbps"], 2), "unit": "GB/s", "cores": threads, "kind": "reference",
-                    "sample": f"ggml-cpu MUL_MAT q4_K 14336x4096 n=1 rotating over 64 matrices (2.1 GB, cold), "
-                              f"{r['runs']} runs in ~10 s, {r['us_per_run']:.1f} us/run"}
-        except Exception as e:  # noqa: BLE001 -- fall through to the port, but say why
-            print(f"[bench] oracle/_ref/ref_bench failed ({e}); timing the oracle port instead", file=sys.stderr)
+            c = _ref_bench(["q4_0", 4096, 4096, 1, threads, 4, 128], 120)
+            base["config1"] = {"value": round(c["gbps"], 2), "unit": "GB/s", "us_per_run": round(c["us_per_run"], 1), "cores": threads,
+                               "kind": "reference",
+                               "sample": "BASELINE.json configs[0]: ggml-cpu MUL_MAT q4_0 4096x4096 n=1, rotating over 128 matrices "
+                                         f"(1.2 GB, cold), {c['runs']} runs in ~4 s"}
+        except Exception as e:  # noqa: BLE001
+            base["config1"] = {"error": str(e)[:200]}
+        return base
+    except Exception as e:  # noqa: BLE001 -- fall back to the port, but say so in the record
+        reason = f"{type(e).__name__}: {e}"[:300]
+        print(f"[bench] oracle/_ref/ref_bench failed ({reason}); timing the 1-core oracle port instead: cpu_baseline is DEGRADED",
+              file=sys.stderr)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import numpy as np
     import oracle_lib as O
@@ -79,12 +99,43 @@ def cpu_baseline(threads):
         O.mul_mat(B.Q4_K, w, x, m, k, 1, "cpu")
         runs += 1
     us = (time.perf_counter() - t0) / runs * 1e6
-    return {"value": round(B.matvec_bytes(B.Q4_K, m, k) / us * 1e-3, 3), "unit": "GB/s", "cores": 1, "kind": "port",
-            "sample": f"oracle (scalar C) q4_K {m}x{k} n=1, {runs} runs in ~10 s"}
+    return {"value": round(B.matvec_bytes(B.Q4_K, m, k) / us * 1e-3, 3), "unit": "GB/s", "cores": 1, "kind": "port", "degraded": True,
+            "degraded_reason": reason,
+            "sample": f"oracle (scalar C restatement) q4_K {m}x{k} n=1, {runs} runs in ~10 s -- NOT the 16-thread reference number"}
+
+
+def end_to_end(budget_s):
+    """BASELINE.json's other half of the metric: llama-bench's tg128 / pp512 for a random-weight Llama-3-8B Q4_K_M GGUF
+    through the reference's libllama (oracle/_ref, built from its sources) with this plugin as the GPU backend
+    (tools/llama_bench_driver.cpp follows llama-bench.cpp:1747-1795).  Run as a child process within a time budget."""
+    tool = os.path.join(ROOT, "tools", "run_llama_bench.sh")
+    need = [os.path.join(ROOT, "oracle", "_ref", x) for x in ("mi355-llama-bench", "make-random-gguf", "libllama.so")]
+    need.append(os.path.join(ROOT, "llm_amd", "lib", "libggml-mi355.so"))
+    missing = [os.path.relpath(x, ROOT) for x in need if not os.path.exists(x)]
+    if missing:
+        return {"error": "not built: " + ", ".join(missing)}
+    t0 = time.perf_counter()
+    try:
+        r = subprocess.run([tool, "8b", "Q4_K_M", "-p", "512", "-n", "128", "-r", "3"], capture_output=True, text=True, timeout=budget_s)
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+        j = json.loads(line)
+    except Exception as e:  # noqa: BLE001
+        return {"error": f"{type(e).__name__}: {e}"[:300]}
+    bytes_per_token = 4.616e9       # weights streamed per decode token (SURVEY 8d)
+    return {"model": "Llama-3-8B Q4_K_M, random-init GGUF (tools/make_random_gguf.cpp), f16 KV, flash attention", "harness":
+            "reference libllama + plugin via GGML_BACKEND_PATH, llama-bench method (3 reps)", "devices": j.get("devices"),
+            "tg128_tps": round(j["tg_avg_ts"], 1), "tg128_stddev": round(j["tg_stddev_ts"], 1),
+            "pp512_tps": round(j["pp_avg_ts"], 1), "pp512_stddev": round(j["pp_stddev_ts"], 1),
+            "tg128_frac_of_hbm_bound": round(j["tg_avg_ts"] * bytes_per_token / (HBM_PEAK_GBPS * 1e9), 4),
+            "seconds": round(time.perf_counter() - t0, 1)}
 
 
 def main():
     args = parse()
+    # the CPU baseline runs first, before this process initialises the GPU (and before torch's threads exist)
+    base = None
+    if int(os.environ.get("RANK", "0")) == 0 and int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.no_cpu_baseline:
+        base = cpu_baseline(min(16, os.cpu_count() or 1))
     import torch
     import torch.distributed as dist
 
@@ -353,7 +404,7 @@ def main():
             traffic = None
     roofline = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
-                "traffic": traffic, "traffic_source": "profiles/r01_bench_traffic.json (rocprofv3 --pmc FETCH_SIZE x2, separate pass)" if traffic else None,
+                "traffic": traffic, "traffic_source": "profiles/r02_bench_traffic.json (rocprofv3 --pmc FETCH_SIZE x2, separate pass)" if traffic else None,
                 "launches": n_launch, "avg_launch_us": round(avg_us, 3),
                 "algorithmic_bytes_per_launch": round(q4k_bytes / n_launch), "all_kernels": kernels}
     n_launches = sum(1 for p in plan) + sum(1 for p in plan if p[0] is not None)
@@ -376,8 +427,10 @@ def main():
                        "decode_tokens_per_s_matvec_only": round(1e3 / ms_per_step, 1)},
             "roofline": roofline,
         }
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(min(16, os.cpu_count() or 1))
+        if base is not None:
+            line["cpu_baseline"] = base
+        if world == 1 and not args.no_e2e:
+            line["e2e"] = end_to_end(240)      # a child process with its own copy of the model (288 GB of HBM: no contention)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

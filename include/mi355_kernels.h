@@ -49,7 +49,7 @@ enum mi355_error {
 };
 
 /* library / device introspection */
-#define MI355_ABI_VERSION 2                             /* bumped on any signature or struct change */
+#define MI355_ABI_VERSION 3                             /* bumped on any signature or struct change */
 MI355_API int         mi355_abi_version(void);          /* == MI355_ABI_VERSION of the header the library was built from;
                                                          * the plugin and the Python binding refuse a library that differs */
 MI355_API int64_t     mi355_args_sizeof(int which);     /* sizeof of 0 mi355_mmvq_args, 1 qkv_rope, 2 glu_matvec, 3 moe_down,
@@ -189,6 +189,11 @@ typedef struct mi355_qkv_rope_args {
      * q8_1((norm_x * rsqrt(mean(norm_x^2) + norm_eps)) * norm_w), act_q / act_ds are not read, norm_out receives the f32
      * result.  norm_x, norm_w and every output of the launch must not overlap. */
     const float *norm_x, *norm_w; float *norm_out; float norm_eps;
+    /* optional indirection for launches replayed from a HIP graph (the plugin's decode graph, ggml-cuda's analogue:
+     * ggml_cuda_cpy_dest_ptrs, ggml-cuda/cpy.cu): the KV-cache rows a token is stored to move with every token while
+     * the captured kernel arguments cannot.  When kv_table is set (device array of pointers) the kernel stores K to
+     * kv_table[2 * kv_slot] and V to kv_table[2 * kv_slot + 1]; k_out / v_out are then only checked, not used. */
+    void *const *kv_table; int32_t kv_slot;
 } mi355_qkv_rope_args;
 MI355_API int mi355_qkv_rope_matvec(const mi355_qkv_rope_args *args, void *stream);
 

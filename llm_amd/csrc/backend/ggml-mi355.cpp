@@ -482,6 +482,8 @@ static ggml_backend_buffer_type_t mi355_split_buffer_type(int main_device, const
 }
 
 // environment switches are read once per process (graph_compute consults them per node)
+#define MI355_KV_SLOTS 512          // fused Q/K/V launches per graph whose K / V destinations go through the table
+#define MI355_KV_RING  8
 #define MI355_ENV_SET(name) ([]() -> bool { static const bool v_ = getenv(name) != nullptr; return v_; }())
 
 // ------------------------------------------------------------------------------------------------
@@ -538,8 +540,39 @@ struct mi355_backend_ctx {
         return p;
     }
 
+    // ---- decode graphs (reference analogue: the CUDA-graph path of ggml-cuda.cu:2579-2905) -------------------------
+    // A decode token's launches (~165) are captured once into a hipGraph and replayed while the ggml graph keeps its
+    // shape: node ops, shapes, strides, parameters and addresses.  The one thing that moves with every token is the
+    // KV-cache row the new K / V are stored to; the fused Q/K/V launch reads those two addresses from a device table
+    // (kv_dev) that is refreshed before each replay, the way ggml-cuda refreshes its cpy destination pointers.
+    struct node_sig {
+        int32_t op, type, flags;
+        const void * data;
+        int64_t ne[4]; size_t nb[4];
+        const void * src[GGML_MAX_SRC];
+        int32_t params[GGML_MAX_OP_PARAMS / sizeof(int32_t)];
+        bool kv_dst;                 // CPY whose destination goes through the table: its address may change
+    };
+    struct graph_cache_t {
+        std::vector<node_sig> sig;   // the last graph seen
+        hipGraphExec_t exec = nullptr;
+        std::vector<int> kv_nodes;   // CPY node indices, two per table slot (K, V), in launch order
+        void ** kv_dev = nullptr;    // device table, MI355_KV_SLOTS * 2 pointers
+        void ** kv_host = nullptr;   // pinned staging ring, MI355_KV_RING copies of the table
+        int  ring = 0;
+        int  recaptures = 0;         // consecutive graphs that had to be captured again
+        bool disabled = false;
+        bool capturing = false, capture_failed = false;
+        int  n_slots = 0;            // slots handed out during the capture in progress
+        long n_replay = 0, n_capture = 0, n_eager = 0;       // GGML_MI355_GRAPH_STATS=1 prints them when the backend is freed
+    } gc;
+
     void * get_scratch(int which, size_t need) {
         if (need <= scratch_size[which]) return scratch[which];
+        if (gc.capturing) {          // no allocation or synchronisation under capture: give up on this capture,
+            gc.capture_failed = true;    // the eager run that follows grows the buffer (nothing captured is ever executed)
+            return scratch[which];
+        }
         if (scratch[which]) {
             HIP_CHECK(hipStreamSynchronize(stream)); // earlier kernels may still read the old block
             HIP_CHECK(hipFree(scratch[which]));
@@ -583,6 +616,12 @@ static void mi355_backend_free(ggml_backend_t backend) {
     mi355_set_device(ctx->device);
     HIP_CHECK(hipStreamSynchronize(ctx->stream));
     for (int i = 0; i < 3; i++) if (ctx->scratch[i]) HIP_CHECK(hipFree(ctx->scratch[i]));
+    if (MI355_ENV_SET("GGML_MI355_GRAPH_STATS"))
+        fprintf(stderr, "[mi355] %s decode graphs: %ld replays, %ld captures, %ld eager runs of capturable graphs%s\n", ctx->name.c_str(),
+                ctx->gc.n_replay, ctx->gc.n_capture, ctx->gc.n_eager, ctx->gc.disabled ? " (disabled)" : "");
+    if (ctx->gc.exec) HIP_CHECK(hipGraphExecDestroy(ctx->gc.exec));
+    if (ctx->gc.kv_dev) HIP_CHECK(hipFree(ctx->gc.kv_dev));
+    if (ctx->gc.kv_host) HIP_CHECK(hipHostFree(ctx->gc.kv_host));
     if (ctx->ev_ready) HIP_CHECK(hipEventDestroy(ctx->ev_ready));
     for (int d = 0; d < MI355_MAX_DEVICES; d++) {
         mi355_backend_ctx::peer_t & p = ctx->peers[d];
@@ -1710,6 +1749,10 @@ static bool mi355_try_fuse_qkv_rope(mi355_backend_ctx * ctx, ggml_cgraph * cgrap
     a.m_q = Mq; a.m_k = Mk; a.m_v = Mv; a.k = K;
     a.act_q = (const int8_t *)ws; a.act_ds = (const float *)(ws + qb);
     a.q_out = (float *)rq->data; a.k_out = ck->data; a.v_out = cv->data;
+    if (ctx->gc.capturing) {
+        if (ctx->gc.n_slots >= MI355_KV_SLOTS) { ctx->gc.capture_failed = true; }
+        else { a.kv_table = ctx->gc.kv_dev; a.kv_slot = ctx->gc.n_slots; }
+    }
     a.k_out_type = (int32_t)ck->type; a.v_out_type = (int32_t)cv->type;
     a.pos = (const int32_t *)rq->src[1]->data; a.freq_factors = rq->src[2] ? (const float *)rq->src[2]->data : nullptr;
     a.head_dim = (int32_t)hd; a.n_dims = rp[1]; a.mode = rp[2]; a.n_ctx_orig = rp[4];
@@ -1726,14 +1769,14 @@ static bool mi355_try_fuse_qkv_rope(mi355_backend_ctx * ctx, ggml_cgraph * cgrap
     if (rc == MI355_E_UNSUPPORTED || rc == MI355_E_SHAPE || rc == MI355_E_ALIGN) return false;
     MI_CHECK(rc);
     for (int m = 1; m < 7; m++) done[idx[m]] = 1;
+    if (a.kv_table) { ctx->gc.kv_nodes.push_back(idx[5]); ctx->gc.kv_nodes.push_back(idx[6]); ctx->gc.n_slots++; }
     ctx->act_invalidate_if_written(rq);
     if (norm_idx >= 0) ctx->act_invalidate_if_written(x);
     return true;
 }
 
-static enum ggml_status mi355_backend_graph_compute(ggml_backend_t backend, ggml_cgraph * cgraph) {
-    mi355_backend_ctx * ctx = (mi355_backend_ctx *)backend->context;
-    mi355_set_device(ctx->device);
+// issue the launches of a graph on ctx->stream (eagerly, or into the stream capture in progress)
+static enum ggml_status mi355_issue_graph(mi355_backend_ctx * ctx, ggml_cgraph * cgraph) {
     ctx->act_cache.valid = false; // tensors may have been rewritten through set_tensor / copies between calls
     const int n = ggml_graph_n_nodes(cgraph);
     const bool fuse = !MI355_ENV_SET("GGML_MI355_NO_FUSE");
@@ -1747,23 +1790,6 @@ static enum ggml_status mi355_backend_graph_compute(ggml_backend_t backend, ggml
         }
     }
     std::vector<char> done(n, 0);    // nodes already computed by a hoisting fusion
-    static const bool time_graph = getenv("GGML_MI355_TIME_GRAPH") != nullptr;   // diagnostics: host time spent issuing a graph
-    struct host_timer {
-        bool on; int n; std::chrono::steady_clock::time_point t0;
-        ~host_timer() {
-            if (!on) return;
-            static double tot = 0, between = 0; static long calls = 0;
-            static std::chrono::steady_clock::time_point last_end;
-            const auto now = std::chrono::steady_clock::now();
-            tot += std::chrono::duration<double, std::micro>(now - t0).count();
-            if (calls) between += std::chrono::duration<double, std::micro>(t0 - last_end).count();
-            last_end = now; calls++;
-            if (calls % 64 == 0) {
-                fprintf(stderr, "[mi355] graph_compute host time: %.1f us avg over 64 calls (%d nodes), %.1f us between calls\n", tot / 64, n, between / 64);
-                tot = between = 0;
-            }
-        }
-    } timer{time_graph, n, std::chrono::steady_clock::now()};
     for (int i = 0; i < n; i++) {
         ggml_tensor * node = ggml_graph_node(cgraph, i);
         if (done[i]) continue;
@@ -1828,6 +1854,154 @@ static enum ggml_status mi355_backend_graph_compute(ggml_backend_t backend, ggml
             return GGML_STATUS_FAILED;
         }
     }
+    return GGML_STATUS_SUCCESS;
+}
+
+// ---- decode graphs: signature, capture, replay -------------------------------------------------------------------
+static bool node_computes(const ggml_tensor * t) {
+    return !(ggml_is_empty(t) || t->op == GGML_OP_NONE || t->op == GGML_OP_RESHAPE || t->op == GGML_OP_VIEW || t->op == GGML_OP_PERMUTE ||
+             t->op == GGML_OP_TRANSPOSE);
+}
+
+// A graph is a candidate when it is a single-token step on this device alone: every MUL_MAT / MUL_MAT_ID has one
+// activation column (prefill graphs change shape from call to call and amortise their launches anyway) and no tensor
+// lives in a row-split buffer (helper streams and cross-device events are not captured; ggml-cuda.cu:2593-2598 likewise).
+static bool mi355_graph_capturable(ggml_cgraph * cgraph) {
+    const int n = ggml_graph_n_nodes(cgraph);
+    if (n < 8) return false;
+    bool any = false;
+    for (int i = 0; i < n; i++) {
+        const ggml_tensor * t = ggml_graph_node((ggml_cgraph *)cgraph, i);
+        if (t->op == GGML_OP_MUL_MAT || t->op == GGML_OP_MUL_MAT_ID) {
+            if (ggml_nelements(t->src[1]) != t->src[1]->ne[0] * (t->op == GGML_OP_MUL_MAT_ID ? t->src[1]->ne[1] : 1)) return false;
+            if (t->op == GGML_OP_MUL_MAT && ggml_is_quantized(t->src[0]->type)) any = true;
+        }
+        for (int k = 0; k < GGML_MAX_SRC; k++) if (t->src[k] && tensor_is_split(t->src[k])) return false;
+    }
+    return any;
+}
+
+static void mi355_graph_signature(ggml_cgraph * cgraph, std::vector<mi355_backend_ctx::node_sig> & sig) {
+    const int n = ggml_graph_n_nodes(cgraph);
+    sig.resize(n);
+    for (int i = 0; i < n; i++) {
+        const ggml_tensor * t = ggml_graph_node((ggml_cgraph *)cgraph, i);
+        mi355_backend_ctx::node_sig & s = sig[i];
+        s.op = (int32_t)t->op; s.type = (int32_t)t->type; s.flags = t->flags; s.data = t->data; s.kv_dst = false;
+        for (int k = 0; k < 4; k++) { s.ne[k] = t->ne[k]; s.nb[k] = t->nb[k]; }
+        for (int k = 0; k < GGML_MAX_SRC; k++) s.src[k] = t->src[k] ? t->src[k]->data : nullptr;
+        memcpy(s.params, t->op_params, sizeof(s.params));
+    }
+}
+
+// same graph as the cached one?  View nodes compute nothing (their addresses count through their consumers' sources);
+// a CPY whose destination goes through the table may move.
+// `captured`: the cached signature belongs to an instantiated graph (only the CPYs it routed through the table may move);
+// before that every CPY destination may move -- whether the launches can follow it is decided at capture time.
+static bool mi355_graph_same(const std::vector<mi355_backend_ctx::node_sig> & a, const std::vector<mi355_backend_ctx::node_sig> & cached,
+                             ggml_cgraph * cgraph, bool captured) {
+    static const bool dbg = getenv("GGML_MI355_GRAPH_DEBUG") != nullptr;
+    if (a.size() != cached.size()) { if (dbg) fprintf(stderr, "[mi355] graph: %zu nodes, cached %zu\n", a.size(), cached.size()); return false; }
+    for (size_t i = 0; i < a.size(); i++) {
+        const mi355_backend_ctx::node_sig & x = a[i], & c = cached[i];
+        const ggml_tensor * t = ggml_graph_node(cgraph, (int)i);
+        bool ok = x.op == c.op && x.type == c.type && !memcmp(x.ne, c.ne, sizeof(x.ne)) && !memcmp(x.nb, c.nb, sizeof(x.nb));
+        // view nodes compute nothing: where they point (their op_params hold the offset) counts through their consumers' sources
+        if (ok && node_computes(t)) ok = x.flags == c.flags && !memcmp(x.params, c.params, sizeof(x.params));
+        if (ok && node_computes(t)) {
+            if (captured ? c.kv_dst : x.op == (int32_t)GGML_OP_CPY) ok = x.src[0] == c.src[0];   // destination (data, src[1]) free to move
+            else ok = x.data == c.data && !memcmp(x.src, c.src, sizeof(x.src));
+        }
+        if (!ok) {
+            if (dbg) fprintf(stderr, "[mi355] graph differs at node %zu %s (%s): data %p / %p, ne0 %lld / %lld\n", i, ggml_op_name(t->op), t->name,
+                             x.data, c.data, (long long)x.ne[0], (long long)c.ne[0]);
+            return false;
+        }
+    }
+    return true;
+}
+
+static void mi355_graph_refresh_kv_table(mi355_backend_ctx * ctx, ggml_cgraph * cgraph) {
+    mi355_backend_ctx::graph_cache_t & gc = ctx->gc;
+    if (gc.kv_nodes.empty()) return;
+    void ** h = gc.kv_host + (size_t)gc.ring * MI355_KV_SLOTS * 2;
+    gc.ring = (gc.ring + 1) % MI355_KV_RING;
+    for (size_t j = 0; j < gc.kv_nodes.size(); j++) h[j] = ggml_graph_node(cgraph, gc.kv_nodes[j])->data;
+    HIP_CHECK(hipMemcpyAsync(gc.kv_dev, h, gc.kv_nodes.size() * sizeof(void *), hipMemcpyHostToDevice, ctx->stream));
+}
+
+static enum ggml_status mi355_backend_graph_compute(ggml_backend_t backend, ggml_cgraph * cgraph) {
+    mi355_backend_ctx * ctx = (mi355_backend_ctx *)backend->context;
+    mi355_set_device(ctx->device);
+    const int n = ggml_graph_n_nodes(cgraph);
+    static const bool time_graph = getenv("GGML_MI355_TIME_GRAPH") != nullptr;   // diagnostics: host time spent issuing a graph
+    struct host_timer {
+        bool on; int n; std::chrono::steady_clock::time_point t0;
+        ~host_timer() {
+            if (!on) return;
+            static double tot = 0, between = 0; static long calls = 0;
+            static std::chrono::steady_clock::time_point last_end;
+            const auto now = std::chrono::steady_clock::now();
+            tot += std::chrono::duration<double, std::micro>(now - t0).count();
+            if (calls) between += std::chrono::duration<double, std::micro>(t0 - last_end).count();
+            last_end = now; calls++;
+            if (calls % 64 == 0) {
+                fprintf(stderr, "[mi355] graph_compute host time: %.1f us avg over 64 calls (%d nodes), %.1f us between calls\n", tot / 64, n, between / 64);
+                tot = between = 0;
+            }
+        }
+    } timer{time_graph, n, std::chrono::steady_clock::now()};
+    mi355_backend_ctx::graph_cache_t & gc = ctx->gc;
+    static const bool graphs_off = getenv("GGML_MI355_NO_GRAPHS") != nullptr;
+    if (graphs_off || gc.disabled || !mi355_graph_capturable(cgraph)) return mi355_issue_graph(ctx, cgraph);
+
+    std::vector<mi355_backend_ctx::node_sig> sig;
+    mi355_graph_signature(cgraph, sig);
+    const bool same = mi355_graph_same(sig, gc.sig, cgraph, gc.exec != nullptr);
+    if (same && gc.exec) {                         // replay
+        gc.recaptures = 0; gc.n_replay++;
+        mi355_graph_refresh_kv_table(ctx, cgraph);
+        HIP_CHECK(hipGraphLaunch(gc.exec, ctx->stream));
+        return GGML_STATUS_SUCCESS;
+    }
+    if (!same) {
+        // first sighting of this graph: run it eagerly (this also sizes the scratch buffers); a second identical one is captured
+        if (gc.exec) { HIP_CHECK(hipGraphExecDestroy(gc.exec)); gc.exec = nullptr; }
+        gc.sig.swap(sig);
+        gc.kv_nodes.clear();
+        if (++gc.recaptures > 8) {                 // a graph that never settles (ggml-cuda.cu:2674-2690 gives up the same way)
+            gc.disabled = true;
+            MI_LOG_INFO("%s: decode graph keeps changing, hipGraph replay disabled for this backend\n", __func__);
+        }
+        gc.n_eager++;
+        return mi355_issue_graph(ctx, cgraph);
+    }
+    // second identical graph: capture
+    if (!gc.kv_dev) {
+        HIP_CHECK(hipMalloc((void **)&gc.kv_dev, MI355_KV_SLOTS * 2 * sizeof(void *)));
+        HIP_CHECK(hipHostMalloc((void **)&gc.kv_host, (size_t)MI355_KV_RING * MI355_KV_SLOTS * 2 * sizeof(void *), hipHostMallocDefault));
+    }
+    gc.kv_nodes.clear(); gc.n_slots = 0; gc.capture_failed = false;
+    HIP_CHECK(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+    gc.capturing = true;
+    const enum ggml_status st = mi355_issue_graph(ctx, cgraph);
+    gc.capturing = false;
+    hipGraph_t graph = nullptr;
+    HIP_CHECK(hipStreamEndCapture(ctx->stream, &graph));
+    if (st != GGML_STATUS_SUCCESS || gc.capture_failed || !graph) {
+        if (graph) HIP_CHECK(hipGraphDestroy(graph));
+        gc.kv_nodes.clear();
+        if (st != GGML_STATUS_SUCCESS) return st;
+        if (++gc.recaptures > 8) gc.disabled = true;
+        gc.n_eager++;
+        return mi355_issue_graph(ctx, cgraph);     // e.g. a scratch buffer had to grow: eager now, capture next time
+    }
+    HIP_CHECK(hipGraphInstantiate(&gc.exec, graph, nullptr, nullptr, 0));
+    HIP_CHECK(hipGraphDestroy(graph));
+    gc.n_capture++;
+    for (int j : gc.kv_nodes) gc.sig[j].kv_dst = true;
+    mi355_graph_refresh_kv_table(ctx, cgraph);
+    HIP_CHECK(hipGraphLaunch(gc.exec, ctx->stream));
     return GGML_STATUS_SUCCESS;
 }
 

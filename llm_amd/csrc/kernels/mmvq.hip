@@ -692,6 +692,7 @@ struct KQkv {
     ActSrc act; int k;
     float * q_out; void * k_out; void * v_out; int k_f16, v_f16;
     const int32_t * pos; const float * ff; RopeP rp;
+    void * const * kv_tab; int kv_slot;      // optional: K / V destinations read from a device table (graph replay)
     STAMP_FIELD
 };
 
@@ -737,6 +738,7 @@ static __device__ __forceinline__ void qkv_body(const KQkv & a, ActStage<0> & st
         if (mat == 0) { a.q_out[r0] = y0; a.q_out[r1] = y1; }
         else {
             void * o = mat == 1 ? a.k_out : a.v_out;
+            if (a.kv_tab) o = a.kv_tab[2 * a.kv_slot + (mat == 1 ? 0 : 1)];
             if (mat == 1 ? a.k_f16 : a.v_f16) { ((__half *)o)[r0] = __float2half_rn(y0); ((__half *)o)[r1] = __float2half_rn(y1); }
             else                              { ((float *)o)[r0] = y0; ((float *)o)[r1] = y1; }
         }
@@ -1200,6 +1202,8 @@ extern "C" int mi355_qkv_rope_matvec(const mi355_qkv_rope_args * p, void * strea
     a.q_out = p->q_out; a.k_out = p->k_out; a.v_out = p->v_out;
     a.k_f16 = p->k_out_type == MI355_TYPE_F16; a.v_f16 = p->v_out_type == MI355_TYPE_F16;
     a.pos = p->pos; a.ff = p->freq_factors;
+    if (p->kv_table && (p->kv_slot < 0 || ((uintptr_t)p->kv_table & 7))) return MI355_E_SHAPE;
+    a.kv_tab = p->kv_table; a.kv_slot = p->kv_slot;
     STAMP_SET(a);
     a.rp = rope_params(p->n_dims, p->mode, p->head_dim, p->n_ctx_orig, p->freq_base, p->freq_scale, p->ext_factor, p->attn_factor,
                        p->beta_fast, p->beta_slow);

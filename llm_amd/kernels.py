@@ -17,7 +17,7 @@ lib = C.CDLL(LIB_PATH)
 
 _vp, _i64, _i32 = C.c_void_p, C.c_int64, C.c_int32
 
-ABI_VERSION = 2          # MI355_ABI_VERSION of include/mi355_kernels.h this binding mirrors
+ABI_VERSION = 3          # MI355_ABI_VERSION of include/mi355_kernels.h this binding mirrors
 
 EXPORTS = [
     "mi355_abi_version", "mi355_args_sizeof", "mi355_error_string", "mi355_blck_size", "mi355_type_size", "mi355_row_size",
@@ -70,6 +70,7 @@ class QkvRopeArgs(C.Structure):
         ("freq_base", C.c_float), ("freq_scale", C.c_float), ("ext_factor", C.c_float), ("attn_factor", C.c_float),
         ("beta_fast", C.c_float), ("beta_slow", C.c_float), ("type_k", C.c_int32),
         ("norm_x", _vp), ("norm_w", _vp), ("norm_out", _vp), ("norm_eps", C.c_float),
+        ("kv_table", _vp), ("kv_slot", _i32),
     ]
 
 

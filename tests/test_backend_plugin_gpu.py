@@ -109,6 +109,30 @@ def test_fusions_are_bit_exact(tmp_path, model):
     assert np.array_equal(outs[0], outs[1])
 
 
+@pytest.mark.parametrize("model", ["tiny", "tinymoe"])
+def test_decode_graph_replay_is_bit_exact(tmp_path, model):
+    """the plugin captures a decode token's launches into a hipGraph and replays it while the ggml graph keeps
+    its shape (the KV-cache rows of the new token go through a device table).  230 decode steps after a 48-token prompt
+    cross the 256-entry KV padding boundary (a re-capture); logits with replay equal the eager run's bit for bit, and
+    nearly all steps were replays."""
+    import numpy as np
+    tool = os.path.join(ROOT, "tools", "run_llama_bench.sh")
+    outs = []
+    for eager in (False, True):
+        path = str(tmp_path / f"logits_{int(eager)}.bin")
+        env = dict(os.environ, GGML_MI355_GRAPH_STATS="1")
+        if eager:
+            env["GGML_MI355_NO_GRAPHS"] = "1"
+        r = subprocess.run([tool, model, "Q4_K_M", "--dump-logits", path, "--decode-steps", "230"], capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stderr[-3000:]
+        outs.append(np.fromfile(path, dtype=np.uint32))
+        if not eager:
+            m = re.search(r"decode graphs: (\d+) replays, (\d+) captures", r.stderr)
+            assert m, r.stderr[-2000:]
+            assert int(m.group(1)) >= 220 and int(m.group(2)) <= 4, m.group(0)
+    assert outs[0].size == outs[1].size and np.array_equal(outs[0], outs[1])
+
+
 def test_row_split_mul_mat_bit_exact_on_virtual_devices():
     """the plugin's split buffer type (`-sm row`).  Two ggml devices mapped onto the one GPU
     (GGML_MI355_VIRTUAL_DEVICES=2) exercise helper streams, the activation copy, cross-stream events and row

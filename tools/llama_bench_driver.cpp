@@ -55,6 +55,7 @@ int main(int argc, char ** argv) {
     std::string model_path, ctk = "f16", ctv = "f16", dump_path, sm = "layer", ts_arg;
     int main_gpu = 0;
     int n_prompt = 512, n_gen = 128, reps = 3, ngl = 99, fa = 1, threads = 8, n_batch = 2048, n_ubatch = 512;
+    int dump_steps = 6;          // single-token decodes of the parity mode
     for (int i = 1; i < argc; i++) {
         const std::string a = argv[i];
         auto next = [&]() { if (i + 1 >= argc) { fprintf(stderr, "missing value for %s\n", a.c_str()); exit(2); } return std::string(argv[++i]); };
@@ -62,6 +63,7 @@ int main(int argc, char ** argv) {
         else if (a == "-r") reps = atoi(next().c_str()); else if (a == "-ngl") ngl = atoi(next().c_str()); else if (a == "-fa") fa = atoi(next().c_str());
         else if (a == "-ctk") ctk = next(); else if (a == "-ctv") ctv = next(); else if (a == "-t") threads = atoi(next().c_str());
         else if (a == "--dump-logits") dump_path = next();
+        else if (a == "--decode-steps") dump_steps = atoi(next().c_str());
         else if (a == "-sm") sm = next(); else if (a == "-mg") main_gpu = atoi(next().c_str()); else if (a == "-ts") ts_arg = next();
         else if (a == "-b") n_batch = atoi(next().c_str()); else if (a == "-ub") n_ubatch = atoi(next().c_str());
         else { fprintf(stderr, "unknown arg %s\n", a.c_str()); return 2; }
@@ -97,7 +99,7 @@ int main(int argc, char ** argv) {
     const int n_vocab = llama_vocab_n_tokens(llama_model_get_vocab(model));
 
     llama_context_params cp = llama_context_default_params();
-    cp.n_ctx = std::max(n_prompt + n_gen, 256) + (dump_path.empty() ? 0 : 256);
+    cp.n_ctx = std::max(n_prompt + n_gen, 256) + (dump_path.empty() ? 0 : 256 + dump_steps);
     cp.n_batch = n_batch; cp.n_ubatch = n_ubatch;
     cp.n_threads = threads; cp.n_threads_batch = threads;
     cp.flash_attn = fa != 0;
@@ -118,7 +120,7 @@ int main(int argc, char ** argv) {
         if (!f) { perror(dump_path.c_str()); return 1; }
         if (llama_decode(ctx, llama_batch_get_one(prompt.data(), (int)prompt.size())) != 0) return 1;
         fwrite(llama_get_logits_ith(ctx, -1), sizeof(float), n_vocab, f);
-        for (int s = 0; s < 6; s++) {
+        for (int s = 0; s < dump_steps; s++) {
             llama_token tok = (llama_token)((s * 104729 + 71) % n_vocab);
             if (llama_decode(ctx, llama_batch_get_one(&tok, 1)) != 0) return 1;
             fwrite(llama_get_logits_ith(ctx, -1), sizeof(float), n_vocab, f);
@@ -130,7 +132,7 @@ int main(int argc, char ** argv) {
             fwrite(llama_get_logits_ith(ctx, -1), sizeof(float), n_vocab, f);
         }
         fclose(f);
-        printf("{\"dumped\": \"%s\", \"n_vocab\": %d, \"rows\": 10, \"devices\": \"%s\"}\n", dump_path.c_str(), n_vocab, devs.c_str());
+        printf("{\"dumped\": \"%s\", \"n_vocab\": %d, \"rows\": %d, \"devices\": \"%s\"}\n", dump_path.c_str(), n_vocab, 4 + dump_steps, devs.c_str());
         llama_free(ctx); llama_model_free(model); llama_backend_free();
         return 0;
     }
