@@ -310,6 +310,11 @@ MI355_API int mi355_act_bf16(const float *x, uint16_t *y, int64_t k, int64_t ne1
                              int64_t nb1, int64_t nb2, int64_t nb3, void *stream);
 MI355_API int mi355_mul_mat_dq(int type, const void *W, int64_t w_row_stride, const uint16_t *act_bf16, int64_t act_row_stride,
                                float *dst, int64_t dst_col_stride, int64_t m, int64_t k, int64_t n, void *stream);
+/* same for a ROW SLICE of a matrix of m_total rows (the row-split path, ggml-cuda.cu:1431-1749): the one choice that changes
+ * the f32 summation order (K cut in two for small matrices) is taken from m_total, so every slice produces the bits the
+ * unsplit matrix would. */
+MI355_API int mi355_mul_mat_dq_slice(int type, const void *W, int64_t w_row_stride, const uint16_t *act_bf16, int64_t act_row_stride,
+                                     float *dst, int64_t dst_col_stride, int64_t m, int64_t m_total, int64_t k, int64_t n, void *stream);
 
 /* MUL_MAT_ID (ggml.c:3000-3036) for prefill-sized batches: dst[t][s][:] = as[ids[t][s]] . b[t][s % b_ne1].
  * The (token, slot) pairs are bucketed by expert ON THE DEVICE (one small kernel; the reference synchronises the

@@ -368,6 +368,13 @@ static enum ggml_status mi355_split_buffer_init_tensor(ggml_backend_buffer_t buf
             (void)hipGetLastError();
             MI_LOG_ERROR("%s: allocating %.2f MiB of %s on device %d failed: %s\n", __func__, rows * row_bytes / 1048576.0,
                          tensor->name, d, hipGetErrorString(err));
+            // give back the slices the earlier devices already hold for this tensor: it stays without an extra
+            for (int e = 0; e < d; e++) {
+                if (extra->data[e]) { mi355_set_device(e); HIP_CHECK(hipFree(extra->data[e])); }
+            }
+            ctx->extras.pop_back();
+            delete extra;
+            tensor->extra = nullptr;
             return GGML_STATUS_ALLOC_FAILED;
         }
     }
@@ -379,6 +386,7 @@ static enum ggml_status mi355_split_buffer_init_tensor(ggml_backend_buffer_t buf
 static void mi355_split_buffer_set_tensor(ggml_backend_buffer_t, ggml_tensor * tensor, const void * data, size_t offset, size_t size) {
     GGML_ASSERT(offset == 0 && size == ggml_nbytes(tensor));
     mi355_split_extra * extra = (mi355_split_extra *)tensor->extra;
+    GGML_ASSERT(extra != nullptr && "split tensor was not initialised (init_tensor failed?)");
     const size_t row_bytes = tensor->nb[1];
     for (int d = 0; d < mi355_device_count(); d++) {
         if (!extra->data[d]) continue;
@@ -391,6 +399,7 @@ static void mi355_split_buffer_set_tensor(ggml_backend_buffer_t, ggml_tensor * t
 static void mi355_split_buffer_get_tensor(ggml_backend_buffer_t, const ggml_tensor * tensor, void * data, size_t offset, size_t size) {
     GGML_ASSERT(offset == 0 && size == ggml_nbytes(tensor));
     const mi355_split_extra * extra = (const mi355_split_extra *)tensor->extra;
+    GGML_ASSERT(extra != nullptr && "split tensor was not initialised (init_tensor failed?)");
     const size_t row_bytes = tensor->nb[1];
     for (int d = 0; d < mi355_device_count(); d++) {
         if (!extra->data[d]) continue;
@@ -400,6 +409,8 @@ static void mi355_split_buffer_get_tensor(ggml_backend_buffer_t, const ggml_tens
     }
 }
 
+// a split buffer owns no memory of its own (slices are allocated per tensor and written whole by set_tensor), so there is
+// nothing to clear; get_max_size is left NULL (no limit: every tensor is its own set of allocations)
 static void mi355_split_buffer_clear(ggml_backend_buffer_t, uint8_t) {}
 
 static const ggml_backend_buffer_i mi355_split_buffer_iface = {
@@ -761,7 +772,7 @@ static void mi355_mul_mat_launch(const ggml_tensor * dst, const char * W, int64_
                 const int64_t arow = (i13 * ne12 + i12) * N;
                 float * d = (float *)(dbase + i13 * dst->nb[3] + i12 * dst->nb[2]);
                 if (path == MM_DQ) {
-                    MI_CHECK(mi355_mul_mat_dq((int)src0->type, Wc, (int64_t)src0->nb[1], (const uint16_t *)act + arow * K, K, d, dcol, M, K, N, stream));
+                    MI_CHECK(mi355_mul_mat_dq_slice((int)src0->type, Wc, (int64_t)src0->nb[1], (const uint16_t *)act + arow * K, K, d, dcol, M, src0->ne[1], K, N, stream));
                 } else if (path == MM_Q_INT8) {
                     MI_CHECK(mi355_mul_mat_q((int)src0->type, Wc, (int64_t)src0->nb[1], aq + arow * K, ads + arow * (K / 32) * 2, d, dcol, M, K, N, stream));
                 } else {
@@ -2265,6 +2276,16 @@ static ggml_backend_reg_t ggml_backend_mi355_reg(void) {
 
 // exported entry points: what ggml_backend_load() looks up with dlsym (ggml-backend-reg.cpp:234-250)
 extern "C" {
-__attribute__((visibility("default"))) ggml_backend_reg_t ggml_backend_init(void) { return ggml_backend_mi355_reg(); }
-__attribute__((visibility("default"))) int ggml_backend_score(void) { return mi355_device_count() > 0 ? 100 : 0; }
+// the kernel library next to this plugin must be the one this file was compiled against: its argument structs are
+// plain C and a stale library would read their tails as garbage
+static bool mi355_kernels_abi_ok() {
+    const bool ok = mi355_abi_version() == MI355_ABI_VERSION && mi355_args_sizeof(0) == (int64_t)sizeof(mi355_mmvq_args) &&
+                    mi355_args_sizeof(1) == (int64_t)sizeof(mi355_qkv_rope_args) && mi355_args_sizeof(2) == (int64_t)sizeof(mi355_glu_matvec_args) &&
+                    mi355_args_sizeof(3) == (int64_t)sizeof(mi355_moe_down_args) && mi355_args_sizeof(4) == (int64_t)sizeof(mi355_fattn_args) &&
+                    mi355_args_sizeof(5) == (int64_t)sizeof(mi355_tensor);
+    if (!ok) MI_LOG_ERROR("ggml-mi355: libmi355_kernels.so has ABI version %d, the plugin was built for %d: rebuild both\n", mi355_abi_version(), MI355_ABI_VERSION);
+    return ok;
+}
+__attribute__((visibility("default"))) ggml_backend_reg_t ggml_backend_init(void) { return mi355_kernels_abi_ok() ? ggml_backend_mi355_reg() : nullptr; }
+__attribute__((visibility("default"))) int ggml_backend_score(void) { return mi355_kernels_abi_ok() && mi355_device_count() > 0 ? 100 : 0; }
 }

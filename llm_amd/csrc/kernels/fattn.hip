@@ -340,7 +340,12 @@ fattn_vec_kernel(const FArgs a) {
     // per wave -- a device-scope fence writes back / invalidates caches and costs microseconds): the barrier waits
     // for every wave's partial stores, then ONE lane counts the arrival with an acq_rel device-scope atomic, which
     // publishes the workgroup's stores and, in the merging workgroup, drops this CU's stale L1 lines.
+    // Ordering: every wave first waits for its OWN partial stores to have left the CU (s_waitcnt vmcnt(0): the barrier's
+    // workgroup-scope fence emits no vmcnt wait on gfx9 without tgsplit, and s_barrier waits on no counter), then the
+    // barrier, then thread 0's agent-scope release (L2 write-back) and the counter add -- so all waves' partials are
+    // ordered before the increment that the merging workgroup, possibly on another XCD, acquires.
     __shared__ int last_flag;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
         int * cnt = a.counters + ((size_t)i3 * a.n_q + iq) * gridDim.x + blockIdx.x;

@@ -303,21 +303,24 @@ act_bf16_kernel(const char * x, uint16_t * y, int k, int ne1, int ne2, int64_t n
     }
 }
 
+// m_total: rows of the WHOLE weight matrix when `a` is a row slice of it (row split).  Whether K is cut in two -- the one
+// choice here that changes the f32 summation order -- is decided from the whole matrix, so a slice produces the bits the
+// unsplit matrix would; the tile height only changes which workgroup computes an element, not how.
 template <int TYPE>
-static int launch(const DArgs & a, hipStream_t s, const char * tag) {
+static int launch(const DArgs & a, int64_t m_total, hipStream_t s, const char * tag) {
     // 128-row tiles reuse each staged activation tile twice as often; 64-row tiles when those would leave CUs idle
     const int64_t nb = (a.n + BN - 1) / BN;
+    const bool full_big = nb * ((m_total + 255) / 256) >= 200 || nb * ((m_total + 127) / 128) >= 384;
+    // few tiles (M <= ~6K at N = 512): also split K in two so that every CU holds two workgroups.  The halves are
+    // added into a zeroed dst with float atomics; with exactly two addends the result is order-independent.
+    const unsigned kz = !full_big && nb * ((m_total + 63) / 64) < 448 && a.k % (2 * BK) == 0 && a.k >= 1024 ? 2 : 1;
     // The loop is bound by the CU-side load path (~10 B/cycle/CU): every workgroup re-reads its activation tile, so
     // the bytes moved per flop fall with the tile height.  256-row tiles (8 waves) when they still cover the chip.
-    if (nb * ((a.m + 255) / 256) >= 200) {
+    if (kz == 1 && nb * ((a.m + 255) / 256) >= 200) {
         MI355_LAUNCH(tag, (mmdq_kernel<TYPE, 256, false>), dim3((unsigned)nb, (unsigned)((a.m + 255) / 256)), dim3(512), 0, s, a);
-    } else if (nb * ((a.m + 127) / 128) >= 384) {
+    } else if (kz == 1 && nb * ((a.m + 127) / 128) >= 384) {
         MI355_LAUNCH(tag, (mmdq_kernel<TYPE, 128, false>), dim3((unsigned)nb, (unsigned)((a.m + 127) / 128)), dim3(256), 0, s, a);
     } else {
-        // few tiles (M <= ~6K at N = 512): also split K in two so that every CU holds two workgroups.  The halves are
-        // added into a zeroed dst with float atomics; with exactly two addends the result is order-independent.
-        const int64_t tiles = nb * ((a.m + 63) / 64);
-        const unsigned kz = tiles < 448 && a.k % (2 * BK) == 0 && a.k >= 1024 ? 2 : 1;
         if (kz > 1) {
             hipError_t e = a.dst_col_stride == a.m
                 ? hipMemsetAsync(a.dst, 0, (size_t)a.n * a.m * sizeof(float), s)
@@ -358,7 +361,13 @@ extern "C" int mi355_act_bf16(const float * x, uint16_t * y, int64_t k, int64_t 
 
 extern "C" int mi355_mul_mat_dq(int type, const void * W, int64_t w_row_stride, const uint16_t * x, int64_t x_row_stride,
                                 float * dst, int64_t dst_col_stride, int64_t m, int64_t k, int64_t n, void * stream) {
+    return mi355_mul_mat_dq_slice(type, W, w_row_stride, x, x_row_stride, dst, dst_col_stride, m, m, k, n, stream);
+}
+
+extern "C" int mi355_mul_mat_dq_slice(int type, const void * W, int64_t w_row_stride, const uint16_t * x, int64_t x_row_stride,
+                                      float * dst, int64_t dst_col_stride, int64_t m, int64_t m_total, int64_t k, int64_t n, void * stream) {
     if (!W || !x || !dst) return MI355_E_NULL;
+    if (m_total < m) return MI355_E_SHAPE;
     const int64_t bs = mi355_blck_size(type);
     if (bs == 0 || type == MI355_TYPE_F32 || type == MI355_TYPE_F16 || type == MI355_TYPE_Q8_1) return MI355_E_TYPE;
     if (m < 0 || n < 0 || k <= 0 || k % bs != 0 || m > 0x7fffffff || n > 0x7fffffff || k > 0x7fffffff) return MI355_E_SHAPE;
@@ -375,11 +384,11 @@ extern "C" int mi355_mul_mat_dq(int type, const void * W, int64_t w_row_stride, 
     a.sorted = a.off = a.tile_off = nullptr; a.n_expert = a.n_used = a.act_ne1 = 0; a.w_expert_stride = 0;
     hipStream_t s = (hipStream_t)stream;
     switch (type) {
-        case MI355_TYPE_Q4_0: return launch<MI355_TYPE_Q4_0>(a, s, "mmdq_q4_0");
-        case MI355_TYPE_Q8_0: return launch<MI355_TYPE_Q8_0>(a, s, "mmdq_q8_0");
-        case MI355_TYPE_Q4_K: return launch<MI355_TYPE_Q4_K>(a, s, "mmdq_q4_K");
-        case MI355_TYPE_Q5_K: return launch<MI355_TYPE_Q5_K>(a, s, "mmdq_q5_K");
-        case MI355_TYPE_Q6_K: return launch<MI355_TYPE_Q6_K>(a, s, "mmdq_q6_K");
+        case MI355_TYPE_Q4_0: return launch<MI355_TYPE_Q4_0>(a, m_total, s, "mmdq_q4_0");
+        case MI355_TYPE_Q8_0: return launch<MI355_TYPE_Q8_0>(a, m_total, s, "mmdq_q8_0");
+        case MI355_TYPE_Q4_K: return launch<MI355_TYPE_Q4_K>(a, m_total, s, "mmdq_q4_K");
+        case MI355_TYPE_Q5_K: return launch<MI355_TYPE_Q5_K>(a, m_total, s, "mmdq_q5_K");
+        case MI355_TYPE_Q6_K: return launch<MI355_TYPE_Q6_K>(a, m_total, s, "mmdq_q6_K");
     }
     return MI355_E_TYPE;
 }

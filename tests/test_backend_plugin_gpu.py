@@ -133,17 +133,19 @@ def test_decode_graph_replay_is_bit_exact(tmp_path, model):
     assert outs[0].size == outs[1].size and np.array_equal(outs[0], outs[1])
 
 
-def test_row_split_mul_mat_bit_exact_on_virtual_devices():
-    """the plugin's split buffer type (`-sm row`).  Two ggml devices mapped onto the one GPU
-    (GGML_MI355_VIRTUAL_DEVICES=2) exercise helper streams, the activation copy, cross-stream events and row
+@pytest.mark.parametrize("ndev", [2, 4, 8])
+def test_row_split_mul_mat_bit_exact_on_virtual_devices(ndev):
+    """the plugin's split buffer type (`-sm row`).  2, 4 or 8 ggml devices mapped onto the one GPU
+    (GGML_MI355_VIRTUAL_DEVICES) exercise helper streams, the activation copy, cross-stream events and row
     offsets; MUL_MAT on a split weight must equal MUL_MAT on the unsplit weight bit for bit, for all five
-    weight types, mat-vec and tile kernel, skewed splits, either device as main (tools/test_split_mul_mat.cpp)."""
+    weight types, mat-vec / skinny / GEMM kernels (incl. the K-cut GEMM at K >= 1024), skewed splits, any device as
+    main, a device in the middle that owns no rows, and Llama-3-70B's row counts (tools/test_split_mul_mat.cpp)."""
     exe = os.path.join(ROOT, "oracle", "_ref", "test-split-mul-mat")
     assert os.path.exists(exe), "oracle/_ref/test-split-mul-mat is not built (make -C oracle drivers)"
-    env = dict(os.environ, GGML_BACKEND_PATH=PLUGIN, GGML_MI355_VIRTUAL_DEVICES="2")
-    r = subprocess.run([exe], env=env, capture_output=True, text=True, timeout=600)
+    env = dict(os.environ, GGML_BACKEND_PATH=PLUGIN, GGML_MI355_VIRTUAL_DEVICES=str(ndev))
+    r = subprocess.run([exe], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-2000:]
-    assert "0 failed" in r.stdout
+    assert " 0 failed" in r.stdout
 
 
 def test_llama_row_split_logits_equal_single_device(tmp_path):

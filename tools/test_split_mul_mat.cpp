@@ -5,7 +5,7 @@
 // the ordinary device buffer; MUL_MAT(W_split, x) and MUL_MAT(W_plain, x) run on the main device's
 // backend and must agree BIT FOR BIT (each output row is computed by the same kernel code either way),
 // and get_tensor of the split tensor must return the bytes that were set.  Needs >= 2 MI355 devices:
-// on a single-GPU box run with GGML_MI355_VIRTUAL_DEVICES=2 (both ggml devices map to the one GPU, so
+// on a single-GPU box run with GGML_MI355_VIRTUAL_DEVICES=2, 4 or 8 (all ggml devices map to the one GPU, so
 // helper streams, the activation copy, cross-stream events and the row offsets are all exercised).
 //   GGML_BACKEND_PATH=.../libggml-mi355.so GGML_MI355_VIRTUAL_DEVICES=2 test-split-mul-mat
 #include "ggml.h"
@@ -30,8 +30,9 @@ static void check(bool ok, const std::string & what) {
 static bool run_case(ggml_backend_reg_t reg, split_buft_fn split_buft, int main_dev, const float * ts, ggml_type type,
                      int64_t M, int64_t K, int64_t N, int64_t ne2) {
     char tag[256];
-    snprintf(tag, sizeof(tag), "%s M=%lld K=%lld N=%lld ne2=%lld main=%d ts=%g,%g", ggml_type_name(type), (long long)M, (long long)K,
-             (long long)N, (long long)ne2, main_dev, ts ? ts[0] : 0.0f, ts ? ts[1] : 0.0f);
+    int tl = snprintf(tag, sizeof(tag), "%s M=%lld K=%lld N=%lld ne2=%lld main=%d ts=", ggml_type_name(type), (long long)M, (long long)K,
+                      (long long)N, (long long)ne2, main_dev);
+    for (int d = 0; ts && d < (int)ggml_backend_reg_dev_count(reg) && tl < (int)sizeof(tag) - 8; d++) tl += snprintf(tag + tl, sizeof(tag) - tl, d ? ",%g" : "%g", ts[d]);
     ggml_backend_dev_t dev = ggml_backend_reg_dev_get(reg, main_dev);
     ggml_backend_t backend = ggml_backend_dev_init(dev, nullptr);
     ggml_backend_buffer_type_t sbuft = split_buft(main_dev, ts);
@@ -116,18 +117,47 @@ int main() {
     check(split_buft(0, even) != split_buft(0, skew), "distinct splits give distinct buffer types");
 
     const ggml_type types[] = { GGML_TYPE_Q4_0, GGML_TYPE_Q8_0, GGML_TYPE_Q4_K, GGML_TYPE_Q5_K, GGML_TYPE_Q6_K };
-    int ran = 0;
-    for (ggml_type t : types) {
-        ran += run_case(reg, split_buft, 0, even, t, 512, 256, 1, 1);      // equal slices, decode
-        ran += run_case(reg, split_buft, 0, even, t, 384, 512, 3, 1);      // 128 / 256 rows
-        ran += run_case(reg, split_buft, 1, even, t, 1024, 256, 8, 1);     // the other device is the main one
-        ran += run_case(reg, split_buft, 0, skew, t, 1024, 512, 5, 2);     // 768 / 256, broadcast over ne2
-        ran += run_case(reg, split_buft, 0, even, t, 512, 512, 33, 1);     // prefill tile kernel on both halves
-        ran += run_case(reg, split_buft, 1, skew, t, 640, 256, 64, 1);     // 384 / 256, tile kernel, main = 1
+    int ran = 0, want = 0;
+    if (ndev == 2) {
+        for (ggml_type t : types) {
+            ran += run_case(reg, split_buft, 0, even, t, 512, 256, 1, 1);      // equal slices, decode
+            ran += run_case(reg, split_buft, 0, even, t, 384, 512, 3, 1);      // 128 / 256 rows
+            ran += run_case(reg, split_buft, 1, even, t, 1024, 256, 8, 1);     // the other device is the main one
+            ran += run_case(reg, split_buft, 0, skew, t, 1024, 512, 5, 2);     // 768 / 256, broadcast over ne2
+            ran += run_case(reg, split_buft, 0, even, t, 512, 512, 33, 1);     // prefill tile kernel on both halves
+            ran += run_case(reg, split_buft, 1, skew, t, 640, 256, 64, 1);     // 384 / 256, tile kernel, main = 1
+            // the prefill GEMM cuts K in two for small matrices (mmdq.hip): the choice must follow the WHOLE matrix, not
+            // the slice, or the f32 summation order of a split matrix differs (K >= 1024, N >= 64)
+            ran += run_case(reg, split_buft, 0, even, t, 4096, 4096, 512, 1);
+            ran += run_case(reg, split_buft, 1, skew, t, 2048, 1024, 64, 1);
+            want += 8;
+        }
+        // fewer rows than the rounding: device 0 owns nothing and must refuse, device 1 owns all and must run
+        check(!run_case(reg, split_buft, 0, even, GGML_TYPE_Q4_K, 100, 256, 1, 1), "main device without rows refuses the op");
+        check(run_case(reg, split_buft, 1, even, GGML_TYPE_Q4_K, 100, 256, 1, 1), "device that owns all rows runs it");
+    } else {
+        // 4 or 8 devices: the row boundaries of Llama-3-70B's matrices (M = 1024: 128 rows per rank at 8; 8192; 28672), a
+        // device in the middle that owns no rows, skewed splits, every kernel regime
+        float all[16] = {0}, hole[16] = {0}, ramp[16] = {0};
+        for (int d = 0; d < ndev; d++) { all[d] = 1.0f; hole[d] = d == 1 ? 0.0f : 1.0f; ramp[d] = (float)(d + 1); }
+        const int last = ndev - 1;
+        for (ggml_type t : types) {
+            ran += run_case(reg, split_buft, 0, all, t, 1024, 1024, 1, 1);        // wk / wv: 128 (or 256) rows per rank
+            ran += run_case(reg, split_buft, 0, all, t, 8192, 512, 1, 1);         // wq / wo / down rows
+            ran += run_case(reg, split_buft, last, all, t, 28672, 256, 2, 1);     // gate / up rows, the last device is main
+            ran += run_case(reg, split_buft, 0, hole, t, 1024, 512, 1, 1);        // device 1 owns nothing
+            ran += run_case(reg, split_buft, 2, hole, t, 2048, 1024, 40, 1);      // ... skinny regime, main = 2
+            ran += run_case(reg, split_buft, ndev / 2, ramp, t, 4096, 1024, 96, 1); // unequal slices (device 0 may own none), GEMM, K cut decided on M = 4096
+            ran += run_case(reg, split_buft, last, ramp, t, 1536, 512, 7, 2);     // broadcast over ne2
+            want += 7;
+        }
+        ran += run_case(reg, split_buft, 0, all, GGML_TYPE_Q4_K, 8192, 8192, 1, 1);    // 70B wq at full size
+        ran += run_case(reg, split_buft, 0, all, GGML_TYPE_Q6_K, 1024, 8192, 1, 1);    // 70B wv (use_more_bits layers)
+        ran += run_case(reg, split_buft, 0, all, GGML_TYPE_Q4_K, 8192, 8192, 512, 1);  // ... prefill
+        want += 3;
+        // the main device owns nothing: refuse
+        check(!run_case(reg, split_buft, 1, hole, GGML_TYPE_Q4_K, 1024, 256, 1, 1), "main device without rows refuses the op");
     }
-    // fewer rows than the rounding: device 0 owns nothing and must refuse, device 1 owns all and must run
-    check(!run_case(reg, split_buft, 0, even, GGML_TYPE_Q4_K, 100, 256, 1, 1), "main device without rows refuses the op");
-    check(run_case(reg, split_buft, 1, even, GGML_TYPE_Q4_K, 100, 256, 1, 1), "device that owns all rows runs it");
-    printf("%d checks ok, %d failed, %d cases ran\n", n_ok, n_fail, ran);
-    return n_fail == 0 && ran >= 30 ? 0 : 1;
+    printf("%d checks ok, %d failed, %d cases ran (of %d)\n", n_ok, n_fail, ran, want);
+    return n_fail == 0 && ran >= want ? 0 : 1;
 }
