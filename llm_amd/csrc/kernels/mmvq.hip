@@ -28,6 +28,7 @@
 #include <stdlib.h>
 #include <string>
 #include <string.h>
+#include <type_traits>
 
 namespace {
 
@@ -358,6 +359,232 @@ struct WStream {
     }
 };
 
+// ================================================================================================
+// LDS-DMA weight stream (q4_K, q5_K, q6_K; decode, one column).
+//
+// The register ring above keeps PF steps (~3 KB per wave) of weights in flight, and every 16-byte lane load of a
+// block-quantized row touches half a cache line twice.  Here a wave streams its rows with global_load_lds_dwordx4: one
+// instruction moves 64 x 16 B = 1 KiB from per-lane source addresses straight into LDS (no VGPR destination), so
+//   * D KiB per wave are in flight at any time, however few registers the kernel has (D = 4..8: 64-128 KB per CU) --
+//     what covers the norm / quantization prologue of the fused launches and the HBM latency of a cold start;
+//   * every byte is requested exactly once (the block header is no longer re-read by the four lanes that share it), so
+//     the loads can be non-temporal;
+//   * the LDS image is ours to lay out: the "image" of a row is its blocks back to back, a q6_K block (210 B, 2-byte
+//     aligned in memory) padded to 224 B so that every field sits at a 16-byte aligned offset (chunk 13 re-reads bytes
+//     194..209 so that d lands at image offset 222).
+// The images of a wave's rows form one byte stream, cut into 1 KiB pieces that go round a private ring of D slots;
+// a piece may span two rows (the source address is per lane).  vmcnt retires in order, so "pieces [0, n) have landed" is
+// `s_waitcnt vmcnt(issued - n)`; the DMA is inline asm (the compiler would drain every DMA before any LDS read), which
+// also means the compiler's own vmcnt bookkeeping never under-waits: extra outstanding operations only make its waits
+// longer.  Units are read back with ds_read_b128 and go through the same decode / dot as the register stream: results
+// are bit-identical.
+// ================================================================================================
+typedef __attribute__((address_space(3))) uint8_t lds_u8;
+
+static __device__ __forceinline__ unsigned lds_addr(const void * p) { return (unsigned)(uintptr_t)(const lds_u8 *)p; }
+
+// 1 KiB: lane l copies 16 B from `gsrc` (its own address) to LDS byte address `lds_dst` (wave-uniform) + 16 l.
+// The lgkmcnt(0) makes this wave's earlier LDS reads of the slot complete before it can be overwritten.
+static __device__ __forceinline__ void dma_piece_nt(const void * gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+static __device__ __forceinline__ void dma_piece_plain(const void * gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+// wait until at most q vector-memory operations of this wave are outstanding (q wave-uniform)
+static __device__ __forceinline__ void wait_vm_le(int q) {
+    switch (q) {
+        case 0:  asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1:  asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+        case 2:  asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 3:  asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 4:  asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 5:  asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+        case 6:  asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 7:  asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+        case 8:  asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 9:  asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+        case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+        case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+        case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+        case 13: asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); break;
+        case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
+        case 15: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
+        default: if (q < 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;   // q >= 16: nothing this deep is ever in flight
+    }
+}
+
+constexpr int DMA_MAX_SLOTS = 16;
+constexpr int MI355_MAX_DEVICES_LDS = 64;
+
+template <int TYPE> struct DmaImg { static constexpr bool OK = false; };
+
+static __device__ __forceinline__ v4i lds16(const lds_u8 * ring, int off) { return *(const __attribute__((address_space(3))) v4i *)(ring + off); }
+
+template <> struct DmaImg<MI355_TYPE_Q4_K> {
+    static constexpr bool OK = true;
+    static constexpr int BLK = 144, IMG = 144, CPB = 9;
+    static __device__ __forceinline__ int src(int c) { return 16 * c; }      // byte offset in the row of image chunk c
+    static __device__ __forceinline__ Unit<MI355_TYPE_Q4_K>::Raw read(const lds_u8 * ring, int mask, int io, int u) {
+        const int g = u & 3;
+        Unit<MI355_TYPE_Q4_K>::Raw r;
+        r.hdr = lds16(ring, io & mask);
+        r.q0  = lds16(ring, (io + 16 + g * 32) & mask);
+        r.q1  = lds16(ring, (io + 32 + g * 32) & mask);
+        return r;
+    }
+};
+template <> struct DmaImg<MI355_TYPE_Q5_K> {
+    static constexpr bool OK = true;
+    static constexpr int BLK = 176, IMG = 176, CPB = 11;
+    static __device__ __forceinline__ int src(int c) { return 16 * c; }
+    static __device__ __forceinline__ Unit<MI355_TYPE_Q5_K>::Raw read(const lds_u8 * ring, int mask, int io, int u) {
+        const int g = u & 3;
+        Unit<MI355_TYPE_Q5_K>::Raw r;
+        r.hdr = lds16(ring, io & mask);
+        r.h0  = lds16(ring, (io + 16) & mask);
+        r.h1  = lds16(ring, (io + 32) & mask);
+        r.q0  = lds16(ring, (io + 48 + g * 32) & mask);
+        r.q1  = lds16(ring, (io + 64 + g * 32) & mask);
+        return r;
+    }
+};
+template <> struct DmaImg<MI355_TYPE_Q6_K> {
+    static constexpr bool OK = true;
+    static constexpr int BLK = 210, IMG = 224, CPB = 14;
+    static __device__ __forceinline__ int src(int c) {
+        const int b = (int)(((unsigned)c * 18725u) >> 18), j = c - 14 * b;         // c / 14 for c < 2^16
+        return b * 210 + (j < 13 ? 16 * j : 194);
+    }
+    static __device__ __forceinline__ Unit<MI355_TYPE_Q6_K>::Raw read(const lds_u8 * ring, int mask, int io, int u) {
+        const int n = (u >> 1) & 1, h = u & 1;
+        Unit<MI355_TYPE_Q6_K>::Raw r;
+        r.qla = lds16(ring, (io + 64 * n + 16 * h) & mask);
+        r.qlb = lds16(ring, (io + 64 * n + 32 + 16 * h) & mask);
+        r.qh  = lds16(ring, (io + 128 + 32 * n + 16 * h) & mask);
+        r.sc  = *(const __attribute__((address_space(3))) v2i *)(ring + ((io + 192 + 8 * n) & mask));
+        r.d   = *(const __attribute__((address_space(3))) uint16_t *)(ring + ((io + 222) & mask));
+        return r;
+    }
+};
+
+template <int TYPE, class RowPtr>
+struct DStream {
+    typedef Unit<TYPE> U;
+    typedef DmaImg<TYPE> I;
+    static_assert(U::ELEMS == 64, "the K-quant units");
+    RowPtr rowp;
+    int nrows, nunits, niter, lane, nb;
+    int cpr, ri;                 // chunks (16 B) and bytes of a row image
+    int npieces, issued;
+    int rr, cc;                  // this lane's next chunk: row index, chunk index within the row image
+    unsigned ring; int slots;    // LDS byte address of the wave's ring, number of 1 KiB slots (a power of two)
+
+    __device__ __forceinline__ DStream(RowPtr rp, int nrows_, int k, unsigned ring_, int slots_) : rowp(rp), nrows(nrows_), ring(ring_), slots(slots_) {
+#ifdef MI355_NO_WEIGHTS
+        nrows = 0;
+#endif
+        nb = k / QK_K; nunits = nb * 4; niter = (nunits + 63) >> 6; lane = threadIdx.x & 63;
+        cpr = nb * I::CPB; ri = cpr * 16;
+        npieces = (nrows * cpr + 63) >> 6; issued = 0;
+        rr = 0; cc = lane;                          // cpr >= 64 (launchers): at most one row boundary per piece
+        if (cc >= cpr) { cc -= cpr; ++rr; }
+    }
+    __device__ __forceinline__ void issue_upto(int target) {
+        target = target < npieces ? target : npieces;
+        while (issued < target) {                       // wave-uniform
+            if (rr < nrows)                             // the last piece may be partial
+                dma_piece_nt(rowp(rr) + I::src(cc), __builtin_amdgcn_readfirstlane(ring + ((unsigned)(issued & (slots - 1)) << 10)));
+            cc += 64;
+            const bool wrap = cc >= cpr;
+            cc -= wrap ? cpr : 0; rr += wrap ? 1 : 0;
+            ++issued;
+        }
+    }
+    // Before the activations are ready only `first` pieces go out: the memory path of a CU returns data in request order,
+    // so a deep burst of weights in front of the other waves' activation / norm-input loads delays the whole launch.
+    __device__ __forceinline__ void begin(int first) { issue_upto(slots < first ? slots : first); }
+    // returns, in lane r, the sum of the wave's r-th row (nrows <= 64)
+    template <class AP>
+    __device__ __forceinline__ float run(const AP act) {
+        const lds_u8 * rg = (const lds_u8 *)(uintptr_t)ring;
+        const int mask = (slots << 10) - 1;
+        float out = 0.0f;
+        issue_upto(slots);                                          // the activations are ready: the ring's full depth
+        for (int r = 0; r < nrows; r++) {
+            float acc = 0.0f;
+            for (int it = 0; it < niter; it++) {
+                const int  u_raw = it * 64 + lane;
+                const bool valid = u_raw < nunits;
+                const int  u     = valid ? u_raw : nunits - 1;
+                const int  bend  = (it + 1) * 16 < nb ? (it + 1) * 16 : nb;
+                const int  C     = r * ri + bend * I::IMG;          // the stream is consumed up to here by this step
+                wait_vm_le(issued - ((C + 1023) >> 10));
+                const typename U::Raw raw = I::read(rg, mask, r * ri + (u >> 2) * I::IMG, u);
+                const typename U::Act av = U::load_act(act, u);
+                issue_upto((C >> 10) + slots);                      // (waits for the LDS reads above: the slots they free are refilled)
+                const float v = U::dot(U::decode(raw, u), av);
+                acc += valid ? v : 0.0f;
+            }
+            const float s = wave_sum(acc);
+            out = lane == r ? s : out;
+        }
+        return out;
+    }
+};
+
+// Slots per wave ring for a workgroup of `nw` waves that may use `lds_budget` bytes of LDS beyond `used`: the largest
+// power of two <= 8 that fits (0: no room, use the register stream).
+// Which launches use the LDS-DMA stream (MI355_DMA_MASK overrides; 0: none).  Measured on the 8B decode sweep, cold weights,
+// hipGraph replay (bench.py): 1.417 ms per step with none, 1.387 with the q6_K mat-vec alone (the robust gain: its 210-byte
+// blocks stop straddling cache lines), 1.378 with all four; llama-bench tg128 486.6 / 492.1 / 493.9 t/s.  The kernels'
+// time is mostly the prologue chain and the per-CU limit on loads in flight (~48 KB), which the DMA ring does not lift.
+enum { DMA_MV_K45 = 1, DMA_MV_K6 = 2, DMA_QKV = 4, DMA_GLU = 8 };
+static bool dma_enabled(int which) {
+    static const int mask = [] { const char * e = getenv("MI355_DMA_MASK"); return e ? atoi(e) : (DMA_MV_K45 | DMA_MV_K6 | DMA_QKV | DMA_GLU); }();
+    return (mask & which) != 0;
+}
+static int dma_slots(size_t used, int nw, size_t lds_budget) {
+    static const int cap = [] { const char * e = getenv("MI355_DMA_SLOTS"); return e ? atoi(e) : 4; }();
+    int s = cap > DMA_MAX_SLOTS ? DMA_MAX_SLOTS : cap;
+    while (s >= 2 && used + (size_t)nw * s * 1024 > lds_budget) s >>= 1;
+    while (s & (s - 1)) s &= s - 1;
+    return s >= 2 ? s : 0;
+}
+
+static int dma_first() {
+    static const int v = [] { const char * e = getenv("MI355_DMA_FIRST"); return e ? atoi(e) : 4; }();
+    return v < 1 ? 1 : v;
+}
+
+template <int TYPE, int PF, bool DMA, class RowPtr>
+static __device__ __forceinline__ auto make_stream(RowPtr rp, int nrows, int k, unsigned ring, int slots) {
+    if constexpr (DMA) return DStream<TYPE, RowPtr>(rp, nrows, k, ring, slots);
+    else               return WStream<TYPE, PF, RowPtr>(rp, nrows, k);
+}
+
+// dynamic LDS beyond 64 KB has to be asked for, per kernel and device
+template <class K>
+static hipError_t allow_lds(K kernel, size_t bytes) {
+    if (bytes <= 64 * 1024) return hipSuccess;
+    static bool done[MI355_MAX_DEVICES_LDS] = {};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= MI355_MAX_DEVICES_LDS || !done[dev]) {
+        e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);   // the kernels' static arrays take < 1 KB
+        if (e != hipSuccess) return e;
+        if (dev >= 0 && dev < MI355_MAX_DEVICES_LDS) done[dev] = true;
+    }
+    return hipSuccess;
+}
+
 // Activations of one token into LDS ([k] int8, then [k/32] {d, sum}), in two phases so that the global loads go out before
 // the weight stream's and the arithmetic runs under its latency.  Three sources:
 //   quantized (act_q / act_ds from mi355_quantize_act): a copy;
@@ -401,13 +628,31 @@ struct ActStage {
     // Stage the activations of one token into LDS ([k] int8, then [k/32] {d, sum}).  Call before the wave's first weight
     // request.  f32 source: the arithmetic of rms_norm_kernel / quantize_kernel (see ActSrc), wave sums added in wave order.
     // The only workgroup barrier (counters zeroed) sits behind the activation requests, before anything else is in flight.
-    __device__ __forceinline__ void stage(const ActSrc & a, int k_, uint8_t * lds, bool store, void * stamps = nullptr) {
+    // dma: a quantized source is copied by LDS-DMA (the image [k] int8 + [k/32] {d, sum} is contiguous in LDS); the caller
+    // then starts its weight stream and calls dma_done(weight pieces issued) -- nothing waits before the weights are asked for
+    bool act_dma = false;
+    __device__ __forceinline__ void stage(const ActSrc & a, int k_, uint8_t * lds, bool store, void * stamps = nullptr, bool dma = false) {
         k = k_; NT = NT_ ? NT_ : (int)blockDim.x;
         const int t = threadIdx.x, wave = wave_id();
         if (t < 4) ctr()[t] = 0;
+        if (!a.x && dma) {
+            const int nq = k >> 4, nch = nq + (k >> 6), np = (nch + 63) >> 6, nw = NT >> 6;     // 16-byte chunks of q, of q + ds; pieces
+            n_stage = nw; act_dma = true;
+            for (int p = wave; p < np; p += nw) {
+                const int c = p * 64 + (t & 63);
+                if (c < nch)
+                    dma_piece_plain(c < nq ? (const uint8_t *)a.q + 16 * c : (const uint8_t *)a.ds + 16 * (c - nq),
+                                    __builtin_amdgcn_readfirstlane(lds_addr(lds) + (unsigned)p * 1024));
+            }
+            __syncthreads();         // counters zeroed (the compiler does not see the DMA: no vmcnt wait here)
+            return;
+        }
         if (a.x) {
             const int nc = k >> 4, nsw = (nc + 63) >> 6;
             n_stage = nsw;
+#ifndef MI355_NO_STAGE_PRIO
+            if (wave < nsw) __builtin_amdgcn_s_setprio(3);       // the launch waits for these waves: they issue ahead of the streaming ones
+#endif
             const bool has = t < nc;
             v4f v[4], wv[4];
             if (has) {
@@ -462,6 +707,13 @@ struct ActStage {
             __syncthreads();
         }
         lds_signal(&ctr()[1]);
+#ifndef MI355_NO_STAGE_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
+    }
+    // after the wave's first weight pieces have been requested (`after` of them): its activation pieces have landed
+    __device__ __forceinline__ void dma_done(int after) {
+        if (act_dma) { wait_vm_le(after); lds_signal(&ctr()[1]); }
     }
     // before the first LDS read of the activations
     __device__ __forceinline__ void wait() { lds_wait(&ctr()[1], (unsigned)n_stage); }
@@ -619,11 +871,12 @@ struct KStream {
     const float * res[MI355_MMVQ_MAX_GROUP]; float * sum[MI355_MMVQ_MAX_GROUP];
     int m[MI355_MMVQ_MAX_GROUP], blk_end[MI355_MMVQ_MAX_GROUP];
     int n, k, rpw;
+    int dma_slots, ring_off, dma_first;     // LDS-DMA stream: 1 KiB slots per wave ring, byte offset of the rings in dynamic LDS, pieces requested before the activations are ready
     ActSrc act;
     STAMP_FIELD
 };
 
-template <int TYPE, bool LDSACT>
+template <int TYPE, bool LDSACT, bool DMA>
 __global__ void __launch_bounds__(MV1_THREADS)
 mmvq1_kernel(const KStream a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -642,7 +895,7 @@ mmvq1_kernel(const KStream a) {
     int nrows = a.m[mi] - row0;
     nrows = nrows < 0 ? 0 : (nrows > a.rpw ? a.rpw : nrows);
     ActStage<MV1_THREADS> st;
-    if (LDSACT) st.stage(a.act, a.k, lds, blockIdx.x == 0, STAMP_PTR(a));
+    if (LDSACT) st.stage(a.act, a.k, lds, blockIdx.x == 0, STAMP_PTR(a), DMA);
     STAMP_AT(STAMP_PTR(a), 4);
     const float * res = a.res[mi];
     const float rv = (res && lane < nrows) ? res[row0 + lane] : 0.0f;
@@ -654,8 +907,10 @@ mmvq1_kernel(const KStream a) {
     const int64_t rs = a.w_row_stride[mi];
 #endif
     auto rowp = [=](int r) { return wmat + (int64_t)r * rs; };
-    WStream<TYPE, PF, decltype(rowp)> ws(rowp, nrows, a.k);
-    ws.begin();
+    typename std::conditional<DMA, DStream<TYPE, decltype(rowp)>, WStream<TYPE, PF, decltype(rowp)>>::type
+        ws = make_stream<TYPE, PF, DMA>(rowp, nrows, a.k, lds_addr(lds) + a.ring_off + wave * (a.dma_slots << 10), a.dma_slots);
+    if constexpr (DMA) ws.begin(a.dma_first); else ws.begin();
+    if constexpr (DMA) st.dma_done(ws.issued);
     float out;
     if (LDSACT) {
         st.wait();
@@ -693,6 +948,7 @@ struct KQkv {
     float * q_out; void * k_out; void * v_out; int k_f16, v_f16;
     const int32_t * pos; const float * ff; RopeP rp;
     void * const * kv_tab; int kv_slot;      // optional: K / V destinations read from a device table (graph replay)
+    int dma_slots, ring_off, dma_first;      // LDS-DMA stream (see KStream)
     STAMP_FIELD
 };
 
@@ -701,7 +957,7 @@ struct KQkv {
 // workgroup may straddle two matrices.  The two rows of pair j end in lanes 2j, 2j + 1; lane 2j rotates and stores.
 constexpr int QKV_MAX_PPW = 4;
 
-template <int TYPE>
+template <int TYPE, bool DMA_>
 static __device__ __forceinline__ void qkv_body(const KQkv & a, ActStage<0> & st, uint8_t * lds, int mat, int pair0, int np) {
     const int lane = threadIdx.x & 63;
     // rows of pair j of this wave: r0 = base + j * step, r1 = r0 + delta (wave-uniform; a wave's pairs sit in one head)
@@ -718,8 +974,12 @@ static __device__ __forceinline__ void qkv_body(const KQkv & a, ActStage<0> & st
     const int64_t rs = a.w_row_stride[mat];
     auto rowp = [=](int r) { return w + (int64_t)((r >> 1) * step + (r & 1) * delta) * rs; };
     constexpr int PF = 2;        // a wave has 2 * ppw * (k / 4096) steps in all: both rows of an 8B pair are in flight at once
-    WStream<TYPE, PF, decltype(rowp)> ws(rowp, 2 * np, a.k);
-    ws.begin();
+    constexpr bool DMA = DMA_ && DmaImg<TYPE>::OK;
+    typename std::conditional<DMA, DStream<TYPE, decltype(rowp)>, WStream<TYPE, PF, decltype(rowp)>>::type
+        ws = make_stream<TYPE, PF, DMA>(rowp, 2 * np, a.k, lds_addr(lds) + a.ring_off + wave_id() * (a.dma_slots << 10), a.dma_slots);
+    if constexpr (DMA_ && !DMA) st.dma_done(0);       // a register-stream body inside a DMA launch: its activation pieces first
+    if constexpr (DMA) ws.begin(a.dma_first); else ws.begin();
+    if constexpr (DMA) st.dma_done(ws.issued);
     // the rotation of pair j (lane 2j) while the weights are in flight: a powf and a sincosf, ~1 us if left to the end
     float rc = 1.0f, rsn = 0.0f;
     if (ic0 >= 0 && lane < 2 * np && !(lane & 1)) rope_cos_sin(a.rp, a.pos[0], a.ff, ic0 + (lane >> 1), rc, rsn);
@@ -748,13 +1008,13 @@ static __device__ __forceinline__ void qkv_body(const KQkv & a, ActStage<0> & st
 
 constexpr int QKV_MAX_WAVES = 12;      // 768 threads: 3 waves per SIMD, 168 VGPRs (the three type bodies of a mixed launch need ~140)
 
-template <int TQ, int TK, int TV>
+template <int TQ, int TK, int TV, bool DMA>
 __global__ void __launch_bounds__(QKV_MAX_WAVES * 64)
 mmvq_qkv_rope_kernel(const KQkv a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     STAMP_AT(STAMP_PTR(a), 0);
     ActStage<0> st;
-    st.stage(a.act, a.k, lds, blockIdx.x == 0, STAMP_PTR(a));
+    st.stage(a.act, a.k, lds, blockIdx.x == 0, STAMP_PTR(a), DMA);
     STAMP_AT(STAMP_PTR(a), 4);
     const int gw = (int)blockIdx.x * (int)(blockDim.x >> 6) + wave_id();
     const int p_first = gw * a.ppw;
@@ -764,12 +1024,12 @@ mmvq_qkv_rope_kernel(const KQkv a) {
     const int mat = pf < a.pair_end[0] ? 0 : (pf < a.pair_end[1] ? 1 : 2);
     const int pair0 = pf - (mat == 0 ? 0 : a.pair_end[mat - 1]);
     if (TQ == TK && TK == TV) {
-        qkv_body<TQ>(a, st, lds, mat, pair0, np);
+        qkv_body<TQ, DMA>(a, st, lds, mat, pair0, np);
     } else {
         // one barrier sequence per branch: every wave of the workgroup executes exactly one of them
-        if (mat == 0)      qkv_body<TQ>(a, st, lds, 0, pair0, np);
-        else if (mat == 1) qkv_body<TK>(a, st, lds, 1, pair0, np);
-        else               qkv_body<TV>(a, st, lds, 2, pair0, np);
+        if (mat == 0)      qkv_body<TQ, DMA>(a, st, lds, 0, pair0, np);
+        else if (mat == 1) qkv_body<TK, DMA>(a, st, lds, 1, pair0, np);
+        else               qkv_body<TV, DMA>(a, st, lds, 2, pair0, np);
     }
 }
 
@@ -788,6 +1048,7 @@ struct KGlu {
     // optional expert routing (MUL_MAT_ID pair of a decode token): blockIdx.y = slot, matrices of expert ids[slot], all slots read
     // the same activations, outputs of slot s at [s * m]
     const int32_t * ids; int n_expert, n_slots; int64_t wg_ex_stride, wu_ex_stride;
+    int dma_slots, ring_off, dma_first;      // LDS-DMA stream (see KStream)
     STAMP_FIELD
 };
 
@@ -806,7 +1067,7 @@ constexpr int GLU_PAIRS   = 4;        // outputs per wave: NT / 64 waves x 4 = 3
 #define GLU_PF 1
 #endif
 
-template <int TYPE, int GLU_THREADS>
+template <int TYPE, int GLU_THREADS, bool DMA>
 __global__ void __launch_bounds__(GLU_THREADS)
 mmvq_glu_kernel(const KGlu a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -814,14 +1075,21 @@ mmvq_glu_kernel(const KGlu a) {
     const int wave = wave_id(), lane = threadIdx.x & 63;
     const int k = a.k;
     constexpr int NW = GLU_THREADS / 64;
-    const int row0 = (blockIdx.x * NW + wave) * GLU_PAIRS;                    // first of this wave's outputs
+    // outputs per wave: GLU_PAIRS, except that when half the waves first normalise and quantize the token (f32 source,
+    // k / 1024 == NW / 2 staging waves) those start their weight stream ~3 us late and take 3 outputs, the others 5
+    int np = GLU_PAIRS, lrow0 = wave * GLU_PAIRS;
+    if (DMA && GLU_THREADS == 512 && a.act.x && (k >> 10) == NW / 2) {
+        np    = wave < NW / 2 ? 3 : 5;
+        lrow0 = wave < NW / 2 ? 3 * wave : 3 * (NW / 2) + 5 * (wave - NW / 2);
+    }
+    const int row0 = blockIdx.x * NW * GLU_PAIRS + lrow0;                     // first of this wave's outputs
     int64_t ex = 0;
     if (a.ids) {
         ex = a.ids[blockIdx.y];
         if (ex < 0 || ex >= a.n_expert) return;      // out-of-range expert id (uniform per workgroup): outputs untouched
     }
     ActStage<GLU_THREADS> st;
-    st.stage(a.act, k, lds, blockIdx.x == 0 && blockIdx.y == 0, STAMP_PTR(a));
+    st.stage(a.act, k, lds, blockIdx.x == 0 && blockIdx.y == 0, STAMP_PTR(a), DMA);
     STAMP_AT(STAMP_PTR(a), 4);
     const int64_t so = (int64_t)blockIdx.y * a.m;     // this slot's outputs
     const uint8_t * wg = a.wg + ex * a.wg_ex_stride + (int64_t)row0 * a.rsg, * wu = a.wu + ex * a.wu_ex_stride + (int64_t)row0 * a.rsu;
@@ -834,8 +1102,10 @@ mmvq_glu_kernel(const KGlu a) {
     // the wave's 8 rows in the order gate 0, up 0, gate 1, up 1, ...: output j ends in lanes 2j (gate) and 2j + 1 (up)
     auto rowp = [=](int r) { return (r & 1) ? wu + (int64_t)(r >> 1) * rsu : wg + (int64_t)(r >> 1) * rsg; };
     constexpr int PF = GLU_PF;
-    WStream<TYPE, PF, decltype(rowp)> ws(rowp, 2 * GLU_PAIRS, k);
-    ws.begin();
+    typename std::conditional<DMA, DStream<TYPE, decltype(rowp)>, WStream<TYPE, PF, decltype(rowp)>>::type
+        ws = make_stream<TYPE, PF, DMA>(rowp, 2 * np, k, lds_addr(lds) + a.ring_off + wave * (a.dma_slots << 10), a.dma_slots);
+    if constexpr (DMA) ws.begin(a.dma_first); else ws.begin();
+    if constexpr (DMA) st.dma_done(ws.issued);
     st.wait();
     STAMP_AT(STAMP_PTR(a), 1);
     const auto lq   = (const __attribute__((address_space(3))) int8_t *)lds;
@@ -845,11 +1115,11 @@ mmvq_glu_kernel(const KGlu a) {
     // even lanes 0..6 finish one output each; the 32 gated values meet in LDS and 8 lanes quantize the block
     const float up = dpp_f32<0xB1>(out);
     float * hs = (float *)(lds + (((size_t)k + (size_t)k / QK * 8 + 15) & ~(size_t)15));
-    if (lane < 2 * GLU_PAIRS && !(lane & 1)) {
+    if (lane < 2 * np && !(lane & 1)) {
         const int j = lane >> 1;
         if (a.gate_out) a.gate_out[so + row0 + j] = out;
         if (a.up_out)   a.up_out[so + row0 + j]   = up;
-        hs[wave * GLU_PAIRS + j] = glu_act(a.op, out) * up;
+        hs[lrow0 + j] = glu_act(a.op, out) * up;
     }
     __syncthreads();
     if (threadIdx.x < NW * GLU_PAIRS / 4) {
@@ -987,14 +1257,31 @@ static int launch_group(const KGroup & a, hipStream_t stream) {
     return MI355_OK;
 }
 
+constexpr size_t LDS_TOTAL = 159 * 1024;            // per CU, less the kernels' small static arrays
+
 template <int TYPE>
-static int launch_stream(const KStream & a, hipStream_t stream) {
+static int launch_stream(KStream & a, hipStream_t stream) {
     const dim3 grid((unsigned)a.blk_end[a.n - 1]);
     const size_t need = (size_t)a.k + (size_t)a.k / QK * 8;
     static const std::string tag = std::string("mmvq_") + type_name(TYPE) + "_n1";
-    if (need <= LDS_ACT_LIMIT)  MI355_LAUNCH(tag.c_str(), (mmvq1_kernel<TYPE, true>), grid, dim3(MV1_THREADS), need, stream, a);
+    if (need <= LDS_ACT_LIMIT) {
+        if constexpr (DmaImg<TYPE>::OK) {
+            const size_t used = (need + 255) & ~(size_t)255;
+            const int slots = a.k % QK_K == 0 && a.k >= 2048 && a.k < (1 << 19) && dma_enabled(TYPE == MI355_TYPE_Q6_K ? DMA_MV_K6 : DMA_MV_K45) ? dma_slots(used, MV1_THREADS / 64, LDS_TOTAL) : 0;
+            if (slots) {
+                a.dma_slots = slots; a.ring_off = (int)used; a.dma_first = dma_first();
+                const size_t total = used + (size_t)(MV1_THREADS / 64) * slots * 1024;
+                hipError_t e = allow_lds(mmvq1_kernel<TYPE, true, true>, total);
+                if (e != hipSuccess) return (int)e;
+                MI355_LAUNCH(tag.c_str(), (mmvq1_kernel<TYPE, true, true>), grid, dim3(MV1_THREADS), total, stream, a);
+                MI355_CHECK_LAUNCH();
+                return MI355_OK;
+            }
+        }
+        MI355_LAUNCH(tag.c_str(), (mmvq1_kernel<TYPE, true, false>), grid, dim3(MV1_THREADS), need, stream, a);
+    }
     else if (a.act.x)           return MI355_E_UNSUPPORTED;
-    else                        MI355_LAUNCH(tag.c_str(), (mmvq1_kernel<TYPE, false>), grid, dim3(MV1_THREADS), 0, stream, a);
+    else                        MI355_LAUNCH(tag.c_str(), (mmvq1_kernel<TYPE, false, false>), grid, dim3(MV1_THREADS), 0, stream, a);
     MI355_CHECK_LAUNCH();
     return MI355_OK;
 }
@@ -1165,7 +1452,21 @@ static int launch_qkv(KQkv & a, hipStream_t stream) {
     if (nw > QKV_MAX_WAVES) return MI355_E_UNSUPPORTED;
     a.ppw = ppw;
     const int grid = (total + nw * ppw - 1) / (nw * ppw);
-    MI355_LAUNCH("mmvq_qkv_rope", (mmvq_qkv_rope_kernel<TQ, TK, TV>), dim3((unsigned)grid), dim3((unsigned)(nw * 64)), need, stream, a);
+    a.dma_slots = 0; a.ring_off = 0;
+    if constexpr (DmaImg<TQ>::OK || DmaImg<TK>::OK || DmaImg<TV>::OK) {
+        const size_t used = (need + 255) & ~(size_t)255;
+        const int slots = a.k % QK_K == 0 && a.k >= 2048 && a.k < (1 << 19) && dma_enabled(DMA_QKV) ? dma_slots(used, nw, LDS_TOTAL) : 0;
+        if (slots) {
+            a.dma_slots = slots; a.ring_off = (int)used; a.dma_first = dma_first();
+            const size_t lds_total = used + (size_t)nw * slots * 1024;
+            hipError_t e = allow_lds(mmvq_qkv_rope_kernel<TQ, TK, TV, true>, lds_total);
+            if (e != hipSuccess) return (int)e;
+            MI355_LAUNCH("mmvq_qkv_rope", (mmvq_qkv_rope_kernel<TQ, TK, TV, true>), dim3((unsigned)grid), dim3((unsigned)(nw * 64)), lds_total, stream, a);
+            MI355_CHECK_LAUNCH();
+            return MI355_OK;
+        }
+    }
+    MI355_LAUNCH("mmvq_qkv_rope", (mmvq_qkv_rope_kernel<TQ, TK, TV, false>), dim3((unsigned)grid), dim3((unsigned)(nw * 64)), need, stream, a);
     MI355_CHECK_LAUNCH();
     return MI355_OK;
 }
@@ -1224,7 +1525,7 @@ extern "C" int mi355_qkv_rope_matvec(const mi355_qkv_rope_args * p, void * strea
 }
 
 template <int TYPE>
-static int launch_glu_mv(const KGlu & a, hipStream_t stream) {
+static int launch_glu_mv(KGlu & a, hipStream_t stream) {
     const size_t need = (((size_t)a.k + (size_t)a.k / QK * 8 + 15) & ~(size_t)15) + 64 * sizeof(float);
     if (need > LDS_ACT_LIMIT) return MI355_E_UNSUPPORTED;
     // 4 outputs per wave.  (8 per wave -- half the workgroups, for grids beyond the 512 workgroups a full chip holds at
@@ -1232,10 +1533,25 @@ static int launch_glu_mv(const KGlu & a, hipStream_t stream) {
 #ifndef GLU_WIDE
 #define GLU_WIDE 0      // 1024-thread workgroups (64 outputs): no faster than two 512-thread workgroups per CU
 #endif
+    a.dma_slots = 0; a.ring_off = 0;
+    if constexpr (DmaImg<TYPE>::OK) {
+        // two workgroups of 8 waves per CU: half the LDS each
+        const size_t used = (need + 255) & ~(size_t)255;
+        const int slots = a.k % QK_K == 0 && a.k >= 2048 && a.k < (1 << 19) && dma_enabled(DMA_GLU) ? dma_slots(used, 8, LDS_TOTAL / 2) : 0;
+        if (slots) {
+            a.dma_slots = slots; a.ring_off = (int)used; a.dma_first = dma_first();
+            const size_t total = used + (size_t)8 * slots * 1024;
+            hipError_t e = allow_lds(mmvq_glu_kernel<TYPE, 512, true>, total);
+            if (e != hipSuccess) return (int)e;
+            MI355_LAUNCH("mmvq_glu", (mmvq_glu_kernel<TYPE, 512, true>), dim3((unsigned)(a.m / 32), (unsigned)(a.ids ? a.n_slots : 1)), dim3(512), total, stream, a);
+            MI355_CHECK_LAUNCH();
+            return MI355_OK;
+        }
+    }
     if (GLU_WIDE && a.m % 64 == 0)
-        MI355_LAUNCH("mmvq_glu", (mmvq_glu_kernel<TYPE, 1024>), dim3((unsigned)(a.m / 64), (unsigned)(a.ids ? a.n_slots : 1)), dim3(1024), need, stream, a);
+        MI355_LAUNCH("mmvq_glu", (mmvq_glu_kernel<TYPE, 1024, false>), dim3((unsigned)(a.m / 64), (unsigned)(a.ids ? a.n_slots : 1)), dim3(1024), need, stream, a);
     else
-        MI355_LAUNCH("mmvq_glu", (mmvq_glu_kernel<TYPE, 512>), dim3((unsigned)(a.m / 32), (unsigned)(a.ids ? a.n_slots : 1)), dim3(512), need, stream, a);
+        MI355_LAUNCH("mmvq_glu", (mmvq_glu_kernel<TYPE, 512, false>), dim3((unsigned)(a.m / 32), (unsigned)(a.ids ? a.n_slots : 1)), dim3(512), need, stream, a);
     MI355_CHECK_LAUNCH();
     return MI355_OK;
 }
