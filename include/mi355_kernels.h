@@ -31,11 +31,17 @@ enum mi355_type {
     MI355_TYPE_F32  = 0,
     MI355_TYPE_F16  = 1,
     MI355_TYPE_Q4_0 = 2,
+    MI355_TYPE_Q4_1 = 3,
+    MI355_TYPE_Q5_0 = 6,
+    MI355_TYPE_Q5_1 = 7,
     MI355_TYPE_Q8_0 = 8,
     MI355_TYPE_Q8_1 = 9,
     MI355_TYPE_Q4_K = 12,
     MI355_TYPE_Q5_K = 13,
     MI355_TYPE_Q6_K = 14,
+    MI355_TYPE_I32  = 26,
+    MI355_TYPE_I64  = 27,
+    MI355_TYPE_BF16 = 30,
 };
 
 enum mi355_error {
@@ -407,6 +413,11 @@ MI355_API int mi355_cpy(const mi355_tensor *src, const mi355_tensor *dst, void *
  * ggml_cuda_op_get_rows (ggml-cuda/getrows.cu); oracle ggml_compute_forward_get_rows (ggml-cpu/ops.cpp). */
 MI355_API int mi355_get_rows(const mi355_tensor *src, const mi355_tensor *ids, const mi355_tensor *dst, void *stream);
 
+/* dst[:, ids[i, b2 % ids.ne1, b3 % ids.ne2], b2, b3] = convert(src[:, i, b2, b3]); src f32, ids i64, dst f32 | f16 | q8_0 (the
+ * KV-cache store of llama.cpp with LLAMA_SET_ROWS, src/llama-kv-cache-unified.cpp:817-892).  Rows with an index outside
+ * [0, dst.ne1) are skipped.  Oracle ggml_compute_forward_set_rows_f32 (ggml-cpu/ops.cpp:5179-5227); ggml-cuda/set-rows.cu. */
+MI355_API int mi355_set_rows(const mi355_tensor *src, const mi355_tensor *ids, const mi355_tensor *dst, void *stream);
+
 /* dst = x * scale + bias (f32, contiguous).  ggml_cuda_op_scale (ggml-cuda/scale.cu). */
 MI355_API int mi355_scale_f32(const mi355_tensor *x, const mi355_tensor *dst, float scale, float bias, void *stream);
 
@@ -422,6 +433,13 @@ MI355_API int mi355_sum_rows_f32(const mi355_tensor *x, const mi355_tensor *dst,
  * dst[m, n, i2, i3] = sum_k a[k, m, i2 / r2, i3 / r3] * b[k, n, i2, i3], one wave per output element.  Replaces the cuBLAS
  * branch of ggml_cuda_mul_mat (ggml-cuda.cu:1988-2063) for this case only. */
 MI355_API int mi355_mul_mat_f32(const mi355_tensor *a, const mi355_tensor *b, const mi355_tensor *dst, void *stream);
+
+/* MUL_MAT on float weights, small batches, any strides (rows contiguous): a f32 | f16 | bf16 [k, m, ne02, ne03], b f32 | f16
+ * [k, n, ne12, ne13] with ne12 % ne02 == 0 and ne13 % ne03 == 0 (broadcast), dst f32 [m, n, ne12, ne13], f32 accumulation.
+ * One pass over the weights per 8 columns; prefill-sized batches of a plain matrix belong on mi355_mul_mat_dq.
+ * mul_mat_vec (ggml-cuda/mmv.cu), ggml_cuda_op_mul_mat_cublas (ggml-cuda.cu:1205-1351); oracle ggml_compute_forward_mul_mat
+ * with vec_dot_type f16 / bf16 / f32 (ggml-cpu/ggml-cpu.c:1196-1388). */
+MI355_API int mi355_mul_mat_f(const mi355_tensor *a, const mi355_tensor *b, const mi355_tensor *dst, void *stream);
 
 /* The router of a MoE layer in one launch, for decode-sized batches (one workgroup per token): logits = gate_inp . x,
  * probs = softmax(logits), order = argsort(probs, descending), w = probs[order[0..n_used)], wsum = sum(w), wn = w / wsum --

@@ -705,6 +705,12 @@ static bool is_weight_type(enum ggml_type t) {
     return t == GGML_TYPE_Q4_0 || t == GGML_TYPE_Q8_0 || t == GGML_TYPE_Q4_K || t == GGML_TYPE_Q5_K || t == GGML_TYPE_Q6_K;
 }
 
+// MUL_MAT also takes the rest of the 32-value block types (mat-vec + bf16 GEMM, no fused / skinny kernels) and float weights
+static bool is_block_weight_type(enum ggml_type t) {
+    return is_weight_type(t) || t == GGML_TYPE_Q4_1 || t == GGML_TYPE_Q5_0 || t == GGML_TYPE_Q5_1;
+}
+static bool is_float_weight_type(enum ggml_type t) { return t == GGML_TYPE_F32 || t == GGML_TYPE_F16 || t == GGML_TYPE_BF16; }
+
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 // MUL_MAT on block-quantized src0 (reference dispatch: ggml_cuda_mul_mat, ggml-cuda.cu:1988-2063;
@@ -719,7 +725,10 @@ static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 // GGML_MI355_MMQ_INT8=1 keeps prefill on the int8 MFMA tile kernel (mmq.hip), GGML_MI355_NO_SKINNY=1 removes the
 // middle row.  The choice depends on (type, N, K) only, never on the row count, so a row-split matrix takes the same
 // path (and produces the same bits) as the unsplit one.
-enum mi355_mm_path { MM_VEC = 0, MM_DQ = 1, MM_SKINNY_K = 2, MM_SKINNY = 3, MM_Q_INT8 = 4 };
+// Float weights (f16 / bf16 / f32: an unquantized GGUF, or K / V of a graph without flash attention) take MM_FLOAT -- the
+// strided, broadcasting mat-vec of mmf.hip straight on src1, one pass over the weights per 8 columns -- up to 16 columns
+// and whenever the GEMM's preconditions fail (K % 64, alignment, f16 src1); beyond, the bf16 GEMM per channel.
+enum mi355_mm_path { MM_VEC = 0, MM_DQ = 1, MM_SKINNY_K = 2, MM_SKINNY = 3, MM_Q_INT8 = 4, MM_FLOAT = 5 };
 // activation format each path consumes (act_cache.fmt): 0 q8_1 SoA, 1 bf16 rows, 2 q8_K planes
 static int mm_path_fmt(int path) { return path == MM_DQ ? 1 : path == MM_SKINNY_K ? 2 : 0; }
 
@@ -728,6 +737,12 @@ static int mi355_mul_mat_path(const ggml_tensor * src0, const ggml_tensor * src1
     static const bool no_skinny = MI355_ENV_SET("GGML_MI355_NO_SKINNY");
     const int64_t K = src0->ne[0], N = src1->ne[1];
     const bool aligned = (((uintptr_t)src1->data | src1->nb[1] | src1->nb[2] | src1->nb[3]) & 15) == 0;
+    if (is_float_weight_type(src0->type)) {
+        return N > 16 && K % 64 == 0 && aligned && src1->type == GGML_TYPE_F32 ? MM_DQ : MM_FLOAT;
+    }
+    if (!is_weight_type(src0->type)) {      // q4_1 / q5_0 / q5_1
+        return N > 8 && K % 64 == 0 && aligned ? MM_DQ : MM_VEC;
+    }
     if (!no_skinny && K % 256 == 0 && aligned && !(N > 8 && int8_mmq)) {
         const bool kq = src0->type == GGML_TYPE_Q4_K || src0->type == GGML_TYPE_Q5_K;
         if (kq  && N >= 4 && N <= (K >= 8192 ? 128 : 64)) return MM_SKINNY_K;
@@ -820,9 +835,15 @@ static mi355_tensor to_mi355_tensor(const ggml_tensor * t);
 static void mi355_mul_mat(mi355_backend_ctx * ctx, ggml_tensor * dst) {
     const ggml_tensor * src0 = dst->src[0];
     const ggml_tensor * src1 = dst->src[1];
-    if (src0->type == GGML_TYPE_F32) {
+    if (src0->type == GGML_TYPE_F32 && src0->ne[1] <= 1024 && src1->type == GGML_TYPE_F32) {
+        // small f32 matrices (the MoE router): the kernel whose summation order the fused router reproduces
         mi355_tensor ta = to_mi355_tensor(src0), tb = to_mi355_tensor(src1), td = to_mi355_tensor(dst);
         MI_CHECK(mi355_mul_mat_f32(&ta, &tb, &td, ctx->stream));
+        return;
+    }
+    if (is_float_weight_type(src0->type) && mi355_mul_mat_path(src0, src1) == MM_FLOAT) {
+        mi355_tensor ta = to_mi355_tensor(src0), tb = to_mi355_tensor(src1), td = to_mi355_tensor(dst);
+        MI_CHECK(mi355_mul_mat_f(&ta, &tb, &td, ctx->stream));
         return;
     }
     const int64_t K = src0->ne[0], M = src0->ne[1];
@@ -2126,12 +2147,18 @@ static bool mi355_dev_supports_op(ggml_backend_dev_t dev, const ggml_tensor * op
                 mi355_row_split(((mi355_split_buft_ctx *)a->buffer->buft->context)->split, ggml_nrows(a), device, &lo, &hi);
                 if (lo == hi) return false;
             }
-            if (a->type == GGML_TYPE_F32) {
-                // small f32 matrices (the MoE router, llama-graph.cpp:660-676): one wave per output element
-                return !tensor_is_split(a) && b->type == GGML_TYPE_F32 && op->type == GGML_TYPE_F32 && a->nb[0] == sizeof(float) &&
-                       b->nb[0] == sizeof(float) && b->ne[2] % a->ne[2] == 0 && b->ne[3] % a->ne[3] == 0 && a->ne[1] <= 1024;
+            if (is_float_weight_type(a->type)) {
+                // float weights: the MoE router (small f32), an unquantized model, K / V without flash attention (mmf.hip,
+                // mmdq.hip); rows contiguous, broadcast over dims 2 / 3, src1 f32 or f16
+                if (tensor_is_split(a) || op->type != GGML_TYPE_F32 || (b->type != GGML_TYPE_F32 && b->type != GGML_TYPE_F16)) return false;
+                if (a->nb[0] != ggml_type_size(a->type) || b->nb[0] != ggml_type_size(b->type) || op->nb[0] != sizeof(float)) return false;
+                if (b->ne[2] % a->ne[2] != 0 || b->ne[3] % a->ne[3] != 0 || b->ne[2] * b->ne[3] > 65535) return false;
+                if ((a->nb[1] | a->nb[2] | a->nb[3]) & (ggml_type_size(a->type) - 1)) return false;
+                if ((b->nb[1] | b->nb[2] | b->nb[3]) & (ggml_type_size(b->type) - 1)) return false;
+                if ((op->nb[1] | op->nb[2] | op->nb[3]) & 3) return false;
+                return true;
             }
-            if (!is_weight_type(a->type) || b->type != GGML_TYPE_F32 || op->type != GGML_TYPE_F32) return false;
+            if (!is_block_weight_type(a->type) || b->type != GGML_TYPE_F32 || op->type != GGML_TYPE_F32) return false;
             if (a->nb[0] != ggml_type_size(a->type) || b->nb[0] != sizeof(float)) return false; // rows contiguous
             if (ggml_is_transposed(a) || !ggml_is_contiguous(op)) return false;
             if (b->ne[2] % a->ne[2] != 0 || b->ne[3] % a->ne[3] != 0) return false;

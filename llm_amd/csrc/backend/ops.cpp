@@ -35,8 +35,8 @@ static bool cpy_types_ok(enum ggml_type s, enum ggml_type d) {
 
 static bool get_rows_type_ok(enum ggml_type t) {
     switch (t) {
-        case GGML_TYPE_F32: case GGML_TYPE_F16: case GGML_TYPE_Q4_0: case GGML_TYPE_Q8_0:
-        case GGML_TYPE_Q4_K: case GGML_TYPE_Q5_K: case GGML_TYPE_Q6_K: return true;
+        case GGML_TYPE_F32: case GGML_TYPE_F16: case GGML_TYPE_BF16: case GGML_TYPE_Q4_0: case GGML_TYPE_Q4_1: case GGML_TYPE_Q5_0:
+        case GGML_TYPE_Q5_1: case GGML_TYPE_Q8_0: case GGML_TYPE_Q4_K: case GGML_TYPE_Q5_K: case GGML_TYPE_Q6_K: return true;
         default: return false;
     }
 }
@@ -71,6 +71,11 @@ bool mi355_ops_supported(const ggml_tensor * op) {
             return cpy_types_ok(a->type, op->type) && op->type != GGML_TYPE_Q8_0;
         case GGML_OP_GET_ROWS:
             return get_rows_type_ok(a->type) && b->type == GGML_TYPE_I32 && is_f32(op) && a->nb[0] == ggml_type_size(a->type);
+        case GGML_OP_SET_ROWS:
+            // the KV-cache store with LLAMA_SET_ROWS (src/llama-kv-cache-unified.cpp:817-892): f32 rows scattered by an i64 index
+            return is_f32(a) && b && b->type == GGML_TYPE_I64 && a->nb[0] == sizeof(float) && op->nb[0] == ggml_type_size(op->type) &&
+                   (op->type == GGML_TYPE_F32 || op->type == GGML_TYPE_F16 || (op->type == GGML_TYPE_Q8_0 && a->ne[0] % 32 == 0)) &&
+                   ((b->nb[0] | b->nb[1] | b->nb[2]) & 7) == 0;
         case GGML_OP_SCALE:
             return is_f32(a) && is_f32(op) && ggml_is_contiguous(a) && ggml_is_contiguous(op);
         case GGML_OP_SOFT_MAX:
@@ -136,6 +141,11 @@ bool mi355_ops_forward(ggml_tensor * node, hipStream_t stream) {
         case GGML_OP_GET_ROWS: {
             mi355_tensor ta = T(a), tb = T(b);
             MI_CHECK(mi355_get_rows(&ta, &tb, &td, stream));
+            return true;
+        }
+        case GGML_OP_SET_ROWS: {
+            mi355_tensor ta = T(a), tb = T(b);
+            MI_CHECK(mi355_set_rows(&ta, &tb, &td, stream));
             return true;
         }
         case GGML_OP_SCALE: {

@@ -34,8 +34,8 @@ const char * mi355_error_string(int err) {
 
 int64_t mi355_blck_size(int type) {
     switch (type) {
-        case MI355_TYPE_F32: case MI355_TYPE_F16: return 1;
-        case MI355_TYPE_Q4_0: case MI355_TYPE_Q8_0: case MI355_TYPE_Q8_1: return QK;
+        case MI355_TYPE_F32: case MI355_TYPE_F16: case MI355_TYPE_BF16: return 1;
+        case MI355_TYPE_Q4_0: case MI355_TYPE_Q4_1: case MI355_TYPE_Q5_0: case MI355_TYPE_Q5_1: case MI355_TYPE_Q8_0: case MI355_TYPE_Q8_1: return QK;
         case MI355_TYPE_Q4_K: case MI355_TYPE_Q5_K: case MI355_TYPE_Q6_K: return QK_K;
     }
     return 0;
@@ -45,7 +45,11 @@ int64_t mi355_type_size(int type) {
     switch (type) {
         case MI355_TYPE_F32:  return 4;
         case MI355_TYPE_F16:  return 2;
+        case MI355_TYPE_BF16: return 2;
         case MI355_TYPE_Q4_0: return 18;
+        case MI355_TYPE_Q4_1: return 20;
+        case MI355_TYPE_Q5_0: return 22;
+        case MI355_TYPE_Q5_1: return 24;
         case MI355_TYPE_Q8_0: return 34;
         case MI355_TYPE_Q8_1: return 36;
         case MI355_TYPE_Q4_K: return 144;

@@ -18,6 +18,25 @@ static __device__ __forceinline__ float deq_elem(const uint8_t * __restrict__ ba
         const float d = h2f(*(const uint16_t *)b);
         const int q = j < 16 ? (b[2 + j] & 0x0F) : (b[2 + j - 16] >> 4);
         return __fmul_rn((float)(q - 8), d);
+    } else if (TYPE == MI355_TYPE_Q4_1) {
+        // dequantize_row_q4_1, ggml-quants.c:269-288: y = q * d + m
+        const uint8_t * b = base + (i / QK) * 20;
+        const int j = i % QK;
+        const float d = h2f(*(const uint16_t *)b), m = h2f(*(const uint16_t *)(b + 2));
+        const int q = j < 16 ? (b[4 + j] & 0x0F) : (b[4 + j - 16] >> 4);
+        return __fadd_rn(__fmul_rn((float)q, d), m);
+    } else if (TYPE == MI355_TYPE_Q5_0 || TYPE == MI355_TYPE_Q5_1) {
+        // dequantize_row_q5_0 / _q5_1, ggml-quants.c:290-341: bit j (low half) / j + 16 (high half) of qh is the 5th bit
+        const int bsz = TYPE == MI355_TYPE_Q5_0 ? 22 : 24, qo = TYPE == MI355_TYPE_Q5_0 ? 6 : 8;
+        const uint8_t * b = base + (i / QK) * bsz;
+        const int j = i % QK;
+        const float d = h2f(*(const uint16_t *)b);
+        const uint8_t * qhp = b + (TYPE == MI355_TYPE_Q5_0 ? 2 : 4);
+        const uint32_t qh = (uint32_t)qhp[0] | ((uint32_t)qhp[1] << 8) | ((uint32_t)qhp[2] << 16) | ((uint32_t)qhp[3] << 24);
+        const int nib = j < 16 ? (b[qo + j] & 0x0F) : (b[qo + j - 16] >> 4);
+        const int q = nib | (int)(((qh >> j) & 1u) << 4);
+        if (TYPE == MI355_TYPE_Q5_0) return __fmul_rn((float)(q - 16), d);
+        return __fadd_rn(__fmul_rn((float)q, d), h2f(*(const uint16_t *)(b + 2)));
     } else if (TYPE == MI355_TYPE_Q8_0) {
         const uint8_t * b = base + (i / QK) * 34;
         const float d = h2f(*(const uint16_t *)b);
@@ -59,6 +78,8 @@ static __device__ __forceinline__ float deq_elem(const uint8_t * __restrict__ ba
         return __fmul_rn(__fmul_rn(d, (float)sc[l / 16 + 2 * g]), (float)q);
     } else if (TYPE == MI355_TYPE_F16) {
         return h2f(((const uint16_t *)base)[i]);
+    } else if (TYPE == MI355_TYPE_BF16) {
+        return __uint_as_float((uint32_t)((const uint16_t *)base)[i] << 16);
     } else if (TYPE == MI355_TYPE_F32) {
         return ((const float *)base)[i];
     }

@@ -1,5 +1,5 @@
 // dequantize.hip -- block dequantization to f32, bit-exact with the reference's
-// dequantize_row_{q4_0,q8_0,q4_K,q5_K,q6_K} (ggml/src/ggml-quants.c:249-267,343-357,1274-1296,
+// dequantize_row_{q4_0,q4_1,q5_0,q5_1,q8_0,q4_K,q5_K,q6_K} (ggml/src/ggml-quants.c:249-357,1274-1296,
 // 1476-1501,1684-1713).  The order of the f32 operations is part of the contract, so every
 // product / difference is an explicit single-rounding intrinsic (no FMA contraction).
 //
@@ -39,6 +39,10 @@ extern "C" int mi355_dequantize_row(int type, const void * blocks, float * y, in
         }
         case MI355_TYPE_F16:  return launch_deq<MI355_TYPE_F16>(blocks, y, n, s);
         case MI355_TYPE_Q4_0: return launch_deq<MI355_TYPE_Q4_0>(blocks, y, n, s);
+        case MI355_TYPE_Q4_1: return launch_deq<MI355_TYPE_Q4_1>(blocks, y, n, s);
+        case MI355_TYPE_Q5_0: return launch_deq<MI355_TYPE_Q5_0>(blocks, y, n, s);
+        case MI355_TYPE_Q5_1: return launch_deq<MI355_TYPE_Q5_1>(blocks, y, n, s);
+        case MI355_TYPE_BF16: return launch_deq<MI355_TYPE_BF16>(blocks, y, n, s);
         case MI355_TYPE_Q8_0: return launch_deq<MI355_TYPE_Q8_0>(blocks, y, n, s);
         case MI355_TYPE_Q8_1: return launch_deq<MI355_TYPE_Q8_1>(blocks, y, n, s);
         case MI355_TYPE_Q4_K: return launch_deq<MI355_TYPE_Q4_K>(blocks, y, n, s);

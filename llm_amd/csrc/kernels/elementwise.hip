@@ -350,6 +350,54 @@ cpy_f32_q8_0_kernel(const T4 s, const T4 d, int64_t nblocks) {
     }
 }
 
+// ---------------------------------------------------------------- set_rows
+// dst[:, ids[i, i2 % ids.ne1, i3 % ids.ne2], i2, i3] = convert(src[:, i, i2, i3])   (ggml_compute_forward_set_rows_f32,
+// ggml-cpu/ops.cpp:5179-5227).  Rows whose index is out of range are skipped (the CPU asserts).
+static __device__ __forceinline__ int64_t set_rows_dst(const T4 & ids, const T4 & d, int64_t i1, int64_t i2, int64_t i3) {
+    const int64_t r = *(const int64_t *)(ids.data + i1 * ids.nb[0] + (i2 % ids.ne[1]) * ids.nb[1] + (i3 % ids.ne[2]) * ids.nb[2]);
+    return r >= 0 && r < d.ne[1] ? r * d.nb[1] + i2 * d.nb[2] + i3 * d.nb[3] : -1;
+}
+
+template <class TD>
+__global__ void __launch_bounds__(256)
+set_rows_kernel(const T4 s, const T4 ids, const T4 d, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int64_t i0 = i % s.ne[0], r = i / s.ne[0];
+        const int64_t i1 = r % s.ne[1], r2 = r / s.ne[1];
+        const int64_t i2 = r2 % s.ne[2], i3 = r2 / s.ne[2];
+        const int64_t o = set_rows_dst(ids, d, i1, i2, i3);
+        if (o >= 0) *(TD *)(d.data + o + i0 * sizeof(TD)) = cvt<float, TD>(*(const float *)(s.data + i0 * 4 + i1 * s.nb[1] + i2 * s.nb[2] + i3 * s.nb[3]));
+    }
+}
+
+// q8_0 destination rows: one lane per 32-value block (quantize_row_q8_0_ref, ggml-quants.c:188-211)
+__global__ void __launch_bounds__(256)
+set_rows_q8_0_kernel(const T4 s, const T4 ids, const T4 d, int64_t nblocks) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t nb0 = s.ne[0] / 32;
+    for (int64_t ib = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; ib < nblocks; ib += stride) {
+        const int64_t b0 = ib % nb0, r = ib / nb0;
+        const int64_t i1 = r % s.ne[1], r2 = r / s.ne[1];
+        const int64_t i2 = r2 % s.ne[2], i3 = r2 / s.ne[2];
+        const int64_t o = set_rows_dst(ids, d, i1, i2, i3);
+        if (o < 0) continue;
+        const float * xs = (const float *)(s.data + b0 * 128 + i1 * s.nb[1] + i2 * s.nb[2] + i3 * s.nb[3]);
+        uint8_t * blk = (uint8_t *)(d.data + o + b0 * 34);
+        float v[32], amax = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 32; j++) { v[j] = xs[j]; amax = fmaxf(amax, fabsf(v[j])); }
+        const float dd = __fdiv_rn(amax, 127.0f);
+        const float id = dd != 0.0f ? __fdiv_rn(1.0f, dd) : 0.0f;
+        *(uint16_t *)blk = __half_as_ushort(__float2half_rn(dd));
+#pragma unroll
+        for (int j = 0; j < 32; j++) {
+            const float r = roundf(__fmul_rn(v[j], id));
+            ((int8_t *)blk)[2 + j] = fabsf(r) < 2147483648.0f ? (int8_t)(int)r : 0;
+        }
+    }
+}
+
 // ---------------------------------------------------------------- get_rows
 template <int TYPE>
 __global__ void __launch_bounds__(256)
@@ -598,6 +646,35 @@ int mi355_cpy(const mi355_tensor * src, const mi355_tensor * dst, void * stream)
     return MI355_OK;
 }
 
+int mi355_set_rows(const mi355_tensor * src, const mi355_tensor * ids, const mi355_tensor * dst, void * stream) {
+    CHECK_T(src); CHECK_T(ids); CHECK_T(dst);
+    if (src->type != MI355_TYPE_F32 || ids->type != MI355_TYPE_I64) return MI355_E_TYPE;
+    if (src->nb[0] != 4 || dst->nb[0] != mi355_type_size(dst->type)) return MI355_E_SHAPE;        // rows contiguous
+    if (src->ne[0] != dst->ne[0] || src->ne[2] != dst->ne[2] || src->ne[3] != dst->ne[3] || ids->ne[0] != src->ne[1] || ids->ne[1] < 1 ||
+        ids->ne[2] < 1 || src->ne[2] % ids->ne[1] != 0 || src->ne[3] % ids->ne[2] != 0 || ids->ne[3] != 1) return MI355_E_SHAPE;
+    if (((uintptr_t)ids->data | ids->nb[0] | ids->nb[1] | ids->nb[2]) & 7) return MI355_E_ALIGN;
+    if (((uintptr_t)src->data | src->nb[1] | src->nb[2] | src->nb[3]) & 3) return MI355_E_ALIGN;
+    const int64_t n = nelem(src);
+    if (n == 0) return MI355_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 block(256);
+    switch (dst->type) {
+        case MI355_TYPE_F32:
+            if (((uintptr_t)dst->data | dst->nb[1] | dst->nb[2] | dst->nb[3]) & 3) return MI355_E_ALIGN;
+            MI355_LAUNCH("set_rows", (set_rows_kernel<float>), dim3(grid_for(n)), block, 0, s, t4(src), t4(ids), t4(dst), n); break;
+        case MI355_TYPE_F16:
+            if (((uintptr_t)dst->data | dst->nb[1] | dst->nb[2] | dst->nb[3]) & 1) return MI355_E_ALIGN;
+            MI355_LAUNCH("set_rows", (set_rows_kernel<__half>), dim3(grid_for(n)), block, 0, s, t4(src), t4(ids), t4(dst), n); break;
+        case MI355_TYPE_Q8_0:
+            if (src->ne[0] % 32) return MI355_E_SHAPE;
+            if (((uintptr_t)dst->data | dst->nb[1] | dst->nb[2] | dst->nb[3]) & 1) return MI355_E_ALIGN;
+            MI355_LAUNCH("set_rows", set_rows_q8_0_kernel, dim3(grid_for(n / 32)), block, 0, s, t4(src), t4(ids), t4(dst), n / 32); break;
+        default: return MI355_E_TYPE;
+    }
+    MI355_CHECK_LAUNCH();
+    return MI355_OK;
+}
+
 int mi355_get_rows(const mi355_tensor * src, const mi355_tensor * ids, const mi355_tensor * dst, void * stream) {
     CHECK_T(src); CHECK_T(ids); CHECK_T(dst);
     if (dst->type != MI355_TYPE_F32) return MI355_E_TYPE;
@@ -611,6 +688,10 @@ int mi355_get_rows(const mi355_tensor * src, const mi355_tensor * ids, const mi3
         case MI355_TYPE_F32:  GR(MI355_TYPE_F32);
         case MI355_TYPE_F16:  GR(MI355_TYPE_F16);
         case MI355_TYPE_Q4_0: GR(MI355_TYPE_Q4_0);
+        case MI355_TYPE_Q4_1: GR(MI355_TYPE_Q4_1);
+        case MI355_TYPE_Q5_0: GR(MI355_TYPE_Q5_0);
+        case MI355_TYPE_Q5_1: GR(MI355_TYPE_Q5_1);
+        case MI355_TYPE_BF16: GR(MI355_TYPE_BF16);
         case MI355_TYPE_Q8_0: GR(MI355_TYPE_Q8_0);
         case MI355_TYPE_Q4_K: GR(MI355_TYPE_Q4_K);
         case MI355_TYPE_Q5_K: GR(MI355_TYPE_Q5_K);

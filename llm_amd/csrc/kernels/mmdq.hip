@@ -50,6 +50,13 @@ template <> struct Raw<MI355_TYPE_Q5_K> { v4i q0, q1, h0, h1, hdr; };
 template <> struct Raw<MI355_TYPE_Q6_K> { v4i l0, l1, h0, h1; uint32_t sc; uint16_t d; };
 template <> struct Raw<MI355_TYPE_Q8_0> { v4i q0, q1; uint16_t d; };
 template <> struct Raw<MI355_TYPE_Q4_0> { v4i qs; uint16_t d; };
+template <> struct Raw<MI355_TYPE_Q4_1> { v4i qs; uint16_t d, m; };
+template <> struct Raw<MI355_TYPE_Q5_0> { v4i qs; uint32_t qh; uint16_t d; };
+template <> struct Raw<MI355_TYPE_Q5_1> { v4i qs; uint32_t qh; uint16_t d, m; };
+// float weights (an unquantized GGUF; K / V of a graph without flash attention): "dequantization" is the conversion to bf16
+template <> struct Raw<MI355_TYPE_F16>  { v4i q[4]; };
+template <> struct Raw<MI355_TYPE_BF16> { v4i q[4]; };
+template <> struct Raw<MI355_TYPE_F32>  { v4i q[8]; };
 
 template <int TYPE>
 static __device__ __forceinline__ Raw<TYPE> load_raw(const uint8_t * wrow, int k) {   // k % 32 == 0
@@ -83,10 +90,28 @@ static __device__ __forceinline__ Raw<TYPE> load_raw(const uint8_t * wrow, int k
         r.q0 = ld16_a2(blk + 2);
         r.q1 = ld16_a2(blk + 18);
         r.d  = ld_u16(blk);
-    } else {
+    } else if constexpr (TYPE == MI355_TYPE_Q4_0) {
         const uint8_t * blk = wrow + (int64_t)(k >> 5) * 18;
         r.qs = ld16_a2(blk + 2);
         r.d  = ld_u16(blk);
+    } else if constexpr (TYPE == MI355_TYPE_Q4_1) {
+        const uint8_t * blk = wrow + (int64_t)(k >> 5) * 20;
+        r.qs = ld16_a2(blk + 4);
+        r.d  = ld_u16(blk); r.m = ld_u16(blk + 2);
+    } else if constexpr (TYPE == MI355_TYPE_Q5_0) {
+        const uint8_t * blk = wrow + (int64_t)(k >> 5) * 22;
+        r.qs = ld16_a2(blk + 6);
+        r.d  = ld_u16(blk); r.qh = (uint32_t)ld_u16(blk + 2) | ((uint32_t)ld_u16(blk + 4) << 16);
+    } else if constexpr (TYPE == MI355_TYPE_Q5_1) {
+        const uint8_t * blk = wrow + (int64_t)(k >> 5) * 24;
+        r.qs = ld16_a2(blk + 8);
+        r.d  = ld_u16(blk); r.m = ld_u16(blk + 2); r.qh = (uint32_t)ld_u16(blk + 4) | ((uint32_t)ld_u16(blk + 6) << 16);
+    } else if constexpr (TYPE == MI355_TYPE_F32) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) r.q[i] = ld16_a2(wrow + (int64_t)k * 4 + 16 * i);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; i++) r.q[i] = ld16_a2(wrow + (int64_t)k * 2 + 16 * i);
     }
     return r;
 }
@@ -144,7 +169,7 @@ static __device__ __forceinline__ void dequant32(const Raw<TYPE> & r, int k, flo
 #pragma unroll
             for (int i = 0; i < 4; i++) f[4 * w + i] = d * (float)(int8_t)(q >> (8 * i));
         }
-    } else {
+    } else if constexpr (TYPE == MI355_TYPE_Q4_0) {
         const float d = h2f(r.d);
 #pragma unroll
         for (int w = 0; w < 4; w++) {
@@ -154,6 +179,45 @@ static __device__ __forceinline__ void dequant32(const Raw<TYPE> & r, int k, flo
                 f[16 + 4 * w + i] = d * (ubyte((r.qs[w] >> 4) & 0x0f0f0f0f, i) - 8.0f);
             }
         }
+    } else if constexpr (TYPE == MI355_TYPE_Q4_1 || TYPE == MI355_TYPE_Q5_0 || TYPE == MI355_TYPE_Q5_1) {
+        // value = (nibble | 5th bit) * d + m; q5_0: (... - 16) * d (ggml-quants.c:269-341); bit e of qh belongs to element e
+        const float d = h2f(r.d);
+        float m = 0.0f, off = 0.0f;
+        uint32_t qh = 0;
+        if constexpr (TYPE != MI355_TYPE_Q5_0) m = h2f(r.m); else off = 16.0f;
+        if constexpr (TYPE != MI355_TYPE_Q4_1) qh = r.qh;
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int e = 4 * w + i;
+                const float lo = ubyte(r.qs[w] & 0x0f0f0f0f, i) + (float)(((qh >> e) & 1u) << 4);
+                const float hi = ubyte((r.qs[w] >> 4) & 0x0f0f0f0f, i) + (float)(((qh >> (e + 16)) & 1u) << 4);
+                f[e]      = d * (lo - off) + m;
+                f[16 + e] = d * (hi - off) + m;
+            }
+        }
+    } else if constexpr (TYPE == MI355_TYPE_F16) {
+#pragma unroll
+        for (int w = 0; w < 4; w++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                f[8 * w + 2 * i]     = h2f((uint16_t)((uint32_t)r.q[w][i] & 0xffff));
+                f[8 * w + 2 * i + 1] = h2f((uint16_t)((uint32_t)r.q[w][i] >> 16));
+            }
+    } else if constexpr (TYPE == MI355_TYPE_BF16) {
+#pragma unroll
+        for (int w = 0; w < 4; w++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                f[8 * w + 2 * i]     = __uint_as_float((uint32_t)r.q[w][i] << 16);
+                f[8 * w + 2 * i + 1] = __uint_as_float((uint32_t)r.q[w][i] & 0xffff0000u);
+            }
+    } else {
+#pragma unroll
+        for (int w = 0; w < 8; w++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) f[4 * w + i] = __int_as_float(r.q[w][i]);
     }
 }
 
@@ -369,7 +433,7 @@ extern "C" int mi355_mul_mat_dq_slice(int type, const void * W, int64_t w_row_st
     if (!W || !x || !dst) return MI355_E_NULL;
     if (m_total < m) return MI355_E_SHAPE;
     const int64_t bs = mi355_blck_size(type);
-    if (bs == 0 || type == MI355_TYPE_F32 || type == MI355_TYPE_F16 || type == MI355_TYPE_Q8_1) return MI355_E_TYPE;
+    if (bs == 0 || type == MI355_TYPE_Q8_1) return MI355_E_TYPE;
     if (m < 0 || n < 0 || k <= 0 || k % bs != 0 || m > 0x7fffffff || n > 0x7fffffff || k > 0x7fffffff) return MI355_E_SHAPE;
     if (k % BK != 0) return MI355_E_UNSUPPORTED;          // caller falls back to the mat-vec kernel
     if ((n + BN - 1) / BN > 0x7fffffff / 2 || (m + 63) / 64 > 65535) return MI355_E_UNSUPPORTED;
@@ -389,6 +453,12 @@ extern "C" int mi355_mul_mat_dq_slice(int type, const void * W, int64_t w_row_st
         case MI355_TYPE_Q4_K: return launch<MI355_TYPE_Q4_K>(a, m_total, s, "mmdq_q4_K");
         case MI355_TYPE_Q5_K: return launch<MI355_TYPE_Q5_K>(a, m_total, s, "mmdq_q5_K");
         case MI355_TYPE_Q6_K: return launch<MI355_TYPE_Q6_K>(a, m_total, s, "mmdq_q6_K");
+        case MI355_TYPE_Q4_1: return launch<MI355_TYPE_Q4_1>(a, m_total, s, "mmdq_q4_1");
+        case MI355_TYPE_Q5_0: return launch<MI355_TYPE_Q5_0>(a, m_total, s, "mmdq_q5_0");
+        case MI355_TYPE_Q5_1: return launch<MI355_TYPE_Q5_1>(a, m_total, s, "mmdq_q5_1");
+        case MI355_TYPE_F16:  return launch<MI355_TYPE_F16>(a, m_total, s, "mmdq_f16");
+        case MI355_TYPE_BF16: return launch<MI355_TYPE_BF16>(a, m_total, s, "mmdq_bf16");
+        case MI355_TYPE_F32:  return launch<MI355_TYPE_F32>(a, m_total, s, "mmdq_f32");
     }
     return MI355_E_TYPE;
 }

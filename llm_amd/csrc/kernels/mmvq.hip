@@ -284,6 +284,114 @@ template <> struct Unit<MI355_TYPE_Q4_0> {
     }
 };
 
+// ---- Q4_1: 20 B = {half d, half m, u8 qs[16]} (ggml-common.h:175-187); value = nibble * d + m (ggml-quants.c:269-288)
+// The block sum of the activations comes with them ({d, sum} of the q8_1 SoA), as for the K-quants' mins.
+struct Act32s { v4i q0, q1; float d, s; };
+template <class AP>
+static __device__ __forceinline__ Act32s load_act32s(const AP a, int u) {
+    Act32s r;
+    r.q0 = *(const v4i *)(a.q + u * 32);
+    r.q1 = *(const v4i *)(a.q + u * 32 + 16);
+    const v2f ds = *(const v2f *)(a.ds + u * 2);
+    r.d = ds.x; r.s = ds.y;
+    return r;
+}
+// bit i of the low 4 bits of b -> bit 0 of byte i
+static __device__ __forceinline__ int spread4(uint32_t b) { return (int)(((b & 0xfu) * 0x00204081u) & 0x01010101u); }
+
+template <> struct Unit<MI355_TYPE_Q4_1> {
+    static constexpr int ELEMS = 32;
+    struct Raw { v4i qs; uint16_t d, m; };
+    struct Dec { v4i lo, hi; float d, m; };
+    typedef Act32s Act;
+    static __device__ __forceinline__ Raw load(const uint8_t * row, int u) {
+        const uint8_t * blk = row + (int64_t)u * 20;
+        Raw r;
+        r.qs = ld16_a2(blk + 4);
+        r.d  = ld_u16(blk); r.m = ld_u16(blk + 2);
+        return r;
+    }
+    static __device__ __forceinline__ Dec decode(const Raw & r, int) {
+        Dec d;
+        d.lo = r.qs & 0x0f0f0f0f; d.hi = (r.qs >> 4) & 0x0f0f0f0f;
+        d.d = h2f(r.d); d.m = h2f(r.m);
+        return d;
+    }
+    template <class AP> static __device__ __forceinline__ Act load_act(const AP a, int u) { return load_act32s(a, u); }
+    static __device__ __forceinline__ float dot(const Dec & w, const Act & a) {
+        int s = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) { s = dot4(w.lo[j], a.q0[j], s); s = dot4(w.hi[j], a.q1[j], s); }
+        return w.d * a.d * (float)s + w.m * (a.d * a.s);
+    }
+};
+
+// ---- Q5_0: 22 B = {half d, u8 qh[4], u8 qs[16]} (ggml-common.h:191-196); value = ((nibble | bit << 4) - 16) * d, bit e of
+// qh belongs to element e (ggml-quants.c:290-314)
+template <> struct Unit<MI355_TYPE_Q5_0> {
+    static constexpr int ELEMS = 32;
+    struct Raw { v4i qs; uint16_t qh0, qh1, d; };
+    struct Dec { v4i lo, hi; float d; };
+    typedef Unit<MI355_TYPE_Q8_0>::Act Act;
+    static __device__ __forceinline__ Raw load(const uint8_t * row, int u) {
+        const uint8_t * blk = row + (int64_t)u * 22;
+        Raw r;
+        r.qs = ld16_a2(blk + 6);
+        r.d = ld_u16(blk); r.qh0 = ld_u16(blk + 2); r.qh1 = ld_u16(blk + 4);
+        return r;
+    }
+    static __device__ __forceinline__ Dec decode(const Raw & r, int) {
+        Dec d;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            d.lo[j] = sub_bytes((r.qs[j] & 0x0f0f0f0f) | (spread4((uint32_t)r.qh0 >> (4 * j)) << 4), 0x10101010);
+            d.hi[j] = sub_bytes(((r.qs[j] >> 4) & 0x0f0f0f0f) | (spread4((uint32_t)r.qh1 >> (4 * j)) << 4), 0x10101010);
+        }
+        d.d = h2f(r.d);
+        return d;
+    }
+    template <class AP> static __device__ __forceinline__ Act load_act(const AP a, int u) { return Unit<MI355_TYPE_Q8_0>::load_act(a, u); }
+    static __device__ __forceinline__ float dot(const Dec & w, const Act & a) {
+        int s = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) { s = dot4(w.lo[j], a.q0[j], s); s = dot4(w.hi[j], a.q1[j], s); }
+        return w.d * a.d * (float)s;
+    }
+};
+
+// ---- Q5_1: 24 B = {half d, half m, u8 qh[4], u8 qs[16]} (ggml-common.h:198-209); value = (nibble | bit << 4) * d + m
+// (ggml-quants.c:316-341)
+template <> struct Unit<MI355_TYPE_Q5_1> {
+    static constexpr int ELEMS = 32;
+    struct Raw { v4i qs; uint16_t qh0, qh1, d, m; };
+    struct Dec { v4i lo, hi; float d, m; };
+    typedef Act32s Act;
+    static __device__ __forceinline__ Raw load(const uint8_t * row, int u) {
+        const uint8_t * blk = row + (int64_t)u * 24;
+        Raw r;
+        r.qs = ld16_a2(blk + 8);
+        r.d = ld_u16(blk); r.m = ld_u16(blk + 2); r.qh0 = ld_u16(blk + 4); r.qh1 = ld_u16(blk + 6);
+        return r;
+    }
+    static __device__ __forceinline__ Dec decode(const Raw & r, int) {
+        Dec d;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            d.lo[j] = (r.qs[j] & 0x0f0f0f0f) | (spread4((uint32_t)r.qh0 >> (4 * j)) << 4);
+            d.hi[j] = ((r.qs[j] >> 4) & 0x0f0f0f0f) | (spread4((uint32_t)r.qh1 >> (4 * j)) << 4);
+        }
+        d.d = h2f(r.d); d.m = h2f(r.m);
+        return d;
+    }
+    template <class AP> static __device__ __forceinline__ Act load_act(const AP a, int u) { return load_act32s(a, u); }
+    static __device__ __forceinline__ float dot(const Dec & w, const Act & a) {
+        int s = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) { s = dot4(w.lo[j], a.q0[j], s); s = dot4(w.hi[j], a.q1[j], s); }
+        return w.d * a.d * (float)s + w.m * (a.d * a.s);
+    }
+};
+
 // ================================================================================================
 // Single-column streaming core (decode: ncols == 1).
 //
@@ -1229,6 +1337,7 @@ static const char * type_name(int t) {
     switch (t) {
         case MI355_TYPE_Q4_0: return "q4_0"; case MI355_TYPE_Q8_0: return "q8_0"; case MI355_TYPE_Q4_K: return "q4_K";
         case MI355_TYPE_Q5_K: return "q5_K"; case MI355_TYPE_Q6_K: return "q6_K";
+        case MI355_TYPE_Q4_1: return "q4_1"; case MI355_TYPE_Q5_0: return "q5_0"; case MI355_TYPE_Q5_1: return "q5_1";
     }
     return "?";
 }
@@ -1328,7 +1437,7 @@ static int validate(const mi355_mmvq_args * p) {
         if (((uintptr_t)p->src_f32 | (uintptr_t)p->norm_w | (uintptr_t)p->norm_out) & 15) return MI355_E_ALIGN;
     } else if (!p->act_q || !p->act_ds) return MI355_E_NULL;
     const int64_t bs = mi355_blck_size(p->type);
-    if (bs == 0 || p->type == MI355_TYPE_F32 || p->type == MI355_TYPE_F16 || p->type == MI355_TYPE_Q8_1) return MI355_E_TYPE;
+    if (bs < QK || p->type == MI355_TYPE_Q8_1) return MI355_E_TYPE;
     if (p->m < 0 || p->k <= 0 || p->k % bs != 0 || p->ncols < 1 || p->ncols > 8 || p->nchannels < 1 ||
         p->nchannels > 65535 || p->ch_ratio < 1 || p->m > 0x7fffffff || p->k > 0x7fffffff) return MI355_E_SHAPE;
     if (p->ids && (p->ids_nused < 1 || p->act_ne1 < 1 || p->n_expert < 1)) return MI355_E_SHAPE;
@@ -1364,6 +1473,9 @@ extern "C" int mi355_mul_mat_vec_q(const mi355_mmvq_args * p, void * stream) {
         case MI355_TYPE_Q4_K: return dispatch_cols<MI355_TYPE_Q4_K>(a, p->ncols, p->nchannels, s);
         case MI355_TYPE_Q5_K: return dispatch_cols<MI355_TYPE_Q5_K>(a, p->ncols, p->nchannels, s);
         case MI355_TYPE_Q6_K: return dispatch_cols<MI355_TYPE_Q6_K>(a, p->ncols, p->nchannels, s);
+        case MI355_TYPE_Q4_1: return dispatch_cols<MI355_TYPE_Q4_1>(a, p->ncols, p->nchannels, s);
+        case MI355_TYPE_Q5_0: return dispatch_cols<MI355_TYPE_Q5_0>(a, p->ncols, p->nchannels, s);
+        case MI355_TYPE_Q5_1: return dispatch_cols<MI355_TYPE_Q5_1>(a, p->ncols, p->nchannels, s);
     }
     return MI355_E_TYPE;
 }
@@ -1421,6 +1533,9 @@ extern "C" int mi355_mul_mat_vec_q_group(const mi355_mmvq_args * p, int n_mats, 
             case MI355_TYPE_Q4_K: return launch_stream<MI355_TYPE_Q4_K>(b, s);
             case MI355_TYPE_Q5_K: return launch_stream<MI355_TYPE_Q5_K>(b, s);
             case MI355_TYPE_Q6_K: return launch_stream<MI355_TYPE_Q6_K>(b, s);
+            case MI355_TYPE_Q4_1: return launch_stream<MI355_TYPE_Q4_1>(b, s);
+            case MI355_TYPE_Q5_0: return launch_stream<MI355_TYPE_Q5_0>(b, s);
+            case MI355_TYPE_Q5_1: return launch_stream<MI355_TYPE_Q5_1>(b, s);
         }
         return MI355_E_TYPE;
     }
@@ -1431,6 +1546,9 @@ extern "C" int mi355_mul_mat_vec_q_group(const mi355_mmvq_args * p, int n_mats, 
         case MI355_TYPE_Q4_K: return dispatch_group_cols<MI355_TYPE_Q4_K>(a, p[0].ncols, s);
         case MI355_TYPE_Q5_K: return dispatch_group_cols<MI355_TYPE_Q5_K>(a, p[0].ncols, s);
         case MI355_TYPE_Q6_K: return dispatch_group_cols<MI355_TYPE_Q6_K>(a, p[0].ncols, s);
+        case MI355_TYPE_Q4_1: return dispatch_group_cols<MI355_TYPE_Q4_1>(a, p[0].ncols, s);
+        case MI355_TYPE_Q5_0: return dispatch_group_cols<MI355_TYPE_Q5_0>(a, p[0].ncols, s);
+        case MI355_TYPE_Q5_1: return dispatch_group_cols<MI355_TYPE_Q5_1>(a, p[0].ncols, s);
     }
     return MI355_E_TYPE;
 }

@@ -23,7 +23,9 @@ extern "C" int mi355_mul_mat(int type, const void * W, int64_t w_row_stride, con
     float  * ads = (float *)((char *)workspace + align_up(mi355_act_q_bytes(k, n), 256));
     int rc = mi355_quantize_act(x, aq, ads, k, n, 1, 1, k * 4, k * n * 4, k * n * 4, stream);
     if (rc) return rc;
-    if (n > 8) {
+    const bool tile_type = type == MI355_TYPE_Q4_0 || type == MI355_TYPE_Q8_0 || type == MI355_TYPE_Q4_K || type == MI355_TYPE_Q5_K ||
+                           type == MI355_TYPE_Q6_K;       // the int8 tile kernel serves these; q4_1 / q5_0 / q5_1 go by column groups
+    if (n > 8 && tile_type) {
         rc = mi355_mul_mat_q(type, W, w_row_stride, aq, ads, dst, m, m, k, n, stream);
         if (rc != MI355_E_UNSUPPORTED) return rc;
     }

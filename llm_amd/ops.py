@@ -354,3 +354,38 @@ def mul_mat_qk(t, w, b, m):
     K.check(K.lib.mi355_mul_mat_qk(t, w.data_ptr(), B.row_size(t, k), q.data_ptr(), d.data_ptr(), bs.data_ptr(), dst.data_ptr(), m, m, k, n,
                                    _stream()), "mi355_mul_mat_qk")
     return dst
+
+
+def _desc(t, type_id):
+    """ggml-style descriptor of a torch tensor of up to 4 dims (last dim fastest), strides honoured"""
+    d = K.Tensor()
+    d.data, d.type = t.data_ptr(), type_id
+    shape, stride = list(t.shape)[::-1], list(t.stride())[::-1]
+    es = t.element_size()
+    for i in range(4):
+        d.ne[i] = shape[i] if i < len(shape) else 1
+        d.nb[i] = stride[i] * es if i < len(shape) else (d.nb[i - 1] * d.ne[i - 1] if i else es)
+    return d
+
+
+def mul_mat_f(type_a, a, b, type_b=B.F32):
+    """MUL_MAT on float weights (mi355_mul_mat_f): a [.., m, k] (f32 | f16 | bf16 bits as a torch tensor of matching width),
+    b [.., n, k] f32 | f16 -> [.., n, m] f32; leading dims broadcast ggml-style."""
+    assert a.is_cuda and b.is_cuda
+    lead = list(b.shape[:-2])
+    dst = torch.empty(lead + [b.shape[-2], a.shape[-2]], dtype=torch.float32, device=b.device)
+    ta, tb, td = _desc(a, type_a), _desc(b, type_b), _desc(dst, B.F32)
+    K.check(K.lib.mi355_mul_mat_f(ta, tb, td, _stream()), "mi355_mul_mat_f")
+    return dst
+
+
+def set_rows(src, ids, dst, type_dst):
+    """GGML_OP_SET_ROWS (mi355_set_rows): src f32 [.., n, k], ids int64 [.., n], dst rows of type_dst (f32 / f16 tensors,
+    or uint8 rows of q8_0 blocks); writes into dst and returns it."""
+    ts, ti = _desc(src, B.F32), _desc(ids, B.I64)
+    td = _desc(dst, type_dst)
+    if type_dst == B.Q8_0:            # uint8 rows of 34-byte blocks: extents in elements, nb[0] the block size
+        td.ne[0] = dst.shape[-1] // 34 * 32
+        td.nb[0] = 34
+    K.check(K.lib.mi355_set_rows(ts, ti, td, _stream()), "mi355_set_rows")
+    return dst

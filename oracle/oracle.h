@@ -26,12 +26,16 @@ enum {
     ORC_TYPE_F32  = 0,
     ORC_TYPE_F16  = 1,
     ORC_TYPE_Q4_0 = 2,
+    ORC_TYPE_Q4_1 = 3,
+    ORC_TYPE_Q5_0 = 6,
+    ORC_TYPE_Q5_1 = 7,
     ORC_TYPE_Q8_0 = 8,
     ORC_TYPE_Q8_1 = 9,
     ORC_TYPE_Q4_K = 12,
     ORC_TYPE_Q5_K = 13,
     ORC_TYPE_Q6_K = 14,
     ORC_TYPE_Q8_K = 15,
+    ORC_TYPE_BF16 = 30,
 };
 
 /* block geometry: elements per block / bytes per block (ggml/src/ggml-common.h:167-334) */

@@ -14,10 +14,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TBO = os.path.join(ROOT, "oracle", "_ref", "test-backend-ops")
 PLUGIN = os.path.join(ROOT, "llm_amd", "lib", "libggml-mi355.so")
 
-OPS = ["MUL_MAT", "MUL_MAT_ID", "FLASH_ATTN_EXT", "ADD", "MUL", "RMS_NORM", "ROPE", "REGLU", "GEGLU", "SWIGLU", "CPY", "CONT", "GET_ROWS",
-       "SCALE", "SOFT_MAX", "ARGSORT", "SUM_ROWS"]
+OPS = ["MUL_MAT", "MUL_MAT_ID", "FLASH_ATTN_EXT", "ADD", "MUL", "SUB", "DIV", "RMS_NORM", "ROPE", "REGLU", "GEGLU", "SWIGLU", "CPY", "CONT", "DUP",
+       "GET_ROWS", "SET_ROWS", "SCALE", "SOFT_MAX", "ARGSORT", "SUM_ROWS"]
 # lower bounds on the number of cases that must actually RUN on the device (not "not supported")
-MIN_RUN = {"MUL_MAT": 100, "MUL_MAT_ID": 100, "FLASH_ATTN_EXT": 1000, "ROPE": 50, "SOFT_MAX": 100}
+MIN_RUN = {"MUL_MAT": 600, "SET_ROWS": 50, "MUL_MAT_ID": 100, "FLASH_ATTN_EXT": 1000, "ROPE": 50, "SOFT_MAX": 100}
 
 
 def _run(op):
@@ -48,6 +48,26 @@ def test_llama_graph_end_to_end_has_no_cpu_compute_split():
     assert '"devices": "CPU, MI355_0"' in r.stdout
 
 
+@pytest.mark.parametrize("ftype", ["Q4_K_M", "F16"])
+def test_llama_graph_without_flash_attention_stays_on_the_device(ftype, tmp_path):
+    """`-fa 0`: K.Q and (softmax).V are MUL_MATs on f16 views of the KV cache (permuted, broadcast over the GQA heads) with a
+    SOFT_MAX between -- the float-weight MUL_MAT of SURVEY 8 f4.  No CPU compute split, logits close to ggml-cpu's."""
+    import numpy as np
+    tool = os.path.join(ROOT, "tools", "run_llama_bench.sh")
+    r = subprocess.run([tool, "tiny", ftype, "-fa", "0", "-p", "64", "-n", "8", "-r", "1"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "graph splits = 2" in r.stderr + r.stdout, (r.stderr + r.stdout)[-3000:]
+    outs = {}
+    for name, ngl in (("cpu", "0"), ("gpu", "99")):
+        path = str(tmp_path / f"nofa_logits_{name}.bin")
+        r = subprocess.run([tool, "tiny", ftype, "-fa", "0", "-ngl", ngl, "--dump-logits", path], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        outs[name] = np.fromfile(path, dtype=np.float32).reshape(10, -1)
+    a, b = outs["cpu"], outs["gpu"]
+    assert np.isfinite(b).all()
+    assert float(((a - b) ** 2).sum() / (a ** 2).sum()) < 2e-3
+
+
 def test_mixtral_style_graph_runs_entirely_on_the_device(tmp_path):
     """tiny random 8-expert llama GGUF (router MUL_MAT f32 -> SOFT_MAX -> ARGSORT/top-k -> GET_ROWS -> SUM_ROWS/DIV ->
     MUL_MAT_ID x3 -> weighted sum): no CPU compute split, and logits close to ggml-cpu's.  The routing is discrete: a
@@ -69,7 +89,7 @@ def test_mixtral_style_graph_runs_entirely_on_the_device(tmp_path):
     assert nmse < 5e-2, nmse
 
 
-@pytest.mark.parametrize("ftype,ctk", [("Q4_K_M", "f16"), ("Q8_0", "q8_0"), ("Q4_0", "f16")])
+@pytest.mark.parametrize("ftype,ctk", [("Q4_K_M", "f16"), ("Q8_0", "q8_0"), ("Q4_0", "f16"), ("Q4_1", "f16"), ("Q5_0", "f16"), ("Q5_1", "f16"), ("F16", "f16")])
 def test_llama_logits_match_ggml_cpu(ftype, ctk, tmp_path):
     """Whole-graph parity (covers the backend's fusions, which test-backend-ops cannot see): logits of a
     48-token prefill + 6 decode steps on MI355_0 vs the same model on the reference's ggml-cpu."""

@@ -35,6 +35,16 @@ def test_dequantize_bit_exact(src, t):
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
 
 
+@pytest.mark.parametrize("src", ["rand", "quant"])
+@pytest.mark.parametrize("t", O.WEIGHT_TYPES2)
+def test_dequantize2_bit_exact(src, t):
+    g = load_gold("dequantize2.gold")
+    tn = O.TYPE_NAMES[t]
+    want = g[f"{src}.deq.{tn}"]
+    got = O.dequantize_row(t, g[f"{src}.blocks.{tn}"], want.size)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
 def test_fp16_roundtrip_all_values():
     # every finite half: to_fp32 then back is the identity; also spot-check RNE on midpoints
     import ctypes as C
@@ -67,6 +77,25 @@ def test_mul_mat_vs_ggml_cpu(tag):
     # the q8_1 contract (what the GPU path computes) sits well inside test-backend-ops' 5e-4
     got81 = O.mul_mat(t, g["w." + tag], g["x." + tag], m, k, n, "q8_1")
     assert O.nmse(want, got81) < 2e-4
+
+
+def _mm2_cases():
+    g = load_gold("mul_mat2.gold")
+    return [k[len("shape."):] for k in g if k.startswith("shape.")]
+
+
+@pytest.mark.parametrize("tag", _mm2_cases())
+def test_mul_mat2_vs_ggml_cpu(tag):
+    """q4_1 / q5_0 / q5_1 and float (f16 / bf16 / f32) weights: the restatement of ggml-cpu's path (activations converted
+    to the weight's vec_dot_type, generic vec_dot) against the ggml-cpu backend's own output."""
+    g = load_gold("mul_mat2.gold")
+    t, m, k, n = (int(x) for x in g["shape." + tag])
+    want = g["dst." + tag].reshape(n, m)
+    got = O.mul_mat(t, g["w." + tag], g["x." + tag], m, k, n, "cpu")
+    assert O.nmse(want, got) < 1e-6
+    if t in O.WEIGHT_TYPES2:
+        got81 = O.mul_mat(t, g["w." + tag], g["x." + tag], m, k, n, "q8_1")
+        assert O.nmse(want, got81) < 2e-4
 
 
 def _mmid_cases():

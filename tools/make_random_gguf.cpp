@@ -4,7 +4,7 @@
 // src/llama-model.cpp:447-596; type map per src/llama-quant.cpp:178-404; tokenizer "no_vocab"
 // (src/llama-vocab.cpp:1383-1403).  Weights are random *valid* blocks (random quants, finite fp16
 // scales), norms are 1.0.
-//   make-random-gguf <out.gguf> <8b|70b|8x7b|tiny|tinymoe> [Q4_K_M|Q8_0|Q4_0]
+//   make-random-gguf <out.gguf> <8b|70b|8x7b|tiny|tinymoe> [Q4_K_M|Q8_0|Q4_0|Q4_1|Q5_0|Q5_1|F16]
 // 8x7b / tinymoe are Mixtral-style (llama architecture with 8 experts, 2 used): ffn_gate_inp f32, ffn_*_exps 3-D;
 // Q4_K_M for 8 experts bumps attn_k / attn_v to Q8_0 and attn_output to Q5_K (llama-quant.cpp:300-311,370-378).
 #include "ggml.h"
@@ -28,6 +28,11 @@ static void fill_blocks(ggml_tensor * t) {
     uint64_t * p = (uint64_t *)t->data;
     for (size_t i = 0; i < nbytes / 8; i++) p[i] = rnd();
     for (size_t i = nbytes / 8 * 8; i < nbytes; i++) ((uint8_t *)t->data)[i] = (uint8_t)rnd();
+    if (t->type == GGML_TYPE_F16) {           // an unquantized model: uniform in +-0.02
+        ggml_fp16_t * h = (ggml_fp16_t *)t->data;
+        for (size_t i = 0; i < nbytes / 2; i++) h[i] = ggml_fp32_to_fp16(((float)(rnd() >> 40) * (1.0f / 16777216.0f) - 0.5f) * 0.04f);
+        return;
+    }
     const size_t ts = ggml_type_size(t->type), nb = nbytes / ts;
     auto put_half = [&](uint8_t * at, float lo, float hi, bool sign) {
         float f = lo + (hi - lo) * (float)(rnd() >> 40) * (1.0f / 16777216.0f);
@@ -39,6 +44,9 @@ static void fill_blocks(ggml_tensor * t) {
         uint8_t * blk = (uint8_t *)t->data + b * ts;
         switch (t->type) {
             case GGML_TYPE_Q4_0: put_half(blk, 0.01f, 0.05f, true); break;
+            case GGML_TYPE_Q5_0: put_half(blk, 0.005f, 0.025f, true); break;
+            case GGML_TYPE_Q4_1: put_half(blk, 0.003f, 0.006f, false); put_half(blk + 2, -0.045f, -0.02f, false); break;   // values centred on 0
+            case GGML_TYPE_Q5_1: put_half(blk, 0.0015f, 0.003f, false); put_half(blk + 2, -0.045f, -0.02f, false); break;
             case GGML_TYPE_Q8_0: put_half(blk, 0.001f, 0.005f, true); break;
             case GGML_TYPE_Q4_K: case GGML_TYPE_Q5_K:
                 put_half(blk, 0.0002f, 0.0008f, false); put_half(blk + 2, 0.0002f, 0.0008f, false); break;
@@ -49,7 +57,7 @@ static void fill_blocks(ggml_tensor * t) {
 }
 
 int main(int argc, char ** argv) {
-    if (argc < 3) { fprintf(stderr, "usage: %s out.gguf 8b|70b|8x7b|tiny|tinymoe [Q4_K_M|Q8_0|Q4_0]\n", argv[0]); return 2; }
+    if (argc < 3) { fprintf(stderr, "usage: %s out.gguf 8b|70b|8x7b|tiny|tinymoe [Q4_K_M|Q8_0|Q4_0|Q4_1|Q5_0|Q5_1|F16]\n", argv[0]); return 2; }
     const std::string out = argv[1], model = argv[2], ftype = argc > 3 ? argv[3] : "Q4_K_M";
     Dims d;
     if (model == "8b")        d = {4096, 32, 32, 8, 14336, 128256, false};
@@ -58,13 +66,14 @@ int main(int argc, char ** argv) {
     else if (model == "8x7b")    { d = {4096, 32, 32, 8, 14336, 32000, false}; d.n_expert = 8; d.n_expert_used = 2; }
     else if (model == "tinymoe") { d = {1024, 4, 8, 2, 2816, 32000, false};    d.n_expert = 8; d.n_expert_used = 2; }
     else { fprintf(stderr, "unknown model %s\n", model.c_str()); return 2; }
-    const ggml_type base = ftype == "Q8_0" ? GGML_TYPE_Q8_0 : ftype == "Q4_0" ? GGML_TYPE_Q4_0 : GGML_TYPE_Q4_K;
+    const ggml_type base = ftype == "Q8_0" ? GGML_TYPE_Q8_0 : ftype == "Q4_0" ? GGML_TYPE_Q4_0 : ftype == "Q4_1" ? GGML_TYPE_Q4_1 :
+                           ftype == "Q5_0" ? GGML_TYPE_Q5_0 : ftype == "Q5_1" ? GGML_TYPE_Q5_1 : ftype == "F16" ? GGML_TYPE_F16 : GGML_TYPE_Q4_K;
     const bool km = ftype == "Q4_K_M";
     const int head_dim = d.n_embd / d.n_head, kv_dim = head_dim * d.n_head_kv;
 
     // size the context: every tensor lives in it until the file is written
     size_t total = 0;
-    auto rs = [&](ggml_type t, int64_t k, int64_t m) { return ggml_row_size(t, k) * m + 1024; };
+    auto rs = [&](ggml_type, int64_t k, int64_t m) { return ggml_row_size(GGML_TYPE_F16, k) * m + 1024; };   // upper bound over the ftypes
     total += rs(GGML_TYPE_Q8_0, d.n_embd, d.n_vocab) * 2;   // upper bound over the ftypes (token_embd + output)
     for (int i = 0; i < d.n_layer; i++)
         total += rs(GGML_TYPE_Q8_0, d.n_embd, d.n_embd) * 2 + rs(GGML_TYPE_Q8_0, d.n_embd, kv_dim) * 2 + rs(GGML_TYPE_Q8_0, d.n_embd, d.n_ff) * 2 +
@@ -87,7 +96,8 @@ int main(int argc, char ** argv) {
     gguf_set_val_u32(g, "llama.rope.dimension_count", head_dim);
     gguf_set_val_f32(g, "llama.rope.freq_base", 500000.0f);
     gguf_set_val_u32(g, "llama.vocab_size", d.n_vocab);
-    gguf_set_val_u32(g, "general.file_type", km ? 15 : (base == GGML_TYPE_Q8_0 ? 7 : 2));
+    gguf_set_val_u32(g, "general.file_type", km ? 15 : base == GGML_TYPE_Q8_0 ? 7 : base == GGML_TYPE_F16 ? 1 : base == GGML_TYPE_Q4_1 ? 3 :
+                                               base == GGML_TYPE_Q5_0 ? 8 : base == GGML_TYPE_Q5_1 ? 9 : 2);
     gguf_set_val_str(g, "tokenizer.ggml.model", "no_vocab");
     if (d.n_expert) {
         gguf_set_val_u32(g, "llama.expert_count", d.n_expert);
