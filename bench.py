@@ -106,24 +106,39 @@ def cpu_baseline(threads):
 
 def end_to_end(budget_s):
     """BASELINE.json's other half of the metric: llama-bench's tg128 / pp512 for a random-weight Llama-3-8B Q4_K_M GGUF
-    through the reference's libllama (oracle/_ref, built from its sources) with this plugin as the GPU backend
-    (tools/llama_bench_driver.cpp follows llama-bench.cpp:1747-1795).  Run as a child process within a time budget."""
-    tool = os.path.join(ROOT, "tools", "run_llama_bench.sh")
-    need = [os.path.join(ROOT, "oracle", "_ref", x) for x in ("mi355-llama-bench", "make-random-gguf", "libllama.so")]
-    need.append(os.path.join(ROOT, "llm_amd", "lib", "libggml-mi355.so"))
+    through the reference's libllama (oracle/_ref, built from its sources) with this plugin as the GPU backend.  The
+    harness is the reference's own llama-bench (tools/llama-bench/llama-bench.cpp, compiled unmodified by `make -C oracle
+    tools`) when it is built, else tools/llama_bench_driver.cpp (same method, llama-bench.cpp:1747-1795).  Run as a child
+    process within a time budget."""
+    ref = os.path.join(ROOT, "oracle", "_ref")
+    plugin = os.path.join(ROOT, "llm_amd", "lib", "libggml-mi355.so")
+    stock = os.path.exists(os.path.join(ref, "llama-bench"))
+    need = [os.path.join(ref, x) for x in ("llama-bench" if stock else "mi355-llama-bench", "make-random-gguf", "libllama.so")] + [plugin]
     missing = [os.path.relpath(x, ROOT) for x in need if not os.path.exists(x)]
     if missing:
         return {"error": "not built: " + ", ".join(missing)}
     t0 = time.perf_counter()
+    gguf = "/tmp/random-8b-Q4_K_M.gguf"
     try:
-        r = subprocess.run([tool, "8b", "Q4_K_M", "-p", "512", "-n", "128", "-r", "3"], capture_output=True, text=True, timeout=budget_s)
-        line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
-        j = json.loads(line)
+        if not os.path.exists(gguf):
+            subprocess.run([os.path.join(ref, "make-random-gguf"), gguf, "8b", "Q4_K_M"], check=True, capture_output=True, timeout=budget_s)
+        if stock:
+            r = subprocess.run([os.path.join(ref, "llama-bench"), "-m", gguf, "-ngl", "99", "-fa", "1", "-p", "512", "-n", "128", "-r", "3", "-o", "json"],
+                               capture_output=True, text=True, timeout=budget_s, env=dict(os.environ, GGML_BACKEND_PATH=plugin))
+            rows = json.loads(r.stdout)
+            pp = [x for x in rows if x["n_prompt"] == 512 and x["n_gen"] == 0][0]
+            tg = [x for x in rows if x["n_gen"] == 128 and x["n_prompt"] == 0][0]
+            j = {"devices": tg["gpu_info"], "tg_avg_ts": tg["avg_ts"], "tg_stddev_ts": tg["stddev_ts"], "pp_avg_ts": pp["avg_ts"], "pp_stddev_ts": pp["stddev_ts"]}
+        else:
+            r = subprocess.run([os.path.join(ROOT, "tools", "run_llama_bench.sh"), "8b", "Q4_K_M", "-p", "512", "-n", "128", "-r", "3"],
+                               capture_output=True, text=True, timeout=budget_s)
+            j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     except Exception as e:  # noqa: BLE001
         return {"error": f"{type(e).__name__}: {e}"[:300]}
     bytes_per_token = 4.616e9       # weights streamed per decode token (SURVEY 8d)
     return {"model": "Llama-3-8B Q4_K_M, random-init GGUF (tools/make_random_gguf.cpp), f16 KV, flash attention", "harness":
-            "reference libllama + plugin via GGML_BACKEND_PATH, llama-bench method (3 reps)", "devices": j.get("devices"),
+            ("the reference's llama-bench (unmodified, oracle/_ref/llama-bench)" if stock else "tools/llama_bench_driver.cpp (llama-bench's method)") +
+            " + reference libllama + plugin via GGML_BACKEND_PATH, 3 reps", "devices": j.get("devices"),
             "tg128_tps": round(j["tg_avg_ts"], 1), "tg128_stddev": round(j["tg_stddev_ts"], 1),
             "pp512_tps": round(j["pp_avg_ts"], 1), "pp512_stddev": round(j["pp_stddev_ts"], 1),
             "tg128_frac_of_hbm_bound": round(j["tg_avg_ts"] * bytes_per_token / (HBM_PEAK_GBPS * 1e9), 4),

@@ -4,7 +4,7 @@
 // src/llama-model.cpp:447-596; type map per src/llama-quant.cpp:178-404; tokenizer "no_vocab"
 // (src/llama-vocab.cpp:1383-1403).  Weights are random *valid* blocks (random quants, finite fp16
 // scales), norms are 1.0.
-//   make-random-gguf <out.gguf> <8b|70b|8x7b|tiny|tinymoe> [Q4_K_M|Q8_0|Q4_0|Q4_1|Q5_0|Q5_1|F16]
+//   make-random-gguf <out.gguf> <8b|70b|8x7b|tiny|tinymoe> [Q4_K_M|Q8_0|Q4_0|Q4_1|Q5_0|Q5_1|F16] [vocab.gguf]
 // 8x7b / tinymoe are Mixtral-style (llama architecture with 8 experts, 2 used): ffn_gate_inp f32, ffn_*_exps 3-D;
 // Q4_K_M for 8 experts bumps attn_k / attn_v to Q8_0 and attn_output to Q5_K (llama-quant.cpp:300-311,370-378).
 #include "ggml.h"
@@ -57,8 +57,11 @@ static void fill_blocks(ggml_tensor * t) {
 }
 
 int main(int argc, char ** argv) {
-    if (argc < 3) { fprintf(stderr, "usage: %s out.gguf 8b|70b|8x7b|tiny|tinymoe [Q4_K_M|Q8_0|Q4_0|Q4_1|Q5_0|Q5_1|F16]\n", argv[0]); return 2; }
+    if (argc < 3) { fprintf(stderr, "usage: %s out.gguf 8b|70b|8x7b|tiny|tinymoe [Q4_K_M|Q8_0|Q4_0|Q4_1|Q5_0|Q5_1|F16] [vocab.gguf]\n", argv[0]); return 2; }
     const std::string out = argv[1], model = argv[2], ftype = argc > 3 ? argv[3] : "Q4_K_M";
+    // optional 4th argument: a vocabulary-only GGUF (the reference keeps some for its tokenizer tests, models/ggml-vocab-*.gguf)
+    // whose tokenizer.* metadata is copied, so that tools which tokenize text (llama-cli) can run the random model
+    const char * vocab_path = argc > 4 ? argv[4] : nullptr;
     Dims d;
     if (model == "8b")        d = {4096, 32, 32, 8, 14336, 128256, false};
     else if (model == "70b")  d = {8192, 80, 64, 8, 28672, 128256, true};
@@ -83,6 +86,17 @@ int main(int argc, char ** argv) {
     ggml_context * ctx = ggml_init(ip);
     if (!ctx) { fprintf(stderr, "ggml_init failed (%zu bytes)\n", total); return 1; }
     gguf_context * g = gguf_init_empty();
+    uint32_t vocab_n = 0;
+    if (vocab_path) {
+        gguf_init_params vp = {true, nullptr};
+        gguf_context * gv = gguf_init_from_file(vocab_path, vp);
+        if (!gv) { fprintf(stderr, "cannot read %s\n", vocab_path); return 1; }
+        gguf_set_kv(g, gv);            // everything; the model keys below overwrite what they name
+        const int64_t kt = gguf_find_key(gv, "tokenizer.ggml.tokens");
+        if (kt >= 0) vocab_n = (uint32_t)gguf_get_arr_n(gv, kt);
+        gguf_free(gv);
+        if (vocab_n) d.n_vocab = (int)vocab_n;
+    }
 
     gguf_set_val_str(g, "general.architecture", "llama");
     gguf_set_val_str(g, "general.name", ("random-llama-" + model + "-" + ftype).c_str());
@@ -98,7 +112,7 @@ int main(int argc, char ** argv) {
     gguf_set_val_u32(g, "llama.vocab_size", d.n_vocab);
     gguf_set_val_u32(g, "general.file_type", km ? 15 : base == GGML_TYPE_Q8_0 ? 7 : base == GGML_TYPE_F16 ? 1 : base == GGML_TYPE_Q4_1 ? 3 :
                                                base == GGML_TYPE_Q5_0 ? 8 : base == GGML_TYPE_Q5_1 ? 9 : 2);
-    gguf_set_val_str(g, "tokenizer.ggml.model", "no_vocab");
+    if (!vocab_path) gguf_set_val_str(g, "tokenizer.ggml.model", "no_vocab");
     if (d.n_expert) {
         gguf_set_val_u32(g, "llama.expert_count", d.n_expert);
         gguf_set_val_u32(g, "llama.expert_used_count", d.n_expert_used);
