@@ -125,7 +125,10 @@ def test_mmvq_vs_oracle_contract(ops, t, m, k, n):
 
 
 @pytest.mark.parametrize("t,m,k", [(B.Q4_K, 4096, 4096), (B.Q4_K, 1024, 14336), (B.Q6_K, 2048, 4096), (B.Q4_0, 4096, 4096),
-                                   (B.Q8_0, 1024, 4096), (B.Q5_K, 1024, 8192)])
+                                   (B.Q8_0, 1024, 4096), (B.Q5_K, 1024, 8192),
+                                   # Llama-3-70B (SURVEY config 4): wq / wo, gate / up, down, wv in its three types
+                                   (B.Q4_K, 8192, 8192), (B.Q4_K, 28672, 8192), (B.Q4_K, 8192, 28672), (B.Q6_K, 8192, 28672),
+                                   (B.Q6_K, 1024, 8192), (B.Q6_K, 128256, 4096)])
 def test_mmvq_model_shapes_linearity(ops, t, m, k):
     # full-size property check: mat-vec is linear in x up to the activation quantization, so
     # compare against the oracle on a row subset and check W.(2x) == 2 W.x exactly (q8_1 scales by 2)
@@ -685,7 +688,8 @@ def test_flash_attn_f16_vs_f64_oracle(ops, d, nh, nhkv, nq, nkv, causal):
 
 
 @pytest.mark.parametrize("tkv", [B.Q8_0, B.Q4_0])
-@pytest.mark.parametrize("d,nh,nhkv,nq,nkv", [(128, 8, 2, 96, 200), (64, 4, 4, 33, 130), (128, 8, 2, 3, 300), (128, 32, 8, 1, 17000)])
+@pytest.mark.parametrize("d,nh,nhkv,nq,nkv", [(128, 8, 2, 96, 200), (64, 4, 4, 33, 130), (128, 8, 2, 3, 300), (128, 32, 8, 1, 17000),
+                                              (128, 8, 2, 512, 2048)])      # SURVEY config 3: a 512-token ubatch at n_kv 2048 (GQA 4)
 def test_flash_attn_quantized_kv_vs_f64_oracle(ops, tkv, d, nh, nhkv, nq, nkv):
     """q8_0 / q4_0 KV cache: the tile kernel dequantizes K/V blocks to f16 while staging (n_q >= 32), the vec
     kernel in registers (decode); both vs the oracle's f64 evaluation on the same quantized rows."""
