@@ -24,7 +24,7 @@
 
 namespace {
 
-constexpr int BN = 128, BK = 64;   // BM (weight rows per workgroup) is a template parameter: 128, or 64 when M is small
+constexpr int BN = 128, BK = 64;   // BM (weight rows per workgroup) is a template parameter: 128, or 64 when M is small; BN the default column tile
 constexpr int PITCH = BK * 2 + 16;   // bytes per LDS row
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -41,6 +41,7 @@ struct DArgs {
     const int * tile_off;    // [n_expert + 1] first column tile of every expert
     int n_expert, n_used, act_ne1;
     int64_t w_expert_stride;
+    int dbg;                 // lab switch of mmdq_ws_kernel (MI355_MMDQ_DBG): 1 producers idle, 2 consumers idle
 };
 
 // 32 consecutive weights of one row, raw, as loaded from global memory
@@ -232,10 +233,13 @@ static __device__ __forceinline__ void store_bf16x32(uint8_t * dst, const float 
     }
 }
 
-template <int TYPE, int BM, bool IDS>
-__global__ void __launch_bounds__(BM == 256 ? 512 : 256)
+// BNT: activation columns per workgroup, 128 or -- with 128 weight rows and 8 waves -- 256: every weight of the tile is
+// dequantized once per BNT columns, so the wide tile halves the dequantization work per flop (the loop's limiter).
+template <int TYPE, int BM, bool IDS, int BNT = 128>
+__global__ void __launch_bounds__(BM == 256 || BNT == 256 ? 512 : 256)
 mmdq_kernel(const DArgs a) {
-    constexpr int NT = BM == 256 ? 512 : 256;                  // threads: 8 waves for the 256-row tile, else 4
+    constexpr int BN = BNT;
+    constexpr int NT = BM == 256 || BNT == 256 ? 512 : 256;    // threads: 8 waves for the 256-row and the 256-column tile, else 4
     constexpr int WAVES_M = BM / 64, WAVES_N = NT / 64 / WAVES_M; // every wave owns 64 weight rows x (BN / WAVES_N) columns
     constexpr int TN = BN / WAVES_N / 32;                      // 32-column MFMA tiles per wave: 1 (BM 64) or 2 (BM 128, 256)
     __shared__ __attribute__((aligned(16))) uint8_t Lw[2][BM * PITCH];
@@ -352,6 +356,153 @@ mmdq_kernel(const DArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Role-split form of the 128 x 256 tile (768 threads).  In mmdq_kernel every wave first dequantizes its share of the next
+// stage (VALU) and then issues its MFMAs, all in step between two barriers -- so the matrix pipe idles while the vector
+// pipe works and the other way round (SQ counters on 14336 x 4096 x 512: MFMA busy 31 %, waves parked 39 %).  Here
+//   * waves 0..7 multiply: a wave owns 64 x 64 of the tile (2 x 2 MFMA tiles), two such waves per SIMD cover each other's
+//     LDS latency;
+//   * waves 8..11 dequantize: 256 threads x 32 weights per stage (load, dequantize, round to bf16, write LDS), fetching two
+//     stages ahead in a register ring -- they hold no accumulators, so the registers are there;
+//   * the activation tile (bf16, a plain copy: 36 KB per stage, two thirds of the LDS writes and of the load instructions of
+//     the uniform kernel) goes global -> LDS by DMA (global_load_lds_dwordx4: no registers, no VALU, no ds_write), issued
+//     by the multiplying waves two stages ahead into a ring of three buffers.  A row of the LDS image is 8 chunks of data and
+//     one of padding (144-byte pitch), so of the 64 lanes of a 1 KiB piece every ninth is masked off.
+// Same arithmetic and per-element summation order as mmdq_kernel (K ascending in steps of 16): bit-identical results.
+// Columns past n are not zero-filled (the DMA cannot): they read a valid column and their products are never stored.
+// ------------------------------------------------------------------------------------------------
+static __device__ __forceinline__ void gemm_dma_piece(const void * gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+template <int TYPE>
+__global__ void __launch_bounds__(768)
+mmdq_ws_kernel(const DArgs a) {
+    constexpr int BMW = 128, BNW = 256, NPIECE = BNW * PITCH / 1024;          // 36 pieces of 1 KiB per activation stage
+    static_assert(BNW * PITCH % 1024 == 0 && (NPIECE + 7) / 8 <= BK / 16 + 1, "whole pieces; at most one per k-step plus one");
+    __shared__ __attribute__((aligned(1024))) uint8_t La[3][BNW * PITCH];
+    __shared__ __attribute__((aligned(16))) uint8_t Lw[2][BMW * PITCH];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n0 = blockIdx.x * BNW, m0 = blockIdx.y * BMW;
+    const int nstage = a.k / BK;
+
+    if (wave >= 8) {                                                  // ---- dequantizing waves
+        const int pt = tid - 512, sr = pt >> 1, hf = pt & 1;          // weight row sr of the tile, 32-value half hf of the stage
+        const int wr = m0 + sr < a.m ? m0 + sr : a.m - 1;
+        const uint8_t * wrow = a.W + (int64_t)wr * a.w_row_stride;
+        constexpr int PFD = 2;
+        Raw<TYPE> wraw[PFD];
+#pragma unroll
+        for (int j = 0; j < PFD; j++) if (j < nstage) wraw[j] = load_raw<TYPE>(wrow, j * BK + hf * 32);
+        auto stash = [&](int slot, int k, int buf) {
+            float f[32];
+            dequant32<TYPE>(wraw[slot], k + hf * 32, f);
+            store_bf16x32(Lw[buf] + sr * PITCH + hf * 64, f);
+        };
+        stash(0, 0, 0);
+        if (PFD < nstage) wraw[0] = load_raw<TYPE>(wrow, PFD * BK + hf * 32);
+        __syncthreads();
+        for (int st0 = 0; st0 < nstage; st0 += PFD) {
+#pragma unroll
+            for (int j = 0; j < PFD; j++) {
+                const int st = st0 + j;                   // the others multiply stage st; this writes stage st + 1 (slot (j + 1) % PFD)
+                if (st < nstage) {
+                    if (st + 1 < nstage && !(a.dbg & 1)) {
+                        stash((j + 1) % PFD, (st + 1) * BK, (st + 1) & 1);
+                        if (st + 1 + PFD < nstage) wraw[(j + 1) % PFD] = load_raw<TYPE>(wrow, (st + 1 + PFD) * BK + hf * 32);
+                    }
+                    __syncthreads();
+                }
+            }
+        }
+        return;
+    }
+
+    // ---- multiplying waves; they also move the activation tile
+    const int wm_ = wave & 1, wn_ = wave >> 1;              // 64 weight rows x 64 columns of the tile
+    const int lr = lane & 31, lh = lane >> 5;
+    // this wave's pieces of a stage's activation image: piece p = wave + 8 i; lane l copies chunk c = 64 p + l: row c / 9,
+    // 16-byte chunk c % 9 of its 144-byte pitch (chunk 8 is padding: lane off)
+    constexpr int MAXP = (NPIECE + 7) / 8;
+    const uint16_t * src[MAXP];
+    bool on[MAXP];
+#pragma unroll
+    for (int i = 0; i < MAXP; i++) {
+        const int p = wave + 8 * i, c = 64 * p + lane, r = (c * 7282) >> 16, j = c - 9 * r;
+        const int col = n0 + r < a.n ? n0 + r : a.n - 1;
+        on[i]  = p < NPIECE && j < 8;
+        src[i] = a.x + (int64_t)col * a.x_row_stride + j * 8;
+    }
+    const unsigned la0 = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) uint8_t *)&La[0][0];
+    auto dma_piece_i = [&](int st, int i) {                 // piece wave + 8 i of stage st -> La[st % 3]
+        if (i < MAXP && wave + 8 * i < NPIECE) {            // wave-uniform
+            const unsigned base = la0 + (unsigned)(st % 3) * (BNW * PITCH);
+            if (on[i]) gemm_dma_piece(src[i] + (int64_t)st * BK, __builtin_amdgcn_readfirstlane(base + (unsigned)(wave + 8 * i) * 1024));
+        }
+    };
+    auto dma_stage = [&](int st) {
+#pragma unroll
+        for (int i = 0; i < MAXP; i++) dma_piece_i(st, i);
+    };
+    v16f acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
+    dma_stage(0);
+    if (nstage > 1) dma_stage(1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    constexpr int KS = BK / 16;
+    for (int st = 0; st < nstage; st++) {
+        const uint8_t * lw = Lw[st & 1], * la = La[st % 3];
+        const bool more = st + 2 < nstage && !(a.dbg & 4);  // stage st + 2 goes out now; its buffer was last read in stage st - 1
+        bf16x8 af[2][2], wf[2][2];                          // fragments of k-step ks in set ks & 1: the next step's are read before this step's MFMAs
+        auto frags = [&](int ks, int set) {
+#pragma unroll
+            for (int t = 0; t < 2; t++) wf[set][t] = *(const bf16x8 *)(lw + (wm_ * 64 + t * 32 + lr) * PITCH + ks * 32 + lh * 16);
+#pragma unroll
+            for (int t = 0; t < 2; t++) af[set][t] = *(const bf16x8 *)(la + (wn_ * 64 + t * 32 + lr) * PITCH + ks * 32 + lh * 16);
+        };
+        if (!(a.dbg & 2)) frags(0, 0);
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) {
+            if (a.dbg & 2) { if (more) { dma_piece_i(st + 2, ks); if (ks == 0) dma_piece_i(st + 2, KS); } continue; }
+            if (ks + 1 < KS) frags(ks + 1, (ks + 1) & 1);
+#pragma unroll
+            for (int tm = 0; tm < 2; tm++)
+#pragma unroll
+                for (int tn = 0; tn < 2; tn++)
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & 1][tn], wf[ks & 1][tm], acc[tm][tn], 0, 0, 0);
+            // the DMA requests ride behind the MFMAs just issued (one piece per k-step, the fifth with the first)
+            if (more) { dma_piece_i(st + 2, ks); if (ks == 0) dma_piece_i(st + 2, KS); }
+        }
+        // stage st + 1 was requested a whole stage ago; what this iteration requested (stage st + 2) may stay in flight
+        if (st + 2 < nstage) {
+            if (wave + 8 * (MAXP - 1) < NPIECE) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(MAXP) : "memory");
+            else                                asm volatile("s_waitcnt vmcnt(%0)" :: "n"(MAXP - 1) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int tm = 0; tm < 2; tm++) {
+        const int m = m0 + wm_ * 64 + tm * 32 + lr;
+#pragma unroll
+        for (int tn = 0; tn < 2; tn++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int n = n0 + wn_ * 64 + tn * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (m < a.m && n < a.n) a.dst[(int64_t)n * a.dst_col_stride + m] = acc[tm][tn][r];
+            }
+    }
+}
+
 // f32 (4-D, strided rows) -> bf16 [rows][k], round to nearest even; one lane per 8 values
 __global__ void __launch_bounds__(256)
 act_bf16_kernel(const char * x, uint16_t * y, int k, int ne1, int ne2, int64_t nb1, int64_t nb2, int64_t nb3) {
@@ -380,7 +531,13 @@ static int launch(const DArgs & a, int64_t m_total, hipStream_t s, const char * 
     const unsigned kz = !full_big && nb * ((m_total + 63) / 64) < 448 && a.k % (2 * BK) == 0 && a.k >= 1024 ? 2 : 1;
     // The loop is bound by the CU-side load path (~10 B/cycle/CU): every workgroup re-reads its activation tile, so
     // the bytes moved per flop fall with the tile height.  256-row tiles (8 waves) when they still cover the chip.
-    if (kz == 1 && nb * ((a.m + 255) / 256) >= 200) {
+    static const int wide = [] { const char * e = getenv("MI355_MMDQ_WIDE"); return e ? atoi(e) : 2; }();   // 0: 256 x 128 tile, 1: 128 x 256 uniform, 2: 128 x 256 role-split
+    const int64_t nb2 = (a.n + 255) / 256;
+    if (wide == 2 && kz == 1 && a.n >= 256 && nb2 * ((a.m + 127) / 128) >= 200 && ((uintptr_t)a.x & 15) == 0 && a.x_row_stride % 8 == 0) {
+        MI355_LAUNCH(tag, (mmdq_ws_kernel<TYPE>), dim3((unsigned)nb2, (unsigned)((a.m + 127) / 128)), dim3(768), 0, s, a);
+    } else if (wide && kz == 1 && a.n >= 256 && nb2 * ((a.m + 127) / 128) >= 200) {
+        MI355_LAUNCH(tag, (mmdq_kernel<TYPE, 128, false, 256>), dim3((unsigned)nb2, (unsigned)((a.m + 127) / 128)), dim3(512), 0, s, a);
+    } else if (kz == 1 && nb * ((a.m + 255) / 256) >= 200) {
         MI355_LAUNCH(tag, (mmdq_kernel<TYPE, 256, false>), dim3((unsigned)nb, (unsigned)((a.m + 255) / 256)), dim3(512), 0, s, a);
     } else if (kz == 1 && nb * ((a.m + 127) / 128) >= 384) {
         MI355_LAUNCH(tag, (mmdq_kernel<TYPE, 128, false>), dim3((unsigned)nb, (unsigned)((a.m + 127) / 128)), dim3(256), 0, s, a);
@@ -446,6 +603,7 @@ extern "C" int mi355_mul_mat_dq_slice(int type, const void * W, int64_t w_row_st
     a.W = (const uint8_t *)W; a.w_row_stride = w_row_stride; a.x = x; a.x_row_stride = x_row_stride;
     a.dst = dst; a.dst_col_stride = dst_col_stride; a.m = (int)m; a.n = (int)n; a.k = (int)k;
     a.sorted = a.off = a.tile_off = nullptr; a.n_expert = a.n_used = a.act_ne1 = 0; a.w_expert_stride = 0;
+    { static const int dbg = [] { const char * e = getenv("MI355_MMDQ_DBG"); return e ? atoi(e) : 0; }(); a.dbg = dbg; }
     hipStream_t s = (hipStream_t)stream;
     switch (type) {
         case MI355_TYPE_Q4_0: return launch<MI355_TYPE_Q4_0>(a, m_total, s, "mmdq_q4_0");
@@ -500,7 +658,7 @@ extern "C" int mi355_mul_mat_id_dq(int type, const void * as, int64_t w_row_stri
     a.W = (const uint8_t *)as; a.w_row_stride = w_row_stride; a.x = act; a.x_row_stride = k;
     a.dst = dst; a.dst_col_stride = m; a.m = (int)m; a.n = (int)(n_tokens * n_used); a.k = (int)k;
     a.sorted = sorted; a.off = off; a.tile_off = tile_off; a.n_expert = (int)n_expert; a.n_used = (int)n_used; a.act_ne1 = (int)b_ne1;
-    a.w_expert_stride = w_expert_stride;
+    a.w_expert_stride = w_expert_stride; a.dbg = 0;
     const int max_tiles = (int)((n_tokens * n_used + BN - 1) / BN + n_expert);   // sum over experts of ceil(cnt_e / BN) never exceeds this
     switch (type) {
         case MI355_TYPE_Q4_0: return launch_ids<MI355_TYPE_Q4_0>(a, max_tiles, s, "mmdq_id_q4_0");
