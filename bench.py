@@ -412,7 +412,7 @@ def main():
     traffic = None
     if world == 1 and not args.no_group:
         try:
-            tr = json.load(open(os.path.join(ROOT, "profiles", "r01_bench_traffic.json")))
+            tr = json.load(open(os.path.join(ROOT, "profiles", "r02_bench_traffic.json")))
             if tr["kernel"].startswith("mmvq_glu") == bool(fused_idx):
                 traffic = tr["traffic_bytes_per_launch"]
         except (OSError, KeyError, ValueError):

@@ -377,32 +377,40 @@ static __device__ __forceinline__ void gemm_dma_piece(const void * gsrc, unsigne
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 
-template <int TYPE>
-__global__ void __launch_bounds__(768)
+// BMW x BNW: 128 x 256 (8 multiplying waves of 64 x 64, 4 dequantizing; wide launches) or 64 x 128 (4 multiplying waves of
+// 64 x 32, 2 dequantizing; two workgroups per CU, with split-K for the launches of few tiles: gridDim.z == 2 adds the two
+// halves of K into a zeroed dst, exactly as mmdq_kernel does).
+template <int TYPE, int BMW, int BNW>
+__global__ void __launch_bounds__(BMW * BNW == 128 * 256 ? 768 : 384)
 mmdq_ws_kernel(const DArgs a) {
-    constexpr int BMW = 128, BNW = 256, NPIECE = BNW * PITCH / 1024;          // 36 pieces of 1 KiB per activation stage
-    static_assert(BNW * PITCH % 1024 == 0 && (NPIECE + 7) / 8 <= BK / 16 + 1, "whole pieces; at most one per k-step plus one");
+    constexpr int TN = BMW == 128 ? 2 : 1;                                    // 32-column MFMA tiles per multiplying wave
+    constexpr int WAVES_M = BMW / 64, NMW = WAVES_M * (BNW / (32 * TN));      // multiplying waves
+    constexpr int NPIECE = BNW * PITCH / 1024;                                // 1 KiB pieces per activation stage: 36 / 18
+    constexpr int MAXP = (NPIECE + NMW - 1) / NMW;
+    static_assert(BNW * PITCH % 1024 == 0 && MAXP <= BK / 16 + 1, "whole pieces; at most one per k-step plus one");
+    static_assert((BMW == 128 && BNW == 256) || (BMW == 64 && BNW == 128), "tile");
     __shared__ __attribute__((aligned(1024))) uint8_t La[3][BNW * PITCH];
     __shared__ __attribute__((aligned(16))) uint8_t Lw[2][BMW * PITCH];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n0 = blockIdx.x * BNW, m0 = blockIdx.y * BMW;
-    const int nstage = a.k / BK;
+    const int kspan = a.k / (int)gridDim.z, kbeg = (int)blockIdx.z * kspan;
+    const int nstage = kspan / BK;
 
-    if (wave >= 8) {                                                  // ---- dequantizing waves
-        const int pt = tid - 512, sr = pt >> 1, hf = pt & 1;          // weight row sr of the tile, 32-value half hf of the stage
+    if (wave >= NMW) {                                                // ---- dequantizing waves
+        const int pt = tid - 64 * NMW, sr = pt >> 1, hf = pt & 1;     // weight row sr of the tile, 32-value half hf of the stage
         const int wr = m0 + sr < a.m ? m0 + sr : a.m - 1;
         const uint8_t * wrow = a.W + (int64_t)wr * a.w_row_stride;
         constexpr int PFD = 2;
         Raw<TYPE> wraw[PFD];
 #pragma unroll
-        for (int j = 0; j < PFD; j++) if (j < nstage) wraw[j] = load_raw<TYPE>(wrow, j * BK + hf * 32);
-        auto stash = [&](int slot, int k, int buf) {
+        for (int j = 0; j < PFD; j++) if (j < nstage) wraw[j] = load_raw<TYPE>(wrow, kbeg + j * BK + hf * 32);
+        auto stash = [&](int slot, int st) {
             float f[32];
-            dequant32<TYPE>(wraw[slot], k + hf * 32, f);
-            store_bf16x32(Lw[buf] + sr * PITCH + hf * 64, f);
+            dequant32<TYPE>(wraw[slot], kbeg + st * BK + hf * 32, f);
+            store_bf16x32(Lw[st & 1] + sr * PITCH + hf * 64, f);
         };
-        stash(0, 0, 0);
-        if (PFD < nstage) wraw[0] = load_raw<TYPE>(wrow, PFD * BK + hf * 32);
+        stash(0, 0);
+        if (PFD < nstage) wraw[0] = load_raw<TYPE>(wrow, kbeg + PFD * BK + hf * 32);
         __syncthreads();
         for (int st0 = 0; st0 < nstage; st0 += PFD) {
 #pragma unroll
@@ -410,8 +418,8 @@ mmdq_ws_kernel(const DArgs a) {
                 const int st = st0 + j;                   // the others multiply stage st; this writes stage st + 1 (slot (j + 1) % PFD)
                 if (st < nstage) {
                     if (st + 1 < nstage && !(a.dbg & 1)) {
-                        stash((j + 1) % PFD, (st + 1) * BK, (st + 1) & 1);
-                        if (st + 1 + PFD < nstage) wraw[(j + 1) % PFD] = load_raw<TYPE>(wrow, (st + 1 + PFD) * BK + hf * 32);
+                        stash((j + 1) % PFD, st + 1);
+                        if (st + 1 + PFD < nstage) wraw[(j + 1) % PFD] = load_raw<TYPE>(wrow, kbeg + (st + 1 + PFD) * BK + hf * 32);
                     }
                     __syncthreads();
                 }
@@ -421,36 +429,35 @@ mmdq_ws_kernel(const DArgs a) {
     }
 
     // ---- multiplying waves; they also move the activation tile
-    const int wm_ = wave & 1, wn_ = wave >> 1;              // 64 weight rows x 64 columns of the tile
+    const int wm_ = wave % WAVES_M, wn_ = wave / WAVES_M;   // 64 weight rows x 32 TN columns of the tile
     const int lr = lane & 31, lh = lane >> 5;
-    // this wave's pieces of a stage's activation image: piece p = wave + 8 i; lane l copies chunk c = 64 p + l: row c / 9,
+    // this wave's pieces of a stage's activation image: piece p = wave + NMW i; lane l copies chunk c = 64 p + l: row c / 9,
     // 16-byte chunk c % 9 of its 144-byte pitch (chunk 8 is padding: lane off)
-    constexpr int MAXP = (NPIECE + 7) / 8;
     const uint16_t * src[MAXP];
     bool on[MAXP];
 #pragma unroll
     for (int i = 0; i < MAXP; i++) {
-        const int p = wave + 8 * i, c = 64 * p + lane, r = (c * 7282) >> 16, j = c - 9 * r;
+        const int p = wave + NMW * i, c = 64 * p + lane, r = (c * 7282) >> 16, j = c - 9 * r;
         const int col = n0 + r < a.n ? n0 + r : a.n - 1;
         on[i]  = p < NPIECE && j < 8;
-        src[i] = a.x + (int64_t)col * a.x_row_stride + j * 8;
+        src[i] = a.x + (int64_t)col * a.x_row_stride + kbeg + j * 8;
     }
     const unsigned la0 = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) uint8_t *)&La[0][0];
-    auto dma_piece_i = [&](int st, int i) {                 // piece wave + 8 i of stage st -> La[st % 3]
-        if (i < MAXP && wave + 8 * i < NPIECE) {            // wave-uniform
+    auto dma_piece_i = [&](int st, int i) {                 // piece wave + NMW i of stage st -> La[st % 3]
+        if (i < MAXP && wave + NMW * i < NPIECE) {          // wave-uniform
             const unsigned base = la0 + (unsigned)(st % 3) * (BNW * PITCH);
-            if (on[i]) gemm_dma_piece(src[i] + (int64_t)st * BK, __builtin_amdgcn_readfirstlane(base + (unsigned)(wave + 8 * i) * 1024));
+            if (on[i]) gemm_dma_piece(src[i] + (int64_t)st * BK, __builtin_amdgcn_readfirstlane(base + (unsigned)(wave + NMW * i) * 1024));
         }
     };
     auto dma_stage = [&](int st) {
 #pragma unroll
         for (int i = 0; i < MAXP; i++) dma_piece_i(st, i);
     };
-    v16f acc[2][2];
+    v16f acc[2][TN];
 #pragma unroll
     for (int i = 0; i < 2; i++)
 #pragma unroll
-        for (int j = 0; j < 2; j++)
+        for (int j = 0; j < TN; j++)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
     dma_stage(0);
@@ -461,12 +468,12 @@ mmdq_ws_kernel(const DArgs a) {
     for (int st = 0; st < nstage; st++) {
         const uint8_t * lw = Lw[st & 1], * la = La[st % 3];
         const bool more = st + 2 < nstage && !(a.dbg & 4);  // stage st + 2 goes out now; its buffer was last read in stage st - 1
-        bf16x8 af[2][2], wf[2][2];                          // fragments of k-step ks in set ks & 1: the next step's are read before this step's MFMAs
+        bf16x8 af[2][TN], wf[2][2];                         // fragments of k-step ks in set ks & 1: the next step's are read before this step's MFMAs
         auto frags = [&](int ks, int set) {
 #pragma unroll
-            for (int t = 0; t < 2; t++) wf[set][t] = *(const bf16x8 *)(lw + (wm_ * 64 + t * 32 + lr) * PITCH + ks * 32 + lh * 16);
+            for (int t = 0; t < 2; t++)  wf[set][t] = *(const bf16x8 *)(lw + (wm_ * 64 + t * 32 + lr) * PITCH + ks * 32 + lh * 16);
 #pragma unroll
-            for (int t = 0; t < 2; t++) af[set][t] = *(const bf16x8 *)(la + (wn_ * 64 + t * 32 + lr) * PITCH + ks * 32 + lh * 16);
+            for (int t = 0; t < TN; t++) af[set][t] = *(const bf16x8 *)(la + (wn_ * 32 * TN + t * 32 + lr) * PITCH + ks * 32 + lh * 16);
         };
         if (!(a.dbg & 2)) frags(0, 0);
 #pragma unroll
@@ -476,15 +483,15 @@ mmdq_ws_kernel(const DArgs a) {
 #pragma unroll
             for (int tm = 0; tm < 2; tm++)
 #pragma unroll
-                for (int tn = 0; tn < 2; tn++)
+                for (int tn = 0; tn < TN; tn++)
                     acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & 1][tn], wf[ks & 1][tm], acc[tm][tn], 0, 0, 0);
             // the DMA requests ride behind the MFMAs just issued (one piece per k-step, the fifth with the first)
             if (more) { dma_piece_i(st + 2, ks); if (ks == 0) dma_piece_i(st + 2, KS); }
         }
         // stage st + 1 was requested a whole stage ago; what this iteration requested (stage st + 2) may stay in flight
         if (st + 2 < nstage) {
-            if (wave + 8 * (MAXP - 1) < NPIECE) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(MAXP) : "memory");
-            else                                asm volatile("s_waitcnt vmcnt(%0)" :: "n"(MAXP - 1) : "memory");
+            if (wave + NMW * (MAXP - 1) < NPIECE) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(MAXP) : "memory");
+            else                                  asm volatile("s_waitcnt vmcnt(%0)" :: "n"(MAXP - 1) : "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -494,11 +501,15 @@ mmdq_ws_kernel(const DArgs a) {
     for (int tm = 0; tm < 2; tm++) {
         const int m = m0 + wm_ * 64 + tm * 32 + lr;
 #pragma unroll
-        for (int tn = 0; tn < 2; tn++)
+        for (int tn = 0; tn < TN; tn++)
 #pragma unroll
             for (int r = 0; r < 16; r++) {
-                const int n = n0 + wn_ * 64 + tn * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (m < a.m && n < a.n) a.dst[(int64_t)n * a.dst_col_stride + m] = acc[tm][tn][r];
+                const int n = n0 + wn_ * 32 * TN + tn * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (m < a.m && n < a.n) {
+                    float * o = a.dst + (int64_t)n * a.dst_col_stride + m;
+                    if (gridDim.z > 1) atomicAdd(o, acc[tm][tn][r]);   // two addends onto 0: the sum does not depend on the order
+                    else *o = acc[tm][tn][r];
+                }
             }
     }
 }
@@ -532,9 +543,11 @@ static int launch(const DArgs & a, int64_t m_total, hipStream_t s, const char * 
     // The loop is bound by the CU-side load path (~10 B/cycle/CU): every workgroup re-reads its activation tile, so
     // the bytes moved per flop fall with the tile height.  256-row tiles (8 waves) when they still cover the chip.
     static const int wide = [] { const char * e = getenv("MI355_MMDQ_WIDE"); return e ? atoi(e) : 2; }();   // 0: 256 x 128 tile, 1: 128 x 256 uniform, 2: 128 x 256 role-split
+    static const int small_ws = [] { const char * e = getenv("MI355_MMDQ_SMALL"); return e ? atoi(e) : 1; }();
     const int64_t nb2 = (a.n + 255) / 256;
-    if (wide == 2 && kz == 1 && a.n >= 256 && nb2 * ((a.m + 127) / 128) >= 200 && ((uintptr_t)a.x & 15) == 0 && a.x_row_stride % 8 == 0) {
-        MI355_LAUNCH(tag, (mmdq_ws_kernel<TYPE>), dim3((unsigned)nb2, (unsigned)((a.m + 127) / 128)), dim3(768), 0, s, a);
+    const bool dma_ok = ((uintptr_t)a.x & 15) == 0 && a.x_row_stride % 8 == 0;      // 16-byte chunks of the activation rows
+    if (wide == 2 && kz == 1 && a.n >= 256 && nb2 * ((a.m + 127) / 128) >= 200 && dma_ok) {
+        MI355_LAUNCH(tag, (mmdq_ws_kernel<TYPE, 128, 256>), dim3((unsigned)nb2, (unsigned)((a.m + 127) / 128)), dim3(768), 0, s, a);
     } else if (wide && kz == 1 && a.n >= 256 && nb2 * ((a.m + 127) / 128) >= 200) {
         MI355_LAUNCH(tag, (mmdq_kernel<TYPE, 128, false, 256>), dim3((unsigned)nb2, (unsigned)((a.m + 127) / 128)), dim3(512), 0, s, a);
     } else if (kz == 1 && nb * ((a.m + 255) / 256) >= 200) {
@@ -548,7 +561,12 @@ static int launch(const DArgs & a, int64_t m_total, hipStream_t s, const char * 
                 : hipMemset2DAsync(a.dst, (size_t)a.dst_col_stride * sizeof(float), 0, (size_t)a.m * sizeof(float), (size_t)a.n, s);
             if (e != hipSuccess) return (int)e;
         }
-        MI355_LAUNCH(tag, (mmdq_kernel<TYPE, 64, false>), dim3((unsigned)nb, (unsigned)((a.m + 63) / 64), kz), dim3(256), 0, s, a);
+        // role-split 64 x 128 tiles where the launch cannot fill the chip anyway (<= one workgroup per CU: M = 1024 at N = 512 runs
+        // 25 us instead of 32); with two resident workgroups per CU the uniform kernel's waves cover each other better (M = 4096: 51 vs 56 us)
+        if (wide == 2 && dma_ok && (small_ws == 2 || (small_ws == 1 && nb * ((a.m + 63) / 64) * kz <= 256)))
+            MI355_LAUNCH(tag, (mmdq_ws_kernel<TYPE, 64, 128>), dim3((unsigned)nb, (unsigned)((a.m + 63) / 64), kz), dim3(384), 0, s, a);
+        else
+            MI355_LAUNCH(tag, (mmdq_kernel<TYPE, 64, false>), dim3((unsigned)nb, (unsigned)((a.m + 63) / 64), kz), dim3(256), 0, s, a);
     }
     MI355_CHECK_LAUNCH();
     return MI355_OK;
