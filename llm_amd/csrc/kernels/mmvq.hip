@@ -24,6 +24,10 @@
 //     d8 * dW_j * sum((qW - off)*q8)                     (q4_0: off 8, q6_K: off 32, q8_0: off 0)
 // i.e. exactly dequant(W) . dequant_q8_1(x) up to f32 summation order.
 #include "common.h"
+#include <algorithm>
+#include <mutex>
+#include <set>
+#include <utility>
 #include "rope.h"
 #include <stdlib.h>
 #include <string>
@@ -658,12 +662,35 @@ static bool dma_enabled(int which) {
     static const int mask = [] { const char * e = getenv("MI355_DMA_MASK"); return e ? atoi(e) : (DMA_MV_K45 | DMA_MV_K6 | DMA_QKV | DMA_GLU); }();
     return (mask & which) != 0;
 }
-static int dma_slots(size_t used, int nw, size_t lds_budget) {
+// Slots a wave's ring must have for type TYPE at row length k.  One step of DStream::run reads min(nb, 16) block images starting
+// at r * (row image) + it * 16 * IMG -- wherever that falls inside a 1 KiB piece -- and all pieces it touches must be resident
+// together: q4_K / q5_K steps (2304 / 2816 B) fit 4 slots at any offset; a q6_K step is 3584 B and fits 4 slots only when
+// every start is a multiple of 512 (row images of whole 16-block steps: K = 4096, 8192, 28672), else 8 (K = 14336: 12.25 KiB per
+// row, the second row of a wave starts 256 B into a piece).
+template <int TYPE>
+static int dma_need_slots(int k) {
+    if constexpr (!DmaImg<TYPE>::OK) return 0;
+    else {
+        const int nb = k / QK_K, img = DmaImg<TYPE>::IMG;
+        const int span = (nb < 16 ? nb : 16) * img;
+        auto gcd = [](int a, int b) { while (b) { const int t = a % b; a = b; b = t; } return a; };
+        const int g = gcd(gcd((nb * img) % 1024, 1024), gcd((16 * img) % 1024, 1024));     // every step starts at a multiple of g
+        const int bytes = span + 1024 - g;
+        int sl = 2;
+        while (sl * 1024 < bytes) sl *= 2;
+        return sl;
+    }
+}
+static int dma_slots(size_t used, int nw, size_t lds_budget, int need) {
     static const int cap = [] { const char * e = getenv("MI355_DMA_SLOTS"); return e ? atoi(e) : 4; }();
     int s = cap > DMA_MAX_SLOTS ? DMA_MAX_SLOTS : cap;
-    while (s >= 2 && used + (size_t)nw * s * 1024 > lds_budget) s >>= 1;
     while (s & (s - 1)) s &= s - 1;
-    return s >= 2 ? s : 0;
+    if (s < need) s = need;
+    if (s < 2 || s > DMA_MAX_SLOTS || used + (size_t)nw * s * 1024 > lds_budget) {
+        s = need;                                   // the budget does not hold the preferred depth: the least that is correct, or none
+        if (s < 2 || s > DMA_MAX_SLOTS || used + (size_t)nw * s * 1024 > lds_budget) return 0;
+    }
+    return s;
 }
 
 static int dma_first() {
@@ -678,20 +705,22 @@ static __device__ __forceinline__ auto make_stream(RowPtr rp, int nrows, int k, 
 }
 
 // dynamic LDS beyond 64 KB has to be asked for, per kernel and device
-template <class K>
-static hipError_t allow_lds(K kernel, size_t bytes) {
+static hipError_t allow_lds_any(const void * fn, size_t bytes) {
     if (bytes <= 64 * 1024) return hipSuccess;
-    static bool done[MI355_MAX_DEVICES_LDS] = {};
+    static std::mutex mu;
+    static std::set<std::pair<const void *, int>> done;
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
-    if (dev < 0 || dev >= MI355_MAX_DEVICES_LDS || !done[dev]) {
-        e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);   // the kernels' static arrays take < 1 KB
-        if (e != hipSuccess) return e;
-        if (dev >= 0 && dev < MI355_MAX_DEVICES_LDS) done[dev] = true;
-    }
+    std::lock_guard<std::mutex> lock(mu);
+    if (done.count({fn, dev})) return hipSuccess;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);   // the kernels' static arrays take < 1 KB
+    if (e != hipSuccess) return e;
+    done.insert({fn, dev});
     return hipSuccess;
 }
+template <class K>
+static hipError_t allow_lds(K kernel, size_t bytes) { return allow_lds_any((const void *)kernel, bytes); }
 
 // Activations of one token into LDS ([k] int8, then [k/32] {d, sum}), in two phases so that the global loads go out before
 // the weight stream's and the arithmetic runs under its latency.  Three sources:
@@ -842,7 +871,7 @@ struct ActLds { const __attribute__((address_space(3))) int8_t * q; const __attr
 
 // One wave, one weight row: the body shared by the single-matrix and the grouped kernel.
 //   wmat: first row of the matrix; row: this wave's row (rows >= m compute on the last row and store nothing)
-template <int TYPE, int NCOLS, bool LDSACT>
+template <int TYPE, int NCOLS, bool LDSACT, int NT = 256>
 static __device__ __forceinline__ void mmvq_row(const uint8_t * wmat, int64_t w_row_stride, int m, int row, const int8_t * gq,
                                                 const float * gds, int k, float * dch, int64_t dst_col_stride, uint8_t * lds,
                                                 const float * res = nullptr, float * sum = nullptr, void * stamps = nullptr) {
@@ -866,9 +895,9 @@ static __device__ __forceinline__ void mmvq_row(const uint8_t * wmat, int64_t w_
     if (LDSACT) {
         // activations -> LDS: [NCOLS][k] int8, then [NCOLS][k/32][2] f32 (columns are contiguous rows of act)
         const int nq = NCOLS * k / 16, nds = NCOLS * (k / QK); // 16-byte chunks of q, {d, sum} pairs
-        for (int i = threadIdx.x; i < nq; i += 256) ((v4i *)lds)[i] = ((const v4i *)gq)[i];
+        for (int i = threadIdx.x; i < nq; i += NT) ((v4i *)lds)[i] = ((const v4i *)gq)[i];
         v2f * lds_ds = (v2f *)(lds + (size_t)NCOLS * k);
-        for (int i = threadIdx.x; i < nds; i += 256) lds_ds[i] = ((const v2f *)gds)[i];
+        for (int i = threadIdx.x; i < nds; i += NT) lds_ds[i] = ((const v2f *)gds)[i];
         __syncthreads();
     }
     STAMP_AT(stamps, 1);
@@ -886,22 +915,45 @@ static __device__ __forceinline__ void mmvq_row(const uint8_t * wmat, int64_t w_
         const int  u     = valid ? u_raw : nunits - 1;
         typename U::Raw nxt;
         if (it + 1 < niter) nxt = U::load(wrow, u_raw + 64 < nunits ? u_raw + 64 : nunits - 1);
-        typename U::Act av[NCOLS];
-        if (LDSACT) {
-            const auto lq  = (const __attribute__((address_space(3))) int8_t *)lds;
-            const auto lds_ = (const __attribute__((address_space(3))) float *)(lds + (size_t)NCOLS * k);
+        if constexpr (NCOLS <= 2) {
+            typename U::Act av[NCOLS];
+            if (LDSACT) {
+                const auto lq  = (const __attribute__((address_space(3))) int8_t *)lds;
+                const auto lds_ = (const __attribute__((address_space(3))) float *)(lds + (size_t)NCOLS * k);
 #pragma unroll
-            for (int c = 0; c < NCOLS; c++) av[c] = U::load_act(ActLds{lq + c * k, lds_ + c * (k / QK) * 2}, u);
+                for (int c = 0; c < NCOLS; c++) av[c] = U::load_act(ActLds{lq + c * k, lds_ + c * (k / QK) * 2}, u);
+            } else {
+#pragma unroll
+                for (int c = 0; c < NCOLS; c++) av[c] = U::load_act(ActPtr{gq + (int64_t)c * k, gds + (int64_t)c * (k / QK) * 2}, u);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const typename U::Dec w = U::decode(cur, u);
+#pragma unroll
+            for (int c = 0; c < NCOLS; c++) {
+                const float v = U::dot(w, av[c]);
+                acc[c] += valid ? v : 0.0f;
+            }
         } else {
+            // 3..8 columns: the unit is decoded once and the columns' activations are read one column at a time (all of them at once
+            // would take 16+ registers per column: 252 VGPRs at 8 columns of q6_K)
+            __builtin_amdgcn_sched_barrier(0);
+            const typename U::Dec w = U::decode(cur, u);
 #pragma unroll
-            for (int c = 0; c < NCOLS; c++) av[c] = U::load_act(ActPtr{gq + (int64_t)c * k, gds + (int64_t)c * (k / QK) * 2}, u);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        const typename U::Dec w = U::decode(cur, u);
-#pragma unroll
-        for (int c = 0; c < NCOLS; c++) {
-            const float v = U::dot(w, av[c]);
-            acc[c] += valid ? v : 0.0f;
+            for (int c = 0; c < NCOLS; c++) {
+                typename U::Act av;
+                if (LDSACT) {
+                    const auto lq  = (const __attribute__((address_space(3))) int8_t *)lds;
+                    const auto lds_ = (const __attribute__((address_space(3))) float *)(lds + (size_t)NCOLS * k);
+                    av = U::load_act(ActLds{lq + c * k, lds_ + c * (k / QK) * 2}, u);
+                } else {
+                    av = U::load_act(ActPtr{gq + (int64_t)c * k, gds + (int64_t)c * (k / QK) * 2}, u);
+                }
+                const float v = U::dot(w, av);
+                acc[c] += valid ? v : 0.0f;
+                // two columns in flight, not all of them: the empty asm pins the dot products before the barrier (being pure,
+                // they would otherwise sink below every column's loads)
+                if ((c & 1) && c + 1 < NCOLS) { asm volatile("" : "+v"(acc[c - 1]), "+v"(acc[c])); __builtin_amdgcn_sched_barrier(0); }
+            }
         }
         if (it + 1 < niter) cur = nxt;
     }
@@ -919,8 +971,10 @@ static __device__ __forceinline__ void mmvq_row(const uint8_t * wmat, int64_t w_
     STAMP_AT(stamps, 3);
 }
 
-template <int TYPE, int NCOLS, bool LDSACT>
-__global__ void __launch_bounds__(256)
+// NT: 256 threads (4 rows per workgroup) or, for 3..8 columns of a tall matrix, 1024 (16 rows): every workgroup stages all
+// NCOLS activation columns in LDS, so with 4 rows it moves more activation bytes (from L2) than weight bytes
+template <int TYPE, int NCOLS, bool LDSACT, int NT = 256>
+__global__ void __launch_bounds__(NT)
 mmvq_kernel(const KArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int wave = threadIdx.x >> 6;
@@ -937,7 +991,7 @@ mmvq_kernel(const KArgs a) {
         ch_w    = ch / a.ch_ratio;
         act_row = (int64_t)ch * a.act_ch_stride;
     }
-    mmvq_row<TYPE, NCOLS, LDSACT>(a.W + ch_w * a.w_ch_stride, a.w_row_stride, a.m, blockIdx.x * 4 + wave,
+    mmvq_row<TYPE, NCOLS, LDSACT, NT>(a.W + ch_w * a.w_ch_stride, a.w_row_stride, a.m, blockIdx.x * (NT / 64) + wave,
                                   a.act_q + act_row * a.k, a.act_ds + act_row * (a.k / QK) * 2, a.k,
                                   a.dst + (int64_t)ch * a.dst_ch_stride, a.dst_col_stride, lds);
 }
@@ -950,13 +1004,13 @@ struct KGroup {
     float * dst[MI355_MMVQ_MAX_GROUP]; int64_t dst_col_stride[MI355_MMVQ_MAX_GROUP];
     int m[MI355_MMVQ_MAX_GROUP], blk_end[MI355_MMVQ_MAX_GROUP];
     const int8_t * act_q; const float * act_ds;
-    int k, n;
+    int k, n, rpb;                                                                // rpb: rows per workgroup the blocks were dealt for (4 or 16)
     const float * res[MI355_MMVQ_MAX_GROUP]; float * sum[MI355_MMVQ_MAX_GROUP];   // optional residual epilogue per matrix
     STAMP_FIELD
 };
 
-template <int TYPE, int NCOLS, bool LDSACT>
-__global__ void __launch_bounds__(256)
+template <int TYPE, int NCOLS, bool LDSACT, int NT = 256>
+__global__ void __launch_bounds__(NT)
 mmvq_group_kernel(const KGroup a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int wave = threadIdx.x >> 6;
@@ -965,7 +1019,7 @@ mmvq_group_kernel(const KGroup a) {
     for (int i = 0; i + 1 < MI355_MMVQ_MAX_GROUP; i++) {
         if (i + 1 < a.n && (int)blockIdx.x >= a.blk_end[i]) { mi = i + 1; blk0 = a.blk_end[i]; }
     }
-    mmvq_row<TYPE, NCOLS, LDSACT>(a.W[mi], a.w_row_stride[mi], a.m[mi], ((int)blockIdx.x - blk0) * 4 + wave, a.act_q, a.act_ds,
+    mmvq_row<TYPE, NCOLS, LDSACT, NT>(a.W[mi], a.w_row_stride[mi], a.m[mi], ((int)blockIdx.x - blk0) * (NT / 64) + wave, a.act_q, a.act_ds,
                                   a.k, a.dst[mi], a.dst_col_stride[mi], lds, a.res[mi], a.sum[mi], STAMP_PTR(a));
 }
 
@@ -1344,11 +1398,24 @@ static const char * type_name(int t) {
 
 static constexpr size_t LDS_ACT_LIMIT = 64 * 1024; // beyond this, activations are read through L1 instead
 
+// 16 rows per workgroup for 3..8 columns when that still gives every CU a workgroup
+static int tall_threads() { static const int t = [] { const char * e = getenv("MI355_MMVQ_TALL"); return e ? atoi(e) : 1024; }(); return t; }
+constexpr size_t LDS_TOTAL = 159 * 1024;            // per CU, less the kernels' small static arrays
+
 template <int TYPE, int NCOLS>
 static int launch(const KArgs & a, int nchannels, hipStream_t stream) {
-    const dim3 grid((unsigned)((a.m + 3) / 4), (unsigned)nchannels);
     const size_t need = (size_t)NCOLS * ((size_t)a.k + (size_t)a.k / QK * 8);
     static const std::string tag = std::string("mmvq_") + type_name(TYPE) + "_n" + std::to_string(NCOLS);
+    if constexpr (NCOLS >= 3) {
+        if (tall_threads() == 1024 && need <= LDS_TOTAL && (int64_t)a.m * nchannels >= 16 * 192 && (need > 48 * 1024 || (int64_t)a.m * nchannels <= 6144)) {
+            hipError_t e = allow_lds_any((const void *)mmvq_kernel<TYPE, NCOLS, true, 1024>, need);
+            if (e != hipSuccess) return (int)e;
+            MI355_LAUNCH(tag.c_str(), (mmvq_kernel<TYPE, NCOLS, true, 1024>), dim3((unsigned)((a.m + 15) / 16), (unsigned)nchannels), dim3(1024), need, stream, a);
+            MI355_CHECK_LAUNCH();
+            return MI355_OK;
+        }
+    }
+    const dim3 grid((unsigned)((a.m + 3) / 4), (unsigned)nchannels);
     if (need <= LDS_ACT_LIMIT) MI355_LAUNCH(tag.c_str(), (mmvq_kernel<TYPE, NCOLS, true>), grid, dim3(256), need, stream, a);
     else                       MI355_LAUNCH(tag.c_str(), (mmvq_kernel<TYPE, NCOLS, false>), grid, dim3(256), 0, stream, a);
     MI355_CHECK_LAUNCH();
@@ -1360,13 +1427,21 @@ static int launch_group(const KGroup & a, hipStream_t stream) {
     const dim3 grid((unsigned)a.blk_end[a.n - 1]);
     const size_t need = (size_t)NCOLS * ((size_t)a.k + (size_t)a.k / QK * 8);
     static const std::string tag = std::string("mmvq_") + type_name(TYPE) + "_n" + std::to_string(NCOLS);
+    if constexpr (NCOLS >= 3) {
+        if (a.rpb == 16) {
+            hipError_t e = allow_lds_any((const void *)mmvq_group_kernel<TYPE, NCOLS, true, 1024>, need);
+            if (e != hipSuccess) return (int)e;
+            MI355_LAUNCH(tag.c_str(), (mmvq_group_kernel<TYPE, NCOLS, true, 1024>), grid, dim3(1024), need, stream, a);
+            MI355_CHECK_LAUNCH();
+            return MI355_OK;
+        }
+    }
+    if (a.rpb != 4) return MI355_E_SHAPE;
     if (need <= LDS_ACT_LIMIT) MI355_LAUNCH(tag.c_str(), (mmvq_group_kernel<TYPE, NCOLS, true>), grid, dim3(256), need, stream, a);
     else                       MI355_LAUNCH(tag.c_str(), (mmvq_group_kernel<TYPE, NCOLS, false>), grid, dim3(256), 0, stream, a);
     MI355_CHECK_LAUNCH();
     return MI355_OK;
 }
-
-constexpr size_t LDS_TOTAL = 159 * 1024;            // per CU, less the kernels' small static arrays
 
 template <int TYPE>
 static int launch_stream(KStream & a, hipStream_t stream) {
@@ -1376,7 +1451,7 @@ static int launch_stream(KStream & a, hipStream_t stream) {
     if (need <= LDS_ACT_LIMIT) {
         if constexpr (DmaImg<TYPE>::OK) {
             const size_t used = (need + 255) & ~(size_t)255;
-            const int slots = a.k % QK_K == 0 && a.k >= 2048 && a.k < (1 << 19) && dma_enabled(TYPE == MI355_TYPE_Q6_K ? DMA_MV_K6 : DMA_MV_K45) ? dma_slots(used, MV1_THREADS / 64, LDS_TOTAL) : 0;
+            const int slots = a.k % QK_K == 0 && a.k >= 2048 && a.k < (1 << 19) && dma_enabled(TYPE == MI355_TYPE_Q6_K ? DMA_MV_K6 : DMA_MV_K45) ? dma_slots(used, MV1_THREADS / 64, LDS_TOTAL, dma_need_slots<TYPE>(a.k)) : 0;
             if (slots) {
                 a.dma_slots = slots; a.ring_off = (int)used; a.dma_first = dma_first();
                 const size_t total = used + (size_t)(MV1_THREADS / 64) * slots * 1024;
@@ -1487,6 +1562,15 @@ extern "C" int mi355_mul_mat_vec_q_group(const mi355_mmvq_args * p, int n_mats, 
     memset(&a, 0, sizeof(a));
     int64_t blocks = 0;
     int n = 0;
+    // rows per workgroup of the multi-column kernel: 16 (1024 threads) for 3..8 columns when the group still gives ~every CU a
+    // workgroup -- a workgroup stages all columns' activations, which with 4 rows is more bytes than the weights it streams
+    int64_t rows_all = 0;
+    for (int i = 0; i < n_mats; i++) rows_all += p[i].m > 0 ? p[i].m : 0;
+    const size_t need_cols = (size_t)(p[0].ncols > 0 ? p[0].ncols : 1) * ((size_t)p[0].k + (size_t)p[0].k / QK * 8);
+    // (measured, q6_K x 8 columns: 4096 x 14336 54 -> 26 us, 4096 x 4096 10.8 -> 9.8 us, but 14336 x 4096 29 -> 34 us: only where the
+    // columns do not fit a 4-row workgroup's LDS budget, or the matrix is short)
+    const int rpb = p[0].ncols >= 3 && p[0].ncols <= 8 && p[0].k > 0 && tall_threads() == 1024 && need_cols <= LDS_TOTAL && rows_all >= 16 * 192 &&
+                    (need_cols > 48 * 1024 || rows_all <= 6144) ? 16 : 4;
     for (int i = 0; i < n_mats; i++) {
         const int rc = validate(&p[i]);
         if (rc != MI355_OK) return rc;
@@ -1499,13 +1583,13 @@ extern "C" int mi355_mul_mat_vec_q_group(const mi355_mmvq_args * p, int n_mats, 
         if ((p[i].residual == nullptr) != (p[i].sum == nullptr)) return MI355_E_NULL;
         if (((uintptr_t)p[i].residual | (uintptr_t)p[i].sum) & 3) return MI355_E_ALIGN;
         a.res[n] = p[i].residual; a.sum[n] = p[i].sum;
-        blocks += (p[i].m + 3) / 4;
+        blocks += (p[i].m + rpb - 1) / rpb;
         if (blocks > 0x7fffffff) return MI355_E_SHAPE;
         a.blk_end[n] = (int)blocks;
         n++;
     }
     if (n == 0) return MI355_OK;
-    a.n = n; a.k = (int)p[0].k; a.act_q = p[0].act_q; a.act_ds = p[0].act_ds;
+    a.n = n; a.k = (int)p[0].k; a.act_q = p[0].act_q; a.act_ds = p[0].act_ds; a.rpb = rpb;
     STAMP_SET(a);
     hipStream_t s = (hipStream_t)stream;
     if (p[0].ncols == 1) {
@@ -1573,7 +1657,7 @@ static int launch_qkv(KQkv & a, hipStream_t stream) {
     a.dma_slots = 0; a.ring_off = 0;
     if constexpr (DmaImg<TQ>::OK || DmaImg<TK>::OK || DmaImg<TV>::OK) {
         const size_t used = (need + 255) & ~(size_t)255;
-        const int slots = a.k % QK_K == 0 && a.k >= 2048 && a.k < (1 << 19) && dma_enabled(DMA_QKV) ? dma_slots(used, nw, LDS_TOTAL) : 0;
+        const int slots = a.k % QK_K == 0 && a.k >= 2048 && a.k < (1 << 19) && dma_enabled(DMA_QKV) ? dma_slots(used, nw, LDS_TOTAL, std::max(dma_need_slots<TQ>(a.k), std::max(dma_need_slots<TK>(a.k), dma_need_slots<TV>(a.k)))) : 0;
         if (slots) {
             a.dma_slots = slots; a.ring_off = (int)used; a.dma_first = dma_first();
             const size_t lds_total = used + (size_t)nw * slots * 1024;
@@ -1655,7 +1739,7 @@ static int launch_glu_mv(KGlu & a, hipStream_t stream) {
     if constexpr (DmaImg<TYPE>::OK) {
         // two workgroups of 8 waves per CU: half the LDS each
         const size_t used = (need + 255) & ~(size_t)255;
-        const int slots = a.k % QK_K == 0 && a.k >= 2048 && a.k < (1 << 19) && dma_enabled(DMA_GLU) ? dma_slots(used, 8, LDS_TOTAL / 2) : 0;
+        const int slots = a.k % QK_K == 0 && a.k >= 2048 && a.k < (1 << 19) && dma_enabled(DMA_GLU) ? dma_slots(used, 8, LDS_TOTAL / 2, dma_need_slots<TYPE>(a.k)) : 0;
         if (slots) {
             a.dma_slots = slots; a.ring_off = (int)used; a.dma_first = dma_first();
             const size_t total = used + (size_t)8 * slots * 1024;

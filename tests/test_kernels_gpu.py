@@ -128,7 +128,9 @@ def test_mmvq_vs_oracle_contract(ops, t, m, k, n):
                                    (B.Q8_0, 1024, 4096), (B.Q5_K, 1024, 8192),
                                    # Llama-3-70B (SURVEY config 4): wq / wo, gate / up, down, wv in its three types
                                    (B.Q4_K, 8192, 8192), (B.Q4_K, 28672, 8192), (B.Q4_K, 8192, 28672), (B.Q6_K, 8192, 28672),
-                                   (B.Q6_K, 1024, 8192), (B.Q6_K, 128256, 4096)])
+                                   (B.Q6_K, 1024, 8192), (B.Q6_K, 128256, 4096),
+                                   # two rows per wave with a row image that is not a whole number of 512-byte steps (q6_K at K = 14336)
+                                   (B.Q6_K, 8192, 14336), (B.Q6_K, 4099, 14336), (B.Q4_K, 8192, 14336), (B.Q5_K, 5000, 14336)])
 def test_mmvq_model_shapes_linearity(ops, t, m, k):
     # full-size property check: mat-vec is linear in x up to the activation quantization, so
     # compare against the oracle on a row subset and check W.(2x) == 2 W.x exactly (q8_1 scales by 2)
@@ -139,9 +141,29 @@ def test_mmvq_model_shapes_linearity(ops, t, m, k):
     y1 = ops.mul_mat(t, wd, dev(x), m).cpu().numpy()
     y2 = ops.mul_mat(t, wd, dev(2 * x), m).cpu().numpy()
     assert np.array_equal(2 * y1, y2)
-    rows = np.arange(0, m, max(1, m // 48))
+    rows = np.arange(0, m, max(1, m // 48) | 1)           # odd stride: rows of both parities (a wave may own 2+ consecutive rows)
     want = O.mul_mat(t, np.ascontiguousarray(w[rows]), x, rows.size, k, 1, "q8_1")
     assert O.nmse(want, y1[:, rows]) <= 1e-10
+
+
+@pytest.mark.parametrize("t", [B.Q4_K, B.Q5_K, B.Q6_K, B.Q8_0, B.Q4_0, B.Q5_1])
+@pytest.mark.parametrize("m,k,n", [(4096, 14336, 8), (4099, 14336, 3), (4096, 4096, 5), (3072, 8192, 7), (14336, 4096, 8)])
+def test_mmvq_multi_column_model_shapes(ops, t, m, k, n):
+    # 3..8 columns at model shapes take the 16-rows-per-workgroup form (all columns staged in LDS, up to 143 KB); a column of
+    # the result is the same arithmetic as the one-column launch on that column, and matches the oracle on a row subset
+    rng = np.random.default_rng(m + k + n)
+    w = B.random_blocks(t, m, k, seed=m + n + t)
+    x = rng.standard_normal((n, k)).astype(np.float32)
+    wd, xd = dev(w), dev(x)
+    aq, ads = ops.quantize_act(xd)
+    got = ops.mul_mat_vec_q(t, wd, m, k, aq, ads, n)
+    for c in (0, n - 1):
+        aq1, ads1 = ops.quantize_act(xd[c:c + 1].contiguous())
+        one = ops.mul_mat_vec_q(t, wd, m, k, aq1, ads1, 1)
+        assert torch.equal(got[c], one[0]), f"column {c}"
+    rows = np.arange(0, m, max(1, m // 32) | 1)
+    want = O.mul_mat(t, np.ascontiguousarray(w[rows]), x, rows.size, k, n, "q8_1")
+    assert O.nmse(want, got.cpu().numpy()[:, rows]) <= 1e-10
 
 
 @pytest.mark.parametrize("t", B.WEIGHT_TYPES)
