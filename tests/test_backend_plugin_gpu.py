@@ -51,63 +51,128 @@ def test_llama_graph_end_to_end_has_no_cpu_compute_split():
 @pytest.mark.parametrize("ftype", ["Q4_K_M", "F16"])
 def test_llama_graph_without_flash_attention_stays_on_the_device(ftype, tmp_path):
     """`-fa 0`: K.Q and (softmax).V are MUL_MATs on f16 views of the KV cache (permuted, broadcast over the GQA heads) with a
-    SOFT_MAX between -- the float-weight MUL_MAT of SURVEY 8 f4.  No CPU compute split, logits close to ggml-cpu's."""
-    import numpy as np
+    SOFT_MAX between -- the float-weight MUL_MAT of SURVEY 8 f4.  No CPU compute split; the logits are as close to the exact twin's as
+    ggml-cpu's are (see test_llama_logits_match_ggml_cpu)."""
     tool = os.path.join(ROOT, "tools", "run_llama_bench.sh")
     r = subprocess.run([tool, "tiny", ftype, "-fa", "0", "-p", "64", "-n", "8", "-r", "1"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     assert "graph splits = 2" in r.stderr + r.stdout, (r.stderr + r.stdout)[-3000:]
-    outs = {}
-    for name, ngl in (("cpu", "0"), ("gpu", "99")):
-        path = str(tmp_path / f"nofa_logits_{name}.bin")
-        r = subprocess.run([tool, "tiny", ftype, "-fa", "0", "-ngl", ngl, "--dump-logits", path], capture_output=True, text=True, timeout=600)
-        assert r.returncode == 0, r.stderr[-3000:]
-        outs[name] = np.fromfile(path, dtype=np.float32).reshape(10, -1)
-    a, b = outs["cpu"], outs["gpu"]
-    assert np.isfinite(b).all()
-    assert float(((a - b) ** 2).sum() / (a ** 2).sum()) < 2e-3
+    e_cpu, e_gpu, d = _logits_vs_exact_twin(tmp_path, "tiny", ftype, extra=("-fa", "0"))
+    assert e_cpu < 5e-2 and e_gpu <= 1.25 * e_cpu + 2e-4 and d <= 2.0 * e_cpu + 2e-4, (e_cpu, e_gpu, d)
 
 
 def test_mixtral_style_graph_runs_entirely_on_the_device(tmp_path):
     """tiny random 8-expert llama GGUF (router MUL_MAT f32 -> SOFT_MAX -> ARGSORT/top-k -> GET_ROWS -> SUM_ROWS/DIV ->
-    MUL_MAT_ID x3 -> weighted sum): no CPU compute split, and logits close to ggml-cpu's.  The routing is discrete: a
-    near-tie between the 2nd and 3rd expert may resolve differently on the two backends, hence the loose bound."""
-    import numpy as np
+    MUL_MAT_ID x3 -> weighted sum): no CPU compute split.  The routing is discrete -- a near-tie between the 2nd and 3rd expert
+    resolves differently under different activation rounding -- so ggml-cpu and the plugin are each measured against the model's
+    exact twin and the plugin has to be as close as ggml-cpu is; test_moe_layers_are_as_close_to_the_exact_twin_as_ggml_cpu
+    looks at the layers one by one."""
     tool = os.path.join(ROOT, "tools", "run_llama_bench.sh")
     r = subprocess.run([tool, "tinymoe", "Q4_K_M", "-p", "64", "-n", "8", "-r", "1"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     assert "graph splits = 2" in r.stderr + r.stdout, (r.stderr + r.stdout)[-3000:]
+    e_cpu, e_gpu, d = _logits_vs_exact_twin(tmp_path, "tinymoe", "Q4_K_M")
+    assert e_cpu < 0.5 and e_gpu <= 1.25 * e_cpu + 1e-3, (e_cpu, e_gpu, d)
+
+
+def _env_for(ngl):
+    """reference runs (-ngl 0) are ggml-cpu alone: with the plugin loaded the scheduler would offload their large batches to it"""
+    env = dict(os.environ)
+    if ngl == "0":
+        env["MI355_NO_PLUGIN"] = "1"
+    return env
+
+
+def _logits_vs_exact_twin(tmp_path, model, ftype, ctk="f16", extra=()):
+    """Logits (48-token prefill, 6 decode steps, batches of 3, 2 and 160 tokens) of the model's exact twin on ggml-cpu (the same
+    random blocks stored dequantized as F32, make-random-gguf <ftype>+F32: f32 activations, nothing rounded but the f16 KV cache), of
+    the model on ggml-cpu alone and of the model on MI355_0 -> NMSE (ggml-cpu vs twin, plugin vs twin, plugin vs ggml-cpu)."""
+    import numpy as np
+    tool = os.path.join(ROOT, "tools", "run_llama_bench.sh")
     outs = {}
-    for name, ngl in (("cpu", "0"), ("gpu", "99")):
-        path = str(tmp_path / f"moe_logits_{name}.bin")
-        r = subprocess.run([tool, "tinymoe", "Q4_K_M", "-ngl", ngl, "--dump-logits", path], capture_output=True, text=True, timeout=600)
+    for name, ft, ngl, kv in (("exact", ftype + "+F32", "0", "f16"), ("cpu", ftype, "0", ctk), ("gpu", ftype, "99", ctk)):
+        path = str(tmp_path / f"logits_{name}.bin")
+        r = subprocess.run([tool, model, ft, "-ngl", ngl, "-ctk", kv, "-ctv", kv, "--dump-logits", path, *extra],
+                           capture_output=True, text=True, timeout=900, env=_env_for(ngl))
         assert r.returncode == 0, r.stderr[-3000:]
+        if name == "gpu":
+            assert "MI355_0" in r.stdout, r.stdout[-500:]
         outs[name] = np.fromfile(path, dtype=np.float32).reshape(10, -1)
-    a, b = outs["cpu"], outs["gpu"]
+    x, a, b = outs["exact"], outs["cpu"], outs["gpu"]
     assert np.isfinite(b).all()
-    nmse = float(((a - b) ** 2).sum() / (a ** 2).sum())
-    assert nmse < 5e-2, nmse
+    nmse = lambda u, v: float(((u - v) ** 2).sum() / (u ** 2).sum())
+    e_cpu, e_gpu, d = nmse(x, a), nmse(x, b), nmse(a, b)
+    print(f"{model} {ftype} kv {ctk} {' '.join(extra)}: ggml-cpu vs exact {e_cpu:.3e}, plugin vs exact {e_gpu:.3e}, plugin vs ggml-cpu {d:.3e}")
+    return e_cpu, e_gpu, d
+
+
+def _read_nodes(path):
+    """--dump-nodes output of tools/llama_bench_driver.cpp -> list of (name, array [ne1*ne2*ne3, ne0]) in graph order"""
+    import numpy as np
+    raw = np.fromfile(path, dtype=np.uint8)
+    out = []
+    for line in open(path + ".idx"):
+        name, typ, ne0, ne1, ne2, ne3, off = line.rstrip("\n").rsplit(" ", 6)
+        if " " in name:             # "... (view)", "... (reshaped)": derived tensors the graph builder did not name itself
+            continue
+        ne0, rows, off = int(ne0), int(ne1) * int(ne2) * int(ne3), int(off)
+        out.append((name, raw[off:off + rows * ne0 * 4].view(np.int32 if typ == "i32" else np.float32).reshape(rows, ne0)))
+    return out
+
+
+def test_moe_layers_are_as_close_to_the_exact_twin_as_ggml_cpu(tmp_path):
+    """Layer-by-layer look at the FUSED Mixtral-style graph (the scheduler's eval callback dumps l_out-<layer>, the experts' weighted sum
+    and the router's choice for a 48-token prompt, 6 decode steps and batches of 3, 2 and 160 tokens).  Three runs: the model's exact
+    twin (F32 weights, ggml-cpu), the model on ggml-cpu alone, the model on MI355_0.  The routing is discrete and the random model is
+    chaotic, so ggml-cpu itself drifts from the twin layer by layer; per layer, the plugin's drift (NMSE of l_out and of ffn_moe_out
+    over all steps) and its count of expert choices that differ from the twin's must not exceed ggml-cpu's by more than a quarter.
+    The device run that dumps only l_out (sub-graphs = whole layers, every fusion active) must equal, bit for bit, the one that
+    also stops at the router's tensors."""
+    import numpy as np
+    tool = os.path.join(ROOT, "tools", "run_llama_bench.sh")
+    full = "l_out,ffn_moe_topk,ffn_moe_out"
+    runs = {}
+    for name, ft, ngl, prefixes in (("exact", "Q4_K_M+F32", "0", full), ("cpu", "Q4_K_M", "0", full), ("gpu", "Q4_K_M", "99", full), ("gpu_layers", "Q4_K_M", "99", "l_out")):
+        path = str(tmp_path / f"nodes_{name}.bin")
+        r = subprocess.run([tool, "tinymoe", ft, "-ngl", ngl, "--dump-logits", str(tmp_path / f"lg_{name}.bin"), "--dump-nodes", path,
+                            "--node-prefix", prefixes], capture_output=True, text=True, timeout=900, env=_env_for(ngl))
+        assert r.returncode == 0, r.stderr[-3000:]
+        runs[name] = _read_nodes(path)
+    names = [n for n, _ in runs["exact"]]
+    assert names == [n for n, _ in runs["cpu"]] == [n for n, _ in runs["gpu"]] and len(names) > 100
+    fine = [(n, a) for n, a in runs["gpu"] if n.startswith("l_out")]
+    assert [n for n, _ in fine] == [n for n, _ in runs["gpu_layers"]]
+    for (n, a), (_, b) in zip(fine, runs["gpu_layers"]):
+        assert np.array_equal(a, b), n
+    num = {}       # (kind, layer) -> [sum |x - cpu|^2, sum |x - gpu|^2, sum |x|^2]  or  [choices differing on cpu, on gpu, choices]
+    for (name, x), (_, a), (_, b) in zip(runs["exact"], runs["cpu"], runs["gpu"]):
+        kind, layer = name.rsplit("-", 1)
+        acc = num.setdefault((kind, int(layer)), [0.0, 0.0, 0.0])
+        if kind == "ffn_moe_topk":
+            sx, sa, sb = np.sort(x, axis=1), np.sort(a, axis=1), np.sort(b, axis=1)
+            acc[0] += int((sx != sa).any(axis=1).sum()); acc[1] += int((sx != sb).any(axis=1).sum()); acc[2] += x.shape[0]
+        else:
+            assert np.isfinite(b).all(), name
+            acc[0] += float(((x - a) ** 2).sum()); acc[1] += float(((x - b) ** 2).sum()); acc[2] += float((x ** 2).sum())
+    for (kind, layer), (ea, eb, n) in sorted(num.items()):
+        print(f"{kind}-{layer}: ggml-cpu {ea / n:.3e}  plugin {eb / n:.3e}" + ("  (fraction of tokens whose experts differ from the twin's)" if kind == "ffn_moe_topk" else "  (NMSE vs the twin)"))
+        if kind == "ffn_moe_topk":
+            assert eb <= 1.25 * ea + 3, (kind, layer, ea, eb, n)
+        else:
+            assert eb / n <= 1.25 * ea / n + 1e-3, (kind, layer, ea / n, eb / n)
 
 
 @pytest.mark.parametrize("ftype,ctk", [("Q4_K_M", "f16"), ("Q8_0", "q8_0"), ("Q4_0", "f16"), ("Q4_1", "f16"), ("Q5_0", "f16"), ("Q5_1", "f16"), ("F16", "f16")])
 def test_llama_logits_match_ggml_cpu(ftype, ctk, tmp_path):
-    """Whole-graph parity (covers the backend's fusions, which test-backend-ops cannot see): logits of a
-    48-token prefill + 6 decode steps on MI355_0 vs the same model on the reference's ggml-cpu."""
-    import numpy as np
-    tool = os.path.join(ROOT, "tools", "run_llama_bench.sh")
-    outs = {}
-    for name, ngl in (("cpu", "0"), ("gpu", "99")):
-        path = str(tmp_path / f"logits_{name}.bin")
-        r = subprocess.run([tool, "tiny", ftype, "-ngl", ngl, "-ctk", ctk, "-ctv", ctk, "--dump-logits", path],
-                           capture_output=True, text=True, timeout=600)
-        assert r.returncode == 0, r.stderr[-3000:]
-        outs[name] = np.fromfile(path, dtype=np.float32).reshape(10, -1)
-    a, b = outs["cpu"], outs["gpu"]
-    assert np.isfinite(b).all()
-    nmse = float(((a - b) ** 2).sum() / (a ** 2).sum())
-    # 4 layers of q8-activation matmuls on a random-weight (chaotic) model; each op's own budget is 5e-4.  With a
-    # q8_0 KV cache the CPU also quantizes Q to q8_0 inside attention (ops.cpp:8056-8099) while we keep Q in f32.
-    assert nmse < (1e-2 if ctk == "q8_0" else 2e-3), nmse
+    """Whole-graph parity (covers the backend's fusions, which test-backend-ops cannot see): logits of a 48-token prefill, 6 decode
+    steps and batches of 3, 2 and 160 tokens on MI355_0 vs the same model on the reference's ggml-cpu.  Both round the activations
+    of every MUL_MAT (ggml-cpu to q8_K / q8_0 / q8_1 per its vec_dot_type, the plugin to q8_1 or bf16), so neither is "the" answer:
+    the yardstick is the model's exact twin -- the same random blocks stored dequantized as F32 (make-random-gguf <ftype>+F32), run
+    on ggml-cpu with f32 activations.  The plugin has to be as close to the twin as ggml-cpu is, and close to ggml-cpu."""
+    e_cpu, e_gpu, d = _logits_vs_exact_twin(tmp_path, "tiny", ftype, ctk)
+    assert e_cpu < 5e-2, e_cpu                      # the yardstick itself is sane
+    assert e_gpu <= 1.25 * e_cpu + 2e-4, (e_gpu, e_cpu)
+    assert d <= 2.0 * e_cpu + 2e-4, (d, e_cpu)        # two roundings of the same exact values
 
 
 @pytest.mark.parametrize("model", ["tiny", "tinymoe"])

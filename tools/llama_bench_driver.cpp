@@ -28,6 +28,36 @@ static ggml_type kv_type(const std::string & s) {
     fprintf(stderr, "unknown kv type %s\n", s.c_str()); exit(2);
 }
 
+// --dump-nodes: every graph node whose name starts with one of the prefixes is written (f32 / i32, rows made contiguous) to
+// `path`, with a line "name type ne0 ne1 ne2 ne3 byte_offset" in `path`.idx -- the scheduler's eval callback
+// (ggml_backend_sched_set_eval_callback, ggml-backend.cpp) computes the graph up to each such node, so whatever lies between
+// two dumped nodes still reaches the backend as one (fusable) sub-graph.
+struct node_dump {
+    FILE * bin = nullptr, * idx = nullptr;
+    std::vector<std::string> prefixes;
+    std::vector<char> buf;
+    long long off = 0;
+};
+static bool node_dump_cb(struct ggml_tensor * t, bool ask, void * user) {
+    node_dump * d = (node_dump *)user;
+    bool match = false;
+    for (const std::string & p : d->prefixes) if (strncmp(t->name, p.c_str(), p.size()) == 0) { match = true; break; }
+    if (ask) return match;
+    if (!match || (t->type != GGML_TYPE_F32 && t->type != GGML_TYPE_I32)) return true;
+    const size_t row = (size_t)t->ne[0] * 4;
+    d->buf.resize(row);
+    fprintf(d->idx, "%s %s %lld %lld %lld %lld %lld\n", t->name, ggml_type_name(t->type), (long long)t->ne[0], (long long)t->ne[1],
+            (long long)t->ne[2], (long long)t->ne[3], d->off);
+    for (int64_t i3 = 0; i3 < t->ne[3]; i3++)
+        for (int64_t i2 = 0; i2 < t->ne[2]; i2++)
+            for (int64_t i1 = 0; i1 < t->ne[1]; i1++) {
+                ggml_backend_tensor_get(t, d->buf.data(), (size_t)(i1 * t->nb[1] + i2 * t->nb[2] + i3 * t->nb[3]), row);
+                fwrite(d->buf.data(), 1, row, d->bin);
+                d->off += (long long)row;
+            }
+    return true;
+}
+
 static bool test_prompt(llama_context * ctx, int n_prompt, int n_batch, int n_vocab) {
     std::vector<llama_token> tokens(n_batch);
     int done = 0;
@@ -52,7 +82,7 @@ static bool test_gen(llama_context * ctx, int n_gen, int n_vocab) {
 }
 
 int main(int argc, char ** argv) {
-    std::string model_path, ctk = "f16", ctv = "f16", dump_path, sm = "layer", ts_arg;
+    std::string model_path, ctk = "f16", ctv = "f16", dump_path, sm = "layer", ts_arg, nodes_path, node_prefixes = "l_out,result_norm";
     int main_gpu = 0;
     int n_prompt = 512, n_gen = 128, reps = 3, ngl = 99, fa = 1, threads = 8, n_batch = 2048, n_ubatch = 512;
     int dump_steps = 6;          // single-token decodes of the parity mode
@@ -64,6 +94,7 @@ int main(int argc, char ** argv) {
         else if (a == "-ctk") ctk = next(); else if (a == "-ctv") ctv = next(); else if (a == "-t") threads = atoi(next().c_str());
         else if (a == "--dump-logits") dump_path = next();
         else if (a == "--decode-steps") dump_steps = atoi(next().c_str());
+        else if (a == "--dump-nodes") nodes_path = next(); else if (a == "--node-prefix") node_prefixes = next();
         else if (a == "-sm") sm = next(); else if (a == "-mg") main_gpu = atoi(next().c_str()); else if (a == "-ts") ts_arg = next();
         else if (a == "-b") n_batch = atoi(next().c_str()); else if (a == "-ub") n_ubatch = atoi(next().c_str());
         else { fprintf(stderr, "unknown arg %s\n", a.c_str()); return 2; }
@@ -105,6 +136,21 @@ int main(int argc, char ** argv) {
     cp.flash_attn = fa != 0;
     cp.type_k = kv_type(ctk); cp.type_v = kv_type(ctv);
     cp.no_perf = true;
+    node_dump nd;
+    if (!nodes_path.empty()) {
+        nd.bin = fopen(nodes_path.c_str(), "wb");
+        nd.idx = fopen((nodes_path + ".idx").c_str(), "w");
+        if (!nd.bin || !nd.idx) { perror(nodes_path.c_str()); return 1; }
+        size_t pos = 0;
+        while (pos <= node_prefixes.size()) {
+            size_t e = node_prefixes.find(',', pos);
+            if (e == std::string::npos) e = node_prefixes.size();
+            if (e > pos) nd.prefixes.push_back(node_prefixes.substr(pos, e - pos));
+            pos = e + 1;
+        }
+        cp.cb_eval = node_dump_cb;
+        cp.cb_eval_user_data = &nd;
+    }
     llama_context * ctx = llama_init_from_model(model, cp);
     if (!ctx) { fprintf(stderr, "failed to create context\n"); return 1; }
 
@@ -132,6 +178,7 @@ int main(int argc, char ** argv) {
             fwrite(llama_get_logits_ith(ctx, -1), sizeof(float), n_vocab, f);
         }
         fclose(f);
+        if (nd.bin) { fclose(nd.bin); fclose(nd.idx); }
         printf("{\"dumped\": \"%s\", \"n_vocab\": %d, \"rows\": %d, \"devices\": \"%s\"}\n", dump_path.c_str(), n_vocab, 4 + dump_steps, devs.c_str());
         llama_free(ctx); llama_model_free(model); llama_backend_free();
         return 0;

@@ -48,8 +48,18 @@ static void fill_blocks(ggml_tensor * t) {
             case GGML_TYPE_Q4_1: put_half(blk, 0.003f, 0.006f, false); put_half(blk + 2, -0.045f, -0.02f, false); break;   // values centred on 0
             case GGML_TYPE_Q5_1: put_half(blk, 0.0015f, 0.003f, false); put_half(blk + 2, -0.045f, -0.02f, false); break;
             case GGML_TYPE_Q8_0: put_half(blk, 0.001f, 0.005f, true); break;
-            case GGML_TYPE_Q4_K: case GGML_TYPE_Q5_K:
-                put_half(blk, 0.0002f, 0.0008f, false); put_half(blk + 2, 0.0002f, 0.0008f, false); break;
+            case GGML_TYPE_Q4_K: case GGML_TYPE_Q5_K: {
+                // w = d sc q - dmin m with q uniform in 0..15 (0..31): centred on 0 when every sub-block's min equals its scale
+                // (6-bit fields of get_scale_min_k4, ggml-quants.c) and dmin = 7.5 d (15.5 d).  Uncentred weights (mean ~0.1) made
+                // the random models' residual stream grow to 1e6, where a comparison with ggml-cpu sees nothing of a layer's work.
+                const float c = t->type == GGML_TYPE_Q4_K ? 7.5f : 15.5f;
+                const float dd = 0.0002f + 0.0006f * (float)(rnd() >> 40) * (1.0f / 16777216.0f);
+                const ggml_fp16_t h = ggml_fp32_to_fp16(dd), hm = ggml_fp32_to_fp16(c * ggml_fp16_to_fp32(h));
+                memcpy(blk, &h, 2); memcpy(blk + 2, &hm, 2);
+                uint8_t * q = blk + 4;
+                for (int j = 0; j < 4; j++) { q[4 + j] = q[j]; q[8 + j] = (uint8_t)((q[8 + j] & 0x0F) | (q[8 + j] << 4)); }
+                break;
+            }
             case GGML_TYPE_Q6_K: put_half(blk + 208, 0.00002f, 0.0001f, true); break;
             default: break;
         }
@@ -58,7 +68,12 @@ static void fill_blocks(ggml_tensor * t) {
 
 int main(int argc, char ** argv) {
     if (argc < 3) { fprintf(stderr, "usage: %s out.gguf 8b|70b|8x7b|tiny|tinymoe [Q4_K_M|Q8_0|Q4_0|Q4_1|Q5_0|Q5_1|F16] [vocab.gguf]\n", argv[0]); return 2; }
-    const std::string out = argv[1], model = argv[2], ftype = argc > 3 ? argv[3] : "Q4_K_M";
+    const std::string out = argv[1], model = argv[2];
+    std::string ftype = argc > 3 ? argv[3] : "Q4_K_M";
+    // "<ftype>+F32": the same random blocks, stored dequantized as F32 -- the model's exact twin, against which both ggml-cpu's and
+    // the plugin's activation rounding can be measured
+    bool exact = false;
+    if (ftype.size() > 4 && ftype.compare(ftype.size() - 4, 4, "+F32") == 0) { exact = true; ftype.resize(ftype.size() - 4); }
     // optional 4th argument: a vocabulary-only GGUF (the reference keeps some for its tokenizer tests, models/ggml-vocab-*.gguf)
     // whose tokenizer.* metadata is copied, so that tools which tokenize text (llama-cli) can run the random model
     const char * vocab_path = argc > 4 ? argv[4] : nullptr;
@@ -82,6 +97,7 @@ int main(int argc, char ** argv) {
         total += rs(GGML_TYPE_Q8_0, d.n_embd, d.n_embd) * 2 + rs(GGML_TYPE_Q8_0, d.n_embd, kv_dim) * 2 + rs(GGML_TYPE_Q8_0, d.n_embd, d.n_ff) * 2 +
                  rs(GGML_TYPE_Q8_0, d.n_ff, d.n_embd) + 3 * (d.n_embd * 4 + 256);
     if (d.n_expert) total = total * d.n_expert + (size_t)d.n_layer * (d.n_embd * d.n_expert * 4 + 1024);   // generous upper bound
+    if (exact) total *= 3;
     ggml_init_params ip = {total + (64u << 20), nullptr, false};
     ggml_context * ctx = ggml_init(ip);
     if (!ctx) { fprintf(stderr, "ggml_init failed (%zu bytes)\n", total); return 1; }
@@ -110,7 +126,7 @@ int main(int argc, char ** argv) {
     gguf_set_val_u32(g, "llama.rope.dimension_count", head_dim);
     gguf_set_val_f32(g, "llama.rope.freq_base", 500000.0f);
     gguf_set_val_u32(g, "llama.vocab_size", d.n_vocab);
-    gguf_set_val_u32(g, "general.file_type", km ? 15 : base == GGML_TYPE_Q8_0 ? 7 : base == GGML_TYPE_F16 ? 1 : base == GGML_TYPE_Q4_1 ? 3 :
+    gguf_set_val_u32(g, "general.file_type", exact ? 0 : km ? 15 : base == GGML_TYPE_Q8_0 ? 7 : base == GGML_TYPE_F16 ? 1 : base == GGML_TYPE_Q4_1 ? 3 :
                                                base == GGML_TYPE_Q5_0 ? 8 : base == GGML_TYPE_Q5_1 ? 9 : 2);
     if (!vocab_path) gguf_set_val_str(g, "tokenizer.ggml.model", "no_vocab");
     if (d.n_expert) {
@@ -118,18 +134,18 @@ int main(int argc, char ** argv) {
         gguf_set_val_u32(g, "llama.expert_used_count", d.n_expert_used);
     }
 
-    auto add_w = [&](const std::string & name, ggml_type t, int64_t k, int64_t m) {
-        ggml_tensor * x = ggml_new_tensor_2d(ctx, t, k, m);
-        ggml_set_name(x, name.c_str());
+    auto finish = [&](ggml_tensor * x, const std::string & name) {
         fill_blocks(x);
+        if (exact) {
+            ggml_tensor * y = ggml_new_tensor_3d(ctx, GGML_TYPE_F32, x->ne[0], x->ne[1], x->ne[2]);
+            ggml_get_type_traits(x->type)->to_float(x->data, (float *)y->data, ggml_nelements(x));
+            x = y;
+        }
+        ggml_set_name(x, name.c_str());
         gguf_add_tensor(g, x);
     };
-    auto add_w3 = [&](const std::string & name, ggml_type t, int64_t k, int64_t m, int64_t e) {
-        ggml_tensor * x = ggml_new_tensor_3d(ctx, t, k, m, e);
-        ggml_set_name(x, name.c_str());
-        fill_blocks(x);
-        gguf_add_tensor(g, x);
-    };
+    auto add_w = [&](const std::string & name, ggml_type t, int64_t k, int64_t m) { finish(ggml_new_tensor_2d(ctx, t, k, m), name); };
+    auto add_w3 = [&](const std::string & name, ggml_type t, int64_t k, int64_t m, int64_t e) { finish(ggml_new_tensor_3d(ctx, t, k, m, e), name); };
     auto add_norm = [&](const std::string & name) {
         ggml_tensor * x = ggml_new_tensor_1d(ctx, GGML_TYPE_F32, d.n_embd);
         ggml_set_name(x, name.c_str());
