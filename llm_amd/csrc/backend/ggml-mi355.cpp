@@ -17,7 +17,10 @@
 #include "ggml-backend-impl.h"
 
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>      // types only: the library is opened with dlopen when GGML_MI355_SPLIT_GATHER=rccl asks for it
+#include <dlfcn.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
@@ -118,6 +121,68 @@ static void mi355_copy_d2d_async(void * dst, int dst_dev, const void * src, int 
         HIP_CHECK(hipMemcpyPeerAsync(dst, mi355_phys(dst_dev), src, mi355_phys(src_dev), n, stream));
     }
 }
+
+// ------------------------------------------------------------------------------------------------
+// RCCL all-gather form of the row-split gather (SURVEY 8e phase A; the reference's "collective" is N-1 peer 2-D copies,
+// ggml-cuda.cu:1659-1690).  GGML_MI355_SPLIT_GATHER=rccl selects it; the default stays the peer-store path (rows written
+// straight into the main device's dst by the mat-vec epilogue: nothing to launch after the kernels, which is what a
+// decode token's 4 KB..14 KB slices want), RCCL is the bandwidth option for prefill-sized results and the reference form
+// of the exchange.  One process, one communicator rank per device (ncclCommInitAll), every device sends its [cols][rows_max]
+// slice and receives all of them; the main device then places each slice's rows into dst.  librccl is opened with dlopen only
+// when the switch is on, so the plugin has no load-time dependency on it.
+// ------------------------------------------------------------------------------------------------
+struct mi355_rccl {
+    bool tried = false, ok = false;
+    void * lib = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char * (*GetErrorString)(ncclResult_t) = nullptr;
+    ncclComm_t comm[MI355_MAX_DEVICES] = {};
+    float * part[MI355_MAX_DEVICES] = {};  size_t part_size[MI355_MAX_DEVICES] = {};   // this device's slice, [cols][rows_max]
+    float * gath[MI355_MAX_DEVICES] = {};  size_t gath_size[MI355_MAX_DEVICES] = {};   // every device's slice, [ndev][cols][rows_max]
+};
+static mi355_rccl & mi355_rccl_state() { static mi355_rccl r; return r; }
+
+static bool mi355_split_gather_rccl() {
+    static const bool want = [] { const char * e = getenv("GGML_MI355_SPLIT_GATHER"); return e && strcmp(e, "rccl") == 0; }();
+    if (!want) return false;
+    mi355_rccl & r = mi355_rccl_state();
+    if (r.tried) return r.ok;
+    r.tried = true;
+    const int ndev = mi355_device_count();
+    for (int d = 0; d < ndev; d++)
+        for (int e = 0; e < d; e++)
+            if (mi355_phys(d) == mi355_phys(e)) {
+                MI_LOG_WARN("%s: GGML_MI355_SPLIT_GATHER=rccl needs one physical GPU per device (virtual devices share one) -- using peer stores\n", MI355_NAME);
+                return false;
+            }
+    r.lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+    if (!r.lib) r.lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!r.lib) { MI_LOG_WARN("%s: cannot open librccl.so (%s) -- using peer stores\n", MI355_NAME, dlerror()); return false; }
+    r.CommInitAll    = (decltype(r.CommInitAll))dlsym(r.lib, "ncclCommInitAll");
+    r.AllGather      = (decltype(r.AllGather))dlsym(r.lib, "ncclAllGather");
+    r.GroupStart     = (decltype(r.GroupStart))dlsym(r.lib, "ncclGroupStart");
+    r.GroupEnd       = (decltype(r.GroupEnd))dlsym(r.lib, "ncclGroupEnd");
+    r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.lib, "ncclGetErrorString");
+    if (!r.CommInitAll || !r.AllGather || !r.GroupStart || !r.GroupEnd || !r.GetErrorString) {
+        MI_LOG_WARN("%s: librccl.so lacks an expected symbol -- using peer stores\n", MI355_NAME);
+        return false;
+    }
+    int devs[MI355_MAX_DEVICES];
+    for (int d = 0; d < ndev; d++) devs[d] = mi355_phys(d);
+    const ncclResult_t rc = r.CommInitAll(r.comm, ndev, devs);
+    if (rc != ncclSuccess) {
+        MI_LOG_WARN("%s: ncclCommInitAll over %d devices failed (%s) -- using peer stores\n", MI355_NAME, ndev, r.GetErrorString(rc));
+        return false;
+    }
+    MI_LOG_INFO("%s: row-split gather by RCCL all-gather over %d devices\n", MI355_NAME, ndev);
+    r.ok = true;
+    return true;
+}
+#define RCCL_CHECK(call) do { const ncclResult_t rc_ = (call); if (rc_ != ncclSuccess) { \
+    MI_LOG_ERROR("%s: %s failed: %s\n", MI355_NAME, #call, mi355_rccl_state().GetErrorString(rc_)); GGML_ABORT("RCCL error"); } } while (0)
 
 // ------------------------------------------------------------------------------------------------
 // device buffer  (reference behaviour: ggml-cuda.cu:543-751)
@@ -881,6 +946,74 @@ static void mi355_mul_mat(mi355_backend_ctx * ctx, ggml_tensor * dst) {
     if (!ctx->ev_ready) HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_ready, hipEventDisableTiming));
     HIP_CHECK(hipEventRecord(ctx->ev_ready, ctx->stream));
     const int ndev = mi355_device_count();
+    // all of dst's columns one after the other (nb[2] = N nb[1], ...): what the 2-D placement after the all-gather assumes
+    const bool flat_cols = dst->nb[2] == (size_t)N * dst->nb[1] && dst->nb[3] == (size_t)ne12 * dst->nb[2];
+    if (flat_cols && mi355_split_gather_rccl()) {
+        // ---- RCCL form: every device computes its rows into a local [cols][rows_max] slice, one all-gather hands every device all
+        // slices, the main device places each slice's rows into dst.  Same kernels on the same row slices as the peer-store form:
+        // the same bits.
+        mi355_rccl & r = mi355_rccl_state();
+        int64_t rows_max = 1;
+        for (int d = 0; d < ndev; d++) rows_max = std::max(rows_max, extra->row_high[d] - extra->row_low[d]);
+        const size_t slice = (size_t)rows * rows_max;                 // floats per device
+        auto grow = [&](float *& buf, size_t & have, size_t need, hipStream_t st) {
+            if (have >= need) return;
+            HIP_CHECK(hipStreamSynchronize(st));
+            if (buf) HIP_CHECK(hipFree(buf));
+            have = (need + (1u << 20)) & ~((size_t)(1u << 20) - 1);
+            HIP_CHECK(hipMalloc((void **)&buf, have));
+        };
+        for (int d = 0; d < ndev; d++) {
+            const bool main = d == ctx->device;
+            hipStream_t st = main ? ctx->stream : ctx->peer(d).stream;
+            mi355_set_device(d);
+            grow(r.part[d], r.part_size[d], slice * sizeof(float), st);
+            grow(r.gath[d], r.gath_size[d], slice * sizeof(float) * ndev, st);
+            const char * act = ws;
+            if (!main) {
+                mi355_backend_ctx::peer_t & p = ctx->peers[d];
+                HIP_CHECK(hipStreamWaitEvent(p.stream, ctx->ev_ready, 0));
+                if (extra->data[d]) {
+                    if (p.act_size < qb + db) {
+                        HIP_CHECK(hipStreamSynchronize(p.stream));
+                        if (p.act) HIP_CHECK(hipFree(p.act));
+                        p.act_size = (qb + db + (1u << 20)) & ~((size_t)(1u << 20) - 1);
+                        HIP_CHECK(hipMalloc(&p.act, p.act_size));
+                        p.act_version = 0;
+                    }
+                    if (p.act_version != ctx->act_version) {
+                        mi355_copy_d2d_async(p.act, d, ws, ctx->device, qb + db, p.stream);
+                        p.act_version = ctx->act_version;
+                    }
+                    act = (const char *)p.act;
+                }
+            }
+            if (extra->data[d]) {
+                // dst as the kernels see it: column stride rows_max, rows [row_low, row_high) of the matrix at [0, rows_d)
+                ggml_tensor local = *dst;
+                local.nb[1] = (size_t)rows_max * sizeof(float);
+                local.nb[2] = (size_t)N * local.nb[1];
+                local.nb[3] = (size_t)ne12 * local.nb[2];
+                local.data  = (char *)r.part[d] - extra->row_low[d] * (int64_t)sizeof(float);
+                mi355_mul_mat_launch(&local, (const char *)extra->data[d], extra->row_low[d], extra->row_high[d] - extra->row_low[d], act, path, st);
+            }
+        }
+        RCCL_CHECK(r.GroupStart());
+        for (int d = 0; d < ndev; d++) {
+            mi355_set_device(d);
+            RCCL_CHECK(r.AllGather(r.part[d], r.gath[d], slice, ncclFloat, r.comm[d], d == ctx->device ? ctx->stream : ctx->peers[d].stream));
+        }
+        RCCL_CHECK(r.GroupEnd());
+        mi355_set_device(ctx->device);
+        for (int d = 0; d < ndev; d++) {
+            const int64_t nr = extra->row_high[d] - extra->row_low[d];
+            if (nr <= 0) continue;
+            HIP_CHECK(hipMemcpy2DAsync((char *)dst->data + extra->row_low[d] * sizeof(float), dst->nb[1],
+                                       r.gath[ctx->device] + (size_t)d * slice, (size_t)rows_max * sizeof(float),
+                                       (size_t)nr * sizeof(float), (size_t)rows, hipMemcpyDeviceToDevice, ctx->stream));
+        }
+        return;
+    }
     for (int d = 0; d < ndev; d++) {
         if (d == ctx->device || !extra->data[d]) continue;
         mi355_backend_ctx::peer_t & p = ctx->peer(d);

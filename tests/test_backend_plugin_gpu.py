@@ -233,6 +233,25 @@ def test_row_split_mul_mat_bit_exact_on_virtual_devices(ndev):
     assert " 0 failed" in r.stdout
 
 
+def test_row_split_rccl_all_gather_one_rank(tmp_path):
+    """GGML_MI355_SPLIT_GATHER=rccl: the row-split gather as an RCCL all-gather (ncclCommInitAll, one rank per device).  A one-GPU box
+    can only give it one rank -- RCCL refuses several ranks on one GPU -- which still runs communicator set-up, the local slice, the
+    collective and the placement into dst on hardware; results equal the unsplit ones bit for bit.  With virtual devices the switch
+    must fall back to the peer-store path (and say so) rather than fail."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "test-split-mul-mat")
+    assert os.path.exists(exe), "oracle/_ref/test-split-mul-mat is not built (make -C oracle drivers)"
+    env = dict(os.environ, GGML_BACKEND_PATH=PLUGIN, GGML_MI355_SPLIT_GATHER="rccl")
+    env.pop("GGML_MI355_VIRTUAL_DEVICES", None)
+    r = subprocess.run([exe], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    assert "RCCL all-gather over 1 devices" in r.stdout + r.stderr, (r.stdout + r.stderr)[-3000:]
+    assert " 0 failed" in r.stdout and "20 cases ran" in r.stdout, r.stdout[-2000:]
+    env["GGML_MI355_VIRTUAL_DEVICES"] = "2"
+    r = subprocess.run([exe], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    assert "using peer stores" in r.stdout + r.stderr, (r.stdout + r.stderr)[-3000:]
+
+
 def test_llama_row_split_logits_equal_single_device(tmp_path):
     """Whole model with `-sm row -ts 1,1` over two virtual devices (layers 0-1 main on MI355_0, 2-3 on MI355_1,
     every weight matrix row-split over both) gives the same logits as the single-device run, to the bit."""

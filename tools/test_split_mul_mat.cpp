@@ -107,9 +107,25 @@ int main() {
     ggml_backend_reg_t reg = ggml_backend_reg_by_name("MI355");
     if (!reg) { printf("MI355 backend not loaded (GGML_BACKEND_PATH?)\n"); return 2; }
     const int ndev = (int)ggml_backend_reg_dev_count(reg);
-    if (ndev < 2) { printf("need >= 2 MI355 devices (GGML_MI355_VIRTUAL_DEVICES=2), have %d\n", ndev); return 2; }
     split_buft_fn split_buft = (split_buft_fn)ggml_backend_reg_get_proc_address(reg, "ggml_backend_split_buffer_type");
     if (!split_buft) { printf("no ggml_backend_split_buffer_type\n"); return 1; }
+    if (ndev == 1) {
+        // one physical device: the "split" is the whole matrix on it.  What this leg is for: GGML_MI355_SPLIT_GATHER=rccl with a
+        // one-rank communicator -- ncclCommInitAll, the local slice, the all-gather and the placement into dst run on hardware
+        // (RCCL refuses the virtual devices of the other legs: they share a GPU), against the unsplit result, bit for bit
+        const float one[16] = {1};
+        const ggml_type types1[] = { GGML_TYPE_Q4_0, GGML_TYPE_Q8_0, GGML_TYPE_Q4_K, GGML_TYPE_Q5_K, GGML_TYPE_Q6_K };
+        int ran1 = 0;
+        for (ggml_type t : types1) {
+            ran1 += run_case(reg, split_buft, 0, one, t, 1024, 1024, 1, 1);
+            ran1 += run_case(reg, split_buft, 0, one, t, 4096, 512, 5, 2);      // broadcast over ne2: 10 columns
+            ran1 += run_case(reg, split_buft, 0, one, t, 2048, 1024, 40, 1);
+            ran1 += run_case(reg, split_buft, 0, one, t, 4096, 4096, 512, 1);
+        }
+        printf("%d checks ok, %d failed, %d cases ran (of %d)\n", n_ok, n_fail, ran1, 20);
+        return n_fail == 0 && ran1 >= 20 ? 0 : 1;
+    }
+    if (ndev < 2) { printf("need MI355 devices (GGML_MI355_VIRTUAL_DEVICES=2), have %d\n", ndev); return 2; }
     // the same (main_device, tensor_split) must give the same object (buffer types are compared by pointer)
     const float even[16] = {1, 1}, skew[16] = {3, 1};
     check(split_buft(0, even) == split_buft(0, even), "split buffer type is a singleton per (main, split)");
