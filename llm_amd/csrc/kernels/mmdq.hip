@@ -21,6 +21,8 @@
 // register set was measured slower: 276-332 VGPRs drop the occupancy to one wave per SIMD.)
 #include "common.h"
 #include "moe_bucket.h"
+#include <algorithm>
+#include <mutex>
 
 namespace {
 
@@ -42,6 +44,7 @@ struct DArgs {
     int n_expert, n_used, act_ne1;
     int64_t w_expert_stride;
     int dbg;                 // lab switch of mmdq_ws_kernel (MI355_MMDQ_DBG): 1 producers idle, 2 consumers idle
+    float * part;            // split-K of the 128 x 256 role-split kernel: K slice z stores its partial tile at part[z][n][m], summed in z order by kz_sum_kernel
 };
 
 // 32 consecutive weights of one row, raw, as loaded from global memory
@@ -507,11 +510,41 @@ mmdq_ws_kernel(const DArgs a) {
                 const int n = n0 + wn_ * 32 * TN + tn * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 if (m < a.m && n < a.n) {
                     float * o = a.dst + (int64_t)n * a.dst_col_stride + m;
-                    if (gridDim.z > 1) atomicAdd(o, acc[tm][tn][r]);   // two addends onto 0: the sum does not depend on the order
+                    if (a.part)            a.part[((int64_t)blockIdx.z * a.n + n) * a.m + m] = acc[tm][tn][r];
+                    else if (gridDim.z > 1) atomicAdd(o, acc[tm][tn][r]);   // two addends onto 0: the sum does not depend on the order
                     else *o = acc[tm][tn][r];
                 }
             }
     }
+}
+
+// dst[n][m] = ((part[0] + part[1]) + part[2]) + ...: the K slices of a split-K launch, added in slice order
+__global__ void __launch_bounds__(256)
+kz_sum_kernel(const float * part, float * dst, int64_t dst_col_stride, int m, int n, int kz) {
+    const int64_t total = (int64_t)m * n, plane = total;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        float v = part[i];
+        for (int z = 1; z < kz; z++) v += part[z * plane + i];
+        dst[(i / m) * dst_col_stride + i % m] = v;
+    }
+}
+
+// per-device workspace of the split-K launches (partial tiles); grows on demand -- an allocation (and a device synchronisation when
+// it grows) inside a call: prefill-sized MUL_MATs are not what a caller captures into a graph, and MI355_MMDQ_KZ=0 keeps every
+// launch on the paths that need none
+static float * kz_workspace(size_t bytes) {
+    static std::mutex mu;
+    static float * buf[64] = {}; static size_t have[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    if (have[dev] < bytes) {
+        if (buf[dev]) { if (hipDeviceSynchronize() != hipSuccess) return nullptr; (void)hipFree(buf[dev]); buf[dev] = nullptr; have[dev] = 0; }
+        const size_t want = (bytes + (8u << 20)) & ~((size_t)(8u << 20) - 1);
+        if (hipMalloc((void **)&buf[dev], want) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        have[dev] = want;
+    }
+    return buf[dev];
 }
 
 // f32 (4-D, strided rows) -> bf16 [rows][k], round to nearest even; one lane per 8 values
@@ -544,8 +577,26 @@ static int launch(const DArgs & a, int64_t m_total, hipStream_t s, const char * 
     // the bytes moved per flop fall with the tile height.  256-row tiles (8 waves) when they still cover the chip.
     static const int wide = [] { const char * e = getenv("MI355_MMDQ_WIDE"); return e ? atoi(e) : 2; }();   // 0: 256 x 128 tile, 1: 128 x 256 uniform, 2: 128 x 256 role-split
     static const int small_ws = [] { const char * e = getenv("MI355_MMDQ_SMALL"); return e ? atoi(e) : 1; }();
+    static const int kz_ws = [] { const char * e = getenv("MI355_MMDQ_KZ"); return e ? atoi(e) : 1; }();
     const int64_t nb2 = (a.n + 255) / 256;
     const bool dma_ok = ((uintptr_t)a.x & 15) == 0 && a.x_row_stride % 8 == 0;      // 16-byte chunks of the activation rows
+    // 128 x 256 tiles of the WHOLE matrix: enough of them for the chip -> one K range; a half / a quarter of that -> K in 2 / 4
+    // slices (M = 4096..8192 at N = 512), each slice's partial tile to the workspace, summed in slice order.  The small tiles such
+    // launches used to take move 2-3x the activation bytes per flop (4096 x 14336 x 512: 143 -> 8x us).
+    const int64_t tiles = nb2 * ((m_total + 127) / 128);
+    int kzw = tiles >= 200 ? 1 : 2 * tiles >= 200 ? 2 : 4 * tiles >= 200 ? 4 : 0;
+    if (kzw > 1 && (!kz_ws || a.k % (BK * kzw) != 0 || a.k / kzw < 1024)) kzw = 0;
+    if (wide == 2 && kzw > 1 && a.n >= 256 && dma_ok) {
+        DArgs b = a;
+        b.part = kz_workspace((size_t)kzw * a.n * a.m * sizeof(float));
+        if (!b.part) return MI355_E_WORKSPACE;
+        MI355_LAUNCH(tag, (mmdq_ws_kernel<TYPE, 128, 256>), dim3((unsigned)nb2, (unsigned)((a.m + 127) / 128), (unsigned)kzw), dim3(768), 0, s, b);
+        MI355_CHECK_LAUNCH();
+        const int64_t total = (int64_t)a.m * a.n;
+        MI355_LAUNCH("mmdq_kz_sum", kz_sum_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 4096)), dim3(256), 0, s, b.part, a.dst, a.dst_col_stride, a.m, a.n, kzw);
+        MI355_CHECK_LAUNCH();
+        return MI355_OK;
+    }
     if (wide == 2 && kz == 1 && a.n >= 256 && nb2 * ((a.m + 127) / 128) >= 200 && dma_ok) {
         MI355_LAUNCH(tag, (mmdq_ws_kernel<TYPE, 128, 256>), dim3((unsigned)nb2, (unsigned)((a.m + 127) / 128)), dim3(768), 0, s, a);
     } else if (wide && kz == 1 && a.n >= 256 && nb2 * ((a.m + 127) / 128) >= 200) {
@@ -563,7 +614,10 @@ static int launch(const DArgs & a, int64_t m_total, hipStream_t s, const char * 
         }
         // role-split 64 x 128 tiles where the launch cannot fill the chip anyway (<= one workgroup per CU: M = 1024 at N = 512 runs
         // 25 us instead of 32); with two resident workgroups per CU the uniform kernel's waves cover each other better (M = 4096: 51 vs 56 us)
-        if (wide == 2 && dma_ok && (small_ws == 2 || (small_ws == 1 && nb * ((a.m + 63) / 64) * kz <= 256)))
+        static const int mid = [] { const char * e = getenv("MI355_MMDQ_MID"); return e ? atoi(e) : 0; }();
+        if (mid && kz == 2 && a.m >= 2048)
+            MI355_LAUNCH(tag, (mmdq_kernel<TYPE, 128, false>), dim3((unsigned)nb, (unsigned)((a.m + 127) / 128), kz), dim3(256), 0, s, a);
+        else if (wide == 2 && dma_ok && (small_ws == 2 || (small_ws == 1 && nb * ((a.m + 63) / 64) * kz <= 256)))
             MI355_LAUNCH(tag, (mmdq_ws_kernel<TYPE, 64, 128>), dim3((unsigned)nb, (unsigned)((a.m + 63) / 64), kz), dim3(384), 0, s, a);
         else
             MI355_LAUNCH(tag, (mmdq_kernel<TYPE, 64, false>), dim3((unsigned)nb, (unsigned)((a.m + 63) / 64), kz), dim3(256), 0, s, a);
@@ -620,7 +674,7 @@ extern "C" int mi355_mul_mat_dq_slice(int type, const void * W, int64_t w_row_st
     DArgs a;
     a.W = (const uint8_t *)W; a.w_row_stride = w_row_stride; a.x = x; a.x_row_stride = x_row_stride;
     a.dst = dst; a.dst_col_stride = dst_col_stride; a.m = (int)m; a.n = (int)n; a.k = (int)k;
-    a.sorted = a.off = a.tile_off = nullptr; a.n_expert = a.n_used = a.act_ne1 = 0; a.w_expert_stride = 0;
+    a.sorted = a.off = a.tile_off = nullptr; a.n_expert = a.n_used = a.act_ne1 = 0; a.w_expert_stride = 0; a.part = nullptr;
     { static const int dbg = [] { const char * e = getenv("MI355_MMDQ_DBG"); return e ? atoi(e) : 0; }(); a.dbg = dbg; }
     hipStream_t s = (hipStream_t)stream;
     switch (type) {
@@ -676,7 +730,7 @@ extern "C" int mi355_mul_mat_id_dq(int type, const void * as, int64_t w_row_stri
     a.W = (const uint8_t *)as; a.w_row_stride = w_row_stride; a.x = act; a.x_row_stride = k;
     a.dst = dst; a.dst_col_stride = m; a.m = (int)m; a.n = (int)(n_tokens * n_used); a.k = (int)k;
     a.sorted = sorted; a.off = off; a.tile_off = tile_off; a.n_expert = (int)n_expert; a.n_used = (int)n_used; a.act_ne1 = (int)b_ne1;
-    a.w_expert_stride = w_expert_stride; a.dbg = 0;
+    a.w_expert_stride = w_expert_stride; a.dbg = 0; a.part = nullptr;
     const int max_tiles = (int)((n_tokens * n_used + BN - 1) / BN + n_expert);   // sum over experts of ceil(cnt_e / BN) never exceeds this
     switch (type) {
         case MI355_TYPE_Q4_0: return launch_ids<MI355_TYPE_Q4_0>(a, max_tiles, s, "mmdq_id_q4_0");

@@ -181,7 +181,9 @@ def test_mmq_int8_mfma_vs_oracle_contract(ops, t, m, k, n):
 
 @pytest.mark.parametrize("t", B.WEIGHT_TYPES)
 @pytest.mark.parametrize("m,k,n", [(128, 256, 128), (130, 1024, 33), (64, 512, 9), (300, 2048, 200), (257, 256, 129), (1024, 4096, 512),
-                                   (12810, 512, 300)])        # the 128 x 256 tile (>= 200 workgroups of it), ragged in both directions
+                                   (12810, 512, 300),         # the 128 x 256 tile (>= 200 workgroups of it), ragged in both directions
+                                   # too few 128 x 256 tiles for the chip: K in 4 / 2 slices, partial tiles summed in slice order
+                                   (4096, 4096, 512), (4100, 14336, 300), (8192, 2048, 512)])
 def test_mmdq_bf16_mfma_vs_dequantized_reference(ops, t, m, k, n):
     """dequantize-in-LDS bf16 MFMA GEMM vs exact dequant(W) @ x in f64 (the ggml contract, ggml.c:2971-2986).
     Error model: two bf16 roundings per product -> NMSE ~ 3e-6; the op's budget is 5e-4 (test-backend-ops)."""

@@ -10,7 +10,10 @@ import llm_amd.blocks as B, llm_amd.kernels as K, llm_amd.ops as ops
 t, m, n = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 s = torch.cuda.current_stream().cuda_stream
 for k in (int(v) for v in sys.argv[4].split(",")):
-    w = torch.from_numpy(B.random_blocks(t, m, k, seed=1)).cuda()
+    if t in B.FLOAT_WEIGHT_TYPES:      # f16 / bf16 / f32 weights: random bits of small magnitude
+        w = (torch.randn((m, k), device="cuda") * 0.02).to({B.F16: torch.float16, B.BF16: torch.bfloat16}.get(t, torch.float32)).view(torch.uint8).reshape(m, -1)
+    else:
+        w = torch.from_numpy(B.random_blocks(t, m, k, seed=1)).cuda()
     y = ops.act_bf16(torch.randn((n, k), device="cuda"))
     dst = torch.empty((n, m), device="cuda")
     run = lambda: K.check(K.lib.mi355_mul_mat_dq(t, w.data_ptr(), B.row_size(t, k), y.data_ptr(), k, dst.data_ptr(), m, m, k, n, s), "dq")
