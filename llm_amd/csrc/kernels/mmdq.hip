@@ -22,7 +22,9 @@
 #include "common.h"
 #include "moe_bucket.h"
 #include <algorithm>
+#include <map>
 #include <mutex>
+#include <utility>
 
 namespace {
 
@@ -529,22 +531,24 @@ kz_sum_kernel(const float * part, float * dst, int64_t dst_col_stride, int m, in
     }
 }
 
-// per-device workspace of the split-K launches (partial tiles); grows on demand -- an allocation (and a device synchronisation when
-// it grows) inside a call: prefill-sized MUL_MATs are not what a caller captures into a graph, and MI355_MMDQ_KZ=0 keeps every
-// launch on the paths that need none
-static float * kz_workspace(size_t bytes) {
+// workspace of the split-K launches (partial tiles), one per (device, stream) -- launches on different streams may overlap; grows
+// on demand: an allocation (and a device synchronisation when it grows) inside a call.  Prefill-sized MUL_MATs are not what a
+// caller captures into a graph, and MI355_MMDQ_KZ=0 keeps every launch on the paths that need none.
+static float * kz_workspace(size_t bytes, hipStream_t stream) {
+    struct Buf { float * p = nullptr; size_t have = 0; };
     static std::mutex mu;
-    static float * buf[64] = {}; static size_t have[64] = {};
+    static std::map<std::pair<int, hipStream_t>, Buf> bufs;
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
     std::lock_guard<std::mutex> lock(mu);
-    if (have[dev] < bytes) {
-        if (buf[dev]) { if (hipDeviceSynchronize() != hipSuccess) return nullptr; (void)hipFree(buf[dev]); buf[dev] = nullptr; have[dev] = 0; }
+    Buf & b = bufs[{dev, stream}];
+    if (b.have < bytes) {
+        if (b.p) { if (hipDeviceSynchronize() != hipSuccess) return nullptr; (void)hipFree(b.p); b.p = nullptr; b.have = 0; }
         const size_t want = (bytes + (8u << 20)) & ~((size_t)(8u << 20) - 1);
-        if (hipMalloc((void **)&buf[dev], want) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-        have[dev] = want;
+        if (hipMalloc((void **)&b.p, want) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        b.have = want;
     }
-    return buf[dev];
+    return b.p;
 }
 
 // f32 (4-D, strided rows) -> bf16 [rows][k], round to nearest even; one lane per 8 values
@@ -588,7 +592,7 @@ static int launch(const DArgs & a, int64_t m_total, hipStream_t s, const char * 
     if (kzw > 1 && (!kz_ws || a.k % (BK * kzw) != 0 || a.k / kzw < 1024)) kzw = 0;
     if (wide == 2 && kzw > 1 && a.n >= 256 && dma_ok) {
         DArgs b = a;
-        b.part = kz_workspace((size_t)kzw * a.n * a.m * sizeof(float));
+        b.part = kz_workspace((size_t)kzw * a.n * a.m * sizeof(float), s);
         if (!b.part) return MI355_E_WORKSPACE;
         MI355_LAUNCH(tag, (mmdq_ws_kernel<TYPE, 128, 256>), dim3((unsigned)nb2, (unsigned)((a.m + 127) / 128), (unsigned)kzw), dim3(768), 0, s, b);
         MI355_CHECK_LAUNCH();
