@@ -41,6 +41,12 @@
  *   GGML_MI355_TIME_GRAPH=1  every 64 calls, print the host time spent inside graph_compute and between calls
  *   GGML_MI355_VIRTUAL_DEVICES=n   expose n ggml devices mapped round-robin onto the physical GPUs (tests the row-split
  *                            path on a one-GPU machine)
+ *   GGML_MI355_NO_GRAPHS=1   decode tokens are launched eagerly, not replayed from a captured hipGraph (GGML_MI355_GRAPH_STATS=1
+ *                            prints replay / capture / eager counts when the backend is freed, GGML_MI355_GRAPH_DEBUG=1 why a graph
+ *                            was captured again)
+ *   GGML_MI355_SPLIT_GATHER=rccl   row split: gather the devices' row slices with an RCCL all-gather (ncclCommInitAll, one rank per
+ *                            physical GPU; librccl.so is opened only then) instead of peer stores into the main device's dst; falls
+ *                            back to peer stores, with a warning, when two devices share a GPU or RCCL cannot be set up
  */
 #ifndef GGML_MI355_H
 #define GGML_MI355_H

@@ -311,7 +311,12 @@ MI355_API int mi355_mul_mat_q(int type, const void *W, int64_t w_row_stride, con
  * [rows][k], 16-byte aligned, k % 8 == 0) -- there is no q8_1 pass on this path.  Same contract and error budget as
  * mi355_mul_mat_q (NMSE <= 5e-4 vs ggml-cpu; measured ~3e-6).  MI355_E_UNSUPPORTED when k % 64 != 0.
  * Replaces the reference's large-batch path (mul_mat_q, or dequantize + hipBLAS GEMM: ggml-cuda.cu:1223-1340).
- *   act_bf16: n columns of k bf16, act_row_stride elements apart (multiple of 8) */
+ *   act_bf16: n columns of k bf16, act_row_stride elements apart (multiple of 8)
+ * Tiles: 128 weight rows x 256 columns, 8 multiplying + 4 dequantizing waves, activation tile by LDS-DMA.  A matrix with too few such
+ * tiles for the chip (e.g. 4096 rows at n = 512) has K cut in 2 or 4 slices whose partial tiles are kept in a workspace the LIBRARY
+ * owns per (device, stream) and are added in slice order (a fixed summation order, no atomics).  That workspace is the one
+ * allocation this library makes inside a call: hipMalloc on first use / growth (with a device synchronisation when it grows), so
+ * such a call must not sit under graph capture; MI355_MMDQ_KZ=0 in the environment keeps every launch on the paths without it. */
 MI355_API int mi355_act_bf16(const float *x, uint16_t *y, int64_t k, int64_t ne1, int64_t ne2, int64_t ne3,
                              int64_t nb1, int64_t nb2, int64_t nb3, void *stream);
 MI355_API int mi355_mul_mat_dq(int type, const void *W, int64_t w_row_stride, const uint16_t *act_bf16, int64_t act_row_stride,
