@@ -326,6 +326,13 @@ MI355_API int mi355_mul_mat_dq(int type, const void *W, int64_t w_row_stride, co
  * unsplit matrix would. */
 MI355_API int mi355_mul_mat_dq_slice(int type, const void *W, int64_t w_row_stride, const uint16_t *act_bf16, int64_t act_row_stride,
                                      float *dst, int64_t dst_col_stride, int64_t m, int64_t m_total, int64_t k, int64_t n, void *stream);
+/* same with the split-K workspace handed in by the caller: mi355_mul_mat_dq_workspace_bytes(m, m_total, k, n) bytes (0 when this shape
+ * needs none), 16-byte aligned, private to the stream.  With it the call allocates nothing (capture-safe); workspace == NULL falls
+ * back to the library's own.  MI355_E_WORKSPACE when it is too small. */
+MI355_API int64_t mi355_mul_mat_dq_workspace_bytes(int64_t m, int64_t m_total, int64_t k, int64_t n);
+MI355_API int mi355_mul_mat_dq_slice_ws(int type, const void *W, int64_t w_row_stride, const uint16_t *act_bf16, int64_t act_row_stride,
+                                        float *dst, int64_t dst_col_stride, int64_t m, int64_t m_total, int64_t k, int64_t n,
+                                        void *workspace, int64_t workspace_bytes, void *stream);
 
 /* MUL_MAT_ID (ggml.c:3000-3036) for prefill-sized batches: dst[t][s][:] = as[ids[t][s]] . b[t][s % b_ne1].
  * The (token, slot) pairs are bucketed by expert ON THE DEVICE (one small kernel; the reference synchronises the

@@ -572,9 +572,9 @@ struct mi355_backend_ctx {
     // device scratch, grown on demand and reused across ops:
     //   [0] q8_1 activations of the MUL_MAT / MUL_MAT_ID in flight   [1] split-KV partials of FLASH_ATTN_EXT
     //   [2] spare activation buffer: a kernel that reads activations AND emits the next ones (mi355_glu_matvec) writes
-    //       here, then [0] and [2] trade places
-    void * scratch[3] = {nullptr, nullptr, nullptr};
-    size_t scratch_size[3] = {0, 0, 0};
+    //       here, then [0] and [2] trade places      [3] partial tiles of a split-K prefill GEMM (mi355_mul_mat_dq_slice_ws)
+    void * scratch[4] = {nullptr, nullptr, nullptr, nullptr};
+    size_t scratch_size[4] = {0, 0, 0, 0};
     void swap_act_scratch() { std::swap(scratch[0], scratch[2]); std::swap(scratch_size[0], scratch_size[2]); }
 
     // the activation tensor whose q8_1 form currently sits in scratch[0]: consecutive MUL_MATs that read
@@ -691,7 +691,7 @@ static void mi355_backend_free(ggml_backend_t backend) {
     mi355_backend_ctx * ctx = (mi355_backend_ctx *)backend->context;
     mi355_set_device(ctx->device);
     HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    for (int i = 0; i < 3; i++) if (ctx->scratch[i]) HIP_CHECK(hipFree(ctx->scratch[i]));
+    for (int i = 0; i < 4; i++) if (ctx->scratch[i]) HIP_CHECK(hipFree(ctx->scratch[i]));
     if (MI355_ENV_SET("GGML_MI355_GRAPH_STATS"))
         fprintf(stderr, "[mi355] %s decode graphs: %ld replays, %ld captures, %ld eager runs of capturable graphs%s\n", ctx->name.c_str(),
                 ctx->gc.n_replay, ctx->gc.n_capture, ctx->gc.n_eager, ctx->gc.disabled ? " (disabled)" : "");
@@ -832,8 +832,9 @@ static mi355_act_layout mi355_act_planes(int path, int64_t K, int64_t rows) {
 
 // the launches of one MUL_MAT over rows [row_low, row_low + M) of the weight matrix whose first owned row is at W;
 // `act` holds all of src1 in the format of `path`
+// gemm_ws / gemm_ws_bytes: split-K workspace of the prefill GEMM for THIS stream (NULL: the kernel library's own, which it allocates)
 static void mi355_mul_mat_launch(const ggml_tensor * dst, const char * W, int64_t row_low, int64_t M,
-                                 const char * act, int path, hipStream_t stream) {
+                                 const char * act, int path, hipStream_t stream, void * gemm_ws = nullptr, int64_t gemm_ws_bytes = 0) {
     const ggml_tensor * src0 = dst->src[0];
     const ggml_tensor * src1 = dst->src[1];
     const int64_t K = src0->ne[0], ne02 = src0->ne[2], ne03 = src0->ne[3];
@@ -852,7 +853,8 @@ static void mi355_mul_mat_launch(const ggml_tensor * dst, const char * W, int64_
                 const int64_t arow = (i13 * ne12 + i12) * N;
                 float * d = (float *)(dbase + i13 * dst->nb[3] + i12 * dst->nb[2]);
                 if (path == MM_DQ) {
-                    MI_CHECK(mi355_mul_mat_dq_slice((int)src0->type, Wc, (int64_t)src0->nb[1], (const uint16_t *)act + arow * K, K, d, dcol, M, src0->ne[1], K, N, stream));
+                    MI_CHECK(mi355_mul_mat_dq_slice_ws((int)src0->type, Wc, (int64_t)src0->nb[1], (const uint16_t *)act + arow * K, K, d, dcol, M, src0->ne[1], K, N,
+                                                       gemm_ws, gemm_ws_bytes, stream));
                 } else if (path == MM_Q_INT8) {
                     MI_CHECK(mi355_mul_mat_q((int)src0->type, Wc, (int64_t)src0->nb[1], aq + arow * K, ads + arow * (K / 32) * 2, d, dcol, M, K, N, stream));
                 } else {
@@ -931,8 +933,17 @@ static void mi355_mul_mat(mi355_backend_ctx * ctx, ggml_tensor * dst) {
         ctx->act_remember(src1, fmt);
     }
 
+    // split-K workspace of the prefill GEMM: from this stream's scratch, so the kernel library allocates nothing
+    void * gemm_ws = nullptr;
+    int64_t gemm_ws_bytes = 0;
+    if (path == MM_DQ) {
+        const int64_t own_rows = tensor_is_split(src0) ? ((const mi355_split_extra *)src0->extra)->row_high[ctx->device] - ((const mi355_split_extra *)src0->extra)->row_low[ctx->device] : M;
+        gemm_ws_bytes = mi355_mul_mat_dq_workspace_bytes(own_rows > 0 ? own_rows : 0, M, K, N);
+        if (gemm_ws_bytes > 0) gemm_ws = ctx->get_scratch(3, (size_t)gemm_ws_bytes);
+        if (gemm_ws && ctx->scratch_size[3] < (size_t)gemm_ws_bytes) { gemm_ws = nullptr; gemm_ws_bytes = 0; }    // under capture the buffer could not grow
+    }
     if (!tensor_is_split(src0)) {
-        mi355_mul_mat_launch(dst, (const char *)src0->data, 0, M, ws, path, ctx->stream);
+        mi355_mul_mat_launch(dst, (const char *)src0->data, 0, M, ws, path, ctx->stream, gemm_ws, gemm_ws_bytes);
         return;
     }
 
@@ -1037,7 +1048,7 @@ static void mi355_mul_mat(mi355_backend_ctx * ctx, ggml_tensor * dst) {
     mi355_set_device(ctx->device);
     if (extra->data[ctx->device]) {
         mi355_mul_mat_launch(dst, (const char *)extra->data[ctx->device], extra->row_low[ctx->device],
-                             extra->row_high[ctx->device] - extra->row_low[ctx->device], ws, path, ctx->stream);
+                             extra->row_high[ctx->device] - extra->row_low[ctx->device], ws, path, ctx->stream, gemm_ws, gemm_ws_bytes);
     }
     for (int d = 0; d < ndev; d++) {
         if (d == ctx->device || !extra->data[d]) continue;

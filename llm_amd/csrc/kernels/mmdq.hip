@@ -566,6 +566,17 @@ act_bf16_kernel(const char * x, uint16_t * y, int k, int ne1, int ne2, int64_t n
     }
 }
 
+// K slices of the 128 x 256 role-split kernel for a matrix of m_total rows: 1 when its tiles fill the chip, 2 / 4 when a half / a
+// quarter of that, 0 when the launch does not take that kernel's split-K form at all
+static int kz_slices(int64_t m_total, int64_t n, int64_t k) {
+    static const int kz_ws = [] { const char * e = getenv("MI355_MMDQ_KZ"); return e ? atoi(e) : 1; }();
+    static const int wide = [] { const char * e = getenv("MI355_MMDQ_WIDE"); return e ? atoi(e) : 2; }();
+    const int64_t tiles = ((n + 255) / 256) * ((m_total + 127) / 128);
+    int kzw = tiles >= 200 ? 1 : 2 * tiles >= 200 ? 2 : 4 * tiles >= 200 ? 4 : 0;
+    if (kzw > 1 && (!kz_ws || wide != 2 || n < 256 || k % (BK * kzw) != 0 || k / kzw < 1024)) kzw = 0;
+    return kzw;
+}
+
 // m_total: rows of the WHOLE weight matrix when `a` is a row slice of it (row split).  Whether K is cut in two -- the one
 // choice here that changes the f32 summation order -- is decided from the whole matrix, so a slice produces the bits the
 // unsplit matrix would; the tile height only changes which workgroup computes an element, not how.
@@ -581,18 +592,15 @@ static int launch(const DArgs & a, int64_t m_total, hipStream_t s, const char * 
     // the bytes moved per flop fall with the tile height.  256-row tiles (8 waves) when they still cover the chip.
     static const int wide = [] { const char * e = getenv("MI355_MMDQ_WIDE"); return e ? atoi(e) : 2; }();   // 0: 256 x 128 tile, 1: 128 x 256 uniform, 2: 128 x 256 role-split
     static const int small_ws = [] { const char * e = getenv("MI355_MMDQ_SMALL"); return e ? atoi(e) : 1; }();
-    static const int kz_ws = [] { const char * e = getenv("MI355_MMDQ_KZ"); return e ? atoi(e) : 1; }();
     const int64_t nb2 = (a.n + 255) / 256;
     const bool dma_ok = ((uintptr_t)a.x & 15) == 0 && a.x_row_stride % 8 == 0;      // 16-byte chunks of the activation rows
     // 128 x 256 tiles of the WHOLE matrix: enough of them for the chip -> one K range; a half / a quarter of that -> K in 2 / 4
     // slices (M = 4096..8192 at N = 512), each slice's partial tile to the workspace, summed in slice order.  The small tiles such
     // launches used to take move 2-3x the activation bytes per flop (4096 x 14336 x 512: 143 -> 8x us).
-    const int64_t tiles = nb2 * ((m_total + 127) / 128);
-    int kzw = tiles >= 200 ? 1 : 2 * tiles >= 200 ? 2 : 4 * tiles >= 200 ? 4 : 0;
-    if (kzw > 1 && (!kz_ws || a.k % (BK * kzw) != 0 || a.k / kzw < 1024)) kzw = 0;
-    if (wide == 2 && kzw > 1 && a.n >= 256 && dma_ok) {
+    const int kzw = kz_slices(m_total, a.n, a.k);
+    if (kzw > 1 && dma_ok) {
         DArgs b = a;
-        b.part = kz_workspace((size_t)kzw * a.n * a.m * sizeof(float), s);
+        if (!b.part) b.part = kz_workspace((size_t)kzw * a.n * a.m * sizeof(float), s);    // no workspace from the caller: the library's own
         if (!b.part) return MI355_E_WORKSPACE;
         MI355_LAUNCH(tag, (mmdq_ws_kernel<TYPE, 128, 256>), dim3((unsigned)nb2, (unsigned)((a.m + 127) / 128), (unsigned)kzw), dim3(768), 0, s, b);
         MI355_CHECK_LAUNCH();
@@ -663,7 +671,20 @@ extern "C" int mi355_mul_mat_dq(int type, const void * W, int64_t w_row_stride, 
 
 extern "C" int mi355_mul_mat_dq_slice(int type, const void * W, int64_t w_row_stride, const uint16_t * x, int64_t x_row_stride,
                                       float * dst, int64_t dst_col_stride, int64_t m, int64_t m_total, int64_t k, int64_t n, void * stream) {
+    return mi355_mul_mat_dq_slice_ws(type, W, w_row_stride, x, x_row_stride, dst, dst_col_stride, m, m_total, k, n, nullptr, 0, stream);
+}
+
+extern "C" int64_t mi355_mul_mat_dq_workspace_bytes(int64_t m, int64_t m_total, int64_t k, int64_t n) {
+    if (m < 0 || m_total < m || k <= 0 || n < 0) return -1;
+    const int kzw = k % BK == 0 ? kz_slices(m_total, n, k) : 0;
+    return kzw > 1 ? (int64_t)kzw * n * m * (int64_t)sizeof(float) : 0;
+}
+
+extern "C" int mi355_mul_mat_dq_slice_ws(int type, const void * W, int64_t w_row_stride, const uint16_t * x, int64_t x_row_stride,
+                                         float * dst, int64_t dst_col_stride, int64_t m, int64_t m_total, int64_t k, int64_t n,
+                                         void * workspace, int64_t workspace_bytes, void * stream) {
     if (!W || !x || !dst) return MI355_E_NULL;
+    if (workspace && (((uintptr_t)workspace & 15) || workspace_bytes < mi355_mul_mat_dq_workspace_bytes(m, m_total, k, n))) return MI355_E_WORKSPACE;
     if (m_total < m) return MI355_E_SHAPE;
     const int64_t bs = mi355_blck_size(type);
     if (bs == 0 || type == MI355_TYPE_Q8_1) return MI355_E_TYPE;
@@ -678,7 +699,7 @@ extern "C" int mi355_mul_mat_dq_slice(int type, const void * W, int64_t w_row_st
     DArgs a;
     a.W = (const uint8_t *)W; a.w_row_stride = w_row_stride; a.x = x; a.x_row_stride = x_row_stride;
     a.dst = dst; a.dst_col_stride = dst_col_stride; a.m = (int)m; a.n = (int)n; a.k = (int)k;
-    a.sorted = a.off = a.tile_off = nullptr; a.n_expert = a.n_used = a.act_ne1 = 0; a.w_expert_stride = 0; a.part = nullptr;
+    a.sorted = a.off = a.tile_off = nullptr; a.n_expert = a.n_used = a.act_ne1 = 0; a.w_expert_stride = 0; a.part = (float *)workspace;
     { static const int dbg = [] { const char * e = getenv("MI355_MMDQ_DBG"); return e ? atoi(e) : 0; }(); a.dbg = dbg; }
     hipStream_t s = (hipStream_t)stream;
     switch (type) {

@@ -533,7 +533,6 @@ static __device__ __forceinline__ void wait_vm_le(int q) {
 }
 
 constexpr int DMA_MAX_SLOTS = 16;
-constexpr int MI355_MAX_DEVICES_LDS = 64;
 
 template <int TYPE> struct DmaImg { static constexpr bool OK = false; };
 
@@ -541,7 +540,7 @@ static __device__ __forceinline__ v4i lds16(const lds_u8 * ring, int off) { retu
 
 template <> struct DmaImg<MI355_TYPE_Q4_K> {
     static constexpr bool OK = true;
-    static constexpr int BLK = 144, IMG = 144, CPB = 9;
+    static constexpr int IMG = 144, CPB = 9;         // bytes of a block's image in LDS, 16-byte chunks per block
     static __device__ __forceinline__ int src(int c) { return 16 * c; }      // byte offset in the row of image chunk c
     static __device__ __forceinline__ Unit<MI355_TYPE_Q4_K>::Raw read(const lds_u8 * ring, int mask, int io, int u) {
         const int g = u & 3;
@@ -554,7 +553,7 @@ template <> struct DmaImg<MI355_TYPE_Q4_K> {
 };
 template <> struct DmaImg<MI355_TYPE_Q5_K> {
     static constexpr bool OK = true;
-    static constexpr int BLK = 176, IMG = 176, CPB = 11;
+    static constexpr int IMG = 176, CPB = 11;
     static __device__ __forceinline__ int src(int c) { return 16 * c; }
     static __device__ __forceinline__ Unit<MI355_TYPE_Q5_K>::Raw read(const lds_u8 * ring, int mask, int io, int u) {
         const int g = u & 3;
@@ -569,7 +568,7 @@ template <> struct DmaImg<MI355_TYPE_Q5_K> {
 };
 template <> struct DmaImg<MI355_TYPE_Q6_K> {
     static constexpr bool OK = true;
-    static constexpr int BLK = 210, IMG = 224, CPB = 14;
+    static constexpr int IMG = 224, CPB = 14;        // 210-byte blocks, re-laid out: see src()
     static __device__ __forceinline__ int src(int c) {
         const int b = (int)(((unsigned)c * 18725u) >> 18), j = c - 14 * b;         // c / 14 for c < 2^16
         return b * 210 + (j < 13 ? 16 * j : 194);

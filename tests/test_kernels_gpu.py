@@ -201,6 +201,30 @@ def test_mmdq_bf16_mfma_vs_dequantized_reference(ops, t, m, k, n):
         assert O.nmse(O.mul_mat(t, w, x, m, k, n, "cpu"), got) <= 5e-4
 
 
+def test_mmdq_split_k_workspace_from_the_caller(ops):
+    """mi355_mul_mat_dq_slice_ws: the split-K partial tiles in a workspace the caller owns (what the plugin does, so the kernel library
+    allocates nothing) -- same bits as with the library's own workspace; the size query is 0 for shapes that need none; a workspace that
+    is too small is refused before anything is launched."""
+    import llm_amd.kernels as K
+    t, m, k, n = B.Q4_K, 4096, 4096, 512
+    rng = np.random.default_rng(5)
+    w = dev(B.random_blocks(t, m, k, seed=9))
+    x = ops.act_bf16(dev(rng.standard_normal((n, k)).astype(np.float32)))
+    s = torch.cuda.current_stream().cuda_stream
+    need = K.lib.mi355_mul_mat_dq_workspace_bytes(m, m, k, n)
+    assert need == 4 * n * m * 4                                    # 64 tiles of 128 x 256: K in four slices
+    assert K.lib.mi355_mul_mat_dq_workspace_bytes(14336, 14336, k, n) == 0
+    assert K.lib.mi355_mul_mat_dq_workspace_bytes(1024, 4096, k, n) == 4 * n * 1024 * 4     # a row slice: the cut of the whole matrix
+    ws = torch.empty(need, dtype=torch.uint8, device="cuda")
+    a = torch.empty((n, m), device="cuda")
+    b = torch.full((n, m), 7.0, device="cuda")
+    K.check(K.lib.mi355_mul_mat_dq_slice(t, w.data_ptr(), B.row_size(t, k), x.data_ptr(), k, a.data_ptr(), m, m, m, k, n, s), "dq_slice")
+    K.check(K.lib.mi355_mul_mat_dq_slice_ws(t, w.data_ptr(), B.row_size(t, k), x.data_ptr(), k, b.data_ptr(), m, m, m, k, n, ws.data_ptr(), need, s), "dq_slice_ws")
+    assert torch.equal(a, b)
+    rc = K.lib.mi355_mul_mat_dq_slice_ws(t, w.data_ptr(), B.row_size(t, k), x.data_ptr(), k, b.data_ptr(), m, m, m, k, n, ws.data_ptr(), need - 16, s)
+    assert rc == K.E_WORKSPACE if hasattr(K, "E_WORKSPACE") else rc == -5
+
+
 def test_mmdq_strided_activations_and_errors(ops):
     import llm_amd.kernels as K
     rng = np.random.default_rng(5)
