@@ -429,6 +429,12 @@ MI355_API int mi355_get_rows(const mi355_tensor *src, const mi355_tensor *ids, c
  * KV-cache store of llama.cpp with LLAMA_SET_ROWS, src/llama-kv-cache-unified.cpp:817-892).  Rows with an index outside
  * [0, dst.ne1) are skipped.  Oracle ggml_compute_forward_set_rows_f32 (ggml-cpu/ops.cpp:5179-5227); ggml-cuda/set-rows.cu. */
 MI355_API int mi355_set_rows(const mi355_tensor *src, const mi355_tensor *ids, const mi355_tensor *dst, void *stream);
+/* K and V rows of one decode token, f32 -> q8_0 rows of the KV cache, in one launch (the two CPY f32 -> q8_0 nodes that follow rope / the V
+ * projection, ggml-cuda/cpy.cu ggml_cpy_f32_q8_0_cuda; arithmetic: quantize_row_q8_0_ref, ggml-quants.c:188-211, bit-exact).  n_k, n_v:
+ * values (multiples of 32).  With kv_table the destinations are read on the device from kv_table[2 * kv_slot] (K) and
+ * kv_table[2 * kv_slot + 1] (V) -- the table of mi355_qkv_rope_args, for graph replay -- and k_dst / v_dst are ignored. */
+MI355_API int mi355_kv_store_q8_0(const float *k_src, int64_t n_k, void *k_dst, const float *v_src, int64_t n_v, void *v_dst,
+                                  void *const *kv_table, int kv_slot, void *stream);
 
 /* dst = x * scale + bias (f32, contiguous).  ggml_cuda_op_scale (ggml-cuda/scale.cu). */
 MI355_API int mi355_scale_f32(const mi355_tensor *x, const mi355_tensor *dst, float scale, float bias, void *stream);

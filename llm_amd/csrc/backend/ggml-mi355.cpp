@@ -573,8 +573,9 @@ struct mi355_backend_ctx {
     //   [0] q8_1 activations of the MUL_MAT / MUL_MAT_ID in flight   [1] split-KV partials of FLASH_ATTN_EXT
     //   [2] spare activation buffer: a kernel that reads activations AND emits the next ones (mi355_glu_matvec) writes
     //       here, then [0] and [2] trade places      [3] partial tiles of a split-K prefill GEMM (mi355_mul_mat_dq_slice_ws)
-    void * scratch[4] = {nullptr, nullptr, nullptr, nullptr};
-    size_t scratch_size[4] = {0, 0, 0, 0};
+    //   [4] a decode token's K and V rows in f32, between the fused Q/K/V launch and their quantization into a q8_0 cache
+    void * scratch[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t scratch_size[5] = {0, 0, 0, 0, 0};
     void swap_act_scratch() { std::swap(scratch[0], scratch[2]); std::swap(scratch_size[0], scratch_size[2]); }
 
     // the activation tensor whose q8_1 form currently sits in scratch[0]: consecutive MUL_MATs that read
@@ -691,7 +692,7 @@ static void mi355_backend_free(ggml_backend_t backend) {
     mi355_backend_ctx * ctx = (mi355_backend_ctx *)backend->context;
     mi355_set_device(ctx->device);
     HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    for (int i = 0; i < 4; i++) if (ctx->scratch[i]) HIP_CHECK(hipFree(ctx->scratch[i]));
+    for (int i = 0; i < 5; i++) if (ctx->scratch[i]) HIP_CHECK(hipFree(ctx->scratch[i]));
     if (MI355_ENV_SET("GGML_MI355_GRAPH_STATS"))
         fprintf(stderr, "[mi355] %s decode graphs: %ld replays, %ld captures, %ld eager runs of capturable graphs%s\n", ctx->name.c_str(),
                 ctx->gc.n_replay, ctx->gc.n_capture, ctx->gc.n_eager, ctx->gc.disabled ? " (disabled)" : "");
@@ -1885,10 +1886,14 @@ static bool mi355_try_fuse_qkv_rope(mi355_backend_ctx * ctx, ggml_cgraph * cgrap
     if (ggml_nelements(rq) != Mq || ggml_nelements(rk) != Mk) return false;
     const int32_t * rp = (const int32_t *)rq->op_params;
     if (rp[2] != 0 && rp[2] != 2) return false;
+    // a q8_0 cache (-ctk q8_0 -ctv q8_0): the fused launch leaves K and V as f32 rows in scratch and one small launch quantizes both
+    // into the cache rows (instead of norm + 3 mat-vecs + 2 ropes + 2 quantizing copies)
+    const bool kv_q8 = ck->type == GGML_TYPE_Q8_0 && cv->type == GGML_TYPE_Q8_0;
     for (ggml_tensor * c : {ck, cv}) {
-        if ((c->type != GGML_TYPE_F16 && c->type != GGML_TYPE_F32) || !ggml_is_contiguous(c) || !ggml_is_contiguous(c->src[0])) return false;
+        if ((c->type != GGML_TYPE_F16 && c->type != GGML_TYPE_F32 && !kv_q8) || !ggml_is_contiguous(c) || !ggml_is_contiguous(c->src[0])) return false;
         if (c->src[0]->type != GGML_TYPE_F32) return false;
     }
+    if (kv_q8 && (Mk % 32 || Mv % 32)) return false;
     if (ck->src[0]->data != rk->data || cv->src[0]->data != mv->data || ggml_nelements(ck) != Mk || ggml_nelements(cv) != Mv) return false;
     // nobody else may read the tensors that will not be materialised
     const ggml_tensor * hidden[4] = {mq, mk, mv, rk};
@@ -1925,11 +1930,22 @@ static bool mi355_try_fuse_qkv_rope(mi355_backend_ctx * ctx, ggml_cgraph * cgrap
     a.m_q = Mq; a.m_k = Mk; a.m_v = Mv; a.k = K;
     a.act_q = (const int8_t *)ws; a.act_ds = (const float *)(ws + qb);
     a.q_out = (float *)rq->data; a.k_out = ck->data; a.v_out = cv->data;
+    void * const * kv_table = nullptr;
+    int kv_slot = 0;
     if (ctx->gc.capturing) {
         if (ctx->gc.n_slots >= MI355_KV_SLOTS) { ctx->gc.capture_failed = true; }
-        else { a.kv_table = ctx->gc.kv_dev; a.kv_slot = ctx->gc.n_slots; }
+        else { kv_table = ctx->gc.kv_dev; kv_slot = ctx->gc.n_slots; }
     }
     a.k_out_type = (int32_t)ck->type; a.v_out_type = (int32_t)cv->type;
+    float * kv_tmp = nullptr;
+    if (kv_q8) {
+        kv_tmp = (float *)ctx->get_scratch(4, (size_t)(Mk + Mv) * sizeof(float));
+        if (ctx->scratch_size[4] < (size_t)(Mk + Mv) * sizeof(float)) return false;       // under capture the buffer could not grow
+        a.k_out = kv_tmp; a.v_out = kv_tmp + Mk;
+        a.k_out_type = a.v_out_type = (int32_t)GGML_TYPE_F32;
+    } else {
+        a.kv_table = kv_table; a.kv_slot = kv_slot;      // the fused launch stores into the cache itself
+    }
     a.pos = (const int32_t *)rq->src[1]->data; a.freq_factors = rq->src[2] ? (const float *)rq->src[2]->data : nullptr;
     a.head_dim = (int32_t)hd; a.n_dims = rp[1]; a.mode = rp[2]; a.n_ctx_orig = rp[4];
     memcpy(&a.freq_base, rp + 5, 4); memcpy(&a.freq_scale, rp + 6, 4); memcpy(&a.ext_factor, rp + 7, 4);
@@ -1944,8 +1960,9 @@ static bool mi355_try_fuse_qkv_rope(mi355_backend_ctx * ctx, ggml_cgraph * cgrap
     const int rc = mi355_qkv_rope_matvec(&a, ctx->stream);
     if (rc == MI355_E_UNSUPPORTED || rc == MI355_E_SHAPE || rc == MI355_E_ALIGN) return false;
     MI_CHECK(rc);
+    if (kv_q8) MI_CHECK(mi355_kv_store_q8_0(kv_tmp, Mk, ck->data, kv_tmp + Mk, Mv, cv->data, kv_table, kv_slot, ctx->stream));
     for (int m = 1; m < 7; m++) done[idx[m]] = 1;
-    if (a.kv_table) { ctx->gc.kv_nodes.push_back(idx[5]); ctx->gc.kv_nodes.push_back(idx[6]); ctx->gc.n_slots++; }
+    if (kv_table) { ctx->gc.kv_nodes.push_back(idx[5]); ctx->gc.kv_nodes.push_back(idx[6]); ctx->gc.n_slots++; }
     ctx->act_invalidate_if_written(rq);
     if (norm_idx >= 0) ctx->act_invalidate_if_written(x);
     return true;

@@ -328,7 +328,33 @@ cpy_kernel(const T4 s, const T4 d, int64_t n) {
         *(TD *)(d.data + off4(d, i, 1)) = cvt<TS, TD>(*(const TS *)(s.data + off4(s, i, 1)));
 }
 
-// f32 -> q8_0: one lane per 32-value block (quantize_row_q8_0_ref, ggml-quants.c:188-211)
+// 32 f32 -> one q8_0 block (quantize_row_q8_0_ref, ggml-quants.c:188-211): the one arithmetic behind CPY, SET_ROWS and the KV store
+static __device__ __forceinline__ void quant_block_q8_0(const float * xs, uint8_t * blk) {
+    float v[32], amax = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 32; j++) { v[j] = xs[j]; amax = fmaxf(amax, fabsf(v[j])); }
+    const float dd = __fdiv_rn(amax, 127.0f);
+    const float id = dd != 0.0f ? __fdiv_rn(1.0f, dd) : 0.0f;
+    *(uint16_t *)blk = __half_as_ushort(__float2half_rn(dd));
+#pragma unroll
+    for (int j = 0; j < 32; j++) {
+        const float r = roundf(__fmul_rn(v[j], id));
+        ((int8_t *)blk)[2 + j] = fabsf(r) < 2147483648.0f ? (int8_t)(int)r : 0;
+    }
+}
+
+// K and V rows of one decode token, f32 -> q8_0 cache rows, in one launch; the destinations come from the arguments or, under graph
+// replay, from the device table the fused Q/K/V launch uses (slot pair 2 s, 2 s + 1)
+__global__ void __launch_bounds__(64)
+kv_store_q8_0_kernel(const float * k_src, int nbk, uint8_t * k_dst, const float * v_src, int nbv, uint8_t * v_dst, void * const * tab, int slot) {
+    const int ib = blockIdx.x * 64 + threadIdx.x;
+    if (ib >= nbk + nbv) return;
+    if (tab) { k_dst = (uint8_t *)tab[2 * slot]; v_dst = (uint8_t *)tab[2 * slot + 1]; }
+    if (ib < nbk) quant_block_q8_0(k_src + 32 * ib, k_dst + 34 * ib);
+    else          quant_block_q8_0(v_src + 32 * (ib - nbk), v_dst + 34 * (ib - nbk));
+}
+
+// f32 -> q8_0: one lane per 32-value block
 __global__ void __launch_bounds__(256)
 cpy_f32_q8_0_kernel(const T4 s, const T4 d, int64_t nblocks) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -336,17 +362,7 @@ cpy_f32_q8_0_kernel(const T4 s, const T4 d, int64_t nblocks) {
         // the 32 source values are consecutive along the source's ne[0] (ne[0] % 32 == 0, nb[0] == 4)
         const float * xs = (const float *)(s.data + off4(s, ib, 32, 32 * sizeof(float)));
         uint8_t * blk = (uint8_t *)(d.data + off4(d, ib, 32));
-        float v[32], amax = 0.0f;
-#pragma unroll
-        for (int j = 0; j < 32; j++) { v[j] = xs[j]; amax = fmaxf(amax, fabsf(v[j])); }
-        const float dd = __fdiv_rn(amax, 127.0f);
-        const float id = dd != 0.0f ? __fdiv_rn(1.0f, dd) : 0.0f;
-        *(uint16_t *)blk = __half_as_ushort(__float2half_rn(dd));
-#pragma unroll
-        for (int j = 0; j < 32; j++) {
-            const float r = roundf(__fmul_rn(v[j], id));
-            ((int8_t *)blk)[2 + j] = fabsf(r) < 2147483648.0f ? (int8_t)(int)r : 0;
-        }
+        quant_block_q8_0(xs, blk);
     }
 }
 
@@ -384,17 +400,7 @@ set_rows_q8_0_kernel(const T4 s, const T4 ids, const T4 d, int64_t nblocks) {
         if (o < 0) continue;
         const float * xs = (const float *)(s.data + b0 * 128 + i1 * s.nb[1] + i2 * s.nb[2] + i3 * s.nb[3]);
         uint8_t * blk = (uint8_t *)(d.data + o + b0 * 34);
-        float v[32], amax = 0.0f;
-#pragma unroll
-        for (int j = 0; j < 32; j++) { v[j] = xs[j]; amax = fmaxf(amax, fabsf(v[j])); }
-        const float dd = __fdiv_rn(amax, 127.0f);
-        const float id = dd != 0.0f ? __fdiv_rn(1.0f, dd) : 0.0f;
-        *(uint16_t *)blk = __half_as_ushort(__float2half_rn(dd));
-#pragma unroll
-        for (int j = 0; j < 32; j++) {
-            const float r = roundf(__fmul_rn(v[j], id));
-            ((int8_t *)blk)[2 + j] = fabsf(r) < 2147483648.0f ? (int8_t)(int)r : 0;
-        }
+        quant_block_q8_0(xs, blk);
     }
 }
 
@@ -642,6 +648,20 @@ int mi355_cpy(const mi355_tensor * src, const mi355_tensor * dst, void * stream)
     } else {
         return MI355_E_TYPE;
     }
+    MI355_CHECK_LAUNCH();
+    return MI355_OK;
+}
+
+int mi355_kv_store_q8_0(const float * k_src, int64_t n_k, void * k_dst, const float * v_src, int64_t n_v, void * v_dst,
+                        void * const * kv_table, int kv_slot, void * stream) {
+    if (!k_src || !v_src || (!kv_table && (!k_dst || !v_dst))) return MI355_E_NULL;
+    if (n_k < 0 || n_v < 0 || n_k % 32 || n_v % 32 || n_k + n_v > 0x7fffffff) return MI355_E_SHAPE;
+    if ((((uintptr_t)k_src | (uintptr_t)v_src) & 3) || (((uintptr_t)k_dst | (uintptr_t)v_dst) & 1) || ((uintptr_t)kv_table & 7)) return MI355_E_ALIGN;
+    if (kv_table && kv_slot < 0) return MI355_E_SHAPE;
+    const int nb = (int)((n_k + n_v) / 32);
+    if (nb == 0) return MI355_OK;
+    MI355_LAUNCH("kv_store", kv_store_q8_0_kernel, dim3((unsigned)((nb + 63) / 64)), dim3(64), 0, (hipStream_t)stream,
+                 k_src, (int)(n_k / 32), (uint8_t *)k_dst, v_src, (int)(n_v / 32), (uint8_t *)v_dst, kv_table, kv_slot);
     MI355_CHECK_LAUNCH();
     return MI355_OK;
 }

@@ -176,7 +176,7 @@ def test_llama_logits_match_ggml_cpu(ftype, ctk, tmp_path):
 
 
 @pytest.mark.parametrize("model", ["tiny", "tinymoe"])
-def test_fusions_are_bit_exact(tmp_path, model):
+def test_fusions_are_bit_exact(tmp_path, model, kv="f16"):
     """The backend's graph-level fusions (RMS_NORM*weight, fused q8_1 quantization, activation cache, Q/K/V + rope + store,
     and for the 8-expert model the one-launch MoE router) keep the f32 op order of the unfused graph: logits with and
     without them are identical to the bit."""
@@ -188,14 +188,20 @@ def test_fusions_are_bit_exact(tmp_path, model):
         env = dict(os.environ)
         if nofuse:
             env["GGML_MI355_NO_FUSE"] = "1"
-        r = subprocess.run([tool, model, "Q4_K_M", "--dump-logits", path], capture_output=True, text=True, timeout=600, env=env)
+        r = subprocess.run([tool, model, "Q4_K_M", "-ctk", kv, "-ctv", kv, "--dump-logits", path], capture_output=True, text=True, timeout=600, env=env)
         assert r.returncode == 0, r.stderr[-3000:]
         outs.append(np.fromfile(path, dtype=np.uint32))
     assert np.array_equal(outs[0], outs[1])
 
 
-@pytest.mark.parametrize("model", ["tiny", "tinymoe"])
-def test_decode_graph_replay_is_bit_exact(tmp_path, model):
+def test_fusions_are_bit_exact_with_a_q8_0_cache(tmp_path):
+    """-ctk q8_0 -ctv q8_0: the fused Q/K/V launch leaves K and V as f32 rows in scratch and mi355_kv_store_q8_0 quantizes both into the
+    cache -- the same bits as RMS_NORM, 3 MUL_MAT, 2 ROPE and 2 CPY f32 -> q8_0 launched one by one"""
+    test_fusions_are_bit_exact(tmp_path, "tiny", kv="q8_0")
+
+
+@pytest.mark.parametrize("model,kv", [("tiny", "f16"), ("tinymoe", "f16"), ("tiny", "q8_0")])
+def test_decode_graph_replay_is_bit_exact(tmp_path, model, kv):
     """the plugin captures a decode token's launches into a hipGraph and replays it while the ggml graph keeps
     its shape (the KV-cache rows of the new token go through a device table).  230 decode steps after a 48-token prompt
     cross the 256-entry KV padding boundary (a re-capture); logits with replay equal the eager run's bit for bit, and
@@ -208,7 +214,7 @@ def test_decode_graph_replay_is_bit_exact(tmp_path, model):
         env = dict(os.environ, GGML_MI355_GRAPH_STATS="1")
         if eager:
             env["GGML_MI355_NO_GRAPHS"] = "1"
-        r = subprocess.run([tool, model, "Q4_K_M", "--dump-logits", path, "--decode-steps", "230"], capture_output=True, text=True, timeout=600, env=env)
+        r = subprocess.run([tool, model, "Q4_K_M", "-ctk", kv, "-ctv", kv, "--dump-logits", path, "--decode-steps", "230"], capture_output=True, text=True, timeout=600, env=env)
         assert r.returncode == 0, r.stderr[-3000:]
         outs.append(np.fromfile(path, dtype=np.uint32))
         if not eager:

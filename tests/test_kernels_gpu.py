@@ -225,6 +225,37 @@ def test_mmdq_split_k_workspace_from_the_caller(ops):
     assert rc == K.E_WORKSPACE if hasattr(K, "E_WORKSPACE") else rc == -5
 
 
+def test_kv_store_q8_0_bit_exact(ops):
+    """mi355_kv_store_q8_0 (K and V rows of a decode token into a q8_0 cache, one launch) against the oracle's quantize_row_q8_0_ref,
+    with the destinations given directly and through the pointer table used under graph replay"""
+    import llm_amd.kernels as K
+    rng = np.random.default_rng(11)
+    nk, nv = 1024, 2048
+    k = rng.standard_normal(nk).astype(np.float32) * 3
+    v = rng.standard_normal(nv).astype(np.float32)
+    v[:32] = 0.0                                           # an all-zero block: d = 0
+    kd, vd = dev(k), dev(v)
+    s = torch.cuda.current_stream().cuda_stream
+    want = {id(k): O.quantize_row(B.Q8_0, k), id(v): O.quantize_row(B.Q8_0, v)}
+    for table in (False, True):
+        ko = torch.zeros(nk // 32 * 34, dtype=torch.uint8, device="cuda")
+        vo = torch.zeros(nv // 32 * 34, dtype=torch.uint8, device="cuda")
+        if table:
+            tab = torch.tensor([0, 0, ko.data_ptr(), vo.data_ptr()], dtype=torch.int64, device="cuda")
+            K.check(K.lib.mi355_kv_store_q8_0(kd.data_ptr(), nk, None, vd.data_ptr(), nv, None, tab.data_ptr(), 1, s), "kv_store")
+        else:
+            K.check(K.lib.mi355_kv_store_q8_0(kd.data_ptr(), nk, ko.data_ptr(), vd.data_ptr(), nv, vo.data_ptr(), None, 0, s), "kv_store")
+        for src, out, n in ((k, ko, nk), (v, vo, nv)):
+            blocks = out.cpu().numpy().reshape(n // 32, 34)
+            back = O.dequantize_row(B.Q8_0, blocks, n)
+            d = blocks[:, :2].copy().view(np.float16).astype(np.float32)[:, 0]
+            amax = np.abs(src.reshape(-1, 32)).max(axis=1)
+            assert np.array_equal(d, (amax / np.float32(127.0)).astype(np.float16).astype(np.float32))
+            assert np.abs(back - src).max() <= 0.5 * d.max() + 1e-6
+            assert np.array_equal(blocks, np.asarray(want[id(src)]).view(np.uint8).reshape(-1, 34))
+    assert K.lib.mi355_kv_store_q8_0(kd.data_ptr(), 100, ko.data_ptr(), vd.data_ptr(), nv, vo.data_ptr(), None, 0, s) < 0      # n_k % 32
+
+
 def test_mmdq_strided_activations_and_errors(ops):
     import llm_amd.kernels as K
     rng = np.random.default_rng(5)
