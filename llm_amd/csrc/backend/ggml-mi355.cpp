@@ -1406,15 +1406,18 @@ static int mi355_collect_matvec_group(ggml_cgraph * cgraph, int i, const std::ve
     return cnt;
 }
 
+// norm_x / norm_w / norm_eps (one column only): src1 = (norm_x * rsqrt(mean(norm_x^2) + eps)) * norm_w is computed, stored and quantized in the
+// launch's prologue (mi355_mmvq_args.src_f32) instead of being read from a launch of its own
 static void mi355_mul_mat_group(mi355_backend_ctx * ctx, ggml_cgraph * cgraph, const int * members, int cnt,
-                                const float * residual = nullptr, float * sum = nullptr) {
+                                const float * residual = nullptr, float * sum = nullptr,
+                                const float * norm_x = nullptr, const float * norm_w = nullptr, float norm_eps = 0.0f) {
     const ggml_tensor * first = ggml_graph_node(cgraph, members[0]);
     const ggml_tensor * src1 = first->src[1];
     const int64_t K = src1->ne[0], N = src1->ne[1];
     const size_t qb = align_up((size_t)mi355_act_q_bytes(K, N), 256);
     const size_t db = align_up((size_t)mi355_act_ds_bytes(K, N), 256);
     char * ws = (char *)ctx->get_scratch(0, qb + db);
-    if (!ctx->act_cached(src1)) {
+    if (!norm_x && !ctx->act_cached(src1)) {
         MI_CHECK(mi355_quantize_act((const float *)src1->data, (int8_t *)ws, (float *)(ws + qb), K, N, 1, 1, src1->nb[1], src1->nb[2], src1->nb[3], ctx->stream));
         ctx->act_remember(src1);
     }
@@ -1428,6 +1431,10 @@ static void mi355_mul_mat_group(mi355_backend_ctx * ctx, ggml_cgraph * cgraph, c
         a[m].act_q = (const int8_t *)ws; a[m].act_ds = (const float *)(ws + qb); a[m].act_ch_stride = N;
         a[m].dst = (float *)node->data; a[m].dst_col_stride = (int64_t)(node->nb[1] / sizeof(float));
         a[m].m = w->ne[1]; a[m].k = K; a[m].ncols = (int32_t)N; a[m].nchannels = 1; a[m].ch_ratio = 1;
+        if (norm_x) {
+            a[m].act_q = nullptr; a[m].act_ds = nullptr;
+            a[m].src_f32 = norm_x; a[m].norm_w = norm_w; a[m].norm_out = (float *)src1->data; a[m].norm_eps = norm_eps;
+        }
     }
     a[0].residual = residual; a[0].sum = sum;      // mat-vec + ADD (cnt == 1)
     MI_CHECK(mi355_mul_mat_vec_q_group(a, cnt, ctx->stream));
@@ -1587,6 +1594,35 @@ static bool mi355_try_fuse_norm_glu_matvec(mi355_backend_ctx * ctx, ggml_cgraph 
     int members[MI355_MMVQ_MAX_GROUP];
     if (mi355_collect_matvec_group(cgraph, i + 2, done, members) != 2 || members[1] != i + 3) return false;
     return mi355_try_fuse_glu_matvec(ctx, cgraph, members, i);
+}
+
+// RMS_NORM -> MUL(weight) -> the group of decode mat-vecs that read it (ffn gate + up where the one-launch GLU form does not apply:
+// Llama-3-70B's 28672 rows), the norm in the grouped launch's prologue.  *consumed = nodes taken after the norm (the MUL and the mat-vecs).
+static bool mi355_try_fuse_norm_group(mi355_backend_ctx * ctx, ggml_cgraph * cgraph, int i, const std::vector<char> & done, int * consumed) {
+    const int n = ggml_graph_n_nodes(cgraph);
+    if (i + 2 >= n || MI355_ENV_SET("GGML_MI355_NO_NORM_GROUP")) return false;
+    if (!decode_norm_pattern(cgraph, i, done)) return false;
+    const ggml_tensor * norm = ggml_graph_node(cgraph, i);
+    const ggml_tensor * mul = ggml_graph_node(cgraph, i + 1);
+    const ggml_tensor * m0 = ggml_graph_node(cgraph, i + 2);
+    if (done[i + 2] || !matvec_groupable(m0) || m0->src[1] != mul || mul->ne[1] != 1) return false;
+    int members[MI355_MMVQ_MAX_GROUP];
+    const int cnt = mi355_collect_matvec_group(cgraph, i + 2, done, members);
+    if (cnt < 2) return false;                       // a single mat-vec: the fused norm + quantize launch and the residual forms serve it
+    for (int m = 0; m < cnt; m++) if (members[m] != i + 2 + m) return false;
+    const ggml_tensor * x = norm->src[0];
+    const ggml_tensor * w = mul->src[0] == norm ? mul->src[1] : mul->src[0];
+    const int64_t K = mul->ne[0];
+    const ggml_tensor * outs[1 + MI355_MMVQ_MAX_GROUP] = {mul};
+    size_t ob[1 + MI355_MMVQ_MAX_GROUP] = {ggml_nbytes(mul)};
+    for (int m = 0; m < cnt; m++) { outs[1 + m] = ggml_graph_node(cgraph, members[m]); ob[1 + m] = ggml_nbytes(outs[1 + m]); }
+    if (!norm_prologue_ok(x, w, K, 16384, outs, ob, 1 + cnt)) return false;
+    float eps;
+    memcpy(&eps, norm->op_params, sizeof(float));
+    mi355_mul_mat_group(ctx, cgraph, members, cnt, nullptr, nullptr, (const float *)x->data, (const float *)w->data, eps);
+    ctx->act_invalidate_if_written(mul);
+    *consumed = 1 + cnt;
+    return true;
 }
 
 // Expert feed-forward input of one decode token in one launch (build_moe_ffn, src/llama-graph.cpp:660-760):
@@ -2037,6 +2073,13 @@ static enum ggml_status mi355_issue_graph(mi355_backend_ctx * ctx, ggml_cgraph *
             mi355_try_fuse_qkv_rope(ctx, cgraph, i + 2, done, i)) {
             i += 2;      // the norm, its MUL and wq; the other six nodes are marked done
             continue;
+        }
+        {
+            int consumed = 0;
+            if (fuse && node->op == GGML_OP_RMS_NORM && mi355_try_fuse_norm_group(ctx, cgraph, i, done, &consumed)) {
+                i += consumed;
+                continue;
+            }
         }
         if (node->op == GGML_OP_RMS_NORM && i + 1 < n && mi355_try_fuse_rms_norm_mul(ctx, cgraph, i)) {
             i++;

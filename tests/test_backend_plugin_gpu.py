@@ -176,7 +176,7 @@ def test_llama_logits_match_ggml_cpu(ftype, ctk, tmp_path):
 
 
 @pytest.mark.parametrize("model", ["tiny", "tinymoe"])
-def test_fusions_are_bit_exact(tmp_path, model, kv="f16"):
+def test_fusions_are_bit_exact(tmp_path, model, kv="f16", extra_env=None):
     """The backend's graph-level fusions (RMS_NORM*weight, fused q8_1 quantization, activation cache, Q/K/V + rope + store,
     and for the 8-expert model the one-launch MoE router) keep the f32 op order of the unfused graph: logits with and
     without them are identical to the bit."""
@@ -185,13 +185,19 @@ def test_fusions_are_bit_exact(tmp_path, model, kv="f16"):
     outs = []
     for nofuse in (False, True):
         path = str(tmp_path / f"logits_{int(nofuse)}.bin")
-        env = dict(os.environ)
+        env = dict(os.environ, **(extra_env or {}))
         if nofuse:
             env["GGML_MI355_NO_FUSE"] = "1"
         r = subprocess.run([tool, model, "Q4_K_M", "-ctk", kv, "-ctv", kv, "--dump-logits", path], capture_output=True, text=True, timeout=600, env=env)
         assert r.returncode == 0, r.stderr[-3000:]
         outs.append(np.fromfile(path, dtype=np.uint32))
     assert np.array_equal(outs[0], outs[1])
+
+
+def test_norm_in_the_grouped_gate_up_launch_is_bit_exact(tmp_path):
+    """Where the one-launch gate/up/GLU form does not apply (Llama-3-70B: 28672 rows; forced here with GGML_MI355_NO_GLU_MATVEC) the ffn norm
+    runs in the prologue of the grouped gate + up mat-vec: same bits as the unfused graph"""
+    test_fusions_are_bit_exact(tmp_path, "tiny", extra_env={"GGML_MI355_NO_GLU_MATVEC": "1"})
 
 
 def test_fusions_are_bit_exact_with_a_q8_0_cache(tmp_path):
