@@ -783,9 +783,9 @@ static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 // contract ggml.c:2971-2986; oracle ggml_compute_forward_mul_mat, ggml-cpu.c:1196-1388)
 //
 // Kernel per batch size N (columns of src1), from tools/bench_skinny.py on MI355X (weights 4096..14336 squared-ish):
-//   N <= 3 (K-quants) / N <= 8 (others)   mat-vec (mmvq.hip), q8_1 activations, HBM-bound at N = 1
-//   up to 64 (128 when K >= 8192)         skinny int8-MFMA kernels (mmsk.hip) in passes of 32 columns: q4_K / q5_K on
-//                                         q8_K activations with the sub-block scales folded into the operands,
+//   N <= 3 (q4_K, q5_K) / 4 (q6_K) / 8 (others)   mat-vec (mmvq.hip), q8_1 activations, HBM-bound at N = 1
+//   up to 64 (128 when K >= 8192)         skinny int8-MFMA kernels (mmsk.hip) in passes of 32 columns: the K-quants on
+//                                         q8_K activations with the integer sub-block scales kept on the matrix core,
 //                                         the other types on q8_1 with a per-block f32 rescale (up to 32 / 64)
 //   beyond                                dequantize-in-LDS bf16 MFMA GEMM (mmdq.hip), bf16 activations
 // GGML_MI355_MMQ_INT8=1 keeps prefill on the int8 MFMA tile kernel (mmq.hip), GGML_MI355_NO_SKINNY=1 removes the
@@ -810,8 +810,10 @@ static int mi355_mul_mat_path(const ggml_tensor * src0, const ggml_tensor * src1
         return N > 8 && K % 64 == 0 && aligned ? MM_DQ : MM_VEC;
     }
     if (!no_skinny && K % 256 == 0 && aligned && !(N > 8 && int8_mmq)) {
-        const bool kq = src0->type == GGML_TYPE_Q4_K || src0->type == GGML_TYPE_Q5_K;
-        if (kq  && N >= 4 && N <= (K >= 8192 ? 128 : 64)) return MM_SKINNY_K;
+        // q8_K activations, integer sub-block scales on the matrix core: q4_K / q5_K digit-split (mmsk2), q6_K one 32x32x16 MFMA per
+        // 16-weight sub-block (mmsk6; up to 4 columns the column-group mat-vec is still ahead: 15.8 against 20.5 us on 4096 x 14336)
+        const bool kq = src0->type == GGML_TYPE_Q4_K || src0->type == GGML_TYPE_Q5_K || src0->type == GGML_TYPE_Q6_K;
+        if (kq  && N >= (src0->type == GGML_TYPE_Q6_K ? 5 : 4) && N <= (K >= 8192 ? 128 : 64)) return MM_SKINNY_K;
         if (!kq && N > 8  && N <= (K >= 8192 ? 64 : 32))  return MM_SKINNY;
     }
     if (N > 8 && int8_mmq && K % 128 == 0) return MM_Q_INT8;
@@ -1072,10 +1074,11 @@ static void mi355_mul_mat_id(mi355_backend_ctx * ctx, ggml_tensor * dst) {
     // a few to a few hundred pairs (SURVEY config 5, T = 8..64): bucket by expert on the device, then every expert's matrix
     // is streamed once per 32 of its columns through the skinny int8-MFMA kernels
     static const int64_t sk_max = getenv("GGML_MI355_MOE_SKINNY_MAX") ? atoll(getenv("GGML_MI355_MOE_SKINNY_MAX")) : 256;
+    static const int64_t sk_min = getenv("GGML_MI355_MOE_SKINNY_MIN") ? atoll(getenv("GGML_MI355_MOE_SKINNY_MIN")) : 20;
     const bool dense_dst = dst->nb[1] == (size_t)M * sizeof(float) && dst->nb[2] == (size_t)M * n_used * sizeof(float) &&
                            ((((uintptr_t)b->data) | b->nb[1] | b->nb[2]) & 15) == 0;
     // (measured on 8x7B Q4_K_M: below ~20 pairs the per-pair mat-vec wins -- 16 pairs: 548 vs 521 t/s -- above 256 the GEMM)
-    if (n_tokens * n_used >= 20 && n_tokens * n_used <= sk_max && K % 256 == 0 && n_expert <= 256 && dense_dst &&
+    if (n_tokens * n_used >= sk_min && n_tokens * n_used <= sk_max && K % 256 == 0 && n_expert <= 256 && dense_dst &&
         !MI355_ENV_SET("GGML_MI355_NO_SKINNY")) {
         const int64_t need = mi355_mul_mat_id_skinny_workspace_bytes((int)as->type, K, n_tokens, b_ne1, n_used, n_expert);
         void * ws = ctx->get_scratch(0, (size_t)need);

@@ -538,6 +538,167 @@ mmsk2_kernel(const S2Args a) {
 #endif
 }
 
+// =====================================================================================================================
+// q6_K on q8_K activations (ggml_vec_dot_q6_K_q8_K, ggml-cpu/quants.c: isum = sum_j sc_j * (q_j . a_j) in integers per 256-value
+// super-block, then one f32 scale d_w * d8).  q6_K's int8 scales sit on 16-weight sub-blocks, half of the 32-deep MFMA used above,
+// which forced two half-empty MFMAs and an f32 rescale per sub-block (mmsk_kernel<q6_K>: ~1 TB/s).  Here one
+// v_mfma_i32_32x32x16_i8 IS one sub-block, and the operands are swapped -- activations as A, weights as B -- so that a lane's 16
+// results belong to ONE weight row (the lane's) and 16 activation columns: the sub-block scale is then a per-lane scalar and is
+// applied in integers, acc_i[r] += sc_j * C[r] (v_mad_i32_i24: |C| <= 16 * 32 * 127, 16 sub-blocks stay below 2^31), with one
+// conversion per super-block: acc[r] += (d_row * d8_col) * float(acc_i[r]).  No digit split, no bsums, no per-sub-block float work.
+// Staging as in mmsk2_kernel (coalesced loads into a wave-private LDS region); the 210-byte block is laid out as a 224-byte image:
+// chunks 0..12 = bytes 0..207, chunk 13 = bytes 194..209 (so d sits at image offset 222).
+template <int WAVES>
+__global__ void __launch_bounds__(WAVES * 64)
+mmsk6_kernel(const S2Args a) {
+    constexpr int BLK = 210, IMG = 224, CH = 14, RPI = 64 / CH, NI = (32 + RPI - 1) / RPI;
+    constexpr int APITCH = 272, WBYTES = 32 * IMG, ABYTES = 32 * APITCH, REGION = WBYTES + ABYTES + 16;   // + a dump slot
+    static_assert(REGION >= 16 * 64 * 4, "the staging region doubles as the reduction buffer");
+    __shared__ __attribute__((aligned(16))) uint8_t lds[WAVES * REGION];
+    __shared__ __attribute__((aligned(16))) float d8s[WAVES][32];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 31, lh = lane >> 5;
+    const int m0 = blockIdx.x * 32;
+    uint8_t * Lw = lds + wave * REGION, * La = Lw + WBYTES;
+    __shared__ int s_row[32], s_pair[32];
+    ColMap cm;
+    if (!col_map(a.ids, a.n, tid, s_row, s_pair, cm)) return;
+
+    const uint8_t * wbase = a.W + cm.w_off + (int64_t)m0 * a.w_row_stride;
+    const int wr_ = lane / CH, wc_ = lane % CH;
+    uint32_t woff[NI], wlds[NI];
+#pragma unroll
+    for (int i = 0; i < NI; i++) {
+        const int r = i * RPI + wr_;
+        const bool v = lane < RPI * CH && r < 32;
+        const int rr = m0 + r < a.m ? r : a.m - 1 - m0;      // rows past the end repeat the last row (never stored)
+        woff[i] = v ? (uint32_t)rr * (uint32_t)a.w_row_stride + (wc_ < 13 ? wc_ * 16 : 194) : 0u;
+        wlds[i] = v ? r * IMG + wc_ * 16 : WBYTES + ABYTES;
+    }
+    uint32_t aoff[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) aoff[i] = (uint32_t)s_row[i * 4 + (lane >> 4)] * (uint32_t)a.k + (lane & 15) * 16;
+    const uint32_t doff = (uint32_t)s_row[lr] * (uint32_t)(a.k / 256) * 4;
+
+    const int nsb = a.k / 256, per = (nsb + cm.ky_cnt - 1) / cm.ky_cnt;
+    const int sb0 = cm.ky_idx * per, sb1 = sb0 + per < nsb ? sb0 + per : nsb;
+    const int perw = (sb1 - sb0 + WAVES - 1) / WAVES;
+    const int my0 = sb0 + wave * perw, my1 = my0 + perw < sb1 ? my0 + perw : sb1;
+
+    float acc[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[r] = 0.0f;
+
+    struct StageW { v4i w[NI]; };
+    struct StageA { v4i q[8]; float d; };
+    auto fetch_w = [&](int sb_) {
+        StageW r;
+        const uint8_t * wb = wbase + (int64_t)sb_ * BLK;
+#pragma unroll
+        for (int i = 0; i < NI; i++) r.w[i] = ld16_a2(wb + woff[i]);
+        return r;
+    };
+    auto fetch_a = [&](int sb_) {
+        StageA r;
+        const int8_t * ab = a.aq + (int64_t)sb_ * 256;
+#pragma unroll
+        for (int i = 0; i < 8; i++) r.q[i] = *(const v4i *)(ab + aoff[i]);
+        r.d = *(const float *)((const uint8_t *)a.ad + (int64_t)sb_ * 4 + doff);
+        return r;
+    };
+    const int last = my1 - 1;
+    auto clampsb = [&](int sb_) { return sb_ < last ? sb_ : last; };
+
+    StageA sa;
+    auto step = [&](int sb, StageW & sw) {
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int i = 0; i < NI; i++) *(v4i *)(Lw + wlds[i]) = sw.w[i];
+#pragma unroll
+        for (int i = 0; i < 8; i++) *(v4i *)(La + (i * 4 + (lane >> 4)) * APITCH + (lane & 15) * 16) = sa.q[i];
+        if (lh == 0) d8s[wave][lr] = sa.d;
+        __builtin_amdgcn_wave_barrier();
+        sa = fetch_a(clampsb(sb + 1));
+        sw = fetch_w(clampsb(sb + 1));
+
+        const uint8_t * wl = Lw + lr * IMG;          // this lane's weight row (both lane halves: its two 8-weight halves of a sub-block)
+        const uint8_t * al = La + lr * APITCH + 8 * lh;   // ... and, as the A operand, activation column lr
+        const v4i scv = *(const v4i *)(wl + 192);
+        const float d = h2f(*(const uint16_t *)(wl + 222));
+        int acc_i[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc_i[r] = 0;
+#pragma unroll
+        for (int n = 0; n < 2; n++)
+#pragma unroll
+            for (int is = 0; is < 2; is++) {
+                // dequantize_row_q6_K (ggml-quants.c:1695-1711): sub-block j = 8 n + 2 qd + is takes ql[64 n + 32 (qd & 1) + 16 is ..], nibble qd >> 1,
+                // and bits 2 qd of qh[32 n + 16 is ..]; this lane: 8 of its 16 weights
+                const v2i ql0 = *(const v2i *)(wl + 64 * n + 16 * is + 8 * lh);
+                const v2i ql1 = *(const v2i *)(wl + 64 * n + 32 + 16 * is + 8 * lh);
+                const v2i qh  = *(const v2i *)(wl + 128 + 32 * n + 16 * is + 8 * lh);
+#pragma unroll
+                for (int qd = 0; qd < 4; qd++) {
+                    const int j = 8 * n + 2 * qd + is;
+                    const v2i ql = (qd & 1) ? ql1 : ql0;
+                    v2i x = ((ql >> (4 * (qd >> 1))) & 0x0f0f0f0f) | (((qh >> (2 * qd)) & 0x03030303) << 4);
+                    x[0] = sub_bytes(x[0], 0x20202020); x[1] = sub_bytes(x[1], 0x20202020);
+                    const v2i av = *(const v2i *)(al + 16 * j);
+                    const v16i zero = {0};
+                    const v16i c = __builtin_amdgcn_mfma_i32_32x32x16_i8(__builtin_bit_cast(long, av), __builtin_bit_cast(long, x), zero, 0, 0, 0);
+                    const int sc = (int)(int8_t)((uint32_t)scv[j >> 2] >> (8 * (j & 3)));
+#pragma unroll
+                    for (int r = 0; r < 16; r++) acc_i[r] += __mul24(c[r], sc);
+                }
+            }
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const v4f d8 = *(const v4f *)&d8s[wave][8 * g + 4 * lh];
+#pragma unroll
+            for (int e = 0; e < 4; e++) acc[4 * g + e] = __builtin_fmaf(d * d8[e], (float)acc_i[4 * g + e], acc[4 * g + e]);
+        }
+    };
+
+    if (my0 < my1) {
+        StageW w0 = fetch_w(my0);
+        sa = fetch_a(my0);
+        for (int sb = my0; sb < my1; sb++) step(sb, w0);
+    }
+
+    // add the waves' tiles (the staging regions are dead: reuse them).  C[r] of lane l: weight row l & 31, column (r&3) + 8 (r>>2) + 4 (l>>5)
+    __syncthreads();
+    float * red = (float *)lds;      // [WAVES][16][64]
+#pragma unroll
+    for (int r = 0; r < 16; r++) red[(wave * 16 + r) * 64 + lane] = acc[r];
+    __syncthreads();
+    for (int e = tid; e < 16 * 64; e += WAVES * 64) {
+        const int r = e >> 6, l = e & 63;
+        float s = 0.0f;
+#pragma unroll
+        for (int w = 0; w < WAVES; w++) s += red[(w * 16 + r) * 64 + l];
+        const int orow = m0 + (l & 31), ocol = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+        if (orow < a.m && ocol < cm.ncol) {
+            float * o = a.dst + (int64_t)s_pair[ocol] * a.dst_col_stride + orow;
+            if (cm.ky_cnt > 1) atomicAdd(o, s); else *o = s;
+        }
+    }
+}
+
+static int launch6(const S2Args & a, hipStream_t s, const char * tag) {
+    const unsigned nb = (unsigned)((a.m + 31) / 32);
+    const unsigned ky = nb < 256 && a.k >= 2048 ? 2 : 1;
+    if (ky > 1) {
+        hipError_t e = a.dst_col_stride == a.m
+            ? hipMemsetAsync(a.dst, 0, (size_t)a.n * a.m * sizeof(float), s)
+            : hipMemset2DAsync(a.dst, (size_t)a.dst_col_stride * sizeof(float), 0, (size_t)a.m * sizeof(float), (size_t)a.n, s);
+        if (e != hipSuccess) return (int)e;
+    }
+    MI355_LAUNCH(tag, (mmsk6_kernel<8>), dim3(nb, ky), dim3(512), 0, s, a);
+    MI355_CHECK_LAUNCH();
+    return MI355_OK;
+}
+
 template <int TYPE>
 static int launch2(const S2Args & a, hipStream_t s, const char * tag) {
     const unsigned nb = (unsigned)((a.m + 31) / 32);
@@ -647,18 +808,19 @@ extern "C" int mi355_mul_mat_skinny_k(int type, const void * W, int64_t w_row_st
                                       const int16_t * act_bsums, float * dst, int64_t dst_col_stride, int64_t m, int64_t k, int64_t n,
                                       void * stream) {
     if (!W || !act_q || !act_d || !act_bsums || !dst) return MI355_E_NULL;
-    if (type != MI355_TYPE_Q4_K && type != MI355_TYPE_Q5_K) return mi355_blck_size(type) ? MI355_E_UNSUPPORTED : MI355_E_TYPE;
+    if (type != MI355_TYPE_Q4_K && type != MI355_TYPE_Q5_K && type != MI355_TYPE_Q6_K) return mi355_blck_size(type) ? MI355_E_UNSUPPORTED : MI355_E_TYPE;
     if (m < 0 || n < 0 || k <= 0 || k % 256 != 0 || m > 0x7fffffff || k > 0x7fffffff || dst_col_stride < m) return MI355_E_SHAPE;
     if (n > 32) return MI355_E_UNSUPPORTED;
     if (w_row_stride > 0x3ffffff || k > 0x3ffffff) return MI355_E_UNSUPPORTED;      // 32-bit lane offsets: 32 rows / 32 columns
     if (((uintptr_t)act_q & 15) || ((uintptr_t)act_d & 3) || ((uintptr_t)act_bsums & 15) || ((uintptr_t)dst & 3)) return MI355_E_ALIGN;
-    if (((uintptr_t)W | (uintptr_t)w_row_stride) & 15) return MI355_E_ALIGN;
+    if (((uintptr_t)W | (uintptr_t)w_row_stride) & (type == MI355_TYPE_Q6_K ? 1 : 15)) return MI355_E_ALIGN;
     if (w_row_stride < mi355_row_size(type, k)) return MI355_E_SHAPE;
     if (m == 0 || n == 0) return MI355_OK;
     S2Args a = {};
     a.W = (const uint8_t *)W; a.w_row_stride = w_row_stride; a.aq = act_q; a.ad = act_d; a.bs = act_bsums;
     a.dst = dst; a.dst_col_stride = dst_col_stride; a.m = (int)m; a.n = (int)n; a.k = (int)k;
     hipStream_t s = (hipStream_t)stream;
+    if (type == MI355_TYPE_Q6_K) return launch6(a, s, "mmsk6_q6_K");
     if (type == MI355_TYPE_Q4_K) return launch2<MI355_TYPE_Q4_K>(a, s, "mmsk2_q4_K");
     return launch2<MI355_TYPE_Q5_K>(a, s, "mmsk2_q5_K");
 }
@@ -668,7 +830,7 @@ extern "C" int mi355_mul_mat_skinny_k(int type, const void * W, int64_t w_row_st
 // columns (the mat-vec path reads it once per pair; the grouped GEMM fills a 128-column tile with a handful of columns)
 static int64_t ids_ws_layout(int type, int64_t k, int64_t rows, int64_t * b0, int64_t * b1, int64_t * b2) {
     auto up = [](int64_t x) { return (x + 255) / 256 * 256; };
-    if (type == MI355_TYPE_Q4_K || type == MI355_TYPE_Q5_K) { *b0 = up(rows * k); *b1 = up(rows * (k / 256) * 4); *b2 = up(rows * (k / 16) * 2); }
+    if (type == MI355_TYPE_Q4_K || type == MI355_TYPE_Q5_K || type == MI355_TYPE_Q6_K) { *b0 = up(rows * k); *b1 = up(rows * (k / 256) * 4); *b2 = up(rows * (k / 16) * 2); }
     else                                                    { *b0 = up(rows * k); *b1 = up(rows * (k / 32) * 8);  *b2 = 0; }
     return *b0 + *b1 + *b2;
 }
@@ -691,8 +853,8 @@ extern "C" int mi355_mul_mat_id_skinny(int type, const void * as, int64_t w_row_
     if (k % 256 != 0) return MI355_E_UNSUPPORTED;
     if (workspace_bytes < mi355_mul_mat_id_skinny_workspace_bytes(type, k, n_tokens, b_ne1, n_used, n_expert)) return MI355_E_WORKSPACE;
     if (((uintptr_t)workspace & 15) || ((uintptr_t)dst & 3) || ((uintptr_t)ids & 3)) return MI355_E_ALIGN;
-    const bool kq = type == MI355_TYPE_Q4_K || type == MI355_TYPE_Q5_K;
-    if (((uintptr_t)as | (uintptr_t)w_row_stride | (uintptr_t)w_expert_stride) & (kq ? 15 : 1)) return MI355_E_ALIGN;
+    const bool kq = type == MI355_TYPE_Q4_K || type == MI355_TYPE_Q5_K || type == MI355_TYPE_Q6_K;      // q8_K activations
+    if (((uintptr_t)as | (uintptr_t)w_row_stride | (uintptr_t)w_expert_stride) & (kq && type != MI355_TYPE_Q6_K ? 15 : 1)) return MI355_E_ALIGN;
     if (w_row_stride < mi355_row_size(type, k)) return MI355_E_SHAPE;
     if (m == 0 || n_tokens == 0) return MI355_OK;
     hipStream_t s = (hipStream_t)stream;
@@ -719,14 +881,14 @@ extern "C" int mi355_mul_mat_id_skinny(int type, const void * as, int64_t w_row_
         S2Args a = {};
         a.W = (const uint8_t *)as; a.w_row_stride = w_row_stride; a.aq = (const int8_t *)ws; a.ad = (const float *)(ws + b0);
         a.bs = (const int16_t *)(ws + b0 + b1); a.dst = dst; a.dst_col_stride = m; a.m = (int)m; a.n = 32; a.k = (int)k; a.ids = I;
-        if (type == MI355_TYPE_Q4_K) MI355_LAUNCH("mmsk2_id_q4_K", (mmsk2_kernel<MI355_TYPE_Q4_K, 8>), dim3(nb, max_tiles), dim3(512), 0, s, a);
-        else                         MI355_LAUNCH("mmsk2_id_q5_K", (mmsk2_kernel<MI355_TYPE_Q5_K, 8>), dim3(nb, max_tiles), dim3(512), 0, s, a);
+        if (type == MI355_TYPE_Q4_K)      MI355_LAUNCH("mmsk2_id_q4_K", (mmsk2_kernel<MI355_TYPE_Q4_K, 8>), dim3(nb, max_tiles), dim3(512), 0, s, a);
+        else if (type == MI355_TYPE_Q5_K) MI355_LAUNCH("mmsk2_id_q5_K", (mmsk2_kernel<MI355_TYPE_Q5_K, 8>), dim3(nb, max_tiles), dim3(512), 0, s, a);
+        else                              MI355_LAUNCH("mmsk6_id_q6_K", (mmsk6_kernel<8>), dim3(nb, max_tiles), dim3(512), 0, s, a);
     } else {
         SArgs a = {};
         a.W = (const uint8_t *)as; a.w_row_stride = w_row_stride; a.aq = (const int8_t *)ws; a.ads = (const float *)(ws + b0);
         a.dst = dst; a.dst_col_stride = m; a.m = (int)m; a.n = 32; a.k = (int)k; a.ids = I;
         switch (type) {
-            case MI355_TYPE_Q6_K: MI355_LAUNCH("mmsk_id_q6_K", (mmsk_kernel<MI355_TYPE_Q6_K>), dim3(nb, max_tiles), dim3(SK_THREADS), 0, s, a); break;
             case MI355_TYPE_Q8_0: MI355_LAUNCH("mmsk_id_q8_0", (mmsk_kernel<MI355_TYPE_Q8_0>), dim3(nb, max_tiles), dim3(SK_THREADS), 0, s, a); break;
             case MI355_TYPE_Q4_0: MI355_LAUNCH("mmsk_id_q4_0", (mmsk_kernel<MI355_TYPE_Q4_0>), dim3(nb, max_tiles), dim3(SK_THREADS), 0, s, a); break;
             default: return MI355_E_TYPE;

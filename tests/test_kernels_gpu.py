@@ -318,7 +318,7 @@ def test_quantize_q8k_bit_exact(ops, n, k):
     assert np.array_equal(bs.cpu().numpy(), rbs)
 
 
-@pytest.mark.parametrize("t", [B.Q4_K, B.Q5_K])
+@pytest.mark.parametrize("t", [B.Q4_K, B.Q5_K, B.Q6_K])      # q6_K: one 32x32x16 MFMA per 16-weight sub-block, scales applied in integers
 @pytest.mark.parametrize("m,k,n", [(32, 256, 1), (130, 512, 2), (4096, 4096, 8), (257, 2048, 31), (1024, 4096, 32), (96, 1024, 70), (2816, 14336, 5)])
 def test_skinny_k_digit_split_vs_q8k_contract(ops, t, m, k, n):
     """K-quant MUL_MAT with the sub-block scales folded into the MFMA operands: the integers are those of

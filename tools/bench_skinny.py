@@ -39,13 +39,13 @@ for t in types:
                 for c0 in range(0, n, 32):
                     K.check(K.lib.mi355_mul_mat_skinny(t, w.data_ptr(), rs, aq[c0:].data_ptr(), ads[c0:].data_ptr(), dst[c0:].data_ptr(), m, m, k, min(32, n - c0), s), "sk")
             res["skinny"] = timed(sk, ["mmsk_%s" % name])
-            if t in (B.Q4_K, B.Q5_K):
+            if t in (B.Q4_K, B.Q5_K, B.Q6_K):
                 q8, d8, bs8 = ops.quantize_act_q8k(x)
                 def sk2():
                     for c0 in range(0, n, 32):
                         K.check(K.lib.mi355_mul_mat_skinny_k(t, w.data_ptr(), rs, q8[c0:].data_ptr(), d8[c0:].data_ptr(), bs8[c0:].data_ptr(),
                                                              dst[c0:].data_ptr(), m, m, k, min(32, n - c0), s), "sk2")
-                res["skinny_k"] = timed(sk2, ["mmsk2_%s" % name])
+                res["skinny_k"] = timed(sk2, ["mmsk2_%s" % name, "mmsk6_%s" % name])
             if n > 8:
                 res["mmdq"] = timed(lambda: K.check(K.lib.mi355_mul_mat_dq(t, w.data_ptr(), rs, xb.data_ptr(), k, dst.data_ptr(), m, m, k, n, s), "dq"), ["mmdq_%s" % name])
             wb = m * rs
