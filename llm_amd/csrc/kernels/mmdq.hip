@@ -520,14 +520,24 @@ mmdq_ws_kernel(const DArgs a) {
     }
 }
 
-// dst[n][m] = ((part[0] + part[1]) + part[2]) + ...: the K slices of a split-K launch, added in slice order
+// dst[n][m] = ((part[0] + part[1]) + part[2]) + ...: the K slices of a split-K launch, added in slice order.  VEC: dst is as dense as
+// the partial planes ([n][m], m % 4 == 0): four elements per lane, no index arithmetic.
+template <bool VEC>
 __global__ void __launch_bounds__(256)
 kz_sum_kernel(const float * part, float * dst, int64_t dst_col_stride, int m, int n, int kz) {
     const int64_t total = (int64_t)m * n, plane = total;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        float v = part[i];
-        for (int z = 1; z < kz; z++) v += part[z * plane + i];
-        dst[(i / m) * dst_col_stride + i % m] = v;
+    if (VEC) {
+        for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < total; i += (int64_t)gridDim.x * 1024) {
+            v4f v = *(const v4f *)(part + i);
+            for (int z = 1; z < kz; z++) v = v + *(const v4f *)(part + z * plane + i);
+            *(v4f *)(dst + i) = v;
+        }
+    } else {
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+            float v = part[i];
+            for (int z = 1; z < kz; z++) v += part[z * plane + i];
+            dst[(i / m) * dst_col_stride + i % m] = v;
+        }
     }
 }
 
@@ -605,7 +615,10 @@ static int launch(const DArgs & a, int64_t m_total, hipStream_t s, const char * 
         MI355_LAUNCH(tag, (mmdq_ws_kernel<TYPE, 128, 256>), dim3((unsigned)nb2, (unsigned)((a.m + 127) / 128), (unsigned)kzw), dim3(768), 0, s, b);
         MI355_CHECK_LAUNCH();
         const int64_t total = (int64_t)a.m * a.n;
-        MI355_LAUNCH("mmdq_kz_sum", kz_sum_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 4096)), dim3(256), 0, s, b.part, a.dst, a.dst_col_stride, a.m, a.n, kzw);
+        if (a.dst_col_stride == a.m && a.m % 4 == 0 && ((uintptr_t)a.dst & 15) == 0 && ((uintptr_t)b.part & 15) == 0)
+            MI355_LAUNCH("mmdq_kz_sum", kz_sum_kernel<true>, dim3((unsigned)std::min<int64_t>((total / 4 + 255) / 256, 2048)), dim3(256), 0, s, b.part, a.dst, a.dst_col_stride, a.m, a.n, kzw);
+        else
+            MI355_LAUNCH("mmdq_kz_sum", kz_sum_kernel<false>, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 4096)), dim3(256), 0, s, b.part, a.dst, a.dst_col_stride, a.m, a.n, kzw);
         MI355_CHECK_LAUNCH();
         return MI355_OK;
     }
