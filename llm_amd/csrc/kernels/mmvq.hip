@@ -666,14 +666,15 @@ static bool dma_enabled(int which) {
 // together: q4_K / q5_K steps (2304 / 2816 B) fit 4 slots at any offset; a q6_K step is 3584 B and fits 4 slots only when
 // every start is a multiple of 512 (row images of whole 16-block steps: K = 4096, 8192, 28672), else 8 (K = 14336: 12.25 KiB per
 // row, the second row of a wave starts 256 B into a piece).
+// multi_row: a wave streams more than one row (the next row's image starts where this one ends, wherever that is inside a piece)
 template <int TYPE>
-static int dma_need_slots(int k) {
+static int dma_need_slots(int k, bool multi_row = true) {
     if constexpr (!DmaImg<TYPE>::OK) return 0;
     else {
         const int nb = k / QK_K, img = DmaImg<TYPE>::IMG;
         const int span = (nb < 16 ? nb : 16) * img;
         auto gcd = [](int a, int b) { while (b) { const int t = a % b; a = b; b = t; } return a; };
-        const int g = gcd(gcd((nb * img) % 1024, 1024), gcd((16 * img) % 1024, 1024));     // every step starts at a multiple of g
+        const int g = gcd(multi_row ? gcd((nb * img) % 1024, 1024) : 1024, gcd((16 * img) % 1024, 1024));     // every step starts at a multiple of g
         const int bytes = span + 1024 - g;
         int sl = 2;
         while (sl * 1024 < bytes) sl *= 2;
@@ -1450,7 +1451,7 @@ static int launch_stream(KStream & a, hipStream_t stream) {
     if (need <= LDS_ACT_LIMIT) {
         if constexpr (DmaImg<TYPE>::OK) {
             const size_t used = (need + 255) & ~(size_t)255;
-            const int slots = a.k % QK_K == 0 && a.k >= 2048 && a.k < (1 << 19) && dma_enabled(TYPE == MI355_TYPE_Q6_K ? DMA_MV_K6 : DMA_MV_K45) ? dma_slots(used, MV1_THREADS / 64, LDS_TOTAL, dma_need_slots<TYPE>(a.k)) : 0;
+            const int slots = a.k % QK_K == 0 && a.k >= 2048 && a.k < (1 << 19) && dma_enabled(TYPE == MI355_TYPE_Q6_K ? DMA_MV_K6 : DMA_MV_K45) ? dma_slots(used, MV1_THREADS / 64, LDS_TOTAL, dma_need_slots<TYPE>(a.k, a.rpw > 1)) : 0;
             if (slots) {
                 a.dma_slots = slots; a.ring_off = (int)used; a.dma_first = dma_first();
                 const size_t total = used + (size_t)(MV1_THREADS / 64) * slots * 1024;
