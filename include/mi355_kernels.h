@@ -55,11 +55,11 @@ enum mi355_error {
 };
 
 /* library / device introspection */
-#define MI355_ABI_VERSION 3                             /* bumped on any signature or struct change */
+#define MI355_ABI_VERSION 4                             /* bumped on any signature or struct change */
 MI355_API int         mi355_abi_version(void);          /* == MI355_ABI_VERSION of the header the library was built from;
                                                          * the plugin and the Python binding refuse a library that differs */
 MI355_API int64_t     mi355_args_sizeof(int which);     /* sizeof of 0 mi355_mmvq_args, 1 qkv_rope, 2 glu_matvec, 3 moe_down,
-                                                         * 4 fattn_args, 5 mi355_tensor; -1 otherwise */
+                                                         * 4 fattn_args, 5 mi355_tensor, 6 qkv_finish_args; -1 otherwise */
 MI355_API const char *mi355_error_string(int err);      /* MI355_E_* or hipGetErrorString */
 MI355_API int64_t     mi355_blck_size(int type);        /* elements per block, 0 if unknown */
 MI355_API int64_t     mi355_type_size(int type);        /* bytes per block, 0 if unknown */
@@ -333,6 +333,45 @@ MI355_API int64_t mi355_mul_mat_dq_workspace_bytes(int64_t m, int64_t m_total, i
 MI355_API int mi355_mul_mat_dq_slice_ws(int type, const void *W, int64_t w_row_stride, const uint16_t *act_bf16, int64_t act_row_stride,
                                         float *dst, int64_t dst_col_stride, int64_t m, int64_t m_total, int64_t k, int64_t n,
                                         void *workspace, int64_t workspace_bytes, void *stream);
+
+/* The prefill GEMM stopped before its last step: the K slices of mi355_mul_mat_dq_slice for this shape are left as *kz planes
+ * [kz][n][m] of f32 in `parts` (kz == 1: the finished product, one plane) -- for a caller whose next kernel reads the product once
+ * anyway and can add the planes on the way (mi355_qkv_finish).  Adding the planes in order, ((p0 + p1) + p2) + p3, gives the bits of
+ * mi355_mul_mat_dq_slice.  parts: mi355_mul_mat_dq_parts_bytes(m, m_total, k, n) bytes, 16-byte aligned. */
+MI355_API int64_t mi355_mul_mat_dq_parts_bytes(int64_t m, int64_t m_total, int64_t k, int64_t n);
+MI355_API int mi355_mul_mat_dq_parts(int type, const void *W, int64_t w_row_stride, const uint16_t *act_bf16, int64_t act_row_stride,
+                                     float *parts, int64_t parts_bytes, int64_t m, int64_t m_total, int64_t k, int64_t n,
+                                     int32_t *kz, void *stream);
+
+/* Q / K / V of a prefill batch after the three GEMMs, in ONE launch: adds the K-slice planes of each product, rotates q and k
+ * (ggml_rope_ext, NORMAL or NEOX), stores q as f32 [n][m_q] and k / v as the rows of the KV cache (f16 or f32, n rows one after the
+ * other).  Replaces, per layer, 3 slice sums + ROPE x 2 (ggml-cuda/rope.cu) + CPY x 2 (ggml-cuda/cpy.cu; llama-kv-cache-unified.cpp:817-891
+ * cpy_k / cpy_v) with the bits those produce one by one. */
+typedef struct mi355_qkv_finish_args {
+    const float *q_parts, *k_parts, *v_parts;              /* planes [kz][n][m] of mi355_mul_mat_dq_parts */
+    int32_t kz_q, kz_k, kz_v;
+    int64_t m_q, m_k, m_v, n;                              /* rows of wq / wk / wv, tokens */
+    float *q_out;                                          /* [n][m_q] */
+    void *k_out, *v_out;                                   /* [n][m_k], [n][m_v] of k_out_type / v_out_type (MI355_TYPE_F16 / F32) */
+    int32_t k_out_type, v_out_type;
+    const int32_t *pos;                                    /* [n] */
+    const float *freq_factors;                             /* [head_dim / 2] or NULL */
+    int32_t head_dim, n_dims, mode, n_ctx_orig;
+    float freq_base, freq_scale, ext_factor, attn_factor, beta_fast, beta_slow;
+} mi355_qkv_finish_args;
+MI355_API int mi355_qkv_finish(const mi355_qkv_finish_args *args, void *stream);
+
+/* Feed-forward input stage of a prefill batch in ONE launch: dst[n][m] = act(Wa x_n)[m] * (Wb x_n)[m] as f32 and, rounded as
+ * mi355_act_bf16 rounds, as bf16 rows ([n][m]) for the ffn_down GEMM.  Replaces MUL_MAT(ffn_gate) MUL_MAT(ffn_up) GLU(split) of
+ * build_ffn (src/llama-graph.cpp:470-640) for n_tokens > 128: 2 x the dequantize + GEMM of ggml-cuda.cu:1200-1260, the gated
+ * activation (ggml-cuda/unary.cu ggml_cuda_op_swiglu & co) and the bf16 conversion before the next GEMM.  Each workgroup tile
+ * holds 64 rows of Wa and the same 64 rows of Wb, so both products of an output element meet in one workgroup; the two f32
+ * products are never written.  Offered only for shapes where mi355_mul_mat_dq runs each product as a single K range of
+ * 128 x 256 tiles (m even, n >= 256, ceil(n / 256) * ceil(m / 128) >= 200, k % 64 == 0): the result then has the bits of
+ * mi355_mul_mat_dq x 2 + mi355_glu_bf16_f32.  Anything else: MI355_E_UNSUPPORTED, and the caller issues the three launches. */
+MI355_API int mi355_glu_mul_mat_dq(int type, int glu_op, const void *Wa, int64_t wa_row_stride, const void *Wb, int64_t wb_row_stride,
+                                   const uint16_t *act_bf16, int64_t act_row_stride, float *dst, int64_t dst_col_stride,
+                                   uint16_t *dst_bf16, int64_t m, int64_t k, int64_t n, void *stream);
 
 /* MUL_MAT_ID (ggml.c:3000-3036) for prefill-sized batches: dst[t][s][:] = as[ids[t][s]] . b[t][s % b_ne1].
  * The (token, slot) pairs are bucketed by expert ON THE DEVICE (one small kernel; the reference synchronises the

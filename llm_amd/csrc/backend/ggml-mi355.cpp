@@ -693,6 +693,15 @@ static void mi355_backend_free(ggml_backend_t backend) {
     mi355_set_device(ctx->device);
     HIP_CHECK(hipStreamSynchronize(ctx->stream));
     for (int i = 0; i < 5; i++) if (ctx->scratch[i]) HIP_CHECK(hipFree(ctx->scratch[i]));
+    if (MI355_ENV_SET("GGML_MI355_KERNEL_TIMES")) {      // per-kernel launch counts and device time of the whole process so far
+        std::vector<char> rep((size_t)mi355_timing_report(nullptr, 0));
+        mi355_timing_report(rep.data(), (int64_t)rep.size());
+        std::string line;
+        for (char c : rep) {
+            if (c == '\n') { fprintf(stderr, "[mi355] kernel %s\n", line.c_str()); line.clear(); }
+            else if (c) line += c;
+        }
+    }
     if (MI355_ENV_SET("GGML_MI355_GRAPH_STATS"))
         fprintf(stderr, "[mi355] %s decode graphs: %ld replays, %ld captures, %ld eager runs of capturable graphs%s\n", ctx->name.c_str(),
                 ctx->gc.n_replay, ctx->gc.n_capture, ctx->gc.n_eager, ctx->gc.disabled ? " (disabled)" : "");
@@ -1582,6 +1591,53 @@ static bool mi355_try_fuse_glu_matvec(mi355_backend_ctx * ctx, ggml_cgraph * cgr
     return true;
 }
 
+// Feed-forward input of a prefill batch in one launch: MUL_MAT(ffn_gate) MUL_MAT(ffn_up) GLU at nodes i, i + 1, i + 2 (either order of
+// the two products) -> mi355_glu_mul_mat_dq, whose tiles hold 64 rows of both matrices.  The two f32 products are NOT written, so they
+// must have no other reader in this graph and must not be graph outputs (a scheduler eval callback that wants to see them gets them
+// as one-node graphs, where this pattern cannot match).  The kernel library offers the fused form only where it has the bits of the
+// three launches; everywhere else it answers MI355_E_UNSUPPORTED and the nodes run one by one.
+static bool mi355_try_fuse_glu_gemm(mi355_backend_ctx * ctx, ggml_cgraph * cgraph, int i, const std::vector<char> & done) {
+    const int n = ggml_graph_n_nodes(cgraph);
+    if (i + 2 >= n || done[i + 1] || done[i + 2] || MI355_ENV_SET("GGML_MI355_NO_GLU_GEMM") || MI355_ENV_SET("GGML_MI355_MMQ_INT8")) return false;
+    const ggml_tensor * m0 = ggml_graph_node(cgraph, i), * m1 = ggml_graph_node(cgraph, i + 1);
+    ggml_tensor * glu = ggml_graph_node(cgraph, i + 2);
+    if (m1->op != GGML_OP_MUL_MAT || glu->op != GGML_OP_GLU || !glu->src[1] || glu->type != GGML_TYPE_F32) return false;
+    const ggml_tensor * ga = glu->src[0], * gb = glu->src[1];       // act(ga) * gb; `swapped` only applies to the single-tensor form
+    if (!((ga == m0 && gb == m1) || (ga == m1 && gb == m0))) return false;
+    const int op = (int)ggml_get_glu_op(glu);
+    if (op < 0 || op > 2) return false;
+    const ggml_tensor * src1 = m0->src[1], * wa = ga->src[0], * wb = gb->src[0];
+    if (m1->src[1] != src1 || src1->type != GGML_TYPE_F32 || src1->ne[2] != 1 || src1->ne[3] != 1) return false;
+    if (wa->type != wb->type || !ggml_are_same_shape(wa, wb) || wa->ne[2] != 1 || wa->ne[3] != 1 || tensor_is_split(wa) || tensor_is_split(wb)) return false;
+    if (mi355_mul_mat_path(wa, src1) != MM_DQ || mi355_mul_mat_path(wb, src1) != MM_DQ) return false;
+    const int64_t K = wa->ne[0], M = wa->ne[1], N = src1->ne[1];
+    if (glu->ne[0] != M || ggml_nrows(glu) != N || !ggml_is_contiguous(glu) || ((uintptr_t)glu->data & 3)) return false;
+    if ((m0->flags | m1->flags) & GGML_TENSOR_FLAG_OUTPUT) return false;
+    for (int j = 0; j < n; j++) {                 // any other reader of the two products?
+        if (j == i + 2) continue;
+        const ggml_tensor * t = ggml_graph_node(cgraph, j);
+        for (int s = 0; s < GGML_MAX_SRC; s++) {
+            const ggml_tensor * r = t->src[s];
+            if (r && (r == m0 || r == m1 || r->view_src == m0 || r->view_src == m1)) return false;
+        }
+    }
+    if (ranges_overlap(glu->data, ggml_nbytes(glu), wa->data, ggml_nbytes(wa)) || ranges_overlap(glu->data, ggml_nbytes(glu), wb->data, ggml_nbytes(wb))) return false;
+
+    uint16_t * act = (uint16_t *)ctx->get_scratch(0, align_up((size_t)N * K * 2, 256));
+    if (!ctx->act_cached(src1, 1)) {
+        MI_CHECK(mi355_act_bf16((const float *)src1->data, act, K, N, 1, 1, src1->nb[1], src1->nb[2], src1->nb[3], ctx->stream));
+        ctx->act_remember(src1, 1);
+    }
+    uint16_t * hbf = (uint16_t *)ctx->get_scratch(2, align_up((size_t)N * M * 2, 256));
+    const int rc = mi355_glu_mul_mat_dq((int)wa->type, op, wa->data, (int64_t)wa->nb[1], wb->data, (int64_t)wb->nb[1], act, K,
+                                        (float *)glu->data, M, hbf, M, K, N, ctx->stream);
+    if (rc == MI355_E_UNSUPPORTED || rc == MI355_E_ALIGN) return false;    // the activations stay cached for the separate launches
+    MI_CHECK(rc);
+    ctx->swap_act_scratch();                      // scratch[0] now holds the bf16 rows of the GLU result, for ffn_down
+    ctx->act_remember(glu, 1);
+    return true;
+}
+
 // RMS_NORM -> MUL(norm weight) -> MUL_MAT(ffn_up) MUL_MAT(ffn_gate) -> GLU of a decode token: five nodes, one launch
 // (the norm runs in the prologue of mi355_glu_matvec).  The norm checks are those of mi355_try_fuse_rms_norm_mul.
 static int mi355_collect_matvec_group(ggml_cgraph * cgraph, int i, const std::vector<char> & done, int * members);
@@ -1875,15 +1931,26 @@ static bool mi355_try_fuse_moe_router(mi355_backend_ctx * ctx, ggml_cgraph * cgr
     return true;
 }
 
-// norm_idx >= 0: nodes norm_idx (RMS_NORM) and norm_idx + 1 (MUL by the norm weight, == x) come right before node i and
-// run in the launch's prologue (attn_norm of every layer): 9 nodes, one launch.
-static bool mi355_try_fuse_qkv_rope(mi355_backend_ctx * ctx, ggml_cgraph * cgraph, int i, std::vector<char> & done, int norm_idx = -1) {
+// The attention input of a llama-style layer as build_attn spells it (src/llama-graph.cpp, llama-kv-cache-unified.cpp:817-891):
+//     q = MUL_MAT(wq, x)  q = ROPE(q)  k = MUL_MAT(wk, x)  k = ROPE(k)  v = MUL_MAT(wv, x)  CPY(k -> cache rows)  CPY(v -> cache rows)
+// starting at node i, for N = x->ne[1] tokens whose cache rows lie one after the other.  Only q (rotated) and the two cache views
+// are materialised by the fused launches, so nobody else may read the four tensors in between.
+struct qkv_nodes {
+    ggml_tensor * mq, * rq, * mk, * rk, * mv, * ck, * cv;
+    int idx[7];
+    bool kv_q8;
+};
+
+static bool qkv_match(ggml_cgraph * cgraph, int i, const std::vector<char> & done, bool (*mm_ok)(const ggml_tensor *), qkv_nodes & q) {
     const int n = ggml_graph_n_nodes(cgraph);
     ggml_tensor * mq = ggml_graph_node(cgraph, i);
-    if (!matvec_groupable(mq) || mq->src[1]->ne[1] != 1) return false;
     const ggml_tensor * x = mq->src[1];
+    if (x->ne[2] != 1 || x->ne[3] != 1) return false;
+    const int64_t N = x->ne[1];
     ggml_tensor * rq = nullptr, * mk = nullptr, * rk = nullptr, * mv = nullptr, * ck = nullptr, * cv = nullptr;
-    int idx[7] = {i, -1, -1, -1, -1, -1, -1}, last = -1;
+    int * idx = q.idx, last = -1;
+    idx[0] = i;
+    for (int m = 1; m < 7; m++) idx[m] = -1;
     const int horizon = i + 24 < n ? i + 24 : n;
     for (int j = i + 1; j < horizon; j++) {
         ggml_tensor * t = ggml_graph_node(cgraph, j);
@@ -1895,7 +1962,7 @@ static bool mi355_try_fuse_qkv_rope(mi355_backend_ctx * ctx, ggml_cgraph * cgrap
             else if (mk && r == mk && !rk) { rk = t; idx[3] = j; }
             else return false;
         } else if (t->op == GGML_OP_MUL_MAT) {
-            if (!matvec_groupable(t) || t->src[1] != x) return false;
+            if (!mm_ok(t) || t->src[1] != x) return false;
             if (!mk)      { mk = t; idx[2] = j; }
             else if (!mv) { mv = t; idx[4] = j; }
             else return false;
@@ -1913,27 +1980,25 @@ static bool mi355_try_fuse_qkv_rope(mi355_backend_ctx * ctx, ggml_cgraph * cgrap
     // shapes and types
     const ggml_tensor * wq = mq->src[0], * wk = mk->src[0], * wv = mv->src[0];
     if (wq->ne[0] != wk->ne[0] || wq->ne[0] != wv->ne[0]) return false;
-    const int64_t K = wq->ne[0], Mq = wq->ne[1], Mk = wk->ne[1], Mv = wv->ne[1], hd = rq->ne[0];
+    const int64_t Mq = wq->ne[1], Mk = wk->ne[1], Mv = wv->ne[1], hd = rq->ne[0];
     if (Mq % 8 || Mk % 8 || Mv % 8 || hd != rk->ne[0] || hd <= 0 || Mq % hd || Mk % hd) return false;
     for (ggml_tensor * r : {rq, rk}) {
-        if (r->type != GGML_TYPE_F32 || !ggml_is_contiguous(r) || !ggml_is_contiguous(r->src[0]) || r->ne[2] != 1 || r->ne[3] != 1) return false;
+        if (r->type != GGML_TYPE_F32 || !ggml_is_contiguous(r) || !ggml_is_contiguous(r->src[0]) || r->ne[2] != N || r->ne[3] != 1) return false;
         if (r->src[1] != rq->src[1] || r->src[2] != rq->src[2]) return false;
         if (memcmp(r->op_params, rq->op_params, 11 * sizeof(int32_t)) != 0) return false;
         if (r->src[1]->type != GGML_TYPE_I32 || (r->src[2] && r->src[2]->type != GGML_TYPE_F32)) return false;
     }
     if (rq->src[0]->data != mq->data || rk->src[0]->data != mk->data) return false;
-    if (ggml_nelements(rq) != Mq || ggml_nelements(rk) != Mk) return false;
+    if (ggml_nelements(rq) != Mq * N || ggml_nelements(rk) != Mk * N) return false;
     const int32_t * rp = (const int32_t *)rq->op_params;
     if (rp[2] != 0 && rp[2] != 2) return false;
-    // a q8_0 cache (-ctk q8_0 -ctv q8_0): the fused launch leaves K and V as f32 rows in scratch and one small launch quantizes both
-    // into the cache rows (instead of norm + 3 mat-vecs + 2 ropes + 2 quantizing copies)
-    const bool kv_q8 = ck->type == GGML_TYPE_Q8_0 && cv->type == GGML_TYPE_Q8_0;
+    q.kv_q8 = ck->type == GGML_TYPE_Q8_0 && cv->type == GGML_TYPE_Q8_0;
     for (ggml_tensor * c : {ck, cv}) {
-        if ((c->type != GGML_TYPE_F16 && c->type != GGML_TYPE_F32 && !kv_q8) || !ggml_is_contiguous(c) || !ggml_is_contiguous(c->src[0])) return false;
+        if ((c->type != GGML_TYPE_F16 && c->type != GGML_TYPE_F32 && !q.kv_q8) || !ggml_is_contiguous(c) || !ggml_is_contiguous(c->src[0])) return false;
         if (c->src[0]->type != GGML_TYPE_F32) return false;
     }
-    if (kv_q8 && (Mk % 32 || Mv % 32)) return false;
-    if (ck->src[0]->data != rk->data || cv->src[0]->data != mv->data || ggml_nelements(ck) != Mk || ggml_nelements(cv) != Mv) return false;
+    if (q.kv_q8 && (Mk % 32 || Mv % 32)) return false;
+    if (ck->src[0]->data != rk->data || cv->src[0]->data != mv->data || ggml_nelements(ck) != Mk * N || ggml_nelements(cv) != Mv * N) return false;
     // nobody else may read the tensors that will not be materialised
     const ggml_tensor * hidden[4] = {mq, mk, mv, rk};
     for (const ggml_tensor * h : hidden) if (h->flags & GGML_TENSOR_FLAG_OUTPUT) return false;
@@ -1948,6 +2013,95 @@ static bool mi355_try_fuse_qkv_rope(mi355_backend_ctx * ctx, ggml_cgraph * cgrap
             for (const ggml_tensor * h : hidden) if (view_root(t->src[sidx]) == h) return false;
         }
     }
+    q.mq = mq; q.rq = rq; q.mk = mk; q.rk = rk; q.mv = mv; q.ck = ck; q.cv = cv;
+    return true;
+}
+
+static void qkv_rope_params(const ggml_tensor * rq, int32_t * n_dims, int32_t * mode, int32_t * n_ctx_orig, float * f6) {
+    const int32_t * rp = (const int32_t *)rq->op_params;
+    *n_dims = rp[1]; *mode = rp[2]; *n_ctx_orig = rp[4];
+    memcpy(f6, rp + 5, 6 * sizeof(float));       // freq_base, freq_scale, ext_factor, attn_factor, beta_fast, beta_slow
+}
+
+// Prefill form: three GEMMs that leave their K-slice planes in scratch (mi355_mul_mat_dq_parts) and ONE launch that adds the planes,
+// rotates q and k and stores k and v into the cache rows (mi355_qkv_finish) -- 4 launches for the 7 nodes' 10 (3 GEMMs, up to 3 slice
+// sums or memsets, 2 ROPE, 2 CPY), and q / k / v cross HBM once less.  Bit-identical to the nodes run one by one.
+static bool prefill_mm_ok(const ggml_tensor * t) {
+    const ggml_tensor * w = t->src[0], * x = t->src[1];
+    return t->op == GGML_OP_MUL_MAT && t->type == GGML_TYPE_F32 && x->type == GGML_TYPE_F32 && w->ne[2] == 1 && w->ne[3] == 1 && !tensor_is_split(w) &&
+           mi355_mul_mat_path(w, x) == MM_DQ;
+}
+
+static bool mi355_try_fuse_qkv_gemm(mi355_backend_ctx * ctx, ggml_cgraph * cgraph, int i, std::vector<char> & done) {
+    ggml_tensor * mq0 = ggml_graph_node(cgraph, i);
+    if (!prefill_mm_ok(mq0) || mq0->src[1]->ne[1] <= 1 || MI355_ENV_SET("GGML_MI355_NO_QKV_GEMM") || MI355_ENV_SET("GGML_MI355_MMQ_INT8")) return false;
+    qkv_nodes q;
+    if (!qkv_match(cgraph, i, done, prefill_mm_ok, q) || q.kv_q8) return false;
+    const ggml_tensor * x = q.mq->src[1];
+    const ggml_tensor * w[3] = {q.mq->src[0], q.mk->src[0], q.mv->src[0]};
+    const int64_t K = x->ne[0], N = x->ne[1], hd = q.rq->ne[0];
+    if (w[2]->ne[1] % 4) return false;
+    // the three plane sets
+    int64_t pb[3], off[3], total = 0;
+    for (int m = 0; m < 3; m++) {
+        pb[m] = mi355_mul_mat_dq_parts_bytes(w[m]->ne[1], w[m]->ne[1], K, N);
+        if (pb[m] <= 0) return false;
+        off[m] = total; total += (int64_t)align_up((size_t)pb[m], 256);
+    }
+    char * parts = (char *)ctx->get_scratch(3, (size_t)total);
+    if (ctx->scratch_size[3] < (size_t)total) return false;
+    // outputs must not alias one another or the positions (they are written by one launch, per element)
+    const ggml_tensor * outs[3] = {q.rq, q.ck, q.cv};
+    for (int a = 0; a < 3; a++) {
+        for (int b = 0; b < a; b++) if (ranges_overlap(outs[a]->data, ggml_nbytes(outs[a]), outs[b]->data, ggml_nbytes(outs[b]))) return false;
+        if (ranges_overlap(outs[a]->data, ggml_nbytes(outs[a]), q.rq->src[1]->data, ggml_nbytes(q.rq->src[1]))) return false;
+    }
+    uint16_t * act = (uint16_t *)ctx->get_scratch(0, align_up((size_t)N * K * 2, 256));
+    if (!ctx->act_cached(x, 1)) {
+        MI_CHECK(mi355_act_bf16((const float *)x->data, act, K, N, 1, 1, x->nb[1], x->nb[2], x->nb[3], ctx->stream));
+        ctx->act_remember(x, 1);
+    }
+    mi355_qkv_finish_args f;
+    memset(&f, 0, sizeof(f));
+    int32_t kz[3] = {0, 0, 0};
+    for (int m = 0; m < 3; m++) {
+        const int rc = mi355_mul_mat_dq_parts((int)w[m]->type, w[m]->data, (int64_t)w[m]->nb[1], act, K, (float *)(parts + off[m]), pb[m], w[m]->ne[1], w[m]->ne[1], K, N,
+                                              &kz[m], ctx->stream);
+        // nothing of the pattern has been written yet when the first product is refused; a later refusal cannot happen for a type
+        // and K the first one took
+        if (m == 0 && (rc == MI355_E_UNSUPPORTED || rc == MI355_E_ALIGN)) return false;
+        MI_CHECK(rc);
+    }
+    f.q_parts = (const float *)(parts + off[0]); f.k_parts = (const float *)(parts + off[1]); f.v_parts = (const float *)(parts + off[2]);
+    f.kz_q = kz[0]; f.kz_k = kz[1]; f.kz_v = kz[2];
+    f.m_q = w[0]->ne[1]; f.m_k = w[1]->ne[1]; f.m_v = w[2]->ne[1]; f.n = N;
+    f.q_out = (float *)q.rq->data; f.k_out = q.ck->data; f.v_out = q.cv->data;
+    f.k_out_type = (int32_t)q.ck->type; f.v_out_type = (int32_t)q.cv->type;
+    f.pos = (const int32_t *)q.rq->src[1]->data; f.freq_factors = q.rq->src[2] ? (const float *)q.rq->src[2]->data : nullptr;
+    f.head_dim = (int32_t)hd;
+    float f6[6];
+    qkv_rope_params(q.rq, &f.n_dims, &f.mode, &f.n_ctx_orig, f6);
+    f.freq_base = f6[0]; f.freq_scale = f6[1]; f.ext_factor = f6[2]; f.attn_factor = f6[3]; f.beta_fast = f6[4]; f.beta_slow = f6[5];
+    MI_CHECK(mi355_qkv_finish(&f, ctx->stream));
+    for (int m = 1; m < 7; m++) done[q.idx[m]] = 1;
+    ctx->act_invalidate_if_written(q.rq);
+    return true;
+}
+
+// Decode form.  norm_idx >= 0: nodes norm_idx (RMS_NORM) and norm_idx + 1 (MUL by the norm weight, == x) come right before node i and
+// run in the launch's prologue (attn_norm of every layer): 9 nodes, one launch.
+static bool mi355_try_fuse_qkv_rope(mi355_backend_ctx * ctx, ggml_cgraph * cgraph, int i, std::vector<char> & done, int norm_idx = -1) {
+    ggml_tensor * mq0 = ggml_graph_node(cgraph, i);
+    if (!matvec_groupable(mq0) || mq0->src[1]->ne[1] != 1) return false;
+    qkv_nodes qn;
+    if (!qkv_match(cgraph, i, done, matvec_groupable, qn)) return false;
+    ggml_tensor * mq = qn.mq, * rq = qn.rq, * mk = qn.mk, * mv = qn.mv, * ck = qn.ck, * cv = qn.cv;
+    const int * idx = qn.idx;
+    const bool kv_q8 = qn.kv_q8;
+    const ggml_tensor * x = mq->src[1];
+    const ggml_tensor * wq = mq->src[0], * wk = mk->src[0], * wv = mv->src[0];
+    const int64_t K = wq->ne[0], Mq = wq->ne[1], Mk = wk->ne[1], Mv = wv->ne[1], hd = rq->ne[0];
+    const int32_t * rp = (const int32_t *)rq->op_params;
     // activations of the token, q8_1
     const size_t qb = align_up((size_t)mi355_act_q_bytes(K, 1), 256), db = align_up((size_t)mi355_act_ds_bytes(K, 1), 256);
     char * ws = (char *)ctx->get_scratch(0, qb + db);
@@ -2040,6 +2194,12 @@ static enum ggml_status mi355_issue_graph(mi355_backend_ctx * ctx, ggml_cgraph *
         // fusion: Q/K/V projections + rope + KV-cache store of one token in one launch
         if (fuse && node->op == GGML_OP_MUL_MAT && node->src[0]->type == GGML_TYPE_F32 && mi355_try_fuse_moe_router(ctx, cgraph, i, done)) continue;
         if (fuse && node->op == GGML_OP_MUL_MAT && mi355_try_fuse_qkv_rope(ctx, cgraph, i, done)) continue;
+        if (fuse && node->op == GGML_OP_MUL_MAT && mi355_try_fuse_qkv_gemm(ctx, cgraph, i, done)) continue;
+        if (fuse && node->op == GGML_OP_MUL_MAT && mi355_try_fuse_glu_gemm(ctx, cgraph, i, done)) {
+            done[i + 1] = 1;
+            done[i + 2] = 1;
+            continue;
+        }
         if (fuse && node->op == GGML_OP_MUL_MAT_ID && mi355_try_fuse_moe_glu_matvec(ctx, cgraph, i, done)) {
             done[i + 1] = 1;
             done[i + 2] = 1;
@@ -2191,7 +2351,8 @@ static enum ggml_status mi355_backend_graph_compute(ggml_backend_t backend, ggml
         }
     } timer{time_graph, n, std::chrono::steady_clock::now()};
     mi355_backend_ctx::graph_cache_t & gc = ctx->gc;
-    static const bool graphs_off = getenv("GGML_MI355_NO_GRAPHS") != nullptr;
+    // GGML_MI355_KERNEL_TIMES: every launch carries an event pair (kernels/timing.h), which a captured graph would not replay
+    static const bool graphs_off = getenv("GGML_MI355_NO_GRAPHS") != nullptr || MI355_ENV_SET("GGML_MI355_KERNEL_TIMES");
     if (graphs_off || gc.disabled || !mi355_graph_capturable(cgraph)) return mi355_issue_graph(ctx, cgraph);
 
     std::vector<mi355_backend_ctx::node_sig> sig;
@@ -2305,6 +2466,7 @@ static ggml_backend_t mi355_dev_init_backend(ggml_backend_dev_t dev, const char 
     ctx->device = dctx->device;
     ctx->name   = dctx->name;
     HIP_CHECK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    if (MI355_ENV_SET("GGML_MI355_KERNEL_TIMES")) mi355_timing_enable(1);
     ggml_backend_t backend = new ggml_backend{
         /* .guid    = */ mi355_guid(),
         /* .iface   = */ mi355_backend_iface,
@@ -2516,7 +2678,7 @@ static bool mi355_kernels_abi_ok() {
     const bool ok = mi355_abi_version() == MI355_ABI_VERSION && mi355_args_sizeof(0) == (int64_t)sizeof(mi355_mmvq_args) &&
                     mi355_args_sizeof(1) == (int64_t)sizeof(mi355_qkv_rope_args) && mi355_args_sizeof(2) == (int64_t)sizeof(mi355_glu_matvec_args) &&
                     mi355_args_sizeof(3) == (int64_t)sizeof(mi355_moe_down_args) && mi355_args_sizeof(4) == (int64_t)sizeof(mi355_fattn_args) &&
-                    mi355_args_sizeof(5) == (int64_t)sizeof(mi355_tensor);
+                    mi355_args_sizeof(5) == (int64_t)sizeof(mi355_tensor) && mi355_args_sizeof(6) == (int64_t)sizeof(mi355_qkv_finish_args);
     if (!ok) MI_LOG_ERROR("ggml-mi355: libmi355_kernels.so has ABI version %d, the plugin was built for %d: rebuild both\n", mi355_abi_version(), MI355_ABI_VERSION);
     return ok;
 }

@@ -14,6 +14,7 @@ int64_t mi355_args_sizeof(int which) {
         case 3: return (int64_t)sizeof(mi355_moe_down_args);
         case 4: return (int64_t)sizeof(mi355_fattn_args);
         case 5: return (int64_t)sizeof(mi355_tensor);
+        case 6: return (int64_t)sizeof(mi355_qkv_finish_args);
     }
     return -1;
 }

@@ -254,6 +254,73 @@ rope_heads_kernel(const T4 x, const int32_t * __restrict__ pos, const float * __
     }
 }
 
+// prefill Q / K / V epilogue: the K-slice planes of the three GEMMs (mi355_mul_mat_dq_parts) -> q rotated (f32), k rotated and v into
+// the KV-cache rows (f16 / f32).  One lane per (rotated pair, token, group of 8 heads) for q and k, one per 4 values for v.  Per
+// element: the slice sum of kz_sum_kernel (mmdq.hip), the rotation of rope_kernel, the conversion of cpy_kernel -- the same bits.
+struct QkvFin {
+    const float * qp, * kp, * vp;      // planes [kz][n][m]
+    int kzq, kzk, kzv, mq, mk, mv, n;
+    float * q_out; char * k_out, * v_out; int k_f16, v_f16;
+    const int32_t * pos; const float * ff; RopeP p;
+};
+
+static __device__ __forceinline__ float plane_sum(const float * p, int64_t i, int64_t plane, int kz) {
+    float v = p[i];
+    for (int z = 1; z < kz; z++) v += p[z * plane + i];
+    return v;
+}
+
+__global__ void __launch_bounds__(256)
+qkv_finish_kernel(const QkvFin a) {
+    const int half = a.p.ne0 / 2, hd = a.p.ne0;
+    const int nhq = a.mq / hd, nhk = a.mk / hd, gq = (nhq + 7) / 8, gk = (nhk + 7) / 8;
+    const int64_t nrope = (int64_t)half * a.n * (gq + gk), nv = (int64_t)a.n * (a.mv / 4);
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nrope + nv; i += stride) {
+        if (i >= nrope) {                              // v: 4 values
+            const int64_t j = (i - nrope) * 4;
+            v4f v = *(const v4f *)(a.vp + j);
+            for (int z = 1; z < a.kzv; z++) v = v + *(const v4f *)(a.vp + (int64_t)z * a.n * a.mv + j);
+            if (a.v_f16) {
+                typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+                const h4 hv = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};      // round to nearest even, as __float2half_rn
+                *(h4 *)(a.v_out + j * 2) = hv;
+            } else {
+                *(v4f *)(a.v_out + j * 4) = v;
+            }
+            continue;
+        }
+        const int ic = (int)(i % half);
+        const int64_t r = i / half;
+        const int tok = (int)(r % a.n), g = (int)(r / a.n);
+        const bool is_k = g >= gq;
+        const int h0 = (is_k ? g - gq : g) * 8, nh = is_k ? nhk : nhq, m = is_k ? a.mk : a.mq, kz = is_k ? a.kzk : a.kzq;
+        const float * part = is_k ? a.kp : a.qp;
+        const int i0 = 2 * ic;
+        const bool pass = i0 >= a.p.n_dims;
+        float c = 1.0f, s = 0.0f;
+        if (!pass) rope_cos_sin(a.p, a.pos[tok], a.ff, ic, c, s);
+        const int e0 = pass ? i0 : (a.p.mode & 2) ? ic : i0, e1 = pass ? i0 + 1 : (a.p.mode & 2) ? ic + a.p.n_dims / 2 : i0 + 1;
+        const int64_t plane = (int64_t)a.n * m, row = (int64_t)tok * m;
+        float x0[8], x1[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int h = h0 + u < nh ? h0 + u : nh - 1;
+            x0[u] = plane_sum(part, row + h * hd + e0, plane, kz);
+            x1[u] = plane_sum(part, row + h * hd + e1, plane, kz);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            if (h0 + u >= nh) break;
+            const float y0 = pass ? x0[u] : x0[u] * c - x1[u] * s, y1 = pass ? x1[u] : x0[u] * s + x1[u] * c;
+            const int64_t o = row + (h0 + u) * hd;
+            if (!is_k)        { a.q_out[o + e0] = y0; a.q_out[o + e1] = y1; }
+            else if (a.k_f16) { ((__half *)a.k_out)[o + e0] = __float2half_rn(y0); ((__half *)a.k_out)[o + e1] = __float2half_rn(y1); }
+            else              { ((float *)a.k_out)[o + e0] = y0; ((float *)a.k_out)[o + e1] = y1; }
+        }
+    }
+}
+
 // ---------------------------------------------------------------- glu
 static __device__ __forceinline__ float act_glu(int op, float x) {
     switch (op) {
@@ -563,6 +630,31 @@ int mi355_rope_f32(const mi355_tensor * x, const int32_t * pos, const float * fr
         MI355_LAUNCH("rope", rope_heads_kernel, dim3(grid_for(npt)), dim3(256), 0, (hipStream_t)stream, t4(x), pos, freq_factors, t4(dst), p, npt);
     else
         MI355_LAUNCH("rope", rope_kernel, dim3(grid_for(npairs)), dim3(256), 0, (hipStream_t)stream, t4(x), pos, freq_factors, t4(dst), p, npairs);
+    MI355_CHECK_LAUNCH();
+    return MI355_OK;
+}
+
+int mi355_qkv_finish(const mi355_qkv_finish_args * f, void * stream) {
+    if (!f || !f->q_parts || !f->k_parts || !f->v_parts || !f->q_out || !f->k_out || !f->v_out || !f->pos) return MI355_E_NULL;
+    if (f->kz_q < 1 || f->kz_k < 1 || f->kz_v < 1 || f->kz_q > 8 || f->kz_k > 8 || f->kz_v > 8) return MI355_E_SHAPE;
+    const int64_t hd = f->head_dim;
+    if (hd <= 0 || (hd & 1) || f->n_dims > hd || (f->n_dims & 1) || f->n < 0 || f->m_q <= 0 || f->m_k <= 0 || f->m_v <= 0 ||
+        f->m_q % hd || f->m_k % hd || f->m_v % 4 || f->n > 0x7fffffff || f->m_q > 0x7fffffff || f->m_k > 0x7fffffff || f->m_v > 0x7fffffff) return MI355_E_SHAPE;
+    if (f->mode != 0 && f->mode != 2) return MI355_E_UNSUPPORTED;
+    if ((f->k_out_type != MI355_TYPE_F16 && f->k_out_type != MI355_TYPE_F32) || (f->v_out_type != MI355_TYPE_F16 && f->v_out_type != MI355_TYPE_F32)) return MI355_E_TYPE;
+    if (((uintptr_t)f->v_parts & 15) || ((uintptr_t)f->v_out & 15) || ((uintptr_t)f->q_parts & 3) || ((uintptr_t)f->k_parts & 3) ||
+        ((uintptr_t)f->q_out & 3) || ((uintptr_t)f->k_out & 3) || ((f->n * f->m_v) & 3)) return MI355_E_ALIGN;
+    if (f->n == 0) return MI355_OK;
+    QkvFin a;
+    a.qp = f->q_parts; a.kp = f->k_parts; a.vp = f->v_parts; a.kzq = f->kz_q; a.kzk = f->kz_k; a.kzv = f->kz_v;
+    a.mq = (int)f->m_q; a.mk = (int)f->m_k; a.mv = (int)f->m_v; a.n = (int)f->n;
+    a.q_out = f->q_out; a.k_out = (char *)f->k_out; a.v_out = (char *)f->v_out;
+    a.k_f16 = f->k_out_type == MI355_TYPE_F16; a.v_f16 = f->v_out_type == MI355_TYPE_F16;
+    a.pos = f->pos; a.ff = f->freq_factors;
+    a.p = rope_params(f->n_dims, f->mode, (int)hd, f->n_ctx_orig, f->freq_base, f->freq_scale, f->ext_factor, f->attn_factor, f->beta_fast, f->beta_slow);
+    const int64_t gq = (f->m_q / hd + 7) / 8, gk = (f->m_k / hd + 7) / 8;
+    const int64_t lanes = hd / 2 * f->n * (gq + gk) + f->n * (f->m_v / 4);
+    MI355_LAUNCH("qkv_finish", qkv_finish_kernel, dim3(grid_for(lanes)), dim3(256), 0, (hipStream_t)stream, a);
     MI355_CHECK_LAUNCH();
     return MI355_OK;
 }

@@ -47,6 +47,9 @@ struct DArgs {
     int64_t w_expert_stride;
     int dbg;                 // lab switch of mmdq_ws_kernel (MI355_MMDQ_DBG): 1 producers idle, 2 consumers idle
     float * part;            // split-K of the 128 x 256 role-split kernel: K slice z stores its partial tile at part[z][n][m], summed in z order by kz_sum_kernel
+    // gate / up / GLU form (mmdq_ws_kernel<..., GLU>): W is the matrix whose product is activated, W2 the one it is multiplied by; m counts
+    // PAIRS of rows (row i of W with row i of W2); dst receives act(W x) * (W2 x) as f32, hbf the same rounded to bf16 ([n][m], for the next GEMM)
+    const uint8_t * W2; int64_t w2_row_stride; uint16_t * hbf; int glu_op;
 };
 
 // 32 consecutive weights of one row, raw, as loaded from global memory
@@ -376,6 +379,16 @@ mmdq_kernel(const DArgs a) {
 // Same arithmetic and per-element summation order as mmdq_kernel (K ascending in steps of 16): bit-identical results.
 // Columns past n are not zero-filled (the DMA cannot): they read a valid column and their products are never stored.
 // ------------------------------------------------------------------------------------------------
+// the gated activation, the arithmetic of elementwise.hip's act_glu (ggml_silu_f32 vec.h:637-639, ggml_gelu_f32, relu)
+static __device__ __forceinline__ float glu_act_dq(int op, float x) {
+    switch (op) {
+        case 0: return x > 0.0f ? x : 0.0f;
+        case 1: { const float c = 0.044715f, s = 0.79788456080286535587989211986876f;
+                  return 0.5f * x * (1.0f + tanhf(s * x * (1.0f + c * x * x))); }
+        default: return x / (1.0f + expf(-x));
+    }
+}
+
 static __device__ __forceinline__ void gemm_dma_piece(const void * gsrc, unsigned lds_dst) {
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
@@ -385,9 +398,10 @@ static __device__ __forceinline__ void gemm_dma_piece(const void * gsrc, unsigne
 // BMW x BNW: 128 x 256 (8 multiplying waves of 64 x 64, 4 dequantizing; wide launches) or 64 x 128 (4 multiplying waves of
 // 64 x 32, 2 dequantizing; two workgroups per CU, with split-K for the launches of few tiles: gridDim.z == 2 adds the two
 // halves of K into a zeroed dst, exactly as mmdq_kernel does).
-template <int TYPE, int BMW, int BNW>
+template <int TYPE, int BMW, int BNW, bool GLU = false>
 __global__ void __launch_bounds__(BMW * BNW == 128 * 256 ? 768 : 384)
 mmdq_ws_kernel(const DArgs a) {
+    static_assert(!GLU || (BMW == 128 && BNW == 256), "the gate / up / GLU form exists for the 128 x 256 tile");
     constexpr int TN = BMW == 128 ? 2 : 1;                                    // 32-column MFMA tiles per multiplying wave
     constexpr int WAVES_M = BMW / 64, NMW = WAVES_M * (BNW / (32 * TN));      // multiplying waves
     constexpr int NPIECE = BNW * PITCH / 1024;                                // 1 KiB pieces per activation stage: 36 / 18
@@ -397,14 +411,16 @@ mmdq_ws_kernel(const DArgs a) {
     __shared__ __attribute__((aligned(1024))) uint8_t La[3][BNW * PITCH];
     __shared__ __attribute__((aligned(16))) uint8_t Lw[2][BMW * PITCH];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int n0 = blockIdx.x * BNW, m0 = blockIdx.y * BMW;
+    // GLU: the tile's 128 weight rows are 64 rows of W (tile rows 0..63) and the SAME 64 rows of W2 (tile rows 64..127)
+    const int n0 = blockIdx.x * BNW, m0 = blockIdx.y * (GLU ? BMW / 2 : BMW);
     const int kspan = a.k / (int)gridDim.z, kbeg = (int)blockIdx.z * kspan;
     const int nstage = kspan / BK;
 
     if (wave >= NMW) {                                                // ---- dequantizing waves
         const int pt = tid - 64 * NMW, sr = pt >> 1, hf = pt & 1;     // weight row sr of the tile, 32-value half hf of the stage
-        const int wr = m0 + sr < a.m ? m0 + sr : a.m - 1;
-        const uint8_t * wrow = a.W + (int64_t)wr * a.w_row_stride;
+        const int srm = GLU ? (sr & 63) : sr;
+        const int wr = m0 + srm < a.m ? m0 + srm : a.m - 1;
+        const uint8_t * wrow = GLU && sr >= 64 ? a.W2 + (int64_t)wr * a.w2_row_stride : a.W + (int64_t)wr * a.w_row_stride;
         constexpr int PFD = 2;
         Raw<TYPE> wraw[PFD];
 #pragma unroll
@@ -502,6 +518,41 @@ mmdq_ws_kernel(const DArgs a) {
         }
         __syncthreads();
     }
+    if constexpr (GLU) {
+        // waves wm_ = 1 hold (W2 x) for the rows whose (W x) the waves wm_ = 0 hold: hand them over through LDS (the stage buffers are
+        // dead; the dequantizing waves have left, the barrier counts the remaining ones), same (register, lane) slot on both sides
+        float * X = (float *)&La[0][0];
+        if (wm_ == 1) {
+#pragma unroll
+            for (int tm = 0; tm < 2; tm++)
+#pragma unroll
+                for (int tn = 0; tn < TN; tn++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) X[(((wn_ * 2 + tm) * TN + tn) * 16 + r) * 64 + lane] = acc[tm][tn][r];
+        }
+        __syncthreads();
+        if (wm_ == 1) return;
+#pragma unroll
+        for (int tm = 0; tm < 2; tm++) {
+            const int m = m0 + tm * 32 + lr;
+#pragma unroll
+            for (int tn = 0; tn < TN; tn++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int n = n0 + wn_ * 32 * TN + tn * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    const float u = X[(((wn_ * 2 + tm) * TN + tn) * 16 + r) * 64 + lane];
+                    const float h = glu_act_dq(a.glu_op, acc[tm][tn][r]) * u;
+                    // two neighbouring rows share one 4-byte store of the bf16 copy (m even: a.m is even here)
+                    const uint32_t hb = (uint32_t)__builtin_bit_cast(uint16_t, (__bf16)h);
+                    const uint32_t nb_ = (uint32_t)__shfl_xor((int)hb, 1, 64);
+                    if (m < a.m && n < a.n) {
+                        a.dst[(int64_t)n * a.dst_col_stride + m] = h;
+                        if (!(lr & 1)) *(uint32_t *)(a.hbf + (int64_t)n * a.m + m) = hb | (nb_ << 16);
+                    }
+                }
+        }
+        return;
+    }
 #pragma unroll
     for (int tm = 0; tm < 2; tm++) {
         const int m = m0 + wm_ * 64 + tm * 32 + lr;
@@ -587,11 +638,26 @@ static int kz_slices(int64_t m_total, int64_t n, int64_t k) {
     return kzw;
 }
 
+// K slices of the 64 x 128 role-split kernel, the tile of the launches too small for the one above (M = 1024 at N = 512: wk, wv): 2 or 4
+// while every workgroup still finds a CU of its own; 0: not that form (one K range, or the two-addend atomic form of the uniform kernel)
+static int kz_slices_small(int64_t m_total, int64_t n, int64_t k) {
+    static const int kz_ws = [] { const char * e = getenv("MI355_MMDQ_KZ"); return e ? atoi(e) : 1; }();
+    static const int wide = [] { const char * e = getenv("MI355_MMDQ_WIDE"); return e ? atoi(e) : 2; }();
+    static const int small_ws = [] { const char * e = getenv("MI355_MMDQ_SMALL"); return e ? atoi(e) : 1; }();
+    if (!kz_ws || wide != 2 || small_ws != 1 || kz_slices(m_total, n, k) != 0) return 0;
+    const int64_t tiles = ((n + BN - 1) / BN) * ((m_total + 63) / 64);
+    for (int kz = 4; kz >= 2; kz /= 2)
+        if (tiles * kz <= 256 && k % (BK * kz) == 0 && k / kz >= 1024) return kz;
+    return 0;
+}
+
 // m_total: rows of the WHOLE weight matrix when `a` is a row slice of it (row split).  Whether K is cut in two -- the one
 // choice here that changes the f32 summation order -- is decided from the whole matrix, so a slice produces the bits the
 // unsplit matrix would; the tile height only changes which workgroup computes an element, not how.
 template <int TYPE>
-static int launch(const DArgs & a, int64_t m_total, hipStream_t s, const char * tag) {
+static int launch(const DArgs & a_in, int64_t m_total, hipStream_t s, const char * tag, int * parts_kz = nullptr) {
+    // parts_kz: the caller wants the K-slice planes, not their sum -- a.part receives [kz][n][m] (kz == 1: a.dst is that plane)
+    DArgs a = a_in;
     // 128-row tiles reuse each staged activation tile twice as often; 64-row tiles when those would leave CUs idle
     const int64_t nb = (a.n + BN - 1) / BN;
     const bool full_big = nb * ((m_total + 255) / 256) >= 200 || nb * ((m_total + 127) / 128) >= 384;
@@ -607,13 +673,16 @@ static int launch(const DArgs & a, int64_t m_total, hipStream_t s, const char * 
     // 128 x 256 tiles of the WHOLE matrix: enough of them for the chip -> one K range; a half / a quarter of that -> K in 2 / 4
     // slices (M = 4096..8192 at N = 512), each slice's partial tile to the workspace, summed in slice order.  The small tiles such
     // launches used to take move 2-3x the activation bytes per flop (4096 x 14336 x 512: 143 -> 8x us).
-    const int kzw = kz_slices(m_total, a.n, a.k);
+    const int kzb = kz_slices(m_total, a.n, a.k), kzs = kz_slices_small(m_total, a.n, a.k);
+    const int kzw = kzb > 1 ? kzb : kzs;
     if (kzw > 1 && dma_ok) {
         DArgs b = a;
         if (!b.part) b.part = kz_workspace((size_t)kzw * a.n * a.m * sizeof(float), s);    // no workspace from the caller: the library's own
         if (!b.part) return MI355_E_WORKSPACE;
-        MI355_LAUNCH(tag, (mmdq_ws_kernel<TYPE, 128, 256>), dim3((unsigned)nb2, (unsigned)((a.m + 127) / 128), (unsigned)kzw), dim3(768), 0, s, b);
+        if (kzb > 1) MI355_LAUNCH(tag, (mmdq_ws_kernel<TYPE, 128, 256>), dim3((unsigned)nb2, (unsigned)((a.m + 127) / 128), (unsigned)kzw), dim3(768), 0, s, b);
+        else         MI355_LAUNCH(tag, (mmdq_ws_kernel<TYPE, 64, 128>), dim3((unsigned)nb, (unsigned)((a.m + 63) / 64), (unsigned)kzw), dim3(384), 0, s, b);
         MI355_CHECK_LAUNCH();
+        if (parts_kz) { *parts_kz = kzw; return MI355_OK; }
         const int64_t total = (int64_t)a.m * a.n;
         if (a.dst_col_stride == a.m && a.m % 4 == 0 && ((uintptr_t)a.dst & 15) == 0 && ((uintptr_t)b.part & 15) == 0)
             MI355_LAUNCH("mmdq_kz_sum", kz_sum_kernel<true>, dim3((unsigned)std::min<int64_t>((total / 4 + 255) / 256, 2048)), dim3(256), 0, s, b.part, a.dst, a.dst_col_stride, a.m, a.n, kzw);
@@ -622,6 +691,8 @@ static int launch(const DArgs & a, int64_t m_total, hipStream_t s, const char * 
         MI355_CHECK_LAUNCH();
         return MI355_OK;
     }
+    a.part = nullptr;             // a caller's workspace is only for the split-K forms above
+    if (parts_kz) *parts_kz = 1;
     if (wide == 2 && kz == 1 && a.n >= 256 && nb2 * ((a.m + 127) / 128) >= 200 && dma_ok) {
         MI355_LAUNCH(tag, (mmdq_ws_kernel<TYPE, 128, 256>), dim3((unsigned)nb2, (unsigned)((a.m + 127) / 128)), dim3(768), 0, s, a);
     } else if (wide && kz == 1 && a.n >= 256 && nb2 * ((a.m + 127) / 128) >= 200) {
@@ -689,15 +760,44 @@ extern "C" int mi355_mul_mat_dq_slice(int type, const void * W, int64_t w_row_st
 
 extern "C" int64_t mi355_mul_mat_dq_workspace_bytes(int64_t m, int64_t m_total, int64_t k, int64_t n) {
     if (m < 0 || m_total < m || k <= 0 || n < 0) return -1;
-    const int kzw = k % BK == 0 ? kz_slices(m_total, n, k) : 0;
+    const int kzb = k % BK == 0 ? kz_slices(m_total, n, k) : 0;
+    const int kzw = kzb > 1 || k % BK != 0 ? kzb : kz_slices_small(m_total, n, k);
     return kzw > 1 ? (int64_t)kzw * n * m * (int64_t)sizeof(float) : 0;
 }
+
+static int dq_run(int type, const void * W, int64_t w_row_stride, const uint16_t * x, int64_t x_row_stride,
+                  float * dst, int64_t dst_col_stride, int64_t m, int64_t m_total, int64_t k, int64_t n,
+                  void * workspace, int64_t workspace_bytes, void * stream, int * parts_kz);
 
 extern "C" int mi355_mul_mat_dq_slice_ws(int type, const void * W, int64_t w_row_stride, const uint16_t * x, int64_t x_row_stride,
                                          float * dst, int64_t dst_col_stride, int64_t m, int64_t m_total, int64_t k, int64_t n,
                                          void * workspace, int64_t workspace_bytes, void * stream) {
+    return dq_run(type, W, w_row_stride, x, x_row_stride, dst, dst_col_stride, m, m_total, k, n, workspace, workspace_bytes, stream, nullptr);
+}
+
+extern "C" int64_t mi355_mul_mat_dq_parts_bytes(int64_t m, int64_t m_total, int64_t k, int64_t n) {
+    const int64_t ws = mi355_mul_mat_dq_workspace_bytes(m, m_total, k, n);
+    if (ws < 0) return ws;
+    return ws > 0 ? ws : n * m * (int64_t)sizeof(float);
+}
+
+extern "C" int mi355_mul_mat_dq_parts(int type, const void * W, int64_t w_row_stride, const uint16_t * x, int64_t x_row_stride,
+                                      float * parts, int64_t parts_bytes, int64_t m, int64_t m_total, int64_t k, int64_t n,
+                                      int32_t * kz, void * stream) {
+    if (!parts || !kz) return MI355_E_NULL;
+    if (((uintptr_t)parts & 15) || parts_bytes < mi355_mul_mat_dq_parts_bytes(m, m_total, k, n)) return MI355_E_WORKSPACE;
+    int nz = 0;
+    // the buffer is both the split-K workspace and, for the launches that do not split, the product itself
+    const int rc = dq_run(type, W, w_row_stride, x, x_row_stride, parts, m, m, m_total, k, n, parts, parts_bytes, stream, &nz);
+    if (rc == MI355_OK) *kz = m == 0 || n == 0 ? 1 : nz;
+    return rc;
+}
+
+static int dq_run(int type, const void * W, int64_t w_row_stride, const uint16_t * x, int64_t x_row_stride,
+                  float * dst, int64_t dst_col_stride, int64_t m, int64_t m_total, int64_t k, int64_t n,
+                  void * workspace, int64_t workspace_bytes, void * stream, int * parts_kz) {
     if (!W || !x || !dst) return MI355_E_NULL;
-    if (workspace && (((uintptr_t)workspace & 15) || workspace_bytes < mi355_mul_mat_dq_workspace_bytes(m, m_total, k, n))) return MI355_E_WORKSPACE;
+    if (!parts_kz && workspace && (((uintptr_t)workspace & 15) || workspace_bytes < mi355_mul_mat_dq_workspace_bytes(m, m_total, k, n))) return MI355_E_WORKSPACE;
     if (m_total < m) return MI355_E_SHAPE;
     const int64_t bs = mi355_blck_size(type);
     if (bs == 0 || type == MI355_TYPE_Q8_1) return MI355_E_TYPE;
@@ -713,20 +813,70 @@ extern "C" int mi355_mul_mat_dq_slice_ws(int type, const void * W, int64_t w_row
     a.W = (const uint8_t *)W; a.w_row_stride = w_row_stride; a.x = x; a.x_row_stride = x_row_stride;
     a.dst = dst; a.dst_col_stride = dst_col_stride; a.m = (int)m; a.n = (int)n; a.k = (int)k;
     a.sorted = a.off = a.tile_off = nullptr; a.n_expert = a.n_used = a.act_ne1 = 0; a.w_expert_stride = 0; a.part = (float *)workspace;
+    a.W2 = nullptr; a.w2_row_stride = 0; a.hbf = nullptr; a.glu_op = 0;
     { static const int dbg = [] { const char * e = getenv("MI355_MMDQ_DBG"); return e ? atoi(e) : 0; }(); a.dbg = dbg; }
     hipStream_t s = (hipStream_t)stream;
     switch (type) {
-        case MI355_TYPE_Q4_0: return launch<MI355_TYPE_Q4_0>(a, m_total, s, "mmdq_q4_0");
-        case MI355_TYPE_Q8_0: return launch<MI355_TYPE_Q8_0>(a, m_total, s, "mmdq_q8_0");
-        case MI355_TYPE_Q4_K: return launch<MI355_TYPE_Q4_K>(a, m_total, s, "mmdq_q4_K");
-        case MI355_TYPE_Q5_K: return launch<MI355_TYPE_Q5_K>(a, m_total, s, "mmdq_q5_K");
-        case MI355_TYPE_Q6_K: return launch<MI355_TYPE_Q6_K>(a, m_total, s, "mmdq_q6_K");
-        case MI355_TYPE_Q4_1: return launch<MI355_TYPE_Q4_1>(a, m_total, s, "mmdq_q4_1");
-        case MI355_TYPE_Q5_0: return launch<MI355_TYPE_Q5_0>(a, m_total, s, "mmdq_q5_0");
-        case MI355_TYPE_Q5_1: return launch<MI355_TYPE_Q5_1>(a, m_total, s, "mmdq_q5_1");
-        case MI355_TYPE_F16:  return launch<MI355_TYPE_F16>(a, m_total, s, "mmdq_f16");
-        case MI355_TYPE_BF16: return launch<MI355_TYPE_BF16>(a, m_total, s, "mmdq_bf16");
-        case MI355_TYPE_F32:  return launch<MI355_TYPE_F32>(a, m_total, s, "mmdq_f32");
+        case MI355_TYPE_Q4_0: return launch<MI355_TYPE_Q4_0>(a, m_total, s, "mmdq_q4_0", parts_kz);
+        case MI355_TYPE_Q8_0: return launch<MI355_TYPE_Q8_0>(a, m_total, s, "mmdq_q8_0", parts_kz);
+        case MI355_TYPE_Q4_K: return launch<MI355_TYPE_Q4_K>(a, m_total, s, "mmdq_q4_K", parts_kz);
+        case MI355_TYPE_Q5_K: return launch<MI355_TYPE_Q5_K>(a, m_total, s, "mmdq_q5_K", parts_kz);
+        case MI355_TYPE_Q6_K: return launch<MI355_TYPE_Q6_K>(a, m_total, s, "mmdq_q6_K", parts_kz);
+        case MI355_TYPE_Q4_1: return launch<MI355_TYPE_Q4_1>(a, m_total, s, "mmdq_q4_1", parts_kz);
+        case MI355_TYPE_Q5_0: return launch<MI355_TYPE_Q5_0>(a, m_total, s, "mmdq_q5_0", parts_kz);
+        case MI355_TYPE_Q5_1: return launch<MI355_TYPE_Q5_1>(a, m_total, s, "mmdq_q5_1", parts_kz);
+        case MI355_TYPE_F16:  return launch<MI355_TYPE_F16>(a, m_total, s, "mmdq_f16", parts_kz);
+        case MI355_TYPE_BF16: return launch<MI355_TYPE_BF16>(a, m_total, s, "mmdq_bf16", parts_kz);
+        case MI355_TYPE_F32:  return launch<MI355_TYPE_F32>(a, m_total, s, "mmdq_f32", parts_kz);
+    }
+    return MI355_E_TYPE;
+}
+
+template <int TYPE>
+static int launch_glu(const DArgs & a, hipStream_t s, const char * tag) {
+    MI355_LAUNCH(tag, (mmdq_ws_kernel<TYPE, 128, 256, true>), dim3((unsigned)((a.n + 255) / 256), (unsigned)((a.m + 63) / 64)), dim3(768), 0, s, a);
+    MI355_CHECK_LAUNCH();
+    return MI355_OK;
+}
+
+// dst[n][m] = act(Wa x)[n][m] * (Wb x)[n][m] and the same rounded to bf16: ffn_gate, ffn_up and the GLU between them in one launch.
+// Offered only where mi355_mul_mat_dq would run each of the two products as ONE K range of 128 x 256 role-split tiles: every
+// element is then accumulated by the same MFMA sequence as there, so the result has the bits of the three separate launches.
+extern "C" int mi355_glu_mul_mat_dq(int type, int glu_op, const void * Wa, int64_t wa_row_stride, const void * Wb, int64_t wb_row_stride,
+                                    const uint16_t * x, int64_t x_row_stride, float * dst, int64_t dst_col_stride, uint16_t * dst_bf16,
+                                    int64_t m, int64_t k, int64_t n, void * stream) {
+    if (!Wa || !Wb || !x || !dst || !dst_bf16) return MI355_E_NULL;
+    const int64_t bs = mi355_blck_size(type);
+    if (bs == 0 || type == MI355_TYPE_Q8_1) return MI355_E_TYPE;
+    if (glu_op < 0 || glu_op > 2) return MI355_E_TYPE;
+    if (m < 0 || n < 0 || k <= 0 || k % bs != 0 || m > 0x7fffffff || n > 0x7fffffff || k > 0x7fffffff) return MI355_E_SHAPE;
+    if (((uintptr_t)x & 15) || (x_row_stride & 7) || ((uintptr_t)dst & 3) || ((uintptr_t)dst_bf16 & 3) || x_row_stride < k) return MI355_E_ALIGN;
+    const bool a16 = type == MI355_TYPE_Q4_K || type == MI355_TYPE_Q5_K;
+    if (((uintptr_t)Wa | (uintptr_t)wa_row_stride | (uintptr_t)Wb | (uintptr_t)wb_row_stride) & (a16 ? 15 : 1)) return MI355_E_ALIGN;
+    if (wa_row_stride < mi355_row_size(type, k) || wb_row_stride < mi355_row_size(type, k) || dst_col_stride < m) return MI355_E_SHAPE;
+    static const int wide = [] { const char * e = getenv("MI355_MMDQ_WIDE"); return e ? atoi(e) : 2; }();
+    // the launch mi355_mul_mat_dq would choose for ONE of the two products (launch<TYPE>() above) must be the single-K-range role-split one
+    if (k % BK != 0 || m % 2 != 0 || wide != 2 || n < 256 || ((n + 255) / 256) * ((m + 127) / 128) < 200 || (m + 63) / 64 > 65535)
+        return MI355_E_UNSUPPORTED;
+    if (m == 0 || n == 0) return MI355_OK;
+    DArgs a;
+    a.W = (const uint8_t *)Wa; a.w_row_stride = wa_row_stride; a.W2 = (const uint8_t *)Wb; a.w2_row_stride = wb_row_stride;
+    a.x = x; a.x_row_stride = x_row_stride; a.dst = dst; a.dst_col_stride = dst_col_stride; a.hbf = dst_bf16; a.glu_op = glu_op;
+    a.m = (int)m; a.n = (int)n; a.k = (int)k;
+    a.sorted = a.off = a.tile_off = nullptr; a.n_expert = a.n_used = a.act_ne1 = 0; a.w_expert_stride = 0; a.part = nullptr; a.dbg = 0;
+    hipStream_t s = (hipStream_t)stream;
+    switch (type) {
+        case MI355_TYPE_Q4_0: return launch_glu<MI355_TYPE_Q4_0>(a, s, "mmdq_glu_q4_0");
+        case MI355_TYPE_Q8_0: return launch_glu<MI355_TYPE_Q8_0>(a, s, "mmdq_glu_q8_0");
+        case MI355_TYPE_Q4_K: return launch_glu<MI355_TYPE_Q4_K>(a, s, "mmdq_glu_q4_K");
+        case MI355_TYPE_Q5_K: return launch_glu<MI355_TYPE_Q5_K>(a, s, "mmdq_glu_q5_K");
+        case MI355_TYPE_Q6_K: return launch_glu<MI355_TYPE_Q6_K>(a, s, "mmdq_glu_q6_K");
+        case MI355_TYPE_Q4_1: return launch_glu<MI355_TYPE_Q4_1>(a, s, "mmdq_glu_q4_1");
+        case MI355_TYPE_Q5_0: return launch_glu<MI355_TYPE_Q5_0>(a, s, "mmdq_glu_q5_0");
+        case MI355_TYPE_Q5_1: return launch_glu<MI355_TYPE_Q5_1>(a, s, "mmdq_glu_q5_1");
+        case MI355_TYPE_F16:  return launch_glu<MI355_TYPE_F16>(a, s, "mmdq_glu_f16");
+        case MI355_TYPE_BF16: return launch_glu<MI355_TYPE_BF16>(a, s, "mmdq_glu_bf16");
+        case MI355_TYPE_F32:  return launch_glu<MI355_TYPE_F32>(a, s, "mmdq_glu_f32");
     }
     return MI355_E_TYPE;
 }
@@ -769,6 +919,7 @@ extern "C" int mi355_mul_mat_id_dq(int type, const void * as, int64_t w_row_stri
     a.dst = dst; a.dst_col_stride = m; a.m = (int)m; a.n = (int)(n_tokens * n_used); a.k = (int)k;
     a.sorted = sorted; a.off = off; a.tile_off = tile_off; a.n_expert = (int)n_expert; a.n_used = (int)n_used; a.act_ne1 = (int)b_ne1;
     a.w_expert_stride = w_expert_stride; a.dbg = 0; a.part = nullptr;
+    a.W2 = nullptr; a.w2_row_stride = 0; a.hbf = nullptr; a.glu_op = 0;
     const int max_tiles = (int)((n_tokens * n_used + BN - 1) / BN + n_expert);   // sum over experts of ceil(cnt_e / BN) never exceeds this
     switch (type) {
         case MI355_TYPE_Q4_0: return launch_ids<MI355_TYPE_Q4_0>(a, max_tiles, s, "mmdq_id_q4_0");

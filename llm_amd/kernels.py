@@ -17,7 +17,7 @@ lib = C.CDLL(LIB_PATH)
 
 _vp, _i64, _i32 = C.c_void_p, C.c_int64, C.c_int32
 
-ABI_VERSION = 3          # MI355_ABI_VERSION of include/mi355_kernels.h this binding mirrors
+ABI_VERSION = 4          # MI355_ABI_VERSION of include/mi355_kernels.h this binding mirrors
 
 EXPORTS = [
     "mi355_abi_version", "mi355_args_sizeof", "mi355_error_string", "mi355_blck_size", "mi355_type_size", "mi355_row_size",
@@ -25,7 +25,7 @@ EXPORTS = [
     "mi355_timing_enable", "mi355_timing_reset", "mi355_timing_read", "mi355_timing_report",
     "mi355_binary_f32", "mi355_rms_norm_f32", "mi355_rms_norm_mul_f32", "mi355_rms_norm_mul_quant_f32", "mi355_glu_quant_f32", "mi355_rms_norm_mul_bf16_f32", "mi355_glu_bf16_f32", "mi355_add_rms_norm_mul_f32", "mi355_mul_mat_vec_q_group", "mi355_qkv_rope_matvec", "mi355_glu_matvec", "mi355_moe_down_matvec", "mi355_rope_f32", "mi355_glu_f32", "mi355_cpy", "mi355_get_rows", "mi355_set_rows", "mi355_mul_mat_f",
     "mi355_scale_f32", "mi355_soft_max_f32", "mi355_flash_attn_ext_workspace_bytes", "mi355_flash_attn_ext", "mi355_flash_attn_ext_quant", "mi355_flash_attn_ext_noalloc_max_bytes", "mi355_flash_attn_ext_noalloc",
-    "mi355_dequantize_row", "mi355_mul_mat_vec_q", "mi355_mul_mat_q", "mi355_mul_mat_skinny", "mi355_quantize_act_q8k", "mi355_mul_mat_skinny_k", "mi355_mul_mat_qk", "mi355_mul_mat_id_skinny_workspace_bytes", "mi355_mul_mat_id_skinny", "mi355_argsort_f32", "mi355_moe_router_f32", "mi355_sum_rows_f32", "mi355_mul_mat_f32", "mi355_mul_mat_dq", "mi355_mul_mat_dq_slice", "mi355_kv_store_q8_0", "mi355_mul_mat_dq_slice_ws", "mi355_mul_mat_dq_workspace_bytes", "mi355_act_bf16", "mi355_mul_mat_id_dq_workspace_bytes", "mi355_mul_mat_id_dq", "mi355_mul_mat_workspace_bytes", "mi355_mul_mat",
+    "mi355_dequantize_row", "mi355_mul_mat_vec_q", "mi355_mul_mat_q", "mi355_mul_mat_skinny", "mi355_quantize_act_q8k", "mi355_mul_mat_skinny_k", "mi355_mul_mat_qk", "mi355_mul_mat_id_skinny_workspace_bytes", "mi355_mul_mat_id_skinny", "mi355_argsort_f32", "mi355_moe_router_f32", "mi355_sum_rows_f32", "mi355_mul_mat_f32", "mi355_mul_mat_dq", "mi355_mul_mat_dq_slice", "mi355_kv_store_q8_0", "mi355_mul_mat_dq_slice_ws", "mi355_glu_mul_mat_dq", "mi355_mul_mat_dq_parts_bytes", "mi355_mul_mat_dq_parts", "mi355_qkv_finish", "mi355_mul_mat_dq_workspace_bytes", "mi355_act_bf16", "mi355_mul_mat_id_dq_workspace_bytes", "mi355_mul_mat_id_dq", "mi355_mul_mat_workspace_bytes", "mi355_mul_mat",
 ]
 
 
@@ -106,6 +106,18 @@ class FattnArgs(C.Structure):
     ]
 
 
+class QkvFinishArgs(C.Structure):
+    """mi355_qkv_finish_args (include/mi355_kernels.h)"""
+    _fields_ = [
+        ("q_parts", _vp), ("k_parts", _vp), ("v_parts", _vp), ("kz_q", _i32), ("kz_k", _i32), ("kz_v", _i32),
+        ("m_q", _i64), ("m_k", _i64), ("m_v", _i64), ("n", _i64), ("q_out", _vp), ("k_out", _vp), ("v_out", _vp),
+        ("k_out_type", _i32), ("v_out_type", _i32), ("pos", _vp), ("freq_factors", _vp),
+        ("head_dim", _i32), ("n_dims", _i32), ("mode", _i32), ("n_ctx_orig", _i32),
+        ("freq_base", C.c_float), ("freq_scale", C.c_float), ("ext_factor", C.c_float), ("attn_factor", C.c_float),
+        ("beta_fast", C.c_float), ("beta_slow", C.c_float),
+    ]
+
+
 lib.mi355_abi_version.restype = C.c_int
 lib.mi355_args_sizeof.restype = _i64
 lib.mi355_args_sizeof.argtypes = [C.c_int]
@@ -140,6 +152,11 @@ lib.mi355_mul_mat_id_dq_workspace_bytes.argtypes = [_i64] * 5
 lib.mi355_mul_mat_id_dq.argtypes = [C.c_int, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _vp] + [_i64] * 6 + [_vp, _i64, _vp]
 lib.mi355_act_bf16.argtypes = [_vp, _vp, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _vp]
 lib.mi355_mul_mat_dq_slice.argtypes = [C.c_int, _vp, C.c_int64, _vp, C.c_int64, _vp, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _vp]
+lib.mi355_mul_mat_dq_parts_bytes.restype = _i64
+lib.mi355_mul_mat_dq_parts_bytes.argtypes = [C.c_int64] * 4
+lib.mi355_mul_mat_dq_parts.argtypes = [C.c_int, _vp, C.c_int64, _vp, C.c_int64, _vp, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.POINTER(C.c_int32), _vp]
+lib.mi355_qkv_finish.argtypes = [C.POINTER(QkvFinishArgs), _vp]
+lib.mi355_glu_mul_mat_dq.argtypes = [C.c_int, C.c_int, _vp, C.c_int64, _vp, C.c_int64, _vp, C.c_int64, _vp, C.c_int64, _vp, C.c_int64, C.c_int64, C.c_int64, _vp]
 lib.mi355_mul_mat_dq_slice_ws.argtypes = [C.c_int, _vp, C.c_int64, _vp, C.c_int64, _vp, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _vp, C.c_int64, _vp]
 lib.mi355_mul_mat_dq_workspace_bytes.argtypes = [C.c_int64, C.c_int64, C.c_int64, C.c_int64]
 lib.mi355_mul_mat_dq_workspace_bytes.restype = C.c_int64
@@ -210,6 +227,6 @@ def check(code, where):
 
 
 # the hand-kept ctypes mirrors must have the C structs' sizes (a stale library or binding would read struct tails as garbage)
-for _which, _cls in enumerate((MmvqArgs, QkvRopeArgs, GluMatvecArgs, MoeDownArgs, FattnArgs, Tensor)):
+for _which, _cls in enumerate((MmvqArgs, QkvRopeArgs, GluMatvecArgs, MoeDownArgs, FattnArgs, Tensor, QkvFinishArgs)):
     if lib.mi355_args_sizeof(_which) != C.sizeof(_cls):
         raise ImportError(f"{_cls.__name__}: ctypes mirror is {C.sizeof(_cls)} bytes, the library's struct {lib.mi355_args_sizeof(_which)}")

@@ -200,6 +200,27 @@ def test_norm_in_the_grouped_gate_up_launch_is_bit_exact(tmp_path):
     test_fusions_are_bit_exact(tmp_path, "tiny", extra_env={"GGML_MI355_NO_GLU_MATVEC": "1"})
 
 
+@pytest.mark.parametrize("ftype", ["Q4_K_M", "Q8_0"])
+def test_gate_up_glu_gemm_is_bit_exact(tmp_path, ftype):
+    """Prefill: MUL_MAT(ffn_gate) MUL_MAT(ffn_up) GLU as ONE launch (mi355_glu_mul_mat_dq; the two f32 products are never written).  A
+    512-token batch through a model with Llama-8B's feed-forward width (14336 x 1024, the smallest shape the fused form is offered
+    for) gives the logits of the unfused graph to the bit, and the fused launch did run (GGML_MI355_NO_GLU_GEMM changes nothing but time)."""
+    import numpy as np
+    tool = os.path.join(ROOT, "tools", "run_llama_bench.sh")
+    outs = {}
+    for name, extra in (("fused", {}), ("no_glu_gemm", {"GGML_MI355_NO_GLU_GEMM": "1"}), ("nofuse", {"GGML_MI355_NO_FUSE": "1"})):
+        path = str(tmp_path / f"logits_{name}.bin")
+        env = dict(os.environ, GGML_MI355_KERNEL_TIMES="1", **extra)
+        r = subprocess.run([tool, "wideffn", ftype, "--big-batch", "512", "--dump-logits", path], capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stderr[-3000:]
+        m = re.search(r"\[mi355\] kernel mmdq_glu_\S+ (\d+) ", r.stderr)
+        outs[name] = (np.fromfile(path, dtype=np.uint32), int(m.group(1)) if m else 0)
+    # one launch: the first of the two layers (the last one computes the feed-forward of the batch's last token only)
+    assert outs["fused"][1] == 1 and outs["no_glu_gemm"][1] == 0 and outs["nofuse"][1] == 0
+    assert np.array_equal(outs["fused"][0], outs["nofuse"][0])
+    assert np.array_equal(outs["fused"][0], outs["no_glu_gemm"][0])
+
+
 def test_fusions_are_bit_exact_with_a_q8_0_cache(tmp_path):
     """-ctk q8_0 -ctv q8_0: the fused Q/K/V launch leaves K and V as f32 rows in scratch and mi355_kv_store_q8_0 quantizes both into the
     cache -- the same bits as RMS_NORM, 3 MUL_MAT, 2 ROPE and 2 CPY f32 -> q8_0 launched one by one"""

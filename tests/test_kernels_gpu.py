@@ -225,6 +225,102 @@ def test_mmdq_split_k_workspace_from_the_caller(ops):
     assert rc == K.E_WORKSPACE if hasattr(K, "E_WORKSPACE") else rc == -5
 
 
+@pytest.mark.parametrize("t", [B.Q4_K, B.Q6_K, B.Q8_0, B.Q4_0])
+@pytest.mark.parametrize("op", [0, 1, 2])
+def test_glu_mul_mat_dq_has_the_bits_of_the_three_launches(ops, t, op):
+    """mi355_glu_mul_mat_dq (ffn_gate, ffn_up and the GLU in one launch, each tile holding 64 rows of both matrices) against
+    mi355_mul_mat_dq x 2 + mi355_glu_bf16_f32: f32 result and bf16 copy bit for bit; ragged m (not a multiple of 64) and n (not
+    a multiple of 256); shapes outside the contract are refused, not approximated."""
+    import ctypes as C
+    import llm_amd.kernels as K
+    if op != 2 and t != B.Q4_K:
+        pytest.skip("the activation is independent of the weight type")
+    m, k, n = 14336 + 36, 1024, 512 - 3                     # m % 4 == 0: the vector path of mi355_glu_bf16_f32
+    rng = np.random.default_rng(17)
+    wa = dev(B.random_blocks(t, m, k, seed=3))
+    wb = dev(B.random_blocks(t, m, k, seed=4))
+    x = ops.act_bf16(dev(rng.standard_normal((n, k)).astype(np.float32)))
+    s = torch.cuda.current_stream().cuda_stream
+    rs = B.row_size(t, k)
+    g = torch.empty((n, m), device="cuda"); u = torch.empty((n, m), device="cuda")
+    K.check(K.lib.mi355_mul_mat_dq(t, wa.data_ptr(), rs, x.data_ptr(), k, g.data_ptr(), m, m, k, n, s), "dq gate")
+    K.check(K.lib.mi355_mul_mat_dq(t, wb.data_ptr(), rs, x.data_ptr(), k, u.data_ptr(), m, m, k, n, s), "dq up")
+    h = torch.empty((n, m), device="cuda"); hb = torch.empty((n, m), dtype=torch.int16, device="cuda")
+    K.check(K.lib.mi355_glu_bf16_f32(op, C.byref(K.Tensor.of(g)), C.byref(K.Tensor.of(u)), C.byref(K.Tensor.of(h)), 0, hb.data_ptr(), s), "glu")
+    h2 = torch.full((n, m), 7.0, device="cuda"); hb2 = torch.full((n, m), 7, dtype=torch.int16, device="cuda")
+    K.check(K.lib.mi355_glu_mul_mat_dq(t, op, wa.data_ptr(), rs, wb.data_ptr(), rs, x.data_ptr(), k, h2.data_ptr(), m, hb2.data_ptr(), m, k, n, s), "glu_dq")
+    torch.cuda.synchronize()
+    assert torch.isfinite(h).all()
+    assert torch.equal(h.view(torch.int32), h2.view(torch.int32))
+    assert torch.equal(hb, hb2)
+    # few tiles (the separate GEMMs would cut K or take small tiles) and odd m: refused
+    for mm, nn in ((4096, 512), (14336, 128), (14335, 512)):
+        rc = K.lib.mi355_glu_mul_mat_dq(t, op, wa.data_ptr(), rs, wb.data_ptr(), rs, x.data_ptr(), k, h2.data_ptr(), mm, hb2.data_ptr(), mm, k, nn, s)
+        assert rc == -6, (mm, nn, rc)                   # MI355_E_UNSUPPORTED
+
+
+@pytest.mark.parametrize("mq,mkv,k,n,hd,n_dims,mode,ff,kv16,tq,tv", [
+    (4096, 1024, 4096, 512, 128, 128, 2, True, True, B.Q4_K, B.Q6_K),       # Llama-8B layer, 512 tokens: every product in 4 K slices
+    (4096, 1024, 4096, 2048, 128, 128, 0, False, True, B.Q4_K, B.Q4_K),     # 2048 tokens: q in one K range, k / v split
+    (1024, 256, 1024, 160, 64, 32, 0, False, False, B.Q8_0, B.Q8_0),        # small shapes, partial rotation, f32 cache
+    (2048, 512, 2048, 300, 128, 128, 2, False, True, B.Q5_K, B.Q5_K),
+])
+def test_qkv_parts_and_finish_have_the_bits_of_the_separate_launches(ops, mq, mkv, k, n, hd, n_dims, mode, ff, kv16, tq, tv):
+    """Prefill Q / K / V: mi355_mul_mat_dq_parts x 3 (the GEMMs stopped before their slice sum) + mi355_qkv_finish (slice sum, rope of
+    q and k, conversion of k and v to the cache type) against mi355_mul_mat_dq x 3, mi355_rope_f32 x 2 and the f32 -> f16 conversion:
+    bit for bit."""
+    import ctypes as C
+    import llm_amd.kernels as K
+    rng = np.random.default_rng(23)
+    s = torch.cuda.current_stream().cuda_stream
+    x = ops.act_bf16(dev(rng.standard_normal((n, k)).astype(np.float32)))
+    pos = dev((np.arange(n) * 3 + 5).astype(np.int32))
+    fac = dev((1.0 + rng.random(hd // 2)).astype(np.float32)) if ff else None
+    rope_kw = dict(n_ctx_orig=4096, freq_base=500000.0, freq_scale=0.5, ext_factor=0.25 if ff else 0.0, attn_factor=1.1, beta_fast=32.0, beta_slow=1.0)
+    ws, ms, ts = [], (mq, mkv, mkv), (tq, tq, tv)
+    want, parts, kzs = [], [], []
+    for i, (m, t) in enumerate(zip(ms, ts)):
+        w = dev(B.random_blocks(t, m, k, seed=40 + i)); ws.append(w)
+        d = torch.empty((n, m), device="cuda")
+        K.check(K.lib.mi355_mul_mat_dq(t, w.data_ptr(), B.row_size(t, k), x.data_ptr(), k, d.data_ptr(), m, m, k, n, s), "dq")
+        want.append(d)
+        nb = K.lib.mi355_mul_mat_dq_parts_bytes(m, m, k, n)
+        assert nb >= n * m * 4
+        p = torch.full((nb // 4,), float("nan"), device="cuda")
+        kz = C.c_int32(0)
+        K.check(K.lib.mi355_mul_mat_dq_parts(t, w.data_ptr(), B.row_size(t, k), x.data_ptr(), k, p.data_ptr(), nb, m, m, k, n, C.byref(kz), s), "dq_parts")
+        assert 1 <= kz.value <= 4 and nb == max(kz.value, 1) * n * m * 4
+        parts.append(p); kzs.append(kz.value)
+        planes = p.view(kz.value, n, m)
+        acc = planes[0].clone()
+        for z in range(1, kz.value):
+            acc += planes[z]
+        assert torch.equal(acc, d)                      # the planes, added in order, are the product
+    q_want = ops.rope(want[0].view(n, mq // hd, hd), pos, n_dims, mode, freq_factors=fac, **rope_kw).view(n, mq)
+    k_want = ops.rope(want[1].view(n, mkv // hd, hd), pos, n_dims, mode, freq_factors=fac, **rope_kw).view(n, mkv)
+    v_want = want[2]
+    kvt = torch.float16 if kv16 else torch.float32
+    k_want, v_want = k_want.to(kvt), v_want.to(kvt)
+    q_out = torch.full((n, mq), 7.0, device="cuda")
+    k_out = torch.full((n, mkv), 7.0, dtype=kvt, device="cuda"); v_out = torch.full((n, mkv), 7.0, dtype=kvt, device="cuda")
+    f = K.QkvFinishArgs()
+    f.q_parts, f.k_parts, f.v_parts = parts[0].data_ptr(), parts[1].data_ptr(), parts[2].data_ptr()
+    f.kz_q, f.kz_k, f.kz_v = kzs
+    f.m_q, f.m_k, f.m_v, f.n = mq, mkv, mkv, n
+    f.q_out, f.k_out, f.v_out = q_out.data_ptr(), k_out.data_ptr(), v_out.data_ptr()
+    f.k_out_type = f.v_out_type = B.F16 if kv16 else B.F32
+    f.pos = pos.data_ptr(); f.freq_factors = fac.data_ptr() if ff else None
+    f.head_dim, f.n_dims, f.mode, f.n_ctx_orig = hd, n_dims, mode, rope_kw["n_ctx_orig"]
+    f.freq_base, f.freq_scale, f.ext_factor, f.attn_factor = rope_kw["freq_base"], rope_kw["freq_scale"], rope_kw["ext_factor"], rope_kw["attn_factor"]
+    f.beta_fast, f.beta_slow = rope_kw["beta_fast"], rope_kw["beta_slow"]
+    K.check(K.lib.mi355_qkv_finish(C.byref(f), s), "qkv_finish")
+    torch.cuda.synchronize()
+    assert torch.isfinite(q_out).all()
+    assert torch.equal(q_out, q_want)
+    assert torch.equal(k_out, k_want)
+    assert torch.equal(v_out, v_want)
+
+
 def test_kv_store_q8_0_bit_exact(ops):
     """mi355_kv_store_q8_0 (K and V rows of a decode token into a q8_0 cache, one launch) against the oracle's quantize_row_q8_0_ref,
     with the destinations given directly and through the pointer table used under graph replay"""

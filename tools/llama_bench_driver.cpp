@@ -86,6 +86,7 @@ int main(int argc, char ** argv) {
     int main_gpu = 0;
     int n_prompt = 512, n_gen = 128, reps = 3, ngl = 99, fa = 1, threads = 8, n_batch = 2048, n_ubatch = 512;
     int dump_steps = 6;          // single-token decodes of the parity mode
+    int big_batch = 160;         // its last, prefill-sized batch
     for (int i = 1; i < argc; i++) {
         const std::string a = argv[i];
         auto next = [&]() { if (i + 1 >= argc) { fprintf(stderr, "missing value for %s\n", a.c_str()); exit(2); } return std::string(argv[++i]); };
@@ -94,6 +95,7 @@ int main(int argc, char ** argv) {
         else if (a == "-ctk") ctk = next(); else if (a == "-ctv") ctv = next(); else if (a == "-t") threads = atoi(next().c_str());
         else if (a == "--dump-logits") dump_path = next();
         else if (a == "--decode-steps") dump_steps = atoi(next().c_str());
+        else if (a == "--big-batch") big_batch = atoi(next().c_str());
         else if (a == "--dump-nodes") nodes_path = next(); else if (a == "--node-prefix") node_prefixes = next();
         else if (a == "-sm") sm = next(); else if (a == "-mg") main_gpu = atoi(next().c_str()); else if (a == "-ts") ts_arg = next();
         else if (a == "-b") n_batch = atoi(next().c_str()); else if (a == "-ub") n_ubatch = atoi(next().c_str());
@@ -130,7 +132,7 @@ int main(int argc, char ** argv) {
     const int n_vocab = llama_vocab_n_tokens(llama_model_get_vocab(model));
 
     llama_context_params cp = llama_context_default_params();
-    cp.n_ctx = std::max(n_prompt + n_gen, 256) + (dump_path.empty() ? 0 : 256 + dump_steps);
+    cp.n_ctx = std::max(n_prompt + n_gen, 256) + (dump_path.empty() ? 0 : 96 + big_batch + dump_steps);
     cp.n_batch = n_batch; cp.n_ubatch = n_ubatch;
     cp.n_threads = threads; cp.n_threads_batch = threads;
     cp.flash_attn = fa != 0;
@@ -157,7 +159,7 @@ int main(int argc, char ** argv) {
     srand(1234);
     if (!dump_path.empty()) {
         // parity mode: a fixed 48-token prompt in one batch, then 6 single-token decodes fed with fixed tokens, then two
-        // small batches (3 and 2 tokens: the multi-column mat-vec path) and one of 160 tokens (the prefill GEMM path and its
+        // small batches (3 and 2 tokens: the multi-column mat-vec path) and one of 160 tokens (--big-batch; the prefill GEMM path and its
         // fused bf16 producers); the logits of the last prompt token and of the last token of every later step are written
         // as raw f32
         std::vector<llama_token> prompt(48);
@@ -171,7 +173,7 @@ int main(int argc, char ** argv) {
             if (llama_decode(ctx, llama_batch_get_one(&tok, 1)) != 0) return 1;
             fwrite(llama_get_logits_ith(ctx, -1), sizeof(float), n_vocab, f);
         }
-        for (int nb : {3, 2, 160}) {
+        for (int nb : {3, 2, big_batch}) {
             std::vector<llama_token> toks(nb);
             for (int t = 0; t < nb; t++) toks[t] = (llama_token)(((long long)t * 15485863 + nb * 31) % n_vocab);
             if (llama_decode(ctx, llama_batch_get_one(toks.data(), nb)) != 0) return 1;
