@@ -454,6 +454,12 @@ MI355_API int mi355_rms_norm_mul_bf16_f32(const mi355_tensor *a, const mi355_ten
                                           const mi355_tensor *dst, float eps, uint16_t *act_bf16, void *stream);
 MI355_API int mi355_glu_bf16_f32(int glu_op, const mi355_tensor *a, const mi355_tensor *b, const mi355_tensor *dst, int swapped,
                                  uint16_t *act_bf16, void *stream);
+/* mi355_rms_norm_mul_bf16_f32 whose first addend is still the kz K-slice planes of the GEMM that produces it (mi355_mul_mat_dq_parts:
+ * [kz][rows][ne0] f32, rows and ne0 those of `sum`): sum = ((p0 + p1) + ...) + b, dst = rms_norm(sum) * w, act_bf16 = bf16(dst).
+ * MUL_MAT(wo / ffn_down) -> ADD(residual) -> RMS_NORM -> MUL without the slice-sum launch and without the product crossing HBM
+ * twice; the bits of the launches run one by one.  Rows of at most 8192 values, ne0 % 16 == 0, else MI355_E_UNSUPPORTED. */
+MI355_API int mi355_parts_add_rms_norm_mul_bf16_f32(const float *a_parts, int kz, const mi355_tensor *b, const mi355_tensor *sum,
+                                                    const float *w, const mi355_tensor *dst, float eps, uint16_t *act_bf16, void *stream);
 
 /* copy / convert with arbitrary strides and equal element counts (ggml_cpy, ggml_cont, ggml_dup):
  * f32 -> f32 | f16 | q8_0, f16 -> f16 | f32.  The q8_0 destination follows quantize_row_q8_0_ref

@@ -1248,7 +1248,11 @@ static mi355_tensor to_mi355_tensor(const ggml_tensor * t) {
 
 // RMS_NORM at node i followed by MUL with the per-feature norm weight; when `add` is given it is the ADD at node
 // i-1 whose result the norm reads (residual add), and all three nodes run as one kernel.
-static bool mi355_try_fuse_rms_norm_mul(mi355_backend_ctx * ctx, ggml_cgraph * cgraph, int i, ggml_tensor * add = nullptr) {
+// `gemm` (with `add`): the MUL_MAT whose product is one addend of `add` has not run yet; it runs here as mi355_mul_mat_dq_parts and the
+// norm kernel adds its K-slice planes on the way in (prefill: wo / ffn_down -> residual ADD -> RMS_NORM -> MUL, no slice-sum launch).
+// Nothing is launched unless the whole chain can be.
+static uint16_t * prefill_act_bf16(mi355_backend_ctx * ctx, const ggml_tensor * src1);
+static bool mi355_try_fuse_rms_norm_mul(mi355_backend_ctx * ctx, ggml_cgraph * cgraph, int i, ggml_tensor * add = nullptr, const ggml_tensor * gemm = nullptr) {
     ggml_tensor * norm = ggml_graph_node(cgraph, i);
     ggml_tensor * mul  = ggml_graph_node(cgraph, i + 1);
     if (mul->op != GGML_OP_MUL || MI355_ENV_SET("GGML_MI355_NO_FUSE")) return false;
@@ -1289,6 +1293,30 @@ static bool mi355_try_fuse_rms_norm_mul(mi355_backend_ctx * ctx, ggml_cgraph * c
     }
     // prefill-sized rows (every MUL_MAT that reads them takes the bf16 GEMM): also emit the bf16 rows, so those MUL_MATs
     // need no conversion launch
+    if (gemm) {
+        // everything the norm kernel could refuse is checked before the GEMM is launched
+        const ggml_tensor * other = add->src[0] == gemm ? add->src[1] : add->src[0];
+        uintptr_t al = (uintptr_t)other->data | (uintptr_t)add->data | (uintptr_t)mul->data | (uintptr_t)w->data;
+        for (int d = 1; d < 4; d++) al |= (uintptr_t)other->nb[d] | (uintptr_t)add->nb[d] | (uintptr_t)mul->nb[d];
+        if (!(rows > 128 && K % 16 == 0 && K <= 8192 && ggml_is_contiguous(mul) && ggml_is_contiguous(add) && (al & 15) == 0) || MI355_ENV_SET("GGML_MI355_MMQ_INT8")) return false;
+        const ggml_tensor * W = gemm->src[0], * src1 = gemm->src[1];
+        const int64_t pb = mi355_mul_mat_dq_parts_bytes(W->ne[1], W->ne[1], W->ne[0], src1->ne[1]);
+        if (pb <= 0 || W->ne[1] != K || src1->ne[1] != rows) return false;
+        float * parts = (float *)ctx->get_scratch(3, (size_t)pb);
+        if (ctx->scratch_size[3] < (size_t)pb) return false;
+        const uint16_t * act = prefill_act_bf16(ctx, src1);
+        int32_t kz = 0;
+        const int rc0 = mi355_mul_mat_dq_parts((int)W->type, W->data, (int64_t)W->nb[1], act, W->ne[0], parts, pb, W->ne[1], W->ne[1], W->ne[0], src1->ne[1], &kz, ctx->stream);
+        if (rc0 == MI355_E_UNSUPPORTED || rc0 == MI355_E_ALIGN) return false;
+        MI_CHECK(rc0);
+        uint16_t * abf = (uint16_t *)ctx->get_scratch(0, align_up((size_t)rows * K * 2, 256));
+        mi355_tensor tb = to_mi355_tensor(other), ts = to_mi355_tensor(add);
+        MI_CHECK(mi355_parts_add_rms_norm_mul_bf16_f32(parts, kz, &tb, &ts, (const float *)w->data, &td, eps, abf, ctx->stream));
+        ctx->act_invalidate_if_written(add);
+        ctx->act_invalidate_if_written(mul);
+        ctx->act_remember(mul, 1);
+        return true;
+    }
     if (rows > 128 && K % 16 == 0 && K <= 8192 && ggml_is_contiguous(mul) && !MI355_ENV_SET("GGML_MI355_MMQ_INT8")) {
         uint16_t * abf = (uint16_t *)ctx->get_scratch(0, align_up((size_t)rows * K * 2, 256));
         mi355_tensor ta = to_mi355_tensor(add ? add->src[0] : x), tb, ts;
@@ -1591,6 +1619,40 @@ static bool mi355_try_fuse_glu_matvec(mi355_backend_ctx * ctx, ggml_cgraph * cgr
     return true;
 }
 
+// bf16 rows of a prefill MUL_MAT's activations in scratch[0] (converted unless the producer already left them there)
+static uint16_t * prefill_act_bf16(mi355_backend_ctx * ctx, const ggml_tensor * src1) {
+    const int64_t K = src1->ne[0], N = src1->ne[1];
+    uint16_t * act = (uint16_t *)ctx->get_scratch(0, align_up((size_t)N * K * 2, 256));
+    if (!ctx->act_cached(src1, 1)) {
+        MI_CHECK(mi355_act_bf16((const float *)src1->data, act, K, N, 1, 1, src1->nb[1], src1->nb[2], src1->nb[3], ctx->stream));
+        ctx->act_remember(src1, 1);
+    }
+    return act;
+}
+
+static bool prefill_mm_ok(const ggml_tensor * t);
+
+// MUL_MAT (wo, ffn_down) -> ADD (residual) -> RMS_NORM -> MUL (norm weight) at nodes i .. i + 3 of a prefill batch: the GEMM leaves its
+// K-slice planes and the norm launch adds them (see mi355_try_fuse_rms_norm_mul).  The product itself is never written, so the ADD must
+// be its only reader.
+static bool mi355_try_fuse_gemm_add_norm(mi355_backend_ctx * ctx, ggml_cgraph * cgraph, int i, const std::vector<char> & done) {
+    const int n = ggml_graph_n_nodes(cgraph);
+    if (i + 3 >= n || done[i + 1] || done[i + 2] || done[i + 3] || MI355_ENV_SET("GGML_MI355_NO_GEMM_NORM")) return false;
+    const ggml_tensor * mm = ggml_graph_node(cgraph, i);
+    ggml_tensor * add = ggml_graph_node(cgraph, i + 1);
+    const ggml_tensor * norm = ggml_graph_node(cgraph, i + 2);
+    if (!prefill_mm_ok(mm) || mm->src[1]->ne[1] <= 128 || mm->src[1]->ne[2] != 1 || mm->src[1]->ne[3] != 1) return false;
+    if (add->op != GGML_OP_ADD || norm->op != GGML_OP_RMS_NORM || norm->src[0] != add || ggml_graph_node(cgraph, i + 3)->op != GGML_OP_MUL) return false;
+    if ((add->src[0] == mm) == (add->src[1] == mm)) return false;             // exactly one addend is the product
+    if (!ggml_is_contiguous(mm) || (mm->flags & GGML_TENSOR_FLAG_OUTPUT)) return false;
+    for (int j = 0; j < n; j++) {
+        if (j == i + 1) continue;
+        const ggml_tensor * t = ggml_graph_node(cgraph, j);
+        for (int s = 0; s < GGML_MAX_SRC; s++) if (t->src[s] && (t->src[s] == mm || t->src[s]->view_src == mm)) return false;
+    }
+    return mi355_try_fuse_rms_norm_mul(ctx, cgraph, i + 2, add, mm);
+}
+
 // Feed-forward input of a prefill batch in one launch: MUL_MAT(ffn_gate) MUL_MAT(ffn_up) GLU at nodes i, i + 1, i + 2 (either order of
 // the two products) -> mi355_glu_mul_mat_dq, whose tiles hold 64 rows of both matrices.  The two f32 products are NOT written, so they
 // must have no other reader in this graph and must not be graph outputs (a scheduler eval callback that wants to see them gets them
@@ -1623,11 +1685,7 @@ static bool mi355_try_fuse_glu_gemm(mi355_backend_ctx * ctx, ggml_cgraph * cgrap
     }
     if (ranges_overlap(glu->data, ggml_nbytes(glu), wa->data, ggml_nbytes(wa)) || ranges_overlap(glu->data, ggml_nbytes(glu), wb->data, ggml_nbytes(wb))) return false;
 
-    uint16_t * act = (uint16_t *)ctx->get_scratch(0, align_up((size_t)N * K * 2, 256));
-    if (!ctx->act_cached(src1, 1)) {
-        MI_CHECK(mi355_act_bf16((const float *)src1->data, act, K, N, 1, 1, src1->nb[1], src1->nb[2], src1->nb[3], ctx->stream));
-        ctx->act_remember(src1, 1);
-    }
+    const uint16_t * act = prefill_act_bf16(ctx, src1);
     uint16_t * hbf = (uint16_t *)ctx->get_scratch(2, align_up((size_t)N * M * 2, 256));
     const int rc = mi355_glu_mul_mat_dq((int)wa->type, op, wa->data, (int64_t)wa->nb[1], wb->data, (int64_t)wb->nb[1], act, K,
                                         (float *)glu->data, M, hbf, M, K, N, ctx->stream);
@@ -2056,11 +2114,7 @@ static bool mi355_try_fuse_qkv_gemm(mi355_backend_ctx * ctx, ggml_cgraph * cgrap
         for (int b = 0; b < a; b++) if (ranges_overlap(outs[a]->data, ggml_nbytes(outs[a]), outs[b]->data, ggml_nbytes(outs[b]))) return false;
         if (ranges_overlap(outs[a]->data, ggml_nbytes(outs[a]), q.rq->src[1]->data, ggml_nbytes(q.rq->src[1]))) return false;
     }
-    uint16_t * act = (uint16_t *)ctx->get_scratch(0, align_up((size_t)N * K * 2, 256));
-    if (!ctx->act_cached(x, 1)) {
-        MI_CHECK(mi355_act_bf16((const float *)x->data, act, K, N, 1, 1, x->nb[1], x->nb[2], x->nb[3], ctx->stream));
-        ctx->act_remember(x, 1);
-    }
+    const uint16_t * act = prefill_act_bf16(ctx, x);
     mi355_qkv_finish_args f;
     memset(&f, 0, sizeof(f));
     int32_t kz[3] = {0, 0, 0};
@@ -2195,6 +2249,10 @@ static enum ggml_status mi355_issue_graph(mi355_backend_ctx * ctx, ggml_cgraph *
         if (fuse && node->op == GGML_OP_MUL_MAT && node->src[0]->type == GGML_TYPE_F32 && mi355_try_fuse_moe_router(ctx, cgraph, i, done)) continue;
         if (fuse && node->op == GGML_OP_MUL_MAT && mi355_try_fuse_qkv_rope(ctx, cgraph, i, done)) continue;
         if (fuse && node->op == GGML_OP_MUL_MAT && mi355_try_fuse_qkv_gemm(ctx, cgraph, i, done)) continue;
+        if (fuse && node->op == GGML_OP_MUL_MAT && mi355_try_fuse_gemm_add_norm(ctx, cgraph, i, done)) {
+            i += 3;
+            continue;
+        }
         if (fuse && node->op == GGML_OP_MUL_MAT && mi355_try_fuse_glu_gemm(ctx, cgraph, i, done)) {
             done[i + 1] = 1;
             done[i + 2] = 1;

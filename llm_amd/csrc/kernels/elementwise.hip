@@ -83,7 +83,10 @@ binary_kernel(const T4 a, const T4 b, const T4 d, int64_t n) {
 template <bool HAS_W, bool HAS_ADD, int NT>
 __global__ void __launch_bounds__(NT)
 rms_norm_kernel(const T4 x, const T4 y, const T4 sum, const float * __restrict__ w, const T4 d, float eps, bool vec,
-                int8_t * __restrict__ aq, float * __restrict__ ads, uint16_t * __restrict__ abf) {
+                int8_t * __restrict__ aq, float * __restrict__ ads, uint16_t * __restrict__ abf,
+                const float * __restrict__ xparts, int kz) {
+    // xparts: x is not in memory yet -- it is the sum of kz planes [kz][rows][n] (the K slices of the GEMM that produces it,
+    // mi355_mul_mat_dq_parts), added here in slice order as kz_sum_kernel would have (16-value-chunk path only; x.data is not read)
     __shared__ float sh[NT / 64];
     const int row = blockIdx.x;
     const int ne1 = (int)x.ne[1], ne2 = (int)x.ne[2];
@@ -106,7 +109,14 @@ rms_norm_kernel(const T4 x, const T4 y, const T4 sum, const float * __restrict__
             if (c < nc) {
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
-                    v[j][q] = ((const v4f *)xr)[4 * c + q];
+                    if (xparts) {
+                        const v4f * pr = (const v4f *)(xparts + (int64_t)row * n) + 4 * c + q;
+                        const int64_t plane4 = (int64_t)gridDim.x * (n >> 2);
+                        v[j][q] = pr[0];
+                        for (int z = 1; z < kz; z++) v[j][q] = v[j][q] + pr[z * plane4];
+                    } else {
+                        v[j][q] = ((const v4f *)xr)[4 * c + q];
+                    }
                     if (HAS_W) wv[j][q] = ((const v4f *)w)[4 * c + q];   // requested now: its latency hides behind the reduction
                     if (HAS_ADD) {
                         v[j][q] = v[j][q] + ((const v4f *)yr)[4 * c + q];
@@ -548,8 +558,10 @@ int mi355_binary_f32(int op, const mi355_tensor * a, const mi355_tensor * b, con
 }
 
 static int launch_rms_norm(const mi355_tensor * x, const mi355_tensor * y, const mi355_tensor * sum, const float * w,
-                           const mi355_tensor * dst, float eps, int8_t * aq, float * ads, void * stream, uint16_t * abf = nullptr) {
+                           const mi355_tensor * dst, float eps, int8_t * aq, float * ads, void * stream, uint16_t * abf = nullptr,
+                           const float * xparts = nullptr, int kz = 0) {
     CHECK_T(x); CHECK_T(dst);
+    if (xparts && (!y || !abf || kz < 1 || kz > 8 || ((uintptr_t)xparts & 15) || x->ne[0] % 16 != 0)) return MI355_E_UNSUPPORTED;
     if (x->type != MI355_TYPE_F32 || dst->type != MI355_TYPE_F32) return MI355_E_TYPE;
     if (!same_shape(x, dst) || x->nb[0] != 4 || dst->nb[0] != 4) return MI355_E_SHAPE;
     const int64_t rows = nrows(x);
@@ -572,14 +584,14 @@ static int launch_rms_norm(const mi355_tensor * x, const mi355_tensor * y, const
     hipStream_t s = (hipStream_t)stream;
     if (x->ne[0] > 4096) {
         const dim3 block(512);
-        if (y)      MI355_LAUNCH("add_rms_norm_mul", (rms_norm_kernel<true, true, 512>), grid, block, 0, s, t4(x), t4(y), t4(sum), w, t4(dst), eps, vec, aq, ads, abf);
-        else if (w) MI355_LAUNCH("rms_norm_mul", (rms_norm_kernel<true, false, 512>), grid, block, 0, s, t4(x), t4(x), t4(x), w, t4(dst), eps, vec, aq, ads, abf);
-        else        MI355_LAUNCH("rms_norm", (rms_norm_kernel<false, false, 512>), grid, block, 0, s, t4(x), t4(x), t4(x), w, t4(dst), eps, vec, aq, ads, abf);
+        if (y)      MI355_LAUNCH("add_rms_norm_mul", (rms_norm_kernel<true, true, 512>), grid, block, 0, s, t4(x), t4(y), t4(sum), w, t4(dst), eps, vec, aq, ads, abf, xparts, kz);
+        else if (w) MI355_LAUNCH("rms_norm_mul", (rms_norm_kernel<true, false, 512>), grid, block, 0, s, t4(x), t4(x), t4(x), w, t4(dst), eps, vec, aq, ads, abf, nullptr, 0);
+        else        MI355_LAUNCH("rms_norm", (rms_norm_kernel<false, false, 512>), grid, block, 0, s, t4(x), t4(x), t4(x), w, t4(dst), eps, vec, aq, ads, abf, nullptr, 0);
     } else {
         const dim3 block(256);
-        if (y)      MI355_LAUNCH("add_rms_norm_mul", (rms_norm_kernel<true, true, 256>), grid, block, 0, s, t4(x), t4(y), t4(sum), w, t4(dst), eps, vec, aq, ads, abf);
-        else if (w) MI355_LAUNCH("rms_norm_mul", (rms_norm_kernel<true, false, 256>), grid, block, 0, s, t4(x), t4(x), t4(x), w, t4(dst), eps, vec, aq, ads, abf);
-        else        MI355_LAUNCH("rms_norm", (rms_norm_kernel<false, false, 256>), grid, block, 0, s, t4(x), t4(x), t4(x), w, t4(dst), eps, vec, aq, ads, abf);
+        if (y)      MI355_LAUNCH("add_rms_norm_mul", (rms_norm_kernel<true, true, 256>), grid, block, 0, s, t4(x), t4(y), t4(sum), w, t4(dst), eps, vec, aq, ads, abf, xparts, kz);
+        else if (w) MI355_LAUNCH("rms_norm_mul", (rms_norm_kernel<true, false, 256>), grid, block, 0, s, t4(x), t4(x), t4(x), w, t4(dst), eps, vec, aq, ads, abf, nullptr, 0);
+        else        MI355_LAUNCH("rms_norm", (rms_norm_kernel<false, false, 256>), grid, block, 0, s, t4(x), t4(x), t4(x), w, t4(dst), eps, vec, aq, ads, abf, nullptr, 0);
     }
     MI355_CHECK_LAUNCH();
     return MI355_OK;
@@ -611,6 +623,17 @@ int mi355_rms_norm_mul_bf16_f32(const mi355_tensor * a, const mi355_tensor * b, 
                                 const mi355_tensor * dst, float eps, uint16_t * act_bf16, void * stream) {
     if (!w || !act_bf16 || ((b == nullptr) != (sum == nullptr))) return MI355_E_NULL;
     return launch_rms_norm(a, b, sum, w, dst, eps, nullptr, nullptr, stream, act_bf16);
+}
+
+int mi355_parts_add_rms_norm_mul_bf16_f32(const float * a_parts, int kz, const mi355_tensor * b, const mi355_tensor * sum, const float * w,
+                                          const mi355_tensor * dst, float eps, uint16_t * act_bf16, void * stream) {
+    if (!a_parts || !b || !sum || !w || !act_bf16) return MI355_E_NULL;
+    CHECK_T(sum);
+    // a has sum's shape and is dense: [rows][ne0] per plane
+    mi355_tensor a = *sum;
+    a.data = (void *)a_parts;
+    a.nb[0] = 4; a.nb[1] = a.ne[0] * 4; a.nb[2] = a.nb[1] * a.ne[1]; a.nb[3] = a.nb[2] * a.ne[2];
+    return launch_rms_norm(&a, b, sum, w, dst, eps, nullptr, nullptr, stream, act_bf16, a_parts, kz);
 }
 
 int mi355_rope_f32(const mi355_tensor * x, const int32_t * pos, const float * freq_factors, const mi355_tensor * dst,

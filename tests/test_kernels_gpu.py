@@ -321,6 +321,35 @@ def test_qkv_parts_and_finish_have_the_bits_of_the_separate_launches(ops, mq, mk
     assert torch.equal(v_out, v_want)
 
 
+@pytest.mark.parametrize("t,m,k,n", [(B.Q4_K, 4096, 4096, 512), (B.Q6_K, 4096, 14336, 512), (B.Q4_K, 4096, 4096, 2048), (B.Q8_0, 1024, 2816, 160), (B.Q4_K, 8192, 2048, 300)])
+def test_gemm_planes_into_add_rms_norm_have_the_bits_of_the_separate_launches(ops, t, m, k, n):
+    """wo / ffn_down of a prefill batch: mi355_mul_mat_dq_parts + mi355_parts_add_rms_norm_mul_bf16_f32 (the norm kernel adds the K-slice
+    planes on the way in) against mi355_mul_mat_dq + mi355_rms_norm_mul_bf16_f32 with the residual add: the sum, the normed rows and
+    their bf16 copy, bit for bit."""
+    import ctypes as C
+    import llm_amd.kernels as K
+    rng = np.random.default_rng(29)
+    s = torch.cuda.current_stream().cuda_stream
+    w = dev(B.random_blocks(t, m, k, seed=50))
+    x = ops.act_bf16(dev(rng.standard_normal((n, k)).astype(np.float32)))
+    res = dev(rng.standard_normal((n, m)).astype(np.float32))
+    nw = dev((0.5 + rng.random(m)).astype(np.float32))
+    T = lambda v: C.byref(K.Tensor.of(v))
+    prod = torch.empty((n, m), device="cuda")
+    K.check(K.lib.mi355_mul_mat_dq(t, w.data_ptr(), B.row_size(t, k), x.data_ptr(), k, prod.data_ptr(), m, m, k, n, s), "dq")
+    sum_a = torch.empty_like(prod); out_a = torch.empty_like(prod); bf_a = torch.empty((n, m), dtype=torch.int16, device="cuda")
+    K.check(K.lib.mi355_rms_norm_mul_bf16_f32(T(prod), T(res), T(sum_a), nw.data_ptr(), T(out_a), 1e-5, bf_a.data_ptr(), s), "norm")
+    nb = K.lib.mi355_mul_mat_dq_parts_bytes(m, m, k, n)
+    parts = torch.empty(nb // 4, device="cuda")
+    kz = C.c_int32(0)
+    K.check(K.lib.mi355_mul_mat_dq_parts(t, w.data_ptr(), B.row_size(t, k), x.data_ptr(), k, parts.data_ptr(), nb, m, m, k, n, C.byref(kz), s), "parts")
+    sum_b = torch.full_like(prod, 7.0); out_b = torch.full_like(prod, 7.0); bf_b = torch.full((n, m), 7, dtype=torch.int16, device="cuda")
+    K.check(K.lib.mi355_parts_add_rms_norm_mul_bf16_f32(parts.data_ptr(), kz.value, T(res), T(sum_b), nw.data_ptr(), T(out_b), 1e-5, bf_b.data_ptr(), s), "parts norm")
+    torch.cuda.synchronize()
+    assert torch.isfinite(out_a).all()
+    assert torch.equal(sum_a, sum_b) and torch.equal(out_a, out_b) and torch.equal(bf_a, bf_b)
+
+
 def test_kv_store_q8_0_bit_exact(ops):
     """mi355_kv_store_q8_0 (K and V rows of a decode token into a q8_0 cache, one launch) against the oracle's quantize_row_q8_0_ref,
     with the destinations given directly and through the pointer table used under graph replay"""
