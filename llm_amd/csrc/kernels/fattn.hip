@@ -164,7 +164,10 @@ static __device__ __forceinline__ void fattn_store(const FArgs & a, int h, int i
 constexpr int FA_THREADS = 512; // 8 waves: the KV loop is a chain of dependent loads, so rows are spread wide
                                  // (1024 threads would cap the kernel at 128 VGPRs and spill for R >= 4)
 
-template <int D, int R, int TK, int TV>
+// U: KV rows per lane group and step.  2: the pipelined loop for long ranges (the rows of step i + 1 are requested before step i is
+// consumed).  8: short contexts in ONE workgroup per head group -- a step requests 8 rows per lane group (256 rows at D = 128) at
+// once, so n_kv <= 512 is one or two memory round trips with no KV split, no partials, no arrival counter and no slice merge.
+template <int D, int R, int TK, int TV, int U = 2>
 __global__ void __launch_bounds__(FA_THREADS)
 fattn_vec_kernel(const FArgs a) {
     constexpr int LPR = D / 8;               // lanes per KV row
@@ -185,10 +188,45 @@ fattn_vec_kernel(const FArgs a) {
     const int iq = blockIdx.y;
     const int i3 = blockIdx.z / a.nsplit, split = blockIdx.z % a.nsplit;
 
+    const char * kbase = a.k + hk * a.k_nb2 + i3 * a.k_nb3;
+    const char * vbase = a.v + hk * a.v_nb2 + i3 * a.v_nb3;
+    // KV slice of this workgroup
+    const int per = (a.n_kv + a.nsplit - 1) / a.nsplit;
+    const int kv0 = split * per, kv1 = kv0 + per < a.n_kv ? kv0 + per : a.n_kv;
+    const float scale = a.logit_softcap != 0.0f ? a.scale / a.logit_softcap : a.scale;
+    const char * mrow[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const int h = h0 + r < hk * ratio + ratio ? h0 + r : hk * ratio + ratio - 1; // clamp (ratio % R != 0)
+        mrow[r] = a.mask ? a.mask + iq * a.m_nb1 + (h % a.m_ne2) * a.m_nb2 + (i3 % a.m_ne3) * a.m_nb3 : nullptr;
+    }
+
+    // A step is U rows per lane group (rows ic, ic + G, ...): K, V and the mask values of a step are requested together, and
+    // the first step's before anything else -- the query loads, which were written by the launch just before this one, then
+    // overlap the first K/V round trip instead of preceding it.
+    // PIPE (U = 2): software pipeline, the rows of step i + 1 are requested before step i is consumed: twice the loads in flight
+    // per round trip, and one rescale of the running sums per two rows.
+    constexpr bool PIPE = U == 2;
+    FaRow<TK> kf[U], kn[PIPE ? U : 1];
+    FaRow<TV> vf[U], vn[PIPE ? U : 1];
+    __half mk[R][U], mkn[PIPE ? R : 1][PIPE ? U : 1];
+    auto request = [&](int at, FaRow<TK> * kd, FaRow<TV> * vd, __half (*md)[U]) {
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int iu = at + u * G < kv1 ? at + u * G : (at < kv1 ? at : kv1 - 1);     // past the end: re-read a valid row, ignored below
+            kd[u].load(kbase + (int64_t)iu * a.k_nb1, j);
+            vd[u].load(vbase + (int64_t)iu * a.v_nb1, j);
+#pragma unroll
+            for (int r = 0; r < R; r++) md[r][u] = mrow[r] ? ((const __half *)mrow[r])[iu] : __half(0.0f);
+        }
+    };
+    int ic = kv0 + g;
+    if (kv0 < kv1) request(ic, kf, vf, mk);
+    FA_STAMP(1);
+
     // this lane's 8 query features for each of the R heads
     FaQ<TK> qf[R];
     float slope[R];
-    const char * mrow[R];
 #pragma unroll
     for (int r = 0; r < R; r++) {
         const int h = h0 + r < hk * ratio + ratio ? h0 + r : hk * ratio + ratio - 1; // clamp (ratio % R != 0)
@@ -196,7 +234,6 @@ fattn_vec_kernel(const FArgs a) {
         const v4f q0 = *(const v4f *)qp, q1 = *(const v4f *)(qp + 4);
         qf[r].set(q0, q1);
         slope[r] = alibi_slope(a, (uint32_t)h);
-        mrow[r] = a.mask ? a.mask + iq * a.m_nb1 + (h % a.m_ne2) * a.m_nb2 + (i3 % a.m_ne3) * a.m_nb3 : nullptr;
     }
     float m[R], l[R], acc[R][8];
 #pragma unroll
@@ -206,42 +243,15 @@ fattn_vec_kernel(const FArgs a) {
         for (int i = 0; i < 8; i++) acc[r][i] = 0.0f;
     }
 
-    const char * kbase = a.k + hk * a.k_nb2 + i3 * a.k_nb3;
-    const char * vbase = a.v + hk * a.v_nb2 + i3 * a.v_nb3;
-    // KV slice of this workgroup
-    const int per = (a.n_kv + a.nsplit - 1) / a.nsplit;
-    const int kv0 = split * per, kv1 = kv0 + per < a.n_kv ? kv0 + per : a.n_kv;
-    const float scale = a.logit_softcap != 0.0f ? a.scale / a.logit_softcap : a.scale;
-
-    // software pipeline: the K/V rows of step i+1 are requested before step i is consumed.  A step is U = 2 rows per lane
-    // group (rows ic and ic + G): twice the loads in flight per round trip, and one rescale of the running sums per two rows.
-    constexpr int U = 2;
-    FaRow<TK> kf[U], kn[U];
-    FaRow<TV> vf[U], vn[U];
-    int ic = kv0 + g;
-    if (ic < kv1) {
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const int iu = ic + u * G < kv1 ? ic + u * G : ic;     // past the end: re-read a valid row, ignored below
-            kf[u].load(kbase + (int64_t)iu * a.k_nb1, j);
-            vf[u].load(vbase + (int64_t)iu * a.v_nb1, j);
-        }
-    }
-    FA_STAMP(1);
     for (; ic < kv1; ic += U * G) {
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const int in = ic + (U + u) * G < kv1 ? ic + (U + u) * G : ic;   // the last step re-reads its own row
-            kn[u].load(kbase + (int64_t)in * a.k_nb1, j);
-            vn[u].load(vbase + (int64_t)in * a.v_nb1, j);
-        }
+        if constexpr (PIPE) request(ic + U * G, kn, vn, mkn);
         float mv[R][U];
 #pragma unroll
         for (int r = 0; r < R; r++) {
 #pragma unroll
             for (int u = 0; u < U; u++) {
                 const int iu = ic + u * G;
-                mv[r][u] = iu >= kv1 ? -INFINITY : (mrow[r] ? slope[r] * __half2float(((const __half *)mrow[r])[iu]) : 0.0f);
+                mv[r][u] = iu >= kv1 ? -INFINITY : (mrow[r] ? slope[r] * __half2float(mk[r][u]) : 0.0f);
             }
         }
 #pragma unroll
@@ -280,8 +290,16 @@ fattn_vec_kernel(const FArgs a) {
                 acc[r][i] = t;
             }
         }
+        if constexpr (PIPE) {
 #pragma unroll
-        for (int u = 0; u < U; u++) { kf[u] = kn[u]; vf[u] = vn[u]; }
+            for (int u = 0; u < U; u++) {
+                kf[u] = kn[u]; vf[u] = vn[u];
+#pragma unroll
+                for (int r = 0; r < R; r++) mk[r][u] = mkn[r][u];
+            }
+        } else {
+            if (ic + U * G < kv1) request(ic + U * G, kf, vf, mk);
+        }
     }
 
     FA_STAMP(2);
@@ -692,7 +710,7 @@ static int launch_mma(const FArgs & a, int tkv, hipStream_t s) {
     return MI355_OK;
 }
 
-template <int D, int R, int TK, int TV>
+template <int D, int R, int TK, int TV, int U = 2>
 static int launch_vec(const FArgs & a, hipStream_t s) {
     const int ratio = a.n_head / a.n_head_kv;
     const int hgroups = (ratio + R - 1) / R;
@@ -700,11 +718,11 @@ static int launch_vec(const FArgs & a, hipStream_t s) {
     constexpr int G = FA_THREADS / (D / 8);
     const size_t sh = ((size_t)R * G * (D + 2) + (size_t)R * G + 2 * R) * sizeof(float);
     if (sh > 48 * 1024) { // raise the dynamic-LDS cap once per instantiation
-        static const hipError_t attr = hipFuncSetAttribute((const void *)fattn_vec_kernel<D, R, TK, TV>,
+        static const hipError_t attr = hipFuncSetAttribute((const void *)fattn_vec_kernel<D, R, TK, TV, U>,
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
         if (attr != hipSuccess) return (int)attr;
     }
-    MI355_LAUNCH("fattn_vec", (fattn_vec_kernel<D, R, TK, TV>), grid, dim3(FA_THREADS), sh, s, a);
+    MI355_LAUNCH("fattn_vec", (fattn_vec_kernel<D, R, TK, TV, U>), grid, dim3(FA_THREADS), sh, s, a);
     MI355_CHECK_LAUNCH();
     return MI355_OK;
 }
@@ -722,8 +740,27 @@ static int fa_heads_per_wg(int64_t ratio, int64_t d, int64_t n_kv) {
     return ratio >= 2 ? 2 : 1;
 }
 
+// short contexts: no KV split, 8 rows per lane group in flight (see fattn_vec_kernel); MI355_FA_SHORT=0 restores the split
+static int fa_short_rows() {
+    static const int v = [] { const char * e = getenv("MI355_FA_SHORT"); return e ? atoi(e) : 512; }();
+    return v;
+}
+// heads per workgroup there: 1 -- the K/V bytes of a short context are nothing, the per-row arithmetic of a second head is the longer
+// chain (Llama-3-8B tg128, n_kv 256: 497.5 t/s with the KV split, 507.1 with 2 heads per workgroup, 514.3 with 1)
+static int fa_short_heads() {
+    static const int v = [] { const char * e = getenv("MI355_FA_SHORT_R"); return e ? atoi(e) : 1; }();
+    return v;
+}
+
 template <int D, int TK, int TV>
 static int dispatch_r(const FArgs & a, hipStream_t s) {
+    if constexpr (D <= 128 && TK == TV) {
+        if (a.nsplit == 1 && a.n_kv <= fa_short_rows() && a.n_kv > 0) {
+            const int ratio = a.n_head / a.n_head_kv;
+            if (ratio >= 2 && fa_short_heads() >= 2) return launch_vec<D, 2, TK, TV, 8>(a, s);
+            return launch_vec<D, 1, TK, TV, 8>(a, s);
+        }
+    }
     switch (fa_heads_per_wg(a.n_head / a.n_head_kv, D, a.n_kv)) {
         case 8: if constexpr (D <= 128) return launch_vec<D, 8, TK, TV>(a, s);
         case 4: return launch_vec<D, 4, TK, TV>(a, s);
@@ -802,7 +839,8 @@ int mi355_flash_attn_ext_quant(const mi355_fattn_args * p, void * workspace, int
     const int64_t ratio = p->n_head / p->n_head_kv;
     const int64_t rr = fa_heads_per_wg(ratio, p->d, p->n_kv);      // R chosen by dispatch_r
     const int64_t n_counters = (int64_t)p->ne3 * p->n_q * p->n_head_kv * ((ratio + rr - 1) / rr);
-    if (workspace && workspace_bytes > WS_HEADER && ((uintptr_t)workspace & 15) == 0 && n_counters * 4 <= WS_HEADER &&
+    const bool short_ctx = p->d <= 128 && p->type_k == p->type_v && p->n_kv <= fa_short_rows();
+    if (!short_ctx && workspace && workspace_bytes > WS_HEADER && ((uintptr_t)workspace & 15) == 0 && n_counters * 4 <= WS_HEADER &&
         base_wgs < 512 && p->n_kv >= 4 * G) {
         // Every slice costs a partial store, a device-scope arrival and a share of the merge, so more slices only pay
         // while they shorten the chain of round trips: one round trip (G rows) per slice up to 8 slices, then slices of

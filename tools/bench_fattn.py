@@ -9,7 +9,7 @@ import llm_amd.kernels as K, llm_amd.ops as ops, llm_amd.blocks as B
 
 nh, nkv, d = 32, 8, 128
 for tkv, name, bpe in ((B.F16, "f16", 2.0), (B.Q8_0, "q8_0", 34 / 32)):
-    for n_kv in (256, 1024, 4096, 16384, 65536):
+    for n_kv in (int(v) for v in os.environ.get("FA_NKV", "256,1024,4096,16384,65536").split(",")):
         q = torch.randn(nh, 1, d, device="cuda")
         if tkv == B.F16:
             # rotate over several caches so that long contexts are read from HBM, not the Infinity Cache
