@@ -550,6 +550,11 @@ MI355_API int     mi355_flash_attn_ext(const mi355_fattn_args *args, void *works
  * MI355_E_UNSUPPORTED.  act_q / act_ds as in mi355_quantize_act. */
 MI355_API int     mi355_flash_attn_ext_quant(const mi355_fattn_args *args, void *workspace, int64_t workspace_bytes,
                                              int8_t *act_q, float *act_ds, void *stream);
+/* same for prefill-sized batches: additionally the bf16 form of dst (rows [ne3][n_q][n_head * d], the rounding of mi355_act_bf16),
+ * so the attention-output GEMM needs no conversion launch.  Only where the matrix-core kernel runs (n_q >= 32, d 64 / 128, K and V
+ * of one type, no ALiBi / softcap), else MI355_E_UNSUPPORTED. */
+MI355_API int     mi355_flash_attn_ext_bf16(const mi355_fattn_args *args, void *workspace, int64_t workspace_bytes,
+                                            uint16_t *act_bf16, void *stream);
 
 /* FLASH_ATTN_EXT for callers that cannot allocate (HIP graph capture, tight serving loops, harnesses that forbid
  * hipMalloc).  NO COUNTERPART IN THE REFERENCE (ggml-cuda takes its split-KV buffer from the backend's pool).  Same

@@ -1211,6 +1211,19 @@ static void mi355_flash_attn(mi355_backend_ctx * ctx, ggml_tensor * dst) {
         }
         if (rc != MI355_E_UNSUPPORTED) MI_CHECK(rc);
     }
+    // prefill: the bf16 rows for the attention-output GEMM from the same kernel
+    if (rows > 128 && ggml_is_contiguous(dst) && K % 8 == 0 && !MI355_ENV_SET("GGML_MI355_NO_FUSE") && !MI355_ENV_SET("GGML_MI355_MMQ_INT8")) {
+        uint16_t * abf = (uint16_t *)ctx->get_scratch(0, align_up((size_t)rows * K * 2, 256));
+        const int rc = mi355_flash_attn_ext_bf16(&a, ws, ws_bytes, abf, ctx->stream);
+        if (rc == MI355_OK) {
+            ggml_tensor as_rows = *dst;
+            as_rows.ne[0] = K; as_rows.ne[1] = a.n_q; as_rows.ne[2] = a.ne3; as_rows.ne[3] = 1;
+            as_rows.nb[0] = sizeof(float); as_rows.nb[1] = K * sizeof(float); as_rows.nb[2] = as_rows.nb[1] * a.n_q; as_rows.nb[3] = as_rows.nb[2] * a.ne3;
+            ctx->act_remember(&as_rows, 1);
+            return;
+        }
+        if (rc != MI355_E_UNSUPPORTED) MI_CHECK(rc);
+    }
     MI_CHECK(mi355_flash_attn_ext(&a, ws, ws_bytes, ctx->stream));
 }
 

@@ -32,6 +32,7 @@ struct FArgs {
     float * part; // [ne3][n_q][n_head][nsplit][D + 2] when nsplit > 1
     int * counters; // [ne3][n_q][gridDim.x] arrival counters of the KV slices (all zero between launches)
     int8_t * act_q; float * act_ds; // optional: q8_1 form of dst (token row = all heads), written with the result
+    uint16_t * act_bf;              // optional (matrix-core kernel): bf16 form of dst, rows [ne3][n_q][n_head * d]
 #ifdef FA_STAMPS
     long long * stamps;             // diagnostic build only (lab/fattn_stamps.hip): [workgroup][8] s_memtime / s_memrealtime
 #endif
@@ -694,6 +695,11 @@ fattn_mma_kernel(const FArgs a) {
             for (int g = 0; g < 4; g++) {
                 v4f v = {o[i][4 * g] * inv, o[i][4 * g + 1] * inv, o[i][4 * g + 2] * inv, o[i][4 * g + 3] * inv};
                 *(v4f *)(op + 32 * i + 8 * g + 4 * lh) = v;
+                if (a.act_bf) {     // the rounding of mi355_act_bf16, for the attention-output GEMM that reads this row next
+                    typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
+                    const bf4 b = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+                    *(bf4 *)(a.act_bf + (((int64_t)i3 * a.n_q + q) * a.n_head + h) * D + 32 * i + 8 * g + 4 * lh) = b;
+                }
             }
     }
 }
@@ -794,8 +800,20 @@ int mi355_flash_attn_ext(const mi355_fattn_args * p, void * workspace, int64_t w
     return mi355_flash_attn_ext_quant(p, workspace, workspace_bytes, nullptr, nullptr, stream);
 }
 
+static int fattn_run(const mi355_fattn_args * p, void * workspace, int64_t workspace_bytes, int8_t * act_q, float * act_ds, uint16_t * act_bf, void * stream);
+
 int mi355_flash_attn_ext_quant(const mi355_fattn_args * p, void * workspace, int64_t workspace_bytes, int8_t * act_q, float * act_ds,
                                void * stream) {
+    return fattn_run(p, workspace, workspace_bytes, act_q, act_ds, nullptr, stream);
+}
+
+int mi355_flash_attn_ext_bf16(const mi355_fattn_args * p, void * workspace, int64_t workspace_bytes, uint16_t * act_bf16, void * stream) {
+    if (!act_bf16) return MI355_E_NULL;
+    if ((uintptr_t)act_bf16 & 7) return MI355_E_ALIGN;
+    return fattn_run(p, workspace, workspace_bytes, nullptr, nullptr, act_bf16, stream);
+}
+
+static int fattn_run(const mi355_fattn_args * p, void * workspace, int64_t workspace_bytes, int8_t * act_q, float * act_ds, uint16_t * act_bf, void * stream) {
     if (!p || !p->q || !p->k || !p->v || !p->dst) return MI355_E_NULL;
     if (p->d != 64 && p->d != 128 && p->d != 256) return MI355_E_UNSUPPORTED;
     if (p->n_head_kv < 1 || p->n_head % p->n_head_kv != 0 || p->n_q < 0 || p->n_kv < 0 || p->ne3 < 1) return MI355_E_SHAPE;
@@ -809,7 +827,7 @@ int mi355_flash_attn_ext_quant(const mi355_fattn_args * p, void * workspace, int
     if (p->n_q == 0 || p->n_head == 0) return MI355_OK;
 
     FArgs a;
-    a.act_q = act_q; a.act_ds = act_ds; a.counters = nullptr;
+    a.act_q = act_q; a.act_ds = act_ds; a.act_bf = nullptr; a.counters = nullptr;
     a.q = (const char *)p->q; a.q_nb1 = p->q_nb1; a.q_nb2 = p->q_nb2; a.q_nb3 = p->q_nb3;
     a.k = (const char *)p->k; a.k_nb1 = p->k_nb1; a.k_nb2 = p->k_nb2; a.k_nb3 = p->k_nb3;
     a.v = (const char *)p->v; a.v_nb1 = p->v_nb1; a.v_nb2 = p->v_nb2; a.v_nb3 = p->v_nb3;
@@ -827,9 +845,10 @@ int mi355_flash_attn_ext_quant(const mi355_fattn_args * p, void * workspace, int
         !(p->max_bias > 0.0f) && p->logit_softcap == 0.0f && p->n_head <= 65535 && p->ne3 <= 65535 &&
         ((p->d_nb1 | p->d_nb2 | p->d_nb3 | (int64_t)(uintptr_t)p->dst) & 15) == 0 && (!p->mask || (p->m_nb1 & 1) == 0)) {
         if (act_q) return MI355_E_UNSUPPORTED;   // the fused q8_1 output exists for decode-sized batches only
-        a.nsplit = 1; a.part = nullptr;
+        a.nsplit = 1; a.part = nullptr; a.act_bf = act_bf;
         return p->d == 128 ? launch_mma<128>(a, p->type_k, (hipStream_t)stream) : launch_mma<64>(a, p->type_k, (hipStream_t)stream);
     }
+    if (act_bf) return MI355_E_UNSUPPORTED;      // the bf16 copy exists for the matrix-core kernel only
     // KV split.  The KV loop is a chain of memory round trips (one per G = 512/(d/8) rows), so for decode-sized
     // grids the range is cut until every workgroup has about one round trip of rows -- all loads of the op are
     // then in flight at once -- up to 64 slices, bounded by the workspace; the partials are merged by

@@ -930,6 +930,34 @@ def test_flash_attn_fused_q8_1_output(ops, nq, nkv, use_ws):
     assert torch.equal(aq, aq2) and torch.equal(ads.view(torch.int32), ads2.view(torch.int32))
 
 
+@pytest.mark.parametrize("tkv,d,nh,nhkv,nq,nkv", [(B.F16, 128, 32, 8, 512, 512), (B.F16, 128, 6, 2, 50, 90), (B.Q8_0, 64, 4, 4, 130, 333), (B.F16, 128, 8, 2, 8, 300)])
+def test_flash_attn_fused_bf16_output(ops, tkv, d, nh, nhkv, nq, nkv):
+    """mi355_flash_attn_ext_bf16 (prefill): dst equals the plain call bit for bit and the bf16 rows equal mi355_act_bf16(dst); ragged
+    query blocks; a decode-sized batch (vec kernel) is refused, not served by something else."""
+    import llm_amd.kernels as K
+    rng = np.random.default_rng(nq + nkv + d)
+    q = dev(rng.standard_normal((nh, nq, d)).astype(np.float32))
+    if tkv == B.F16:
+        k = dev(rng.standard_normal((nhkv, nkv, d)).astype(np.float16).view(np.uint8).reshape(nhkv, nkv, -1))
+        v = dev(rng.standard_normal((nhkv, nkv, d)).astype(np.float16).view(np.uint8).reshape(nhkv, nkv, -1))
+    else:
+        k = dev(B.random_blocks(tkv, nhkv * nkv, d, seed=11).reshape(nhkv, nkv, -1))
+        v = dev(B.random_blocks(tkv, nhkv * nkv, d, seed=12).reshape(nhkv, nkv, -1))
+    m = np.zeros(((nq + 63) // 64 * 64, nkv), np.float16)
+    for i in range(nq):
+        m[i, i + nkv - nq + 1:] = -np.inf
+    mask = dev(m.view(np.int16))
+    if nq < 32:
+        with pytest.raises(K.Mi355Error):
+            ops.flash_attn_ext(q, k, v, mask, tkv, nkv, 0.088, bf16=True)
+        return
+    plain = ops.flash_attn_ext(q, k, v, mask, tkv, nkv, 0.088)
+    dst, abf = ops.flash_attn_ext(q, k, v, mask, tkv, nkv, 0.088, bf16=True)
+    assert torch.isfinite(dst).all()
+    assert torch.equal(plain.view(torch.int32), dst.view(torch.int32))
+    assert torch.equal(abf, ops.act_bf16(dst.view(nq, nh * d)).view(torch.int16).view(nq, nh * d))
+
+
 @pytest.mark.parametrize("t", B.WEIGHT_TYPES)
 @pytest.mark.parametrize("m,k,n_exp,n_used,n_tok,b1", [(192, 256, 8, 2, 40, 1), (130, 512, 4, 2, 200, 2), (64, 256, 8, 3, 33, 3), (256, 1024, 8, 2, 512, 1)])
 def test_mul_mat_id_grouped_gemm(ops, t, m, k, n_exp, n_used, n_tok, b1):
