@@ -793,7 +793,7 @@ static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 //
 // Kernel per batch size N (columns of src1), from tools/bench_skinny.py on MI355X (weights 4096..14336 squared-ish):
 //   N <= 3 (q4_K, q5_K) / 4 (q6_K) / 8 (others)   mat-vec (mmvq.hip), q8_1 activations, HBM-bound at N = 1
-//   up to 64 (128 when K >= 8192)         skinny int8-MFMA kernels (mmsk.hip) in passes of 32 columns: the K-quants on
+//   up to 32 (K-quants; GGML_MI355_SKINNY_MAX) skinny int8-MFMA kernels (mmsk.hip), one pass of 32 columns: the K-quants on
 //                                         q8_K activations with the integer sub-block scales kept on the matrix core,
 //                                         the other types on q8_1 with a per-block f32 rescale (up to 32 / 64)
 //   beyond                                dequantize-in-LDS bf16 MFMA GEMM (mmdq.hip), bf16 activations
@@ -822,7 +822,11 @@ static int mi355_mul_mat_path(const ggml_tensor * src0, const ggml_tensor * src1
         // q8_K activations, integer sub-block scales on the matrix core: q4_K / q5_K digit-split (mmsk2), q6_K one 32x32x16 MFMA per
         // 16-weight sub-block (mmsk6; up to 4 columns the column-group mat-vec is still ahead: 15.8 against 20.5 us on 4096 x 14336)
         const bool kq = src0->type == GGML_TYPE_Q4_K || src0->type == GGML_TYPE_Q5_K || src0->type == GGML_TYPE_Q6_K;
-        if (kq  && N >= (src0->type == GGML_TYPE_Q6_K ? 5 : 4) && N <= (K >= 8192 ? 128 : 64)) return MM_SKINNY_K;
+        // One pass of 32 columns.  A second pass streams the weights again, and since the GEMM splits K its time is flat up to 128
+        // columns (4096 x 14336 q4_K: 41 us at 33..128 columns against 37 / 56 / 74 for 2 / 3 / 4 skinny passes; 4096 x 4096: 18 against
+        // 24 for 2), and the GEMM path brings the fused Q/K/V finish with it: 8B pp64 6889 -> 7545 t/s, pp128 12.3k -> 13.8k.
+        static const int64_t skinny_max = [] { const char * e = getenv("GGML_MI355_SKINNY_MAX"); return e ? atoll(e) : 32; }();
+        if (kq  && N >= (src0->type == GGML_TYPE_Q6_K ? 5 : 4) && N <= skinny_max) return MM_SKINNY_K;
         if (!kq && N > 8  && N <= (K >= 8192 ? 64 : 32))  return MM_SKINNY;
     }
     if (N > 8 && int8_mmq && K % 128 == 0) return MM_Q_INT8;

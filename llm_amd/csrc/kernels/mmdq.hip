@@ -422,7 +422,10 @@ mmdq_ws_kernel(const DArgs a) {
         const int srm = GLU ? (sr & 63) : sr;
         const int wr = m0 + srm < a.m ? m0 + srm : a.m - 1;
         const uint8_t * wrow = GLU && sr >= 64 ? a.W2 + (int64_t)wr * a.w2_row_stride : a.W + (int64_t)wr * a.w_row_stride;
-        constexpr int PFD = 2;
+#ifndef MMDQ_PFD
+#define MMDQ_PFD 2        // stages of raw weight bytes a dequantizing thread holds in flight
+#endif
+        constexpr int PFD = MMDQ_PFD;
         Raw<TYPE> wraw[PFD];
 #pragma unroll
         for (int j = 0; j < PFD; j++) if (j < nstage) wraw[j] = load_raw<TYPE>(wrow, kbeg + j * BK + hf * 32);
@@ -629,13 +632,15 @@ act_bf16_kernel(const char * x, uint16_t * y, int k, int ne1, int ne2, int64_t n
 }
 
 // K slices of the 128 x 256 role-split kernel for a matrix of m_total rows: 1 when its tiles fill the chip, 2 / 4 when a half / a
-// quarter of that, 0 when the launch does not take that kernel's split-K form at all
+// quarter / an eighth of that, 0 when the launch does not take that kernel's split-K form at all
 static int kz_slices(int64_t m_total, int64_t n, int64_t k) {
     static const int kz_ws = [] { const char * e = getenv("MI355_MMDQ_KZ"); return e ? atoi(e) : 1; }();
     static const int wide = [] { const char * e = getenv("MI355_MMDQ_WIDE"); return e ? atoi(e) : 2; }();
     const int64_t tiles = ((n + 255) / 256) * ((m_total + 127) / 128);
-    int kzw = tiles >= 200 ? 1 : 2 * tiles >= 200 ? 2 : 4 * tiles >= 200 ? 4 : 0;
-    if (kzw > 1 && (!kz_ws || wide != 2 || n < 256 || k % (BK * kzw) != 0 || k / kzw < 1024)) kzw = 0;
+    int kzw = tiles >= 200 ? 1 : 2 * tiles >= 200 ? 2 : 4 * tiles >= 200 ? 4 : 8 * tiles >= 200 ? 8 : 0;
+    // more than 128 columns: a partly empty 256-column tile still beats two 128-column ones (14336 x 4096 x 192: 69 -> 48 us);
+    // 8 slices where K is long enough (4096 x 14336 x 256: 32 tiles; the 64 x 128 tile took 73 us there)
+    if (kzw > 1 && (!kz_ws || wide != 2 || n <= 128 || k % (BK * kzw) != 0 || k / kzw < 1024)) kzw = 0;
     return kzw;
 }
 
@@ -694,7 +699,7 @@ static int launch(const DArgs & a_in, int64_t m_total, hipStream_t s, const char
     }
     a.part = nullptr;             // a caller's workspace is only for the split-K forms above
     if (parts_kz) *parts_kz = 1;
-    if (wide == 2 && kz == 1 && a.n >= 256 && nb2 * ((a.m + 127) / 128) >= 200 && dma_ok) {
+    if (wide == 2 && kz == 1 && a.n > 128 && nb2 * ((a.m + 127) / 128) >= 200 && dma_ok) {
         MI355_LAUNCH(tag, (mmdq_ws_kernel<TYPE, 128, 256>), dim3((unsigned)nb2, (unsigned)((a.m + 127) / 128)), dim3(768), 0, s, a);
     } else if (wide && kz == 1 && a.n >= 256 && nb2 * ((a.m + 127) / 128) >= 200) {
         MI355_LAUNCH(tag, (mmdq_kernel<TYPE, 128, false, 256>), dim3((unsigned)nb2, (unsigned)((a.m + 127) / 128)), dim3(512), 0, s, a);
