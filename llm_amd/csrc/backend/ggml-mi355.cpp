@@ -803,6 +803,9 @@ static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 // Float weights (f16 / bf16 / f32: an unquantized GGUF, or K / V of a graph without flash attention) take MM_FLOAT -- the
 // strided, broadcasting mat-vec of mmf.hip straight on src1, one pass over the weights per 8 columns -- up to 16 columns
 // and whenever the GEMM's preconditions fail (K % 64, alignment, f16 src1); beyond, the bf16 GEMM per channel.
+// batches of more rows than this are "prefill-sized": the K-quant MUL_MATs that read them take the bf16 GEMM, so fused producers (norm,
+// GLU, attention) store the bf16 rows alongside their f32 result.  A consumer that wants another format converts for itself, as always.
+#define MI355_BF16_ROWS_ABOVE 32
 enum mi355_mm_path { MM_VEC = 0, MM_DQ = 1, MM_SKINNY_K = 2, MM_SKINNY = 3, MM_Q_INT8 = 4, MM_FLOAT = 5 };
 // activation format each path consumes (act_cache.fmt): 0 q8_1 SoA, 1 bf16 rows, 2 q8_K planes
 static int mm_path_fmt(int path) { return path == MM_DQ ? 1 : path == MM_SKINNY_K ? 2 : 0; }
@@ -1216,7 +1219,7 @@ static void mi355_flash_attn(mi355_backend_ctx * ctx, ggml_tensor * dst) {
         if (rc != MI355_E_UNSUPPORTED) MI_CHECK(rc);
     }
     // prefill: the bf16 rows for the attention-output GEMM from the same kernel
-    if (rows > 128 && ggml_is_contiguous(dst) && K % 8 == 0 && !MI355_ENV_SET("GGML_MI355_NO_FUSE") && !MI355_ENV_SET("GGML_MI355_MMQ_INT8")) {
+    if (rows > MI355_BF16_ROWS_ABOVE && ggml_is_contiguous(dst) && K % 8 == 0 && !MI355_ENV_SET("GGML_MI355_NO_FUSE") && !MI355_ENV_SET("GGML_MI355_MMQ_INT8")) {
         uint16_t * abf = (uint16_t *)ctx->get_scratch(0, align_up((size_t)rows * K * 2, 256));
         const int rc = mi355_flash_attn_ext_bf16(&a, ws, ws_bytes, abf, ctx->stream);
         if (rc == MI355_OK) {
@@ -1315,7 +1318,7 @@ static bool mi355_try_fuse_rms_norm_mul(mi355_backend_ctx * ctx, ggml_cgraph * c
         const ggml_tensor * other = add->src[0] == gemm ? add->src[1] : add->src[0];
         uintptr_t al = (uintptr_t)other->data | (uintptr_t)add->data | (uintptr_t)mul->data | (uintptr_t)w->data;
         for (int d = 1; d < 4; d++) al |= (uintptr_t)other->nb[d] | (uintptr_t)add->nb[d] | (uintptr_t)mul->nb[d];
-        if (!(rows > 128 && K % 16 == 0 && K <= 8192 && ggml_is_contiguous(mul) && ggml_is_contiguous(add) && (al & 15) == 0) || MI355_ENV_SET("GGML_MI355_MMQ_INT8")) return false;
+        if (!(rows > MI355_BF16_ROWS_ABOVE && K % 16 == 0 && K <= 8192 && ggml_is_contiguous(mul) && ggml_is_contiguous(add) && (al & 15) == 0) || MI355_ENV_SET("GGML_MI355_MMQ_INT8")) return false;
         const ggml_tensor * W = gemm->src[0], * src1 = gemm->src[1];
         const int64_t pb = mi355_mul_mat_dq_parts_bytes(W->ne[1], W->ne[1], W->ne[0], src1->ne[1]);
         if (pb <= 0 || W->ne[1] != K || src1->ne[1] != rows) return false;
@@ -1334,7 +1337,7 @@ static bool mi355_try_fuse_rms_norm_mul(mi355_backend_ctx * ctx, ggml_cgraph * c
         ctx->act_remember(mul, 1);
         return true;
     }
-    if (rows > 128 && K % 16 == 0 && K <= 8192 && ggml_is_contiguous(mul) && !MI355_ENV_SET("GGML_MI355_MMQ_INT8")) {
+    if (rows > MI355_BF16_ROWS_ABOVE && K % 16 == 0 && K <= 8192 && ggml_is_contiguous(mul) && !MI355_ENV_SET("GGML_MI355_MMQ_INT8")) {
         uint16_t * abf = (uint16_t *)ctx->get_scratch(0, align_up((size_t)rows * K * 2, 256));
         mi355_tensor ta = to_mi355_tensor(add ? add->src[0] : x), tb, ts;
         if (add) { tb = to_mi355_tensor(add->src[1]); ts = to_mi355_tensor(add); }
@@ -1380,7 +1383,7 @@ static bool mi355_glu_with_quant(mi355_backend_ctx * ctx, ggml_tensor * node) {
                                          for (int d = 0; d < 4; d++) { r.ne[d] = t->ne[d]; r.nb[d] = (int64_t)t->nb[d]; } return r; };
     mi355_tensor ta = T(a), tb, td = T(node);
     if (b) tb = T(b);
-    if (rows > 128 && b && K % 4 == 0 && !MI355_ENV_SET("GGML_MI355_MMQ_INT8")) {   // prefill: bf16 rows for the ffn_down GEMM
+    if (rows > MI355_BF16_ROWS_ABOVE && b && K % 4 == 0 && !MI355_ENV_SET("GGML_MI355_MMQ_INT8")) {   // prefill: bf16 rows for the ffn_down GEMM
         uint16_t * abf = (uint16_t *)ctx->get_scratch(0, align_up((size_t)rows * K * 2, 256));
         const int rc = mi355_glu_bf16_f32((int)ggml_get_glu_op(node), &ta, &tb, &td, ((const int32_t *)node->op_params)[1], abf, ctx->stream);
         if (rc == MI355_E_UNSUPPORTED) return false;
@@ -1658,7 +1661,7 @@ static bool mi355_try_fuse_gemm_add_norm(mi355_backend_ctx * ctx, ggml_cgraph * 
     const ggml_tensor * mm = ggml_graph_node(cgraph, i);
     ggml_tensor * add = ggml_graph_node(cgraph, i + 1);
     const ggml_tensor * norm = ggml_graph_node(cgraph, i + 2);
-    if (!prefill_mm_ok(mm) || mm->src[1]->ne[1] <= 128 || mm->src[1]->ne[2] != 1 || mm->src[1]->ne[3] != 1) return false;
+    if (!prefill_mm_ok(mm) || mm->src[1]->ne[1] <= MI355_BF16_ROWS_ABOVE || mm->src[1]->ne[2] != 1 || mm->src[1]->ne[3] != 1) return false;
     if (add->op != GGML_OP_ADD || norm->op != GGML_OP_RMS_NORM || norm->src[0] != add || ggml_graph_node(cgraph, i + 3)->op != GGML_OP_MUL) return false;
     if ((add->src[0] == mm) == (add->src[1] == mm)) return false;             // exactly one addend is the product
     if (!ggml_is_contiguous(mm) || (mm->flags & GGML_TENSOR_FLAG_OUTPUT)) return false;
