@@ -2114,7 +2114,7 @@ static bool mi355_try_fuse_qkv_gemm(mi355_backend_ctx * ctx, ggml_cgraph * cgrap
     ggml_tensor * mq0 = ggml_graph_node(cgraph, i);
     if (!prefill_mm_ok(mq0) || mq0->src[1]->ne[1] <= 1 || MI355_ENV_SET("GGML_MI355_NO_QKV_GEMM") || MI355_ENV_SET("GGML_MI355_MMQ_INT8")) return false;
     qkv_nodes q;
-    if (!qkv_match(cgraph, i, done, prefill_mm_ok, q) || q.kv_q8) return false;
+    if (!qkv_match(cgraph, i, done, prefill_mm_ok, q)) return false;
     const ggml_tensor * x = q.mq->src[1];
     const ggml_tensor * w[3] = {q.mq->src[0], q.mk->src[0], q.mv->src[0]};
     const int64_t K = x->ne[0], N = x->ne[1], hd = q.rq->ne[0];
@@ -2134,6 +2134,15 @@ static bool mi355_try_fuse_qkv_gemm(mi355_backend_ctx * ctx, ggml_cgraph * cgrap
         for (int b = 0; b < a; b++) if (ranges_overlap(outs[a]->data, ggml_nbytes(outs[a]), outs[b]->data, ggml_nbytes(outs[b]))) return false;
         if (ranges_overlap(outs[a]->data, ggml_nbytes(outs[a]), q.rq->src[1]->data, ggml_nbytes(q.rq->src[1]))) return false;
     }
+    // a q8_0 cache: k and v leave the finish launch as f32 rows in scratch and one more launch quantizes both into the cache rows
+    // (mi355_kv_store_q8_0, the arithmetic of the CPY f32 -> q8_0 it replaces), as on the decode path
+    const int64_t Mk = w[1]->ne[1], Mv = w[2]->ne[1];
+    float * kv_tmp = nullptr;
+    if (q.kv_q8) {
+        const size_t need = (size_t)N * (Mk + Mv) * sizeof(float);
+        kv_tmp = (float *)ctx->get_scratch(4, need);
+        if (ctx->scratch_size[4] < need || N * (Mk > Mv ? Mk : Mv) > 0x7fffffff) return false;
+    }
     const uint16_t * act = prefill_act_bf16(ctx, x);
     mi355_qkv_finish_args f;
     memset(&f, 0, sizeof(f));
@@ -2151,12 +2160,14 @@ static bool mi355_try_fuse_qkv_gemm(mi355_backend_ctx * ctx, ggml_cgraph * cgrap
     f.m_q = w[0]->ne[1]; f.m_k = w[1]->ne[1]; f.m_v = w[2]->ne[1]; f.n = N;
     f.q_out = (float *)q.rq->data; f.k_out = q.ck->data; f.v_out = q.cv->data;
     f.k_out_type = (int32_t)q.ck->type; f.v_out_type = (int32_t)q.cv->type;
+    if (kv_tmp) { f.k_out = kv_tmp; f.v_out = kv_tmp + N * Mk; f.k_out_type = f.v_out_type = (int32_t)GGML_TYPE_F32; }
     f.pos = (const int32_t *)q.rq->src[1]->data; f.freq_factors = q.rq->src[2] ? (const float *)q.rq->src[2]->data : nullptr;
     f.head_dim = (int32_t)hd;
     float f6[6];
     qkv_rope_params(q.rq, &f.n_dims, &f.mode, &f.n_ctx_orig, f6);
     f.freq_base = f6[0]; f.freq_scale = f6[1]; f.ext_factor = f6[2]; f.attn_factor = f6[3]; f.beta_fast = f6[4]; f.beta_slow = f6[5];
     MI_CHECK(mi355_qkv_finish(&f, ctx->stream));
+    if (kv_tmp) MI_CHECK(mi355_kv_store_q8_0(kv_tmp, N * Mk, q.ck->data, kv_tmp + N * Mk, N * Mv, q.cv->data, nullptr, 0, ctx->stream));
     for (int m = 1; m < 7; m++) done[q.idx[m]] = 1;
     ctx->act_invalidate_if_written(q.rq);
     return true;
