@@ -343,6 +343,15 @@ MI355_API int mi355_mul_mat_dq_parts(int type, const void *W, int64_t w_row_stri
                                      float *parts, int64_t parts_bytes, int64_t m, int64_t m_total, int64_t k, int64_t n,
                                      int32_t *kz, void *stream);
 
+/* mi355_mul_mat_dq_parts for TWO matrices of m rows each and the same activations in ONE launch -- wk and wv of a GQA model (M = 1024
+ * at prefill), each of which alone is a split-K launch of small tiles that fills half the chip.  The planes hold the bits of the two
+ * separate calls.  Same type, or q4_K / q5_K with q6_K; only where mi355_mul_mat_dq_parts would take its small-tile split form
+ * (*kz >= 2), else MI355_E_UNSUPPORTED and the caller issues the two calls.  parts_a / parts_b: parts_bytes_each bytes each. */
+MI355_API int mi355_mul_mat_dq_parts_pair(int type_a, const void *Wa, int64_t wa_row_stride, float *parts_a,
+                                          int type_b, const void *Wb, int64_t wb_row_stride, float *parts_b, int64_t parts_bytes_each,
+                                          const uint16_t *act_bf16, int64_t act_row_stride, int64_t m, int64_t k, int64_t n,
+                                          int32_t *kz, void *stream);
+
 /* Q / K / V of a prefill batch after the three GEMMs, in ONE launch: adds the K-slice planes of each product, rotates q and k
  * (ggml_rope_ext, NORMAL or NEOX), stores q as f32 [n][m_q] and k / v as the rows of the KV cache (f16 or f32, n rows one after the
  * other).  Replaces, per layer, 3 slice sums + ROPE x 2 (ggml-cuda/rope.cu) + CPY x 2 (ggml-cuda/cpy.cu; llama-kv-cache-unified.cpp:817-891

@@ -2147,7 +2147,18 @@ static bool mi355_try_fuse_qkv_gemm(mi355_backend_ctx * ctx, ggml_cgraph * cgrap
     mi355_qkv_finish_args f;
     memset(&f, 0, sizeof(f));
     int32_t kz[3] = {0, 0, 0};
+    bool paired = false;
     for (int m = 0; m < 3; m++) {
+        if (m == 2 && paired) break;
+        if (m == 1 && Mk == Mv && pb[1] == pb[2] && !MI355_ENV_SET("GGML_MI355_NO_QKV_PAIR")) {
+            // wk and wv (M = 1024 each in a GQA model) in one launch: each alone fills half the chip
+            int32_t kzp = 0;
+            const int rcp = mi355_mul_mat_dq_parts_pair((int)w[1]->type, w[1]->data, (int64_t)w[1]->nb[1], (float *)(parts + off[1]),
+                                                        (int)w[2]->type, w[2]->data, (int64_t)w[2]->nb[1], (float *)(parts + off[2]), pb[1],
+                                                        act, K, Mk, K, N, &kzp, ctx->stream);
+            if (rcp == MI355_OK) { kz[1] = kz[2] = kzp; paired = true; continue; }
+            if (rcp != MI355_E_UNSUPPORTED && rcp != MI355_E_ALIGN) MI_CHECK(rcp);
+        }
         const int rc = mi355_mul_mat_dq_parts((int)w[m]->type, w[m]->data, (int64_t)w[m]->nb[1], act, K, (float *)(parts + off[m]), pb[m], w[m]->ne[1], w[m]->ne[1], K, N,
                                               &kz[m], ctx->stream);
         // nothing of the pattern has been written yet when the first product is refused; a later refusal cannot happen for a type

@@ -24,6 +24,7 @@
 #include <algorithm>
 #include <map>
 #include <mutex>
+#include <type_traits>
 #include <utility>
 
 namespace {
@@ -50,6 +51,9 @@ struct DArgs {
     // gate / up / GLU form (mmdq_ws_kernel<..., GLU>): W is the matrix whose product is activated, W2 the one it is multiplied by; m counts
     // PAIRS of rows (row i of W with row i of W2); dst receives act(W x) * (W2 x) as f32, hbf the same rounded to bf16 ([n][m], for the next GEMM)
     const uint8_t * W2; int64_t w2_row_stride; uint16_t * hbf; int glu_op;
+    // pair form (mmdq_ws_kernel<..., TYPE2>): workgroups with blockIdx.y >= y2 compute a SECOND product, W2 (type TYPE2, m2 rows) times the
+    // same activations, into part2 -- two small matrices (wk, wv) share one launch and the chip instead of taking turns on half of it
+    int y2, m2; float * part2;
 };
 
 // 32 consecutive weights of one row, raw, as loaded from global memory
@@ -398,10 +402,16 @@ static __device__ __forceinline__ void gemm_dma_piece(const void * gsrc, unsigne
 // BMW x BNW: 128 x 256 (8 multiplying waves of 64 x 64, 4 dequantizing; wide launches) or 64 x 128 (4 multiplying waves of
 // 64 x 32, 2 dequantizing; two workgroups per CU, with split-K for the launches of few tiles: gridDim.z == 2 adds the two
 // halves of K into a zeroed dst, exactly as mmdq_kernel does).
-template <int TYPE, int BMW, int BNW, bool GLU = false>
+template <int TYPE, int BMW, int BNW, bool GLU = false, int TYPE2 = -1>
 __global__ void __launch_bounds__(BMW * BNW == 128 * 256 ? 768 : 384)
-mmdq_ws_kernel(const DArgs a) {
+mmdq_ws_kernel(const DArgs a_in) {
     static_assert(!GLU || (BMW == 128 && BNW == 256), "the gate / up / GLU form exists for the 128 x 256 tile");
+    constexpr bool PAIR = TYPE2 >= 0;
+    static_assert(!PAIR || !GLU, "pair and GLU forms are separate");
+    const bool second = PAIR && (int)blockIdx.y >= a_in.y2;
+    DArgs a = a_in;
+    if (PAIR && second) { a.W = a_in.W2; a.w_row_stride = a_in.w2_row_stride; a.m = a_in.m2; a.part = a_in.part2; }
+    const int by = PAIR && second ? (int)blockIdx.y - a_in.y2 : (int)blockIdx.y;
     constexpr int TN = BMW == 128 ? 2 : 1;                                    // 32-column MFMA tiles per multiplying wave
     constexpr int WAVES_M = BMW / 64, NMW = WAVES_M * (BNW / (32 * TN));      // multiplying waves
     constexpr int NPIECE = BNW * PITCH / 1024;                                // 1 KiB pieces per activation stage: 36 / 18
@@ -412,7 +422,7 @@ mmdq_ws_kernel(const DArgs a) {
     __shared__ __attribute__((aligned(16))) uint8_t Lw[2][BMW * PITCH];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // GLU: the tile's 128 weight rows are 64 rows of W (tile rows 0..63) and the SAME 64 rows of W2 (tile rows 64..127)
-    const int n0 = blockIdx.x * BNW, m0 = blockIdx.y * (GLU ? BMW / 2 : BMW);
+    const int n0 = blockIdx.x * BNW, m0 = by * (GLU ? BMW / 2 : BMW);
     const int kspan = a.k / (int)gridDim.z, kbeg = (int)blockIdx.z * kspan;
     const int nstage = kspan / BK;
 
@@ -426,29 +436,37 @@ mmdq_ws_kernel(const DArgs a) {
 #define MMDQ_PFD 2        // stages of raw weight bytes a dequantizing thread holds in flight
 #endif
         constexpr int PFD = MMDQ_PFD;
-        Raw<TYPE> wraw[PFD];
+        auto produce = [&](auto type_tag) {
+            constexpr int T = decltype(type_tag)::value;
+            Raw<T> wraw[PFD];
 #pragma unroll
-        for (int j = 0; j < PFD; j++) if (j < nstage) wraw[j] = load_raw<TYPE>(wrow, kbeg + j * BK + hf * 32);
-        auto stash = [&](int slot, int st) {
-            float f[32];
-            dequant32<TYPE>(wraw[slot], kbeg + st * BK + hf * 32, f);
-            store_bf16x32(Lw[st & 1] + sr * PITCH + hf * 64, f);
-        };
-        stash(0, 0);
-        if (PFD < nstage) wraw[0] = load_raw<TYPE>(wrow, kbeg + PFD * BK + hf * 32);
-        __syncthreads();
-        for (int st0 = 0; st0 < nstage; st0 += PFD) {
+            for (int j = 0; j < PFD; j++) if (j < nstage) wraw[j] = load_raw<T>(wrow, kbeg + j * BK + hf * 32);
+            auto stash = [&](int slot, int st) {
+                float f[32];
+                dequant32<T>(wraw[slot], kbeg + st * BK + hf * 32, f);
+                store_bf16x32(Lw[st & 1] + sr * PITCH + hf * 64, f);
+            };
+            stash(0, 0);
+            if (PFD < nstage) wraw[0] = load_raw<T>(wrow, kbeg + PFD * BK + hf * 32);
+            __syncthreads();
+            for (int st0 = 0; st0 < nstage; st0 += PFD) {
 #pragma unroll
-            for (int j = 0; j < PFD; j++) {
-                const int st = st0 + j;                   // the others multiply stage st; this writes stage st + 1 (slot (j + 1) % PFD)
-                if (st < nstage) {
-                    if (st + 1 < nstage && !(a.dbg & 1)) {
-                        stash((j + 1) % PFD, st + 1);
-                        if (st + 1 + PFD < nstage) wraw[(j + 1) % PFD] = load_raw<TYPE>(wrow, kbeg + (st + 1 + PFD) * BK + hf * 32);
+                for (int j = 0; j < PFD; j++) {
+                    const int st = st0 + j;                   // the others multiply stage st; this writes stage st + 1 (slot (j + 1) % PFD)
+                    if (st < nstage) {
+                        if (st + 1 < nstage && !(a.dbg & 1)) {
+                            stash((j + 1) % PFD, st + 1);
+                            if (st + 1 + PFD < nstage) wraw[(j + 1) % PFD] = load_raw<T>(wrow, kbeg + (st + 1 + PFD) * BK + hf * 32);
+                        }
+                        __syncthreads();
                     }
-                    __syncthreads();
                 }
             }
+        };
+        if constexpr (PAIR && TYPE2 != TYPE) {
+            if (second) produce(std::integral_constant<int, TYPE2>{}); else produce(std::integral_constant<int, TYPE>{});
+        } else {
+            produce(std::integral_constant<int, TYPE>{});
         }
         return;
     }
@@ -819,7 +837,7 @@ static int dq_run(int type, const void * W, int64_t w_row_stride, const uint16_t
     a.W = (const uint8_t *)W; a.w_row_stride = w_row_stride; a.x = x; a.x_row_stride = x_row_stride;
     a.dst = dst; a.dst_col_stride = dst_col_stride; a.m = (int)m; a.n = (int)n; a.k = (int)k;
     a.sorted = a.off = a.tile_off = nullptr; a.n_expert = a.n_used = a.act_ne1 = 0; a.w_expert_stride = 0; a.part = (float *)workspace;
-    a.W2 = nullptr; a.w2_row_stride = 0; a.hbf = nullptr; a.glu_op = 0;
+    a.W2 = nullptr; a.w2_row_stride = 0; a.hbf = nullptr; a.glu_op = 0; a.y2 = 0; a.m2 = 0; a.part2 = nullptr;
     { static const int dbg = [] { const char * e = getenv("MI355_MMDQ_DBG"); return e ? atoi(e) : 0; }(); a.dbg = dbg; }
     hipStream_t s = (hipStream_t)stream;
     switch (type) {
@@ -870,6 +888,7 @@ extern "C" int mi355_glu_mul_mat_dq(int type, int glu_op, const void * Wa, int64
     a.x = x; a.x_row_stride = x_row_stride; a.dst = dst; a.dst_col_stride = dst_col_stride; a.hbf = dst_bf16; a.glu_op = glu_op;
     a.m = (int)m; a.n = (int)n; a.k = (int)k;
     a.sorted = a.off = a.tile_off = nullptr; a.n_expert = a.n_used = a.act_ne1 = 0; a.w_expert_stride = 0; a.part = nullptr; a.dbg = 0;
+    a.y2 = 0; a.m2 = 0; a.part2 = nullptr;
     hipStream_t s = (hipStream_t)stream;
     switch (type) {
         case MI355_TYPE_Q4_0: return launch_glu<MI355_TYPE_Q4_0>(a, s, "mmdq_glu_q4_0");
@@ -885,6 +904,51 @@ extern "C" int mi355_glu_mul_mat_dq(int type, int glu_op, const void * Wa, int64
         case MI355_TYPE_F32:  return launch_glu<MI355_TYPE_F32>(a, s, "mmdq_glu_f32");
     }
     return MI355_E_TYPE;
+}
+
+template <int TA, int TB>
+static int launch_pair(const DArgs & a, int kz, hipStream_t s) {
+    const unsigned ty = (unsigned)((a.m + 63) / 64);
+    MI355_LAUNCH("mmdq_pair", (mmdq_ws_kernel<TA, 64, 128, false, TB>), dim3((unsigned)((a.n + BN - 1) / BN), 2 * ty, (unsigned)kz), dim3(384), 0, s, a);
+    MI355_CHECK_LAUNCH();
+    return MI355_OK;
+}
+
+// Two products of the same activations in ONE launch: mi355_mul_mat_dq_parts for Wa and for Wb (both m rows), where each alone would be
+// a split-K launch of 64 x 128 tiles that leaves half the chip idle (wk and wv of a GQA model at prefill: M = 1024).  Every workgroup
+// computes what it would have computed in the separate launch, so the planes hold the same bits.  Same type, or a q4_K / q5_K matrix
+// with a q6_K one (llama.cpp's Q4_K_M / Q5_K_M recipes give attn_v more bits); anything else: MI355_E_UNSUPPORTED, two launches.
+extern "C" int mi355_mul_mat_dq_parts_pair(int type_a, const void * Wa, int64_t wa_row_stride, float * parts_a,
+                                           int type_b, const void * Wb, int64_t wb_row_stride, float * parts_b, int64_t parts_bytes_each,
+                                           const uint16_t * x, int64_t x_row_stride, int64_t m, int64_t k, int64_t n, int32_t * kz, void * stream) {
+    if (!Wa || !Wb || !parts_a || !parts_b || !x || !kz) return MI355_E_NULL;
+    const int64_t bsa = mi355_blck_size(type_a), bsb = mi355_blck_size(type_b);
+    if (bsa == 0 || bsb == 0 || type_a == MI355_TYPE_Q8_1 || type_b == MI355_TYPE_Q8_1) return MI355_E_TYPE;
+    if (m <= 0 || n <= 0 || k <= 0 || k % bsa != 0 || k % bsb != 0 || m > 0x7fffffff || n > 0x7fffffff || k > 0x7fffffff) return MI355_E_SHAPE;
+    if (k % BK != 0 || 2 * ((m + 63) / 64) > 65535) return MI355_E_UNSUPPORTED;
+    const int nz = kz_slices(m, n, k) == 0 ? kz_slices_small(m, n, k) : 0;
+    if (nz < 2) return MI355_E_UNSUPPORTED;               // not the launch form this entry pairs up
+    if (((uintptr_t)x & 15) || (x_row_stride & 7) || x_row_stride < k || (((uintptr_t)parts_a | (uintptr_t)parts_b) & 15)) return MI355_E_ALIGN;
+    if (parts_bytes_each < (int64_t)nz * n * m * (int64_t)sizeof(float)) return MI355_E_WORKSPACE;
+    const bool a16 = type_a == MI355_TYPE_Q4_K || type_a == MI355_TYPE_Q5_K, b16 = type_b == MI355_TYPE_Q4_K || type_b == MI355_TYPE_Q5_K;
+    if ((((uintptr_t)Wa | (uintptr_t)wa_row_stride) & (a16 ? 15 : 1)) || (((uintptr_t)Wb | (uintptr_t)wb_row_stride) & (b16 ? 15 : 1))) return MI355_E_ALIGN;
+    if (wa_row_stride < mi355_row_size(type_a, k) || wb_row_stride < mi355_row_size(type_b, k)) return MI355_E_SHAPE;
+    DArgs a;
+    a.W = (const uint8_t *)Wa; a.w_row_stride = wa_row_stride; a.W2 = (const uint8_t *)Wb; a.w2_row_stride = wb_row_stride;
+    a.x = x; a.x_row_stride = x_row_stride; a.dst = parts_a; a.dst_col_stride = m; a.hbf = nullptr; a.glu_op = 0;
+    a.m = (int)m; a.n = (int)n; a.k = (int)k; a.part = parts_a; a.part2 = parts_b; a.m2 = (int)m; a.y2 = (int)((m + 63) / 64);
+    a.sorted = a.off = a.tile_off = nullptr; a.n_expert = a.n_used = a.act_ne1 = 0; a.w_expert_stride = 0; a.dbg = 0;
+    hipStream_t s = (hipStream_t)stream;
+    *kz = nz;
+#define PAIR_CASE(TA, TB) if (type_a == TA && type_b == TB) return launch_pair<TA, TB>(a, nz, s)
+    PAIR_CASE(MI355_TYPE_Q4_K, MI355_TYPE_Q4_K); PAIR_CASE(MI355_TYPE_Q4_K, MI355_TYPE_Q6_K);
+    PAIR_CASE(MI355_TYPE_Q5_K, MI355_TYPE_Q5_K); PAIR_CASE(MI355_TYPE_Q5_K, MI355_TYPE_Q6_K);
+    PAIR_CASE(MI355_TYPE_Q6_K, MI355_TYPE_Q6_K); PAIR_CASE(MI355_TYPE_Q8_0, MI355_TYPE_Q8_0);
+    PAIR_CASE(MI355_TYPE_Q4_0, MI355_TYPE_Q4_0); PAIR_CASE(MI355_TYPE_Q4_1, MI355_TYPE_Q4_1);
+    PAIR_CASE(MI355_TYPE_Q5_0, MI355_TYPE_Q5_0); PAIR_CASE(MI355_TYPE_Q5_1, MI355_TYPE_Q5_1);
+    PAIR_CASE(MI355_TYPE_F16, MI355_TYPE_F16);   PAIR_CASE(MI355_TYPE_BF16, MI355_TYPE_BF16);
+#undef PAIR_CASE
+    return MI355_E_UNSUPPORTED;
 }
 
 // workspace of mi355_mul_mat_id_dq: bf16 activations [n_tokens * b_ne1][k], then the routing tables
@@ -925,7 +989,7 @@ extern "C" int mi355_mul_mat_id_dq(int type, const void * as, int64_t w_row_stri
     a.dst = dst; a.dst_col_stride = m; a.m = (int)m; a.n = (int)(n_tokens * n_used); a.k = (int)k;
     a.sorted = sorted; a.off = off; a.tile_off = tile_off; a.n_expert = (int)n_expert; a.n_used = (int)n_used; a.act_ne1 = (int)b_ne1;
     a.w_expert_stride = w_expert_stride; a.dbg = 0; a.part = nullptr;
-    a.W2 = nullptr; a.w2_row_stride = 0; a.hbf = nullptr; a.glu_op = 0;
+    a.W2 = nullptr; a.w2_row_stride = 0; a.hbf = nullptr; a.glu_op = 0; a.y2 = 0; a.m2 = 0; a.part2 = nullptr;
     const int max_tiles = (int)((n_tokens * n_used + BN - 1) / BN + n_expert);   // sum over experts of ceil(cnt_e / BN) never exceeds this
     switch (type) {
         case MI355_TYPE_Q4_0: return launch_ids<MI355_TYPE_Q4_0>(a, max_tiles, s, "mmdq_id_q4_0");

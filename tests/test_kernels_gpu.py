@@ -321,6 +321,39 @@ def test_qkv_parts_and_finish_have_the_bits_of_the_separate_launches(ops, mq, mk
     assert torch.equal(v_out, v_want)
 
 
+@pytest.mark.parametrize("ta,tb,m,k,n", [(B.Q4_K, B.Q6_K, 1024, 4096, 512), (B.Q4_K, B.Q4_K, 1024, 4096, 200), (B.Q8_0, B.Q8_0, 1000, 2048, 300),
+                                          (B.Q5_K, B.Q6_K, 512, 8192, 512)])
+def test_mul_mat_dq_parts_pair_has_the_bits_of_two_calls(ops, ta, tb, m, k, n):
+    """mi355_mul_mat_dq_parts_pair (wk and wv of a prefill batch in one launch) against two mi355_mul_mat_dq_parts calls: the same number
+    of K slices and the same planes, bit for bit; a shape whose single launch would not be the small-tile split form is refused."""
+    import ctypes as C
+    import llm_amd.kernels as K
+    rng = np.random.default_rng(31)
+    s = torch.cuda.current_stream().cuda_stream
+    x = ops.act_bf16(dev(rng.standard_normal((n, k)).astype(np.float32)))
+    wa, wb = dev(B.random_blocks(ta, m, k, seed=60)), dev(B.random_blocks(tb, m, k, seed=61))
+    nb = K.lib.mi355_mul_mat_dq_parts_bytes(m, m, k, n)
+    single, kzs = [], []
+    for t, w in ((ta, wa), (tb, wb)):
+        p = torch.full((nb // 4,), float("nan"), device="cuda")
+        kz = C.c_int32(0)
+        K.check(K.lib.mi355_mul_mat_dq_parts(t, w.data_ptr(), B.row_size(t, k), x.data_ptr(), k, p.data_ptr(), nb, m, m, k, n, C.byref(kz), s), "parts")
+        single.append(p); kzs.append(kz.value)
+    pa = torch.full((nb // 4,), float("nan"), device="cuda"); pb = torch.full((nb // 4,), float("nan"), device="cuda")
+    kz = C.c_int32(0)
+    K.check(K.lib.mi355_mul_mat_dq_parts_pair(ta, wa.data_ptr(), B.row_size(ta, k), pa.data_ptr(), tb, wb.data_ptr(), B.row_size(tb, k), pb.data_ptr(), nb,
+                                              x.data_ptr(), k, m, k, n, C.byref(kz), s), "pair")
+    torch.cuda.synchronize()
+    assert kz.value == kzs[0] == kzs[1] and kz.value >= 2
+    used = kz.value * n * m
+    assert torch.isfinite(pa[:used]).all() and torch.isfinite(pb[:used]).all()
+    assert torch.equal(pa[:used], single[0][:used]) and torch.equal(pb[:used], single[1][:used])
+    # K = 512: too short to split, the single launch would not be the split form -> refused (MI355_E_UNSUPPORTED), nothing launched
+    rc = K.lib.mi355_mul_mat_dq_parts_pair(ta, wa.data_ptr(), B.row_size(ta, 512), pa.data_ptr(), tb, wb.data_ptr(), B.row_size(tb, 512), pb.data_ptr(), nb,
+                                           x.data_ptr(), k, m, 512, n, C.byref(kz), s)
+    assert rc == -6
+
+
 @pytest.mark.parametrize("t,m,k,n", [(B.Q4_K, 4096, 4096, 512), (B.Q6_K, 4096, 14336, 512), (B.Q4_K, 4096, 4096, 2048), (B.Q8_0, 1024, 2816, 160), (B.Q4_K, 8192, 2048, 300)])
 def test_gemm_planes_into_add_rms_norm_have_the_bits_of_the_separate_launches(ops, t, m, k, n):
     """wo / ffn_down of a prefill batch: mi355_mul_mat_dq_parts + mi355_parts_add_rms_norm_mul_bf16_f32 (the norm kernel adds the K-slice
