@@ -481,22 +481,29 @@ template <> struct MmaChunk<MI355_TYPE_Q4_0> {
     }
 };
 
-template <int D, int TKV>
-__global__ void __launch_bounds__(MMA_THREADS, 2)
+// SPLIT: for launches of fewer (head, 32-query) units than the chip has SIMDs -- every prefill ubatch of 512 tokens: 32 heads x 16
+// blocks = 512 -- a unit is shared by TWO waves that take alternate 64-row KV blocks (a workgroup stages 128 rows per step for 2 units x
+// 2 halves) and merge their (m, l, O) through LDS at the end: twice the workgroups, half the chain of KV steps per wave.
+template <int D, int TKV, bool SPLIT = false>
+__global__ void __launch_bounds__(MMA_THREADS, SPLIT ? 1 : 2)
 fattn_mma_kernel(const FArgs a) {
+    constexpr int BKV = SPLIT ? 2 * MMA_BKV : MMA_BKV;      // KV rows staged per step
+    constexpr int UNITS = SPLIT ? MMA_WAVES / 2 : MMA_WAVES;
     constexpr int KP = D * 2 + 16;          // K tile row pitch (bytes)
     constexpr int VP = D * 2 + 64;          // V tile row pitch (bytes): 4 consecutive rows land on 4 disjoint groups of 16 banks, so
                                             // the transposed reads below (4 rows x 64 B per 32-lane half) are conflict-free
     constexpr int DT = D / 32, KS = D / 16;
-    __shared__ __attribute__((aligned(16))) uint8_t Ks[MMA_BKV * KP];
-    __shared__ __attribute__((aligned(16))) uint8_t Vs[MMA_BKV * VP];   // row-major like K; consumed column-wise with ds_read_b64_tr_b16
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ __attribute__((aligned(16))) uint8_t Ks[BKV * KP];
+    __shared__ __attribute__((aligned(16))) uint8_t Vs[BKV * VP];   // row-major like K; consumed column-wise with ds_read_b64_tr_b16
+    const int tid = threadIdx.x, lane = tid & 63, wave_ = tid >> 6;
+    const int wave = SPLIT ? wave_ % UNITS : wave_;           // the (head, query block) unit of this wave inside the workgroup
+    const int koff = SPLIT ? (wave_ / UNITS) * MMA_BKV : 0;   // its 64 rows of every staged step
     const int lr = lane & 31, lh = lane >> 5;
     // The 4 waves share every K/V tile: they take up to 4 heads of one KV head (GQA) and, if that leaves waves over, further
     // 32-query blocks -- so a tile is staged once for 4 x 32 (head, query) rows and the causal skip works on 32-query blocks.
     const int ratio = a.n_head / a.n_head_kv;
-    const int hpw = ratio % 4 == 0 ? 4 : ratio % 2 == 0 ? 2 : 1;               // heads per workgroup (divides the GQA ratio)
-    const int qpw = MMA_WAVES / hpw;                                          // 32-query blocks per workgroup
+    const int hpw = UNITS == 4 && ratio % 4 == 0 ? 4 : ratio % 2 == 0 ? 2 : 1;  // heads per workgroup (divides the GQA ratio)
+    const int qpw = UNITS / hpw;                                              // 32-query blocks per workgroup
     const int h = (int)blockIdx.y * hpw + wave % hpw, i3 = blockIdx.z;
     const int hk = h / ratio;
     const int q = ((int)blockIdx.x * qpw + wave / hpw) * 32 + lr;
@@ -531,7 +538,7 @@ fattn_mma_kernel(const FArgs a) {
         for (int r = 0; r < 16; r++) o[i][r] = 0.0f;
     float m = -INFINITY, l = 0.0f;
 
-    constexpr int CH = MMA_BKV * D * 2 / 16 / MMA_THREADS;   // 16-byte chunks per thread per tile
+    constexpr int CH = BKV * D * 2 / 16 / MMA_THREADS;   // 16-byte chunks per thread per tile
     const bool mvec = mrow && (((uintptr_t)a.mask | (uintptr_t)a.m_nb1 | (uintptr_t)a.m_nb2 | (uintptr_t)a.m_nb3) & 7) == 0;   // 4 mask values per load
     typedef _Float16 mh4 __attribute__((ext_vector_type(4)));
     // mask tile of this wave for the block at kv0: 2 S^T tiles x 16 kv rows per lane, kept packed (f16)
@@ -591,22 +598,22 @@ fattn_mma_kernel(const FArgs a) {
     // The mask loads run two blocks ahead (requested during block j-1, voted on at the top of block j for block j+1), so the
     // vote does not wait on memory either.
     mh4 mcur[2][4], mnxt[2][4], mnx2[2][4];
-    issue_mask(0, mnxt);
+    issue_mask(koff, mnxt);
     bool any_n = mask_any(mnxt);
     bool wg_n = __syncthreads_or(any_n);
     if (wg_n) issue(0);
-    issue_mask(MMA_BKV, mnx2);                              // (rows past n_kv read as -inf without touching memory)
-    for (int kv0 = 0; kv0 < a.n_kv; kv0 += MMA_BKV) {
+    issue_mask(BKV + koff, mnx2);                           // (rows past n_kv read as -inf without touching memory)
+    for (int kv0 = 0; kv0 < a.n_kv; kv0 += BKV) {
         const bool wg = wg_n, any = any_n;
 #pragma unroll
         for (int t = 0; t < 2; t++)
 #pragma unroll
             for (int g = 0; g < 4; g++) { mcur[t][g] = mnxt[t][g]; mnxt[t][g] = mnx2[t][g]; }
-        any_n = kv0 + MMA_BKV < a.n_kv ? mask_any(mnxt) : false;
+        any_n = kv0 + BKV < a.n_kv ? mask_any(mnxt) : false;
         wg_n = __syncthreads_or(any_n);                     // (also: the previous block is fully consumed, the tiles are free)
         if (wg) commit();
-        if (wg_n) issue(kv0 + MMA_BKV);
-        issue_mask(kv0 + 2 * MMA_BKV, mnx2);
+        if (wg_n) issue(kv0 + BKV);
+        issue_mask(kv0 + 2 * BKV + koff, mnx2);
         if (!wg) continue;
         __syncthreads();
         if (!__any(any)) continue;     // whole tile masked out for every query of this wave (uniform per wave; every wave still
@@ -627,7 +634,7 @@ fattn_mma_kernel(const FArgs a) {
             for (int r = 0; r < 16; r++) sacc[t][r] = 0.0f;
 #pragma unroll
             for (int ks = 0; ks < KS; ks++) {
-                const half8 kf = *(const half8 *)(Ks + (32 * t + lr) * KP + ks * 32 + lh * 16);
+                const half8 kf = *(const half8 *)(Ks + (koff + 32 * t + lr) * KP + ks * 32 + lh * 16);
                 sacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], sacc[t], 0, 0, 0);
             }
         }
@@ -668,7 +675,7 @@ fattn_mma_kernel(const FArgs a) {
         {
             typedef short tr4 __attribute__((ext_vector_type(4)));
             const int q4 = (lane & 15) >> 2, p4 = lane & 3;
-            const uint8_t * vb = Vs + (4 * lh + q4) * VP + (16 * ((lane >> 4) & 1) + 4 * p4) * 2;
+            const uint8_t * vb = Vs + (koff + 4 * lh + q4) * VP + (16 * ((lane >> 4) & 1) + 4 * p4) * 2;
 #pragma unroll
             for (int i = 0; i < DT; i++)
 #pragma unroll
@@ -686,6 +693,30 @@ fattn_mma_kernel(const FArgs a) {
         }
     }
 
+    if constexpr (SPLIT) {
+        // the two waves of a unit hold the online-softmax state of alternate KV blocks: the second hands (O, m, l) over through the
+        // tiles (free after the barrier), same register and lane on both sides, and the first merges with the usual rescale
+        static_assert(UNITS * 64 * (DT * 16 + 2) * 4 <= BKV * KP, "the hand-over fits the K tile");
+        float * X = (float *)Ks + (size_t)wave * (DT * 16 + 2) * 64;
+        __syncthreads();
+        if (koff) {
+#pragma unroll
+            for (int i = 0; i < DT; i++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) X[(i * 16 + r) * 64 + lane] = o[i][r];
+            X[(DT * 16) * 64 + lane] = m; X[(DT * 16 + 1) * 64 + lane] = l;
+        }
+        __syncthreads();
+        if (koff) return;
+        const float m1 = X[(DT * 16) * 64 + lane], l1 = X[(DT * 16 + 1) * 64 + lane];
+        const float mn = fmaxf(m, m1), msafe = mn == -INFINITY ? 0.0f : mn;
+        const float c0 = __builtin_amdgcn_exp2f(m - msafe), c1 = __builtin_amdgcn_exp2f(m1 - msafe);     // -inf -> 0
+        l = l * c0 + l1 * c1;
+#pragma unroll
+        for (int i = 0; i < DT; i++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) o[i][r] = o[i][r] * c0 + X[(i * 16 + r) * 64 + lane] * c1;
+    }
     if (q < a.n_q) {
         const float inv = 1.0f / l;
         float * op = (float *)(a.dst + (int64_t)h * a.d_nb1 + (int64_t)q * a.d_nb2 + (int64_t)i3 * a.d_nb3);
@@ -707,6 +738,18 @@ fattn_mma_kernel(const FArgs a) {
 template <int D>
 static int launch_mma(const FArgs & a, int tkv, hipStream_t s) {
     const int ratio = a.n_head / a.n_head_kv;
+    // fewer (head, 32-query) units than SIMDs, and more than one KV step each: two waves per unit (MI355_FA_MMA_SPLIT=0: never)
+    static const int split_on = [] { const char * e = getenv("MI355_FA_MMA_SPLIT"); return e ? atoi(e) : 1; }();
+    const int64_t units = (int64_t)((a.n_q + 31) / 32) * a.n_head * a.ne3;
+    if (split_on && units < 1024 && a.n_kv > MMA_BKV) {
+        const int hpw = ratio % 2 == 0 ? 2 : 1, qpw = (MMA_WAVES / 2) / hpw, bq = 32 * qpw;
+        const dim3 grid((unsigned)((a.n_q + bq - 1) / bq), (unsigned)(a.n_head / hpw), (unsigned)a.ne3);
+        if (tkv == MI355_TYPE_F16)       MI355_LAUNCH("fattn_mma", (fattn_mma_kernel<D, MI355_TYPE_F16, true>), grid, dim3(MMA_THREADS), 0, s, a);
+        else if (tkv == MI355_TYPE_Q8_0) MI355_LAUNCH("fattn_mma", (fattn_mma_kernel<D, MI355_TYPE_Q8_0, true>), grid, dim3(MMA_THREADS), 0, s, a);
+        else                             MI355_LAUNCH("fattn_mma", (fattn_mma_kernel<D, MI355_TYPE_Q4_0, true>), grid, dim3(MMA_THREADS), 0, s, a);
+        MI355_CHECK_LAUNCH();
+        return MI355_OK;
+    }
     const int hpw = ratio % 4 == 0 ? 4 : ratio % 2 == 0 ? 2 : 1, qpw = MMA_WAVES / hpw, bq = 32 * qpw;
     const dim3 grid((unsigned)((a.n_q + bq - 1) / bq), (unsigned)(a.n_head / hpw), (unsigned)a.ne3);
     if (tkv == MI355_TYPE_F16)       MI355_LAUNCH("fattn_mma", (fattn_mma_kernel<D, MI355_TYPE_F16>), grid, dim3(MMA_THREADS), 0, s, a);
