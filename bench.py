@@ -327,10 +327,31 @@ def main():
         if prev[2] == 0 and mats[p[3][0]].src == "ffn_act":
             p[0] = None          # ffn_down reads the q8_1 activations the fused launch just wrote
 
+    # lab: BENCH_PREFETCH_MB=<x> reads the first x MB of the NEXT launch's weights on a second stream while a
+    # launch runs, so that its first loads come from the memory-side cache; off by default
+    pf_mb = float(os.environ.get("BENCH_PREFETCH_MB", "0"))
+    pf_wgs = int(os.environ.get("BENCH_PREFETCH_WGS", "64"))
+    pf_stream = torch.cuda.Stream() if pf_mb > 0 else None
+
+    def prefetch_next(j):
+        if j + 1 >= len(plan):
+            return
+        cur = torch.cuda.current_stream()
+        ev = torch.cuda.Event()
+        ev.record(cur)
+        pf_stream.wait_event(ev)
+        left = int(pf_mb * 1e6)
+        for i in plan[j + 1][3]:
+            nb = min(left // len(plan[j + 1][3]), weights[i].numel()) // 16 * 16
+            if nb > 0:
+                K.check(K.lib.mi355_prefetch(weights[i].data_ptr(), nb, pf_wgs, pf_stream.cuda_stream), "mi355_prefetch")
+
     def step():
         """one decode token's mat-vecs on the current stream"""
         stream = torch.cuda.current_stream().cuda_stream
-        for (need_q, arr, n, idx), g in zip(plan, gathers):
+        for j, ((need_q, arr, n, idx), g) in enumerate(zip(plan, gathers)):
+            if pf_stream is not None:
+                prefetch_next(j)
             if need_q is not None:
                 quantize(need_q, stream)
             if n == 0:
@@ -348,6 +369,10 @@ def main():
                 else:
                     for i in idx:
                         all_gather_rows(outs[i] if backend == "nccl" else outs[i].cpu(), mats[i].m, rank, world, dist)
+        if pf_stream is not None:      # join the second stream (a captured graph must end on one stream)
+            ev = torch.cuda.Event()
+            ev.record(pf_stream)
+            torch.cuda.current_stream().wait_event(ev)
 
     def barrier():
         if world > 1:

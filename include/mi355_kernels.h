@@ -470,6 +470,11 @@ MI355_API int mi355_glu_bf16_f32(int glu_op, const mi355_tensor *a, const mi355_
 MI355_API int mi355_parts_add_rms_norm_mul_bf16_f32(const float *a_parts, int kz, const mi355_tensor *b, const mi355_tensor *sum,
                                                     const float *w, const mi355_tensor *dst, float eps, uint16_t *act_bf16, void *stream);
 
+/* Reads `bytes` at p (16-byte aligned) with `workgroups` workgroups and drops them: pulls a weight range into the memory-side cache
+ * ahead of the launch that streams it, from a second stream beside the previous launch.  No counterpart in the reference; measured
+ * in bench.py (BENCH_PREFETCH_MB), see DESIGN.md section 8. */
+MI355_API int mi355_prefetch(const void *p, int64_t bytes, int workgroups, void *stream);
+
 /* copy / convert with arbitrary strides and equal element counts (ggml_cpy, ggml_cont, ggml_dup):
  * f32 -> f32 | f16 | q8_0, f16 -> f16 | f32.  The q8_0 destination follows quantize_row_q8_0_ref
  * (ggml-quants.c:188-211).  ggml_cuda_cpy (ggml-cuda/cpy.cu); oracle ggml_compute_forward_dup (ggml-cpu/ops.cpp). */

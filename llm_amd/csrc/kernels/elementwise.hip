@@ -1111,6 +1111,33 @@ moe_router_kernel(const char * x, int64_t x_stride, const char * gate, int64_t g
 
 } // namespace
 
+// ---------------------------------------------------------------- prefetch (lab)
+// reads `bytes` at p with 16-byte loads and drops them: pulls a weight range into the memory-side cache ahead of the launch that
+// streams it (run on a second stream beside the previous launch).  The accumulated value is stored only if it equals a magic
+// number, which keeps the loads alive.
+__global__ void __launch_bounds__(256)
+prefetch_kernel(const v4i * __restrict__ p, int64_t n16, int * sink) {
+    v4i acc = {0, 0, 0, 0};
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 3 * stride < n16; i += 4 * stride) {
+        const v4i a = p[i], b = p[i + stride], c = p[i + 2 * stride], d = p[i + 3 * stride];
+        acc = acc ^ a ^ b ^ c ^ d;
+    }
+    for (; i < n16; i += stride) acc = acc ^ p[i];
+    if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x5a17c3d9 && sink) *sink = acc.x;
+}
+
+extern "C" int mi355_prefetch(const void * p, int64_t bytes, int workgroups, void * stream) {
+    if (!p) return MI355_E_NULL;
+    if (bytes < 0 || workgroups < 1 || workgroups > 65535) return MI355_E_SHAPE;
+    if ((uintptr_t)p & 15) return MI355_E_ALIGN;
+    if (bytes < 16) return MI355_OK;
+    MI355_LAUNCH("prefetch", prefetch_kernel, dim3((unsigned)workgroups), dim3(256), 0, (hipStream_t)stream, (const v4i *)p, bytes / 16, (int *)nullptr);
+    MI355_CHECK_LAUNCH();
+    return MI355_OK;
+}
+
 extern "C" int mi355_argsort_f32(const mi355_tensor * x, const mi355_tensor * dst, int descending, void * stream) {
     if (!x || !dst || !x->data || !dst->data) return MI355_E_NULL;
     if (x->type != MI355_TYPE_F32 || x->nb[0] != 4 || dst->nb[0] != 4 || !same_shape(x, dst)) return MI355_E_SHAPE;
