@@ -193,6 +193,75 @@ rms_norm_kernel(const T4 x, const T4 y, const T4 sum, const float * __restrict__
     for (int i = threadIdx.x; i < n; i += NT) { float o = xr[i] * scale; if (HAS_W) o *= w[i]; dr[i] = o; }
 }
 
+// Prefill form of "K-slice planes + residual -> sum, RMS norm * weight, bf16 rows" for rows of at most 4096 values: a workgroup takes
+// TWO rows and requests both before it touches the first, so the second row's loads are in flight while the first is reduced and
+// stored (with one row per workgroup the whole launch loads, then reduces, then stores in step: 60 MB in 20 us).  Thread c owns
+// chunk c of 16 values, the per-thread partial sums and the wave / block reduction are those of rms_norm_kernel: the same bits.
+template <int KZ>
+__global__ void __launch_bounds__(256)
+add_rms_norm_planes_kernel(const float * __restrict__ parts, int64_t plane, const float * y, int64_t ys, float * sum, int64_t ss,
+                           const float * __restrict__ w, float * d, int64_t ds, uint16_t * __restrict__ abf, int n, int rows, float eps) {
+    // (y, sum and d may be the same memory -- an in-place residual add, a norm result on the dead residual -- hence no __restrict__:
+    // every load of a row precedes every store to it in program order, per thread on the same indices)
+    __shared__ float sh[4];
+    const int c = threadIdx.x, nc = n >> 4;
+    const bool on = c < nc;
+    const int r0 = blockIdx.x, r1 = blockIdx.x + gridDim.x;
+    v4f P[2][KZ][4], Y[2][4], W[4];
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const int r = u ? r1 : r0;
+        if (on && r < rows) {
+#pragma unroll
+            for (int z = 0; z < KZ; z++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) P[u][z][q] = ((const v4f *)(parts + z * plane + (int64_t)r * n))[4 * c + q];
+#pragma unroll
+            for (int q = 0; q < 4; q++) Y[u][q] = ((const v4f *)(y + (int64_t)r * ys))[4 * c + q];
+        }
+        if (u == 0 && on) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) W[q] = ((const v4f *)w)[4 * c + q];
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const int r = u ? r1 : r0;
+        if (r >= rows) break;                      // uniform over the workgroup
+        v4f v[4];
+        float s = 0.0f;
+        if (on) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                v[q] = P[u][0][q];
+#pragma unroll
+                for (int z = 1; z < KZ; z++) v[q] = v[q] + P[u][z][q];
+                v[q] = v[q] + Y[u][q];
+                ((v4f *)(sum + (int64_t)r * ss))[4 * c + q] = v[q];
+                s += v[q].x * v[q].x + v[q].y * v[q].y + v[q].z * v[q].z + v[q].w * v[q].w;
+            }
+        }
+        s = block_sum_n<4>(s, sh);
+        const float scale = 1.0f / sqrtf(s / (float)n + eps);
+        if (on) {
+            float o[16];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                v4f t = v[q] * scale;
+                t = t * W[q];
+                ((v4f *)(d + (int64_t)r * ds))[4 * c + q] = t;
+                o[4 * q] = t.x; o[4 * q + 1] = t.y; o[4 * q + 2] = t.z; o[4 * q + 3] = t.w;
+            }
+            typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+            bf8 b0, b1;
+#pragma unroll
+            for (int i = 0; i < 8; i++) { b0[i] = (__bf16)o[i]; b1[i] = (__bf16)o[8 + i]; }
+            bf8 * bo = (bf8 *)(abf + (int64_t)r * n + 16 * c);
+            bo[0] = b0; bo[1] = b1;
+        }
+    }
+}
+
 // ---------------------------------------------------------------- rope
 // one lane per rotated pair; rows = (head i1, token i2, batch i3)
 __global__ void __launch_bounds__(256)
@@ -693,6 +762,25 @@ int mi355_parts_add_rms_norm_mul_bf16_f32(const float * a_parts, int kz, const m
     mi355_tensor a = *sum;
     a.data = (void *)a_parts;
     a.nb[0] = 4; a.nb[1] = a.ne[0] * 4; a.nb[2] = a.nb[1] * a.ne[1]; a.nb[3] = a.nb[2] * a.ne[2];
+    // two rows per workgroup (see add_rms_norm_planes_kernel) where the shapes are the plain ones of a prefill layer
+    CHECK_T(b); CHECK_T(dst);
+    static const bool two_rows = getenv("MI355_NORM_TWO_ROWS") == nullptr || atoi(getenv("MI355_NORM_TWO_ROWS")) != 0;
+    const int64_t n = sum->ne[0], rows = sum->ne[1];
+    uintptr_t al = (uintptr_t)a_parts | (uintptr_t)b->data | (uintptr_t)sum->data | (uintptr_t)dst->data | (uintptr_t)w | (uintptr_t)act_bf16 |
+                   (uintptr_t)b->nb[1] | (uintptr_t)sum->nb[1] | (uintptr_t)dst->nb[1];
+    if (two_rows && kz >= 1 && kz <= 4 && n % 16 == 0 && n <= 4096 && rows >= 2 && rows <= 0x7fffffff && sum->ne[2] == 1 && sum->ne[3] == 1 &&
+        same_shape(b, sum) && same_shape(dst, sum) && b->type == MI355_TYPE_F32 && sum->type == MI355_TYPE_F32 && dst->type == MI355_TYPE_F32 &&
+        b->nb[0] == 4 && sum->nb[0] == 4 && dst->nb[0] == 4 && (al & 15) == 0) {
+        const dim3 grid((unsigned)((rows + 1) / 2));
+        const int64_t plane = rows * n;
+        hipStream_t s = (hipStream_t)stream;
+#define NORM_PLANES(KZ) MI355_LAUNCH("add_rms_norm_mul", add_rms_norm_planes_kernel<KZ>, grid, dim3(256), 0, s, a_parts, plane, (const float *)b->data, \
+        (int64_t)(b->nb[1] / 4), (float *)sum->data, (int64_t)(sum->nb[1] / 4), w, (float *)dst->data, (int64_t)(dst->nb[1] / 4), act_bf16, (int)n, (int)rows, eps)
+        switch (kz) { case 1: NORM_PLANES(1); break; case 2: NORM_PLANES(2); break; case 3: NORM_PLANES(3); break; default: NORM_PLANES(4); break; }
+#undef NORM_PLANES
+        MI355_CHECK_LAUNCH();
+        return MI355_OK;
+    }
     return launch_rms_norm(&a, b, sum, w, dst, eps, nullptr, nullptr, stream, act_bf16, a_parts, kz);
 }
 
