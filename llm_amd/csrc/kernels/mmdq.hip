@@ -541,38 +541,36 @@ mmdq_ws_kernel(const DArgs a_in) {
         if (!(a.dbg & 8)) __syncthreads();
     }
     if constexpr (GLU) {
-        // waves wm_ = 1 hold (W2 x) for the rows whose (W x) the waves wm_ = 0 hold: hand them over through LDS (the stage buffers are
-        // dead; the dequantizing waves have left, the barrier counts the remaining ones), same (register, lane) slot on both sides
-        float * X = (float *)&La[0][0];
-        if (wm_ == 1) {
+        // waves wm_ = 0 hold (W x) for the tile's 64 row pairs, waves wm_ = 1 hold (W2 x) for the same rows.  They swap halves through
+        // LDS (the stage buffers are dead; the dequantizing waves have left, the barrier counts the remaining ones; same (register,
+        // lane) slot on both sides): wm_ = 0 keeps rows 0..31 and receives their (W2 x), wm_ = 1 keeps rows 32..63 and receives their
+        // (W x) -- so both wave sets do half of the activation arithmetic and of the stores.
+        float * X = (float *)&La[0][0] + (size_t)(wn_ * 2 + wm_) * TN * 16 * 64;
+        const float * Xo = (const float *)&La[0][0] + (size_t)(wn_ * 2 + (wm_ ^ 1)) * TN * 16 * 64;
+        const int give = wm_ ^ 1, keep = wm_;             // tile-row block (tm) handed over / kept
 #pragma unroll
-            for (int tm = 0; tm < 2; tm++)
+        for (int tn = 0; tn < TN; tn++)
 #pragma unroll
-                for (int tn = 0; tn < TN; tn++)
-#pragma unroll
-                    for (int r = 0; r < 16; r++) X[(((wn_ * 2 + tm) * TN + tn) * 16 + r) * 64 + lane] = acc[tm][tn][r];
-        }
+            for (int r = 0; r < 16; r++) X[(tn * 16 + r) * 64 + lane] = give ? acc[1][tn][r] : acc[0][tn][r];
         __syncthreads();
-        if (wm_ == 1) return;
+        const int m = m0 + keep * 32 + lr;
 #pragma unroll
-        for (int tm = 0; tm < 2; tm++) {
-            const int m = m0 + tm * 32 + lr;
+        for (int tn = 0; tn < TN; tn++)
 #pragma unroll
-            for (int tn = 0; tn < TN; tn++)
-#pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    const int n = n0 + wn_ * 32 * TN + tn * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    const float u = X[(((wn_ * 2 + tm) * TN + tn) * 16 + r) * 64 + lane];
-                    const float h = glu_act_dq(a.glu_op, acc[tm][tn][r]) * u;
-                    // two neighbouring rows share one 4-byte store of the bf16 copy (m even: a.m is even here)
-                    const uint32_t hb = (uint32_t)__builtin_bit_cast(uint16_t, (__bf16)h);
-                    const uint32_t nb_ = (uint32_t)__shfl_xor((int)hb, 1, 64);
-                    if (m < a.m && n < a.n) {
-                        a.dst[(int64_t)n * a.dst_col_stride + m] = h;
-                        if (!(lr & 1)) *(uint32_t *)(a.hbf + (int64_t)n * a.m + m) = hb | (nb_ << 16);
-                    }
+            for (int r = 0; r < 16; r++) {
+                const int n = n0 + wn_ * 32 * TN + tn * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const float other = Xo[(tn * 16 + r) * 64 + lane];
+                const float mine = keep ? acc[1][tn][r] : acc[0][tn][r];
+                const float g = wm_ == 0 ? mine : other, u = wm_ == 0 ? other : mine;
+                const float h = glu_act_dq(a.glu_op, g) * u;
+                // two neighbouring rows share one 4-byte store of the bf16 copy (m even: a.m is even here)
+                const uint32_t hb = (uint32_t)__builtin_bit_cast(uint16_t, (__bf16)h);
+                const uint32_t nb_ = (uint32_t)__shfl_xor((int)hb, 1, 64);
+                if (m < a.m && n < a.n) {
+                    a.dst[(int64_t)n * a.dst_col_stride + m] = h;
+                    if (!(lr & 1)) *(uint32_t *)(a.hbf + (int64_t)n * a.m + m) = hb | (nb_ << 16);
                 }
-        }
+            }
         return;
     }
 #pragma unroll
