@@ -197,14 +197,14 @@ rms_norm_kernel(const T4 x, const T4 y, const T4 sum, const float * __restrict__
 // TWO rows and requests both before it touches the first, so the second row's loads are in flight while the first is reduced and
 // stored (with one row per workgroup the whole launch loads, then reduces, then stores in step: 60 MB in 20 us).  Thread c owns
 // chunk c of 16 values, the per-thread partial sums and the wave / block reduction are those of rms_norm_kernel: the same bits.
-template <int KZ>
-__global__ void __launch_bounds__(256)
+template <int KZ, int NT>
+__global__ void __launch_bounds__(NT)
 add_rms_norm_planes_kernel(const float * __restrict__ parts, int64_t plane, const float * y, int64_t ys, float * sum, int64_t ss,
                            const float * __restrict__ w, float * d, int64_t ds, uint16_t * __restrict__ abf, int n, int rows, float eps) {
     // (y, sum and d may be the same memory -- an in-place residual add, a norm result on the dead residual -- hence no __restrict__:
     // every load of a row precedes every store to it in program order, per thread on the same indices)
-    __shared__ float sh[4];
-    const int c = threadIdx.x, nc = n >> 4;
+    __shared__ float sh[NT / 64];
+    const int c = threadIdx.x, nc = n >> 4;       // NT = 256 for rows of up to 4096 values, 512 up to 8192: rms_norm_kernel's own choice
     const bool on = c < nc;
     const int r0 = blockIdx.x, r1 = blockIdx.x + gridDim.x;
     v4f P[2][KZ][4], Y[2][4], W[4];
@@ -241,7 +241,7 @@ add_rms_norm_planes_kernel(const float * __restrict__ parts, int64_t plane, cons
                 s += v[q].x * v[q].x + v[q].y * v[q].y + v[q].z * v[q].z + v[q].w * v[q].w;
             }
         }
-        s = block_sum_n<4>(s, sh);
+        s = block_sum_n<NT / 64>(s, sh);
         const float scale = 1.0f / sqrtf(s / (float)n + eps);
         if (on) {
             float o[16];
@@ -768,16 +768,18 @@ int mi355_parts_add_rms_norm_mul_bf16_f32(const float * a_parts, int kz, const m
     const int64_t n = sum->ne[0], rows = sum->ne[1];
     uintptr_t al = (uintptr_t)a_parts | (uintptr_t)b->data | (uintptr_t)sum->data | (uintptr_t)dst->data | (uintptr_t)w | (uintptr_t)act_bf16 |
                    (uintptr_t)b->nb[1] | (uintptr_t)sum->nb[1] | (uintptr_t)dst->nb[1];
-    if (two_rows && kz >= 1 && kz <= 4 && n % 16 == 0 && n <= 4096 && rows >= 2 && rows <= 0x7fffffff && sum->ne[2] == 1 && sum->ne[3] == 1 &&
+    if (two_rows && kz >= 1 && kz <= 4 && n % 16 == 0 && n <= 8192 && rows >= 2 && rows <= 0x7fffffff && sum->ne[2] == 1 && sum->ne[3] == 1 &&
         same_shape(b, sum) && same_shape(dst, sum) && b->type == MI355_TYPE_F32 && sum->type == MI355_TYPE_F32 && dst->type == MI355_TYPE_F32 &&
         b->nb[0] == 4 && sum->nb[0] == 4 && dst->nb[0] == 4 && (al & 15) == 0) {
         const dim3 grid((unsigned)((rows + 1) / 2));
         const int64_t plane = rows * n;
         hipStream_t s = (hipStream_t)stream;
-#define NORM_PLANES(KZ) MI355_LAUNCH("add_rms_norm_mul", add_rms_norm_planes_kernel<KZ>, grid, dim3(256), 0, s, a_parts, plane, (const float *)b->data, \
+#define NORM_PLANES_NT(KZ, NT) MI355_LAUNCH("add_rms_norm_mul", (add_rms_norm_planes_kernel<KZ, NT>), grid, dim3(NT), 0, s, a_parts, plane, (const float *)b->data, \
         (int64_t)(b->nb[1] / 4), (float *)sum->data, (int64_t)(sum->nb[1] / 4), w, (float *)dst->data, (int64_t)(dst->nb[1] / 4), act_bf16, (int)n, (int)rows, eps)
+#define NORM_PLANES(KZ) do { if (n > 4096) NORM_PLANES_NT(KZ, 512); else NORM_PLANES_NT(KZ, 256); } while (0)
         switch (kz) { case 1: NORM_PLANES(1); break; case 2: NORM_PLANES(2); break; case 3: NORM_PLANES(3); break; default: NORM_PLANES(4); break; }
 #undef NORM_PLANES
+#undef NORM_PLANES_NT
         MI355_CHECK_LAUNCH();
         return MI355_OK;
     }

@@ -354,7 +354,7 @@ def test_mul_mat_dq_parts_pair_has_the_bits_of_two_calls(ops, ta, tb, m, k, n):
     assert rc == -6
 
 
-@pytest.mark.parametrize("t,m,k,n", [(B.Q4_K, 4096, 4096, 512), (B.Q6_K, 4096, 14336, 512), (B.Q4_K, 4096, 4096, 2048), (B.Q8_0, 1024, 2816, 160), (B.Q4_K, 8192, 2048, 300)])
+@pytest.mark.parametrize("t,m,k,n", [(B.Q4_K, 4096, 4096, 512), (B.Q6_K, 4096, 14336, 512), (B.Q4_K, 4096, 4096, 2048), (B.Q8_0, 1024, 2816, 160), (B.Q4_K, 8192, 2048, 300), (B.Q4_K, 8192, 8192, 511)])
 def test_gemm_planes_into_add_rms_norm_have_the_bits_of_the_separate_launches(ops, t, m, k, n):
     """wo / ffn_down of a prefill batch: mi355_mul_mat_dq_parts + mi355_parts_add_rms_norm_mul_bf16_f32 (the norm kernel adds the K-slice
     planes on the way in) against mi355_mul_mat_dq + mi355_rms_norm_mul_bf16_f32 with the residual add: the sum, the normed rows and
