@@ -1197,7 +1197,8 @@ static void mi355_flash_attn(mi355_backend_ctx * ctx, ggml_tensor * dst) {
     // a workspace lets the KV range be split; only worth having for decode-sized batches
     void * ws = nullptr;
     int64_t ws_bytes = 0;
-    if (a.n_kv >= 128 && a.n_head_kv * a.n_q * a.ne3 < 512) {
+    // (decode-sized batches; and the 512-token ubatches of a long prompt, whose KV blocks are dealt to two workgroups per unit group)
+    if ((a.n_kv >= 128 && a.n_head_kv * a.n_q * a.ne3 < 512) || (a.n_q >= 32 && a.n_kv >= 1024 && (a.n_q + 31) / 32 * a.n_head * a.ne3 < 1024)) {
         ws_bytes = mi355_flash_attn_ext_workspace_bytes(&a);
         ws = ctx->get_scratch(1, (size_t)ws_bytes);
     }

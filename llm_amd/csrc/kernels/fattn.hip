@@ -33,6 +33,7 @@ struct FArgs {
     int * counters; // [ne3][n_q][gridDim.x] arrival counters of the KV slices (all zero between launches)
     int8_t * act_q; float * act_ds; // optional: q8_1 form of dst (token row = all heads), written with the result
     uint16_t * act_bf;              // optional (matrix-core kernel): bf16 form of dst, rows [ne3][n_q][n_head * d]
+    int kvs;                        // matrix-core kernel: KV blocks dealt to kvs workgroups per unit group (blockIdx.z % kvs), partials merged after
 #ifdef FA_STAMPS
     long long * stamps;             // diagnostic build only (lab/fattn_stamps.hip): [workgroup][8] s_memtime / s_memrealtime
 #endif
@@ -504,9 +505,11 @@ fattn_mma_kernel(const FArgs a) {
     const int ratio = a.n_head / a.n_head_kv;
     const int hpw = UNITS == 4 && ratio % 4 == 0 ? 4 : ratio % 2 == 0 ? 2 : 1;  // heads per workgroup (divides the GQA ratio)
     const int qpw = UNITS / hpw;                                              // 32-query blocks per workgroup
-    const int h = (int)blockIdx.y * hpw + wave % hpw, i3 = blockIdx.z;
+    const int kvs = SPLIT ? 1 : a.kvs, zs = SPLIT ? 0 : (int)blockIdx.z % kvs;    // this workgroup's share of the KV blocks: zs, zs + kvs, ...
+    const int h = (int)blockIdx.y * hpw + wave % hpw, i3 = (int)blockIdx.z / kvs;
     const int hk = h / ratio;
     const int q = ((int)blockIdx.x * qpw + wave / hpw) * 32 + lr;
+    const int KV_BEG = zs * BKV, KV_STEP = kvs * BKV;
     const int qc = q < a.n_q ? q : a.n_q - 1;
 
     // Q^T operand: this lane's query row, features 16 ks + 8 lh .. + 8, pre-scaled, f16
@@ -598,22 +601,22 @@ fattn_mma_kernel(const FArgs a) {
     // The mask loads run two blocks ahead (requested during block j-1, voted on at the top of block j for block j+1), so the
     // vote does not wait on memory either.
     mh4 mcur[2][4], mnxt[2][4], mnx2[2][4];
-    issue_mask(koff, mnxt);
-    bool any_n = mask_any(mnxt);
+    issue_mask(KV_BEG + koff, mnxt);
+    bool any_n = KV_BEG < a.n_kv ? mask_any(mnxt) : false;
     bool wg_n = __syncthreads_or(any_n);
-    if (wg_n) issue(0);
-    issue_mask(BKV + koff, mnx2);                           // (rows past n_kv read as -inf without touching memory)
-    for (int kv0 = 0; kv0 < a.n_kv; kv0 += BKV) {
+    if (wg_n) issue(KV_BEG);
+    issue_mask(KV_BEG + KV_STEP + koff, mnx2);              // (rows past n_kv read as -inf without touching memory)
+    for (int kv0 = KV_BEG; kv0 < a.n_kv; kv0 += KV_STEP) {
         const bool wg = wg_n, any = any_n;
 #pragma unroll
         for (int t = 0; t < 2; t++)
 #pragma unroll
             for (int g = 0; g < 4; g++) { mcur[t][g] = mnxt[t][g]; mnxt[t][g] = mnx2[t][g]; }
-        any_n = kv0 + BKV < a.n_kv ? mask_any(mnxt) : false;
+        any_n = kv0 + KV_STEP < a.n_kv ? mask_any(mnxt) : false;
         wg_n = __syncthreads_or(any_n);                     // (also: the previous block is fully consumed, the tiles are free)
         if (wg) commit();
-        if (wg_n) issue(kv0 + BKV);
-        issue_mask(kv0 + 2 * BKV + koff, mnx2);
+        if (wg_n) issue(kv0 + KV_STEP);
+        issue_mask(kv0 + 2 * KV_STEP + koff, mnx2);
         if (!wg) continue;
         __syncthreads();
         if (!__any(any)) continue;     // whole tile masked out for every query of this wave (uniform per wave; every wave still
@@ -717,6 +720,19 @@ fattn_mma_kernel(const FArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; r++) o[i][r] = o[i][r] * c0 + X[(i * 16 + r) * 64 + lane] * c1;
     }
+    if (!SPLIT && kvs > 1) {
+        // partial state of this share of the KV blocks: (O unnormalised, m in the log2 domain, l) per (token, head); fattn_mma_merge_kernel adds them
+        if (q < a.n_q) {
+            float * pp = a.part + ((((int64_t)i3 * a.n_q + q) * a.n_head + h) * kvs + zs) * (D + 4);      // 16-byte aligned rows
+#pragma unroll
+            for (int i = 0; i < DT; i++)
+#pragma unroll
+                for (int g = 0; g < 4; g++)
+                    *(v4f *)(pp + 32 * i + 8 * g + 4 * lh) = v4f{o[i][4 * g], o[i][4 * g + 1], o[i][4 * g + 2], o[i][4 * g + 3]};
+            if (lh == 0) { pp[D] = m; pp[D + 1] = l; }
+        }
+        return;
+    }
     if (q < a.n_q) {
         const float inv = 1.0f / l;
         float * op = (float *)(a.dst + (int64_t)h * a.d_nb1 + (int64_t)q * a.d_nb2 + (int64_t)i3 * a.d_nb3);
@@ -735,9 +751,55 @@ fattn_mma_kernel(const FArgs a) {
     }
 }
 
+// merge of the kvs partial states of every (token, head) row: O = sum_s O_s 2^(m_s - M) / sum_s l_s 2^(m_s - M); one lane per 4 features
+template <int D>
+__global__ void __launch_bounds__(256)
+fattn_mma_merge_kernel(const FArgs a, int64_t rows) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t row = i / (D / 4);
+    const int d4 = (int)(i % (D / 4));
+    if (row >= rows) return;
+    const float * pp = a.part + row * a.kvs * (D + 4);
+    float M = -INFINITY;
+    for (int s = 0; s < a.kvs; s++) M = fmaxf(M, pp[s * (D + 4) + D]);
+    const float msafe = M == -INFINITY ? 0.0f : M;
+    v4f O = {0.0f, 0.0f, 0.0f, 0.0f};
+    float L = 0.0f;
+    for (int s = 0; s < a.kvs; s++) {
+        const float w = __builtin_amdgcn_exp2f(pp[s * (D + 4) + D] - msafe);      // -inf -> 0
+        L += pp[s * (D + 4) + D + 1] * w;
+        O = O + *(const v4f *)(pp + s * (D + 4) + 4 * d4) * w;
+    }
+    const float inv = 1.0f / L;
+    const v4f v = O * inv;
+    const int h = (int)(row % a.n_head);
+    const int64_t t = row / a.n_head;
+    const int q = (int)(t % a.n_q), i3 = (int)(t / a.n_q);
+    *(v4f *)((float *)(a.dst + (int64_t)h * a.d_nb1 + (int64_t)q * a.d_nb2 + (int64_t)i3 * a.d_nb3) + 4 * d4) = v;
+    if (a.act_bf) {
+        typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
+        const bf4 b = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+        *(bf4 *)(a.act_bf + row * D + 4 * d4) = b;
+    }
+}
+
 template <int D>
 static int launch_mma(const FArgs & a, int tkv, hipStream_t s) {
     const int ratio = a.n_head / a.n_head_kv;
+    if (a.kvs > 1) {
+        // KV blocks dealt to kvs workgroups per group of 4 units (the loop is bound by the CU's global-load rate, ~11 B/clk: the bytes
+        // a CU stages per query row are what counts -- half the KV rows for twice the queries of the two-wave form), merged afterwards
+        const int hpw = ratio % 4 == 0 ? 4 : ratio % 2 == 0 ? 2 : 1, qpw = MMA_WAVES / hpw, bq = 32 * qpw;
+        const dim3 grid((unsigned)((a.n_q + bq - 1) / bq), (unsigned)(a.n_head / hpw), (unsigned)(a.ne3 * a.kvs));
+        if (tkv == MI355_TYPE_F16)       MI355_LAUNCH("fattn_mma", (fattn_mma_kernel<D, MI355_TYPE_F16>), grid, dim3(MMA_THREADS), 0, s, a);
+        else if (tkv == MI355_TYPE_Q8_0) MI355_LAUNCH("fattn_mma", (fattn_mma_kernel<D, MI355_TYPE_Q8_0>), grid, dim3(MMA_THREADS), 0, s, a);
+        else                             MI355_LAUNCH("fattn_mma", (fattn_mma_kernel<D, MI355_TYPE_Q4_0>), grid, dim3(MMA_THREADS), 0, s, a);
+        MI355_CHECK_LAUNCH();
+        const int64_t rows = (int64_t)a.ne3 * a.n_q * a.n_head;
+        MI355_LAUNCH("fattn_merge", fattn_mma_merge_kernel<D>, dim3((unsigned)((rows * (D / 4) + 255) / 256)), dim3(256), 0, s, a, rows);
+        MI355_CHECK_LAUNCH();
+        return MI355_OK;
+    }
     // fewer (head, 32-query) units than SIMDs, and more than one KV step each: two waves per unit (MI355_FA_MMA_SPLIT=0: never)
     static const int split_on = [] { const char * e = getenv("MI355_FA_MMA_SPLIT"); return e ? atoi(e) : 1; }();
     const int64_t units = (int64_t)((a.n_q + 31) / 32) * a.n_head * a.ne3;
@@ -835,8 +897,9 @@ constexpr int64_t WS_HEADER = 65536;
 
 int64_t mi355_flash_attn_ext_workspace_bytes(const mi355_fattn_args * p) {
     if (!p) return -1;
-    // header + partials for the largest split the launcher may choose
-    return WS_HEADER + (int64_t)p->ne3 * p->n_q * p->n_head * 64 * (p->d + 2) * (int64_t)sizeof(float);
+    // header + partials for the largest split the launcher may choose: 64 slices for the vec kernel, 8 shares for the matrix-core one
+    const int64_t slices = p->n_q >= 32 ? 8 : 64;
+    return WS_HEADER + (int64_t)p->ne3 * p->n_q * p->n_head * slices * (p->d + (p->n_q >= 32 ? 4 : 2)) * (int64_t)sizeof(float);
 }
 
 int mi355_flash_attn_ext(const mi355_fattn_args * p, void * workspace, int64_t workspace_bytes, void * stream) {
@@ -870,7 +933,7 @@ static int fattn_run(const mi355_fattn_args * p, void * workspace, int64_t works
     if (p->n_q == 0 || p->n_head == 0) return MI355_OK;
 
     FArgs a;
-    a.act_q = act_q; a.act_ds = act_ds; a.act_bf = nullptr; a.counters = nullptr;
+    a.act_q = act_q; a.act_ds = act_ds; a.act_bf = nullptr; a.counters = nullptr; a.kvs = 1;
     a.q = (const char *)p->q; a.q_nb1 = p->q_nb1; a.q_nb2 = p->q_nb2; a.q_nb3 = p->q_nb3;
     a.k = (const char *)p->k; a.k_nb1 = p->k_nb1; a.k_nb2 = p->k_nb2; a.k_nb3 = p->k_nb3;
     a.v = (const char *)p->v; a.v_nb1 = p->v_nb1; a.v_nb2 = p->v_nb2; a.v_nb3 = p->v_nb3;
@@ -888,7 +951,18 @@ static int fattn_run(const mi355_fattn_args * p, void * workspace, int64_t works
         !(p->max_bias > 0.0f) && p->logit_softcap == 0.0f && p->n_head <= 65535 && p->ne3 <= 65535 &&
         ((p->d_nb1 | p->d_nb2 | p->d_nb3 | (int64_t)(uintptr_t)p->dst) & 15) == 0 && (!p->mask || (p->m_nb1 & 1) == 0)) {
         if (act_q) return MI355_E_UNSUPPORTED;   // the fused q8_1 output exists for decode-sized batches only
-        a.nsplit = 1; a.part = nullptr; a.act_bf = act_bf;
+        a.nsplit = 1; a.part = nullptr; a.act_bf = act_bf; a.kvs = 1;
+        // fewer units than SIMDs (a 512-token ubatch) against a long context: deal the KV blocks to 4 workgroups per unit group (two per CU)
+        // (MI355_FA_KVS: shares, 0 = never; MI355_FA_KVS_MIN: shortest context, default 1024)
+        static const int kvs_env = [] { const char * e = getenv("MI355_FA_KVS"); return e ? atoi(e) : 4; }();
+        static const int kvs_min = [] { const char * e = getenv("MI355_FA_KVS_MIN"); return e ? atoi(e) : 1024; }();
+        const int64_t units = (int64_t)((p->n_q + 31) / 32) * p->n_head * p->ne3;
+        const int64_t part_bytes = (int64_t)p->ne3 * p->n_q * p->n_head * kvs_env * (p->d + 4) * (int64_t)sizeof(float);
+        if (kvs_env > 1 && kvs_env <= 8 && units < 1024 && p->n_kv >= kvs_min && workspace && ((uintptr_t)workspace & 15) == 0 &&
+            workspace_bytes >= WS_HEADER + part_bytes && p->ne3 * kvs_env <= 65535) {
+            a.kvs = kvs_env;
+            a.part = (float *)((char *)workspace + WS_HEADER);
+        }
         return p->d == 128 ? launch_mma<128>(a, p->type_k, (hipStream_t)stream) : launch_mma<64>(a, p->type_k, (hipStream_t)stream);
     }
     if (act_bf) return MI355_E_UNSUPPORTED;      // the bf16 copy exists for the matrix-core kernel only

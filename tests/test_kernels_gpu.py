@@ -904,7 +904,9 @@ def test_flash_attn_golden(ops, tag):
                                                       (64, 8, 8, 1, 9000, False), (128, 32, 8, 1, 1000, True),
                                                       # prefill tile kernel: GQA 2 (two heads x two query blocks per workgroup), GQA 3 (one head x four),
                                                       # a long causal prompt whose upper-triangle blocks are never staged
-                                                      (128, 4, 2, 70, 130, True), (128, 6, 2, 50, 90, True), (128, 8, 2, 700, 700, True)])
+                                                      (128, 4, 2, 70, 130, True), (128, 6, 2, 50, 90, True), (128, 8, 2, 700, 700, True),
+                                                      # a 512-token ubatch late in a long prompt: KV blocks dealt to two workgroups per unit group + merge
+                                                      (128, 32, 8, 512, 2048, True), (64, 8, 2, 100, 1100, True), (128, 6, 2, 33, 1029, False)])
 def test_flash_attn_f16_vs_f64_oracle(ops, d, nh, nhkv, nq, nkv, causal):
     """prefill shapes take the matrix-core tile kernel (n_q >= 32), decode shapes the split-KV vec kernel; both
     against the oracle's double-precision evaluation of the op on the same f16 K/V."""
@@ -963,7 +965,8 @@ def test_flash_attn_fused_q8_1_output(ops, nq, nkv, use_ws):
     assert torch.equal(aq, aq2) and torch.equal(ads.view(torch.int32), ads2.view(torch.int32))
 
 
-@pytest.mark.parametrize("tkv,d,nh,nhkv,nq,nkv", [(B.F16, 128, 32, 8, 512, 512), (B.F16, 128, 6, 2, 50, 90), (B.Q8_0, 64, 4, 4, 130, 333), (B.F16, 128, 8, 2, 8, 300)])
+@pytest.mark.parametrize("tkv,d,nh,nhkv,nq,nkv", [(B.F16, 128, 32, 8, 512, 512), (B.F16, 128, 6, 2, 50, 90), (B.Q8_0, 64, 4, 4, 130, 333), (B.F16, 128, 8, 2, 8, 300),
+                                                  (B.F16, 128, 32, 8, 512, 1536)])
 def test_flash_attn_fused_bf16_output(ops, tkv, d, nh, nhkv, nq, nkv):
     """mi355_flash_attn_ext_bf16 (prefill): dst equals the plain call bit for bit and the bf16 rows equal mi355_act_bf16(dst); ragged
     query blocks; a decode-sized batch (vec kernel) is refused, not served by something else."""
