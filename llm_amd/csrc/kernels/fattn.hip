@@ -512,23 +512,6 @@ fattn_mma_kernel(const FArgs a) {
     const int KV_BEG = zs * BKV, KV_STEP = kvs * BKV;
     const int qc = q < a.n_q ? q : a.n_q - 1;
 
-    // Q^T operand: this lane's query row, features 16 ks + 8 lh .. + 8, pre-scaled, f16
-    // (the scores live in the log2 domain: Q carries scale * log2(e), the mask is multiplied by log2(e) when it is added, and
-    // the exponentials are bare v_exp_f32)
-    constexpr float LOG2E = 1.4426950408889634f;
-    const float qs = a.scale * LOG2E;
-    half8 qf[KS];
-    {
-        const float * qp = (const float *)(a.q + (int64_t)qc * a.q_nb1 + (int64_t)h * a.q_nb2 + (int64_t)i3 * a.q_nb3);
-#pragma unroll
-        for (int ks = 0; ks < KS; ks++) {
-            const v4f x0 = *(const v4f *)(qp + 16 * ks + 8 * lh), x1 = *(const v4f *)(qp + 16 * ks + 8 * lh + 4);
-            qf[ks][0] = (_Float16)(x0.x * qs); qf[ks][1] = (_Float16)(x0.y * qs);
-            qf[ks][2] = (_Float16)(x0.z * qs); qf[ks][3] = (_Float16)(x0.w * qs);
-            qf[ks][4] = (_Float16)(x1.x * qs); qf[ks][5] = (_Float16)(x1.y * qs);
-            qf[ks][6] = (_Float16)(x1.z * qs); qf[ks][7] = (_Float16)(x1.w * qs);
-        }
-    }
     const __half * mrow = a.mask ? (const __half *)(a.mask + (int64_t)qc * a.m_nb1 + (int64_t)(h % a.m_ne2) * a.m_nb2 +
                                                     (int64_t)(i3 % a.m_ne3) * a.m_nb3) : nullptr;
     const char * kbase = a.k + (int64_t)hk * a.k_nb2 + (int64_t)i3 * a.k_nb3;
@@ -601,11 +584,31 @@ fattn_mma_kernel(const FArgs a) {
     // The mask loads run two blocks ahead (requested during block j-1, voted on at the top of block j for block j+1), so the
     // vote does not wait on memory either.
     mh4 mcur[2][4], mnxt[2][4], mnx2[2][4];
+    // prologue: the first K/V rows, the first two mask tiles and the queries are all requested before anything waits -- one memory
+    // round trip instead of three (queries -> mask vote -> K/V).  The first block is fetched without asking the mask: it is almost
+    // never masked out for a whole workgroup, and a wasted fetch costs less than a round trip.
+    if (KV_BEG < a.n_kv) issue(KV_BEG);
     issue_mask(KV_BEG + koff, mnxt);
+    issue_mask(KV_BEG + KV_STEP + koff, mnx2);              // (rows past n_kv read as -inf without touching memory)
+    // Q^T operand: this lane's query row, features 16 ks + 8 lh .. + 8, pre-scaled, f16
+    // (the scores live in the log2 domain: Q carries scale * log2(e), the mask is multiplied by log2(e) when it is added, and
+    // the exponentials are bare v_exp_f32)
+    constexpr float LOG2E = 1.4426950408889634f;
+    const float qs = a.scale * LOG2E;
+    half8 qf[KS];
+    {
+        const float * qp = (const float *)(a.q + (int64_t)qc * a.q_nb1 + (int64_t)h * a.q_nb2 + (int64_t)i3 * a.q_nb3);
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) {
+            const v4f x0 = *(const v4f *)(qp + 16 * ks + 8 * lh), x1 = *(const v4f *)(qp + 16 * ks + 8 * lh + 4);
+            qf[ks][0] = (_Float16)(x0.x * qs); qf[ks][1] = (_Float16)(x0.y * qs);
+            qf[ks][2] = (_Float16)(x0.z * qs); qf[ks][3] = (_Float16)(x0.w * qs);
+            qf[ks][4] = (_Float16)(x1.x * qs); qf[ks][5] = (_Float16)(x1.y * qs);
+            qf[ks][6] = (_Float16)(x1.z * qs); qf[ks][7] = (_Float16)(x1.w * qs);
+        }
+    }
     bool any_n = KV_BEG < a.n_kv ? mask_any(mnxt) : false;
     bool wg_n = __syncthreads_or(any_n);
-    if (wg_n) issue(KV_BEG);
-    issue_mask(KV_BEG + KV_STEP + koff, mnx2);              // (rows past n_kv read as -inf without touching memory)
     for (int kv0 = KV_BEG; kv0 < a.n_kv; kv0 += KV_STEP) {
         const bool wg = wg_n, any = any_n;
 #pragma unroll
