@@ -463,6 +463,12 @@ MI355_API int mi355_rms_norm_mul_bf16_f32(const mi355_tensor *a, const mi355_ten
                                           const mi355_tensor *dst, float eps, uint16_t *act_bf16, void *stream);
 MI355_API int mi355_glu_bf16_f32(int glu_op, const mi355_tensor *a, const mi355_tensor *b, const mi355_tensor *dst, int swapped,
                                  uint16_t *act_bf16, void *stream);
+/* the fused norm for batches of 4..32 rows whose consumers are the K-quant skinny kernels: dst = rms_norm(a [+ b]) * w (sum = a + b
+ * also stored when b is given) plus the q8_K planes of dst (mi355_quantize_act_q8k layout and arithmetic: act_q int8 [rows][ne0],
+ * act_d f32 [rows][ne0 / 256], act_bsums int16 [rows][ne0 / 16]).  ne0 % 256 == 0, rows of at most 8192 values, 16-byte aligned,
+ * else MI355_E_UNSUPPORTED.  Replaces a norm launch + a quantization launch (norm.cu + quantize.cu in the reference). */
+MI355_API int mi355_rms_norm_mul_q8k_f32(const mi355_tensor *a, const mi355_tensor *b, const mi355_tensor *sum, const float *w,
+                                         const mi355_tensor *dst, float eps, int8_t *act_q, float *act_d, int16_t *act_bsums, void *stream);
 /* mi355_rms_norm_mul_bf16_f32 whose first addend is still the kz K-slice planes of the GEMM that produces it (mi355_mul_mat_dq_parts:
  * [kz][rows][ne0] f32, rows and ne0 those of `sum`): sum = ((p0 + p1) + ...) + b, dst = rms_norm(sum) * w, act_bf16 = bf16(dst).
  * MUL_MAT(wo / ffn_down) -> ADD(residual) -> RMS_NORM -> MUL without the slice-sum launch and without the product crossing HBM

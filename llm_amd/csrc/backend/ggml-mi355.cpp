@@ -1303,8 +1303,33 @@ static bool mi355_try_fuse_rms_norm_mul(mi355_backend_ctx * ctx, ggml_cgraph * c
     float eps;
     memcpy(&eps, norm->op_params, sizeof(float));
     mi355_tensor tx = to_mi355_tensor(x), td = to_mi355_tensor(mul);
-    // decode-sized rows: also emit the q8_1 form for the MUL_MATs that read the result
     const int64_t rows = ggml_nrows(mul), K = mul->ne[0];
+    // batches whose MUL_MATs take the K-quant skinny kernels (5..32 rows; the first MUL_MAT that reads the result tells): also emit
+    // the q8_K planes they read, instead of a quantization launch per batch and norm (126 such launches in a 16-token 8B step)
+    if (!gemm && rows > 1 && rows <= 64 && K % 256 == 0 && K <= 8192 && ggml_is_contiguous(mul) && !MI355_ENV_SET("GGML_MI355_NO_NORM_Q8K")) {
+        const int nn = ggml_graph_n_nodes(cgraph);
+        int fmt = -1;
+        for (int j = i + 2; j < nn && j < i + 16 && fmt < 0; j++) {
+            const ggml_tensor * t = ggml_graph_node(cgraph, j);
+            if (t->op == GGML_OP_MUL_MAT && t->src[1] == mul && !tensor_is_split(t->src[0])) fmt = mm_path_fmt(mi355_mul_mat_path(t->src[0], mul));
+        }
+        if (fmt == 2) {
+            const mi355_act_layout L = mi355_act_planes(MM_SKINNY_K, K, rows);
+            char * ws = (char *)ctx->get_scratch(0, L.total());
+            mi355_tensor ta = to_mi355_tensor(add ? add->src[0] : x), tb, ts;
+            if (add) { tb = to_mi355_tensor(add->src[1]); ts = to_mi355_tensor(add); }
+            const int rc = mi355_rms_norm_mul_q8k_f32(&ta, add ? &tb : nullptr, add ? &ts : nullptr, (const float *)w->data, &td, eps,
+                                                      (int8_t *)ws, (float *)(ws + L.b0), (int16_t *)(ws + L.b0 + L.b1), ctx->stream);
+            if (rc == MI355_OK) {
+                if (add) ctx->act_invalidate_if_written(add);
+                ctx->act_invalidate_if_written(mul);
+                ctx->act_remember(mul, 2);
+                return true;
+            }
+            if (rc != MI355_E_UNSUPPORTED) MI_CHECK(rc);
+        }
+    }
+    // decode-sized rows: also emit the q8_1 form for the MUL_MATs that read the result
     const bool quant = rows <= 8 && K % 32 == 0 && K <= 8192 && ggml_is_contiguous(mul);
     int8_t * aq = nullptr; float * ads = nullptr;
     if (quant) {

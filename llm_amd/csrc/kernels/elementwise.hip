@@ -74,6 +74,40 @@ binary_kernel(const T4 a, const T4 b, const T4 d, int64_t n) {
     }
 }
 
+// q8_K planes (quantize_row_q8_K_ref, ggml-quants.c:2471-2508; the arithmetic of quant_q8k_kernel in mmsk.hip) of 16 consecutive
+// values per lane: the 16 lanes of a DPP row own one 256-value block (amax and the first element that attains it are reduced
+// over the row), a lane's 16 values are exactly one bsums entry.  All 16 lanes of a row must be active.
+static __device__ __forceinline__ void quant16_q8k(const float (&o)[16], int8_t * q16, float * d_blk, int16_t * bs1, int lane16) {
+    float ax = 0.0f, mine = 0.0f;
+    int idx = 0;
+#pragma unroll
+    for (int j = 0; j < 16; j++) { const float t = fabsf(o[j]); if (t > ax) { ax = t; idx = j; mine = o[j]; } }
+    float amax = ax;
+#pragma unroll
+    for (int m = 8; m > 0; m >>= 1) amax = fmaxf(amax, __shfl_xor(amax, m, 16));
+    int first = ax == amax ? lane16 * 16 + idx : 1024;          // first occurrence on ties (the reference scans with a strict >)
+#pragma unroll
+    for (int m = 8; m > 0; m >>= 1) first = min(first, __shfl_xor(first, m, 16));
+    const float maxv = __shfl(mine, (first >> 4) & 15, 16);
+    int packed[4] = {0, 0, 0, 0}, sum = 0;
+    float d = 0.0f;
+    if (amax != 0.0f) {
+        const float iscale = __fdiv_rn(-127.0f, maxv);
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const float val = __fadd_rn(__fmul_rn(iscale, o[j]), 12582912.0f);      // nearest_int, ggml-quants.c:559-565
+            int qi = (__float_as_int(val) & 0x007fffff) - 0x00400000;
+            qi = qi < 127 ? qi : 127;
+            sum += qi;
+            packed[j >> 2] |= (qi & 0xff) << (8 * (j & 3));
+        }
+        d = __fdiv_rn(1.0f, iscale);
+    }
+    *(v4i *)q16 = v4i{packed[0], packed[1], packed[2], packed[3]};
+    *bs1 = (int16_t)sum;
+    if (lane16 == 0) *d_blk = d;
+}
+
 // ---------------------------------------------------------------- rms norm (one block per row)
 // y = x * rsqrt(mean(x^2) + eps) [* w]: the row is read once with 128-bit loads and kept in registers
 // (rows up to 8192 floats); rows that are longer or not 16-byte aligned take the two-pass path.
@@ -84,7 +118,9 @@ template <bool HAS_W, bool HAS_ADD, int NT>
 __global__ void __launch_bounds__(NT)
 rms_norm_kernel(const T4 x, const T4 y, const T4 sum, const float * __restrict__ w, const T4 d, float eps, bool vec,
                 int8_t * __restrict__ aq, float * __restrict__ ads, uint16_t * __restrict__ abf,
-                const float * __restrict__ xparts, int kz) {
+                const float * __restrict__ xparts, int kz, int16_t * __restrict__ kbs) {
+    // kbs: the quantized form is q8_K planes (aq = int8 [rows][n], ads = d [rows][n / 256], kbs = bsums [rows][n / 16]) for the K-quant
+    // skinny kernels of 4..32-column batches, instead of q8_1 (n % 256 == 0)
     // xparts: x is not in memory yet -- it is the sum of kz planes [kz][rows][n] (the K slices of the GEMM that produces it,
     // mi355_mul_mat_dq_parts), added here in slice order as kz_sum_kernel would have (16-value-chunk path only; x.data is not read)
     __shared__ float sh[NT / 64];
@@ -140,7 +176,8 @@ rms_norm_kernel(const T4 x, const T4 y, const T4 sum, const float * __restrict__
                     ((v4f *)dr)[4 * c + q] = t;
                     o[4 * q] = t.x; o[4 * q + 1] = t.y; o[4 * q + 2] = t.z; o[4 * q + 3] = t.w;
                 }
-                if (aq) quant16_soa(o, aq + (int64_t)row * n + 16 * c, ads + ((int64_t)row * (n / QK) + (c >> 1)) * 2, (c & 1) == 0);
+                if (aq && kbs) quant16_q8k(o, aq + (int64_t)row * n + 16 * c, ads + (int64_t)row * (n >> 8) + (c >> 4), kbs + (int64_t)row * (n >> 4) + c, c & 15);
+                else if (aq) quant16_soa(o, aq + (int64_t)row * n + 16 * c, ads + ((int64_t)row * (n / QK) + (c >> 1)) * 2, (c & 1) == 0);
                 if (abf) {      // bf16 form of the row for the prefill GEMM (the rounding of mi355_act_bf16)
                     typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
                     bf8 b0, b1;
@@ -688,8 +725,9 @@ int mi355_binary_f32(int op, const mi355_tensor * a, const mi355_tensor * b, con
 
 static int launch_rms_norm(const mi355_tensor * x, const mi355_tensor * y, const mi355_tensor * sum, const float * w,
                            const mi355_tensor * dst, float eps, int8_t * aq, float * ads, void * stream, uint16_t * abf = nullptr,
-                           const float * xparts = nullptr, int kz = 0) {
+                           const float * xparts = nullptr, int kz = 0, int16_t * kbs = nullptr) {
     CHECK_T(x); CHECK_T(dst);
+    if (kbs && (!aq || !ads || !w || x->ne[0] % 256 != 0 || (((uintptr_t)aq | (uintptr_t)kbs) & 15) || ((uintptr_t)ads & 3))) return MI355_E_UNSUPPORTED;
     if (xparts && (!y || !abf || kz < 1 || kz > 8 || ((uintptr_t)xparts & 15) || x->ne[0] % 16 != 0)) return MI355_E_UNSUPPORTED;
     if (x->type != MI355_TYPE_F32 || dst->type != MI355_TYPE_F32) return MI355_E_TYPE;
     if (!same_shape(x, dst) || x->nb[0] != 4 || dst->nb[0] != 4) return MI355_E_SHAPE;
@@ -713,14 +751,14 @@ static int launch_rms_norm(const mi355_tensor * x, const mi355_tensor * y, const
     hipStream_t s = (hipStream_t)stream;
     if (x->ne[0] > 4096) {
         const dim3 block(512);
-        if (y)      MI355_LAUNCH("add_rms_norm_mul", (rms_norm_kernel<true, true, 512>), grid, block, 0, s, t4(x), t4(y), t4(sum), w, t4(dst), eps, vec, aq, ads, abf, xparts, kz);
-        else if (w) MI355_LAUNCH("rms_norm_mul", (rms_norm_kernel<true, false, 512>), grid, block, 0, s, t4(x), t4(x), t4(x), w, t4(dst), eps, vec, aq, ads, abf, nullptr, 0);
-        else        MI355_LAUNCH("rms_norm", (rms_norm_kernel<false, false, 512>), grid, block, 0, s, t4(x), t4(x), t4(x), w, t4(dst), eps, vec, aq, ads, abf, nullptr, 0);
+        if (y)      MI355_LAUNCH("add_rms_norm_mul", (rms_norm_kernel<true, true, 512>), grid, block, 0, s, t4(x), t4(y), t4(sum), w, t4(dst), eps, vec, aq, ads, abf, xparts, kz, kbs);
+        else if (w) MI355_LAUNCH("rms_norm_mul", (rms_norm_kernel<true, false, 512>), grid, block, 0, s, t4(x), t4(x), t4(x), w, t4(dst), eps, vec, aq, ads, abf, nullptr, 0, kbs);
+        else        MI355_LAUNCH("rms_norm", (rms_norm_kernel<false, false, 512>), grid, block, 0, s, t4(x), t4(x), t4(x), w, t4(dst), eps, vec, aq, ads, abf, nullptr, 0, (int16_t *)nullptr);
     } else {
         const dim3 block(256);
-        if (y)      MI355_LAUNCH("add_rms_norm_mul", (rms_norm_kernel<true, true, 256>), grid, block, 0, s, t4(x), t4(y), t4(sum), w, t4(dst), eps, vec, aq, ads, abf, xparts, kz);
-        else if (w) MI355_LAUNCH("rms_norm_mul", (rms_norm_kernel<true, false, 256>), grid, block, 0, s, t4(x), t4(x), t4(x), w, t4(dst), eps, vec, aq, ads, abf, nullptr, 0);
-        else        MI355_LAUNCH("rms_norm", (rms_norm_kernel<false, false, 256>), grid, block, 0, s, t4(x), t4(x), t4(x), w, t4(dst), eps, vec, aq, ads, abf, nullptr, 0);
+        if (y)      MI355_LAUNCH("add_rms_norm_mul", (rms_norm_kernel<true, true, 256>), grid, block, 0, s, t4(x), t4(y), t4(sum), w, t4(dst), eps, vec, aq, ads, abf, xparts, kz, kbs);
+        else if (w) MI355_LAUNCH("rms_norm_mul", (rms_norm_kernel<true, false, 256>), grid, block, 0, s, t4(x), t4(x), t4(x), w, t4(dst), eps, vec, aq, ads, abf, nullptr, 0, kbs);
+        else        MI355_LAUNCH("rms_norm", (rms_norm_kernel<false, false, 256>), grid, block, 0, s, t4(x), t4(x), t4(x), w, t4(dst), eps, vec, aq, ads, abf, nullptr, 0, (int16_t *)nullptr);
     }
     MI355_CHECK_LAUNCH();
     return MI355_OK;
@@ -739,6 +777,12 @@ int mi355_rms_norm_mul_quant_f32(const mi355_tensor * x, const float * w, const 
                                  int8_t * act_q, float * act_ds, void * stream) {
     if (!w || !act_q || !act_ds) return MI355_E_NULL;
     return launch_rms_norm(x, nullptr, nullptr, w, dst, eps, act_q, act_ds, stream);
+}
+
+int mi355_rms_norm_mul_q8k_f32(const mi355_tensor * a, const mi355_tensor * b, const mi355_tensor * sum, const float * w,
+                               const mi355_tensor * dst, float eps, int8_t * act_q, float * act_d, int16_t * act_bsums, void * stream) {
+    if (!w || !act_q || !act_d || !act_bsums || ((b == nullptr) != (sum == nullptr))) return MI355_E_NULL;
+    return launch_rms_norm(a, b, sum, w, dst, eps, act_q, act_d, stream, nullptr, nullptr, 0, act_bsums);
 }
 
 int mi355_add_rms_norm_mul_f32(const mi355_tensor * a, const mi355_tensor * b, const mi355_tensor * sum, const float * w,

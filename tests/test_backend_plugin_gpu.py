@@ -84,7 +84,7 @@ def _env_for(ngl):
 
 
 def _logits_vs_exact_twin(tmp_path, model, ftype, ctk="f16", extra=()):
-    """Logits (48-token prefill, 6 decode steps, batches of 3, 2 and 160 tokens) of the model's exact twin on ggml-cpu (the same
+    """Logits (48-token prefill, 6 decode steps, batches of 3, 2, 12 and 160 tokens) of the model's exact twin on ggml-cpu (the same
     random blocks stored dequantized as F32, make-random-gguf <ftype>+F32: f32 activations, nothing rounded but the f16 KV cache), of
     the model on ggml-cpu alone and of the model on MI355_0 -> NMSE (ggml-cpu vs twin, plugin vs twin, plugin vs ggml-cpu)."""
     import numpy as np
@@ -97,7 +97,7 @@ def _logits_vs_exact_twin(tmp_path, model, ftype, ctk="f16", extra=()):
         assert r.returncode == 0, r.stderr[-3000:]
         if name == "gpu":
             assert "MI355_0" in r.stdout, r.stdout[-500:]
-        outs[name] = np.fromfile(path, dtype=np.float32).reshape(10, -1)
+        outs[name] = np.fromfile(path, dtype=np.float32).reshape(11, -1)
     x, a, b = outs["exact"], outs["cpu"], outs["gpu"]
     assert np.isfinite(b).all()
     nmse = lambda u, v: float(((u - v) ** 2).sum() / (u ** 2).sum())
@@ -122,7 +122,7 @@ def _read_nodes(path):
 
 def test_moe_layers_are_as_close_to_the_exact_twin_as_ggml_cpu(tmp_path):
     """Layer-by-layer look at the FUSED Mixtral-style graph (the scheduler's eval callback dumps l_out-<layer>, the experts' weighted sum
-    and the router's choice for a 48-token prompt, 6 decode steps and batches of 3, 2 and 160 tokens).  Three runs: the model's exact
+    and the router's choice for a 48-token prompt, 6 decode steps and batches of 3, 2, 12 and 160 tokens).  Three runs: the model's exact
     twin (F32 weights, ggml-cpu), the model on ggml-cpu alone, the model on MI355_0.  The routing is discrete and the random model is
     chaotic, so ggml-cpu itself drifts from the twin layer by layer; per layer, the plugin's drift (NMSE of l_out and of ffn_moe_out
     over all steps) and its count of expert choices that differ from the twin's must not exceed ggml-cpu's by more than a quarter.
@@ -165,7 +165,7 @@ def test_moe_layers_are_as_close_to_the_exact_twin_as_ggml_cpu(tmp_path):
 @pytest.mark.parametrize("ftype,ctk", [("Q4_K_M", "f16"), ("Q8_0", "q8_0"), ("Q4_0", "f16"), ("Q4_1", "f16"), ("Q5_0", "f16"), ("Q5_1", "f16"), ("F16", "f16")])
 def test_llama_logits_match_ggml_cpu(ftype, ctk, tmp_path):
     """Whole-graph parity (covers the backend's fusions, which test-backend-ops cannot see): logits of a 48-token prefill, 6 decode
-    steps and batches of 3, 2 and 160 tokens on MI355_0 vs the same model on the reference's ggml-cpu.  Both round the activations
+    steps and batches of 3, 2, 12 and 160 tokens on MI355_0 vs the same model on the reference's ggml-cpu.  Both round the activations
     of every MUL_MAT (ggml-cpu to q8_K / q8_0 / q8_1 per its vec_dot_type, the plugin to q8_1 or bf16), so neither is "the" answer:
     the yardstick is the model's exact twin -- the same random blocks stored dequantized as F32 (make-random-gguf <ftype>+F32), run
     on ggml-cpu with f32 activations.  The plugin has to be as close to the twin as ggml-cpu is, and close to ggml-cpu."""

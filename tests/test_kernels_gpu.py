@@ -818,6 +818,39 @@ def test_norm_and_glu_bf16_forms(ops, rows, n, with_add):
     assert torch.equal(g0.view(torch.int32), g1.view(torch.int32)) and torch.equal(bf, ops.act_bf16(g1))
 
 
+@pytest.mark.parametrize("rows,n,with_add", [(16, 4096, True), (5, 4096, False), (32, 8192, True), (12, 256, False), (7, 1024, True)])
+def test_norm_q8k_form(ops, rows, n, with_add):
+    """5..32-row batches: mi355_rms_norm_mul_q8k_f32 == the plain kernels bit for bit, and its q8_K planes (quants, block
+    scales, sums of 16) == mi355_quantize_act_q8k of that f32 result. One row holds a zero block and a repeated maximum."""
+    import llm_amd.kernels as K
+    rng = np.random.default_rng(rows * 7 + n)
+    xh = rng.standard_normal((rows, n)).astype(np.float32)
+    yh = rng.standard_normal((rows, n)).astype(np.float32)
+    xh[1, :256] = 0.0; yh[1, :256] = 0.0                 # a block of zeros: d = 0, all quants 0
+    xh[2, 5] = xh[2, 77] = 9.0; yh[2, 5] = yh[2, 77] = 0.0    # |max| twice in one block: the first occurrence gives the sign
+    if n > 256:
+        xh[2, 300] = 9.0; xh[2, 400] = -9.0; yh[2, 300] = yh[2, 400] = 0.0
+    x, y = dev(xh), dev(yh)
+    w = dev(np.ones(n, dtype=np.float32) if rows == 7 else rng.standard_normal(n).astype(np.float32))
+    T, s = K.Tensor.of, torch.cuda.current_stream().cuda_stream
+    su0, d0, su1, d1 = (torch.empty_like(x) for _ in range(4))
+    q = torch.empty((rows, n), dtype=torch.int8, device="cuda")
+    d = torch.empty((rows, n // 256), dtype=torch.float32, device="cuda")
+    bs = torch.empty((rows, n // 16), dtype=torch.int16, device="cuda")
+    if with_add:
+        K.check(K.lib.mi355_add_rms_norm_mul_f32(T(x), T(y), T(su0), w.data_ptr(), T(d0), 1e-5, None, None, s), "add_rms_norm_mul")
+        K.check(K.lib.mi355_rms_norm_mul_q8k_f32(T(x), T(y), T(su1), w.data_ptr(), T(d1), 1e-5, q.data_ptr(), d.data_ptr(), bs.data_ptr(), s), "q8k")
+        assert torch.equal(su0.view(torch.int32), su1.view(torch.int32))
+    else:
+        K.check(K.lib.mi355_rms_norm_mul_f32(T(x), w.data_ptr(), T(d0), 1e-5, s), "rms_norm_mul")
+        K.check(K.lib.mi355_rms_norm_mul_q8k_f32(T(x), None, None, w.data_ptr(), T(d1), 1e-5, q.data_ptr(), d.data_ptr(), bs.data_ptr(), s), "q8k")
+    assert torch.isfinite(d1).all() and torch.equal(d0.view(torch.int32), d1.view(torch.int32))
+    rq, rd, rbs = ops.quantize_act_q8k(d1)
+    assert torch.equal(q, rq.view(rows, n))
+    assert torch.equal(d.view(torch.int32), rd.view(rows, n // 256).view(torch.int32))
+    assert torch.equal(bs, rbs.view(rows, n // 16))
+
+
 @pytest.mark.parametrize("rows,n", [(1, 4096), (3, 1024), (8, 8192), (2, 96), (1, 4128)])
 @pytest.mark.parametrize("with_add", [False, True])
 def test_fused_norm_matches_separate_ops(ops, rows, n, with_add):

@@ -132,7 +132,7 @@ int main(int argc, char ** argv) {
     const int n_vocab = llama_vocab_n_tokens(llama_model_get_vocab(model));
 
     llama_context_params cp = llama_context_default_params();
-    cp.n_ctx = std::max(n_prompt + n_gen, 256) + (dump_path.empty() ? 0 : 96 + big_batch + dump_steps);
+    cp.n_ctx = std::max(n_prompt + n_gen, 256) + (dump_path.empty() ? 0 : 112 + big_batch + dump_steps);
     cp.n_batch = n_batch; cp.n_ubatch = n_ubatch;
     cp.n_threads = threads; cp.n_threads_batch = threads;
     cp.flash_attn = fa != 0;
@@ -159,8 +159,8 @@ int main(int argc, char ** argv) {
     srand(1234);
     if (!dump_path.empty()) {
         // parity mode: a fixed 48-token prompt in one batch, then 6 single-token decodes fed with fixed tokens, then two
-        // small batches (3 and 2 tokens: the multi-column mat-vec path) and one of 160 tokens (--big-batch; the prefill GEMM path and its
-        // fused bf16 producers); the logits of the last prompt token and of the last token of every later step are written
+        // small batches (3 and 2 tokens: the multi-column mat-vec path), one of 12 tokens (the skinny kernels and the q8_K planes
+        // written by the norm kernel) and one of 160 tokens (--big-batch; the prefill GEMM path and its fused bf16 producers); the logits of the last prompt token and of the last token of every later step are written
         // as raw f32
         std::vector<llama_token> prompt(48);
         for (size_t i = 0; i < prompt.size(); i++) prompt[i] = (llama_token)((i * 7919 + 13) % n_vocab);
@@ -173,7 +173,7 @@ int main(int argc, char ** argv) {
             if (llama_decode(ctx, llama_batch_get_one(&tok, 1)) != 0) return 1;
             fwrite(llama_get_logits_ith(ctx, -1), sizeof(float), n_vocab, f);
         }
-        for (int nb : {3, 2, big_batch}) {
+        for (int nb : {3, 2, 12, big_batch}) {
             std::vector<llama_token> toks(nb);
             for (int t = 0; t < nb; t++) toks[t] = (llama_token)(((long long)t * 15485863 + nb * 31) % n_vocab);
             if (llama_decode(ctx, llama_batch_get_one(toks.data(), nb)) != 0) return 1;
@@ -181,7 +181,7 @@ int main(int argc, char ** argv) {
         }
         fclose(f);
         if (nd.bin) { fclose(nd.bin); fclose(nd.idx); }
-        printf("{\"dumped\": \"%s\", \"n_vocab\": %d, \"rows\": %d, \"devices\": \"%s\"}\n", dump_path.c_str(), n_vocab, 4 + dump_steps, devs.c_str());
+        printf("{\"dumped\": \"%s\", \"n_vocab\": %d, \"rows\": %d, \"devices\": \"%s\"}\n", dump_path.c_str(), n_vocab, 5 + dump_steps, devs.c_str());
         llama_free(ctx); llama_model_free(model); llama_backend_free();
         return 0;
     }
