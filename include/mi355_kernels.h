@@ -469,6 +469,12 @@ MI355_API int mi355_glu_bf16_f32(int glu_op, const mi355_tensor *a, const mi355_
  * else MI355_E_UNSUPPORTED.  Replaces a norm launch + a quantization launch (norm.cu + quantize.cu in the reference). */
 MI355_API int mi355_rms_norm_mul_q8k_f32(const mi355_tensor *a, const mi355_tensor *b, const mi355_tensor *sum, const float *w,
                                          const mi355_tensor *dst, float eps, int8_t *act_q, float *act_d, int16_t *act_bsums, void *stream);
+
+/* GLU (mi355_glu_f32's arguments) that also writes the q8_K planes of its result, as mi355_rms_norm_mul_q8k_f32 does for the norm:
+ * batches of 5..32 rows, whose ffn_down (ggml_mul_mat, llama-graph.cpp build_ffn) takes mi355_mul_mat_skinny_k.  dst->ne[0] % 256 == 0,
+ * 16-byte aligned rows; MI355_E_UNSUPPORTED otherwise.  Planes bit-identical to mi355_quantize_act_q8k(dst). */
+MI355_API int mi355_glu_q8k_f32(int glu_op, const mi355_tensor *a, const mi355_tensor *b, const mi355_tensor *dst, int swapped,
+                                int8_t *act_q, float *act_d, int16_t *act_bsums, void *stream);
 /* mi355_rms_norm_mul_bf16_f32 whose first addend is still the kz K-slice planes of the GEMM that produces it (mi355_mul_mat_dq_parts:
  * [kz][rows][ne0] f32, rows and ne0 those of `sum`): sum = ((p0 + p1) + ...) + b, dst = rms_norm(sum) * w, act_bf16 = bf16(dst).
  * MUL_MAT(wo / ffn_down) -> ADD(residual) -> RMS_NORM -> MUL without the slice-sum launch and without the product crossing HBM

@@ -1235,14 +1235,15 @@ static void mi355_flash_attn(mi355_backend_ctx * ctx, ggml_tensor * dst) {
     MI_CHECK(mi355_flash_attn_ext(&a, ws, ws_bytes, ctx->stream));
 }
 
-static bool mi355_glu_with_quant(mi355_backend_ctx * ctx, ggml_tensor * node);
+static bool mi355_glu_with_quant(mi355_backend_ctx * ctx, ggml_tensor * node, const ggml_tensor * next);
 
-static bool mi355_compute_forward(mi355_backend_ctx * ctx, ggml_tensor * node) {
+// next: the node after `node` in the graph (NULL at the end), for producers that write the activation format of their reader
+static bool mi355_compute_forward(mi355_backend_ctx * ctx, ggml_tensor * node, const ggml_tensor * next = nullptr) {
     switch (node->op) {
         case GGML_OP_MUL_MAT:        mi355_mul_mat(ctx, node);    return true;
         case GGML_OP_MUL_MAT_ID:     mi355_mul_mat_id(ctx, node); return true;
         case GGML_OP_FLASH_ATTN_EXT: mi355_flash_attn(ctx, node); return true;
-        case GGML_OP_GLU:            if (mi355_glu_with_quant(ctx, node)) return true; break;
+        case GGML_OP_GLU:            if (mi355_glu_with_quant(ctx, node, next)) return true; break;
         default: break;
     }
     return mi355_ops_forward(node, ctx->stream);
@@ -1400,8 +1401,9 @@ static bool mi355_try_fuse_rms_norm_mul(mi355_backend_ctx * ctx, ggml_cgraph * c
     return true;
 }
 
-// GLU whose result feeds ffn_down at decode: fused q8_1 quantization of the output
-static bool mi355_glu_with_quant(mi355_backend_ctx * ctx, ggml_tensor * node) {
+// GLU whose result feeds ffn_down: the activation format ffn_down reads (q8_1 at decode, q8_K planes for 5..32 rows over a K-quant,
+// bf16 rows for the prefill GEMM) is written by the same launch
+static bool mi355_glu_with_quant(mi355_backend_ctx * ctx, ggml_tensor * node, const ggml_tensor * next) {
     const ggml_tensor * a = node->src[0], * b = node->src[1];
     const int64_t rows = ggml_nrows(node), K = node->ne[0];
     if (!ggml_is_contiguous(node) || MI355_ENV_SET("GGML_MI355_NO_FUSE")) return false;
@@ -1416,6 +1418,15 @@ static bool mi355_glu_with_quant(mi355_backend_ctx * ctx, ggml_tensor * node) {
         MI_CHECK(rc);
         ctx->act_remember(node, 1);
         return true;
+    }
+    if (next && next->op == GGML_OP_MUL_MAT && next->src[1] == node && !tensor_is_split(next->src[0]) && rows > 1 && K % 256 == 0 &&
+        mi355_mul_mat_path(next->src[0], node) == MM_SKINNY_K && !MI355_ENV_SET("GGML_MI355_NO_NORM_Q8K")) {
+        const mi355_act_layout L = mi355_act_planes(MM_SKINNY_K, K, rows);
+        char * ws = (char *)ctx->get_scratch(0, L.total());
+        const int rc = mi355_glu_q8k_f32((int)ggml_get_glu_op(node), &ta, b ? &tb : nullptr, &td, ((const int32_t *)node->op_params)[1],
+                                         (int8_t *)ws, (float *)(ws + L.b0), (int16_t *)(ws + L.b0 + L.b1), ctx->stream);
+        if (rc == MI355_OK) { ctx->act_remember(node, 2); return true; }
+        if (rc != MI355_E_UNSUPPORTED) MI_CHECK(rc);
     }
     if (rows > 8 || K % 32 != 0) return false;
     const size_t qb = align_up((size_t)mi355_act_q_bytes(K, rows), 256), db = align_up((size_t)mi355_act_ds_bytes(K, rows), 256);
@@ -2374,7 +2385,7 @@ static enum ggml_status mi355_issue_graph(mi355_backend_ctx * ctx, ggml_cgraph *
             i++;
             continue;
         }
-        if (!mi355_compute_forward(ctx, node)) {
+        if (!mi355_compute_forward(ctx, node, i + 1 < n ? ggml_graph_node(cgraph, i + 1) : nullptr)) {
             MI_LOG_ERROR("%s: op not supported %s (%s)\n", __func__, node->name, ggml_op_name(node->op));
             return GGML_STATUS_FAILED;
         }

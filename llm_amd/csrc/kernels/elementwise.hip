@@ -546,6 +546,27 @@ glu_quant_kernel(int op, const char * a, const char * b, int64_t a_row, int64_t 
     quant4_soa(o, aq + r * nc + 4 * i, ads + (r * (nc / QK) + (i >> 3)) * 2, (i & 7) == 0);
 }
 
+// vectorized split-GLU that also writes the q8_K planes of the result (batches of 5..32 rows: the result feeds ffn_down's skinny kernel).
+// 16 values per lane, nc % 256 == 0: whole 16-lane rows (one q8_K block each) leave together
+__global__ void __launch_bounds__(256)
+glu_q8k_kernel(int op, const char * a, const char * b, int64_t a_row, int64_t b_row, char * d, int64_t d_row, int nc,
+               int8_t * __restrict__ aq, float * __restrict__ ad, int16_t * __restrict__ kbs) {
+    const int c = blockIdx.y * 256 + threadIdx.x;    // 16-value chunk inside the row
+    if (c * 16 >= nc) return;
+    const int64_t r = blockIdx.x;
+    v4f x[4], g[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) { x[j] = ((const v4f *)(a + r * a_row))[4 * c + j]; g[j] = ((const v4f *)(b + r * b_row))[4 * c + j]; }
+    float o[16];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        o[4 * j + 0] = act_glu(op, x[j].x) * g[j].x; o[4 * j + 1] = act_glu(op, x[j].y) * g[j].y;
+        o[4 * j + 2] = act_glu(op, x[j].z) * g[j].z; o[4 * j + 3] = act_glu(op, x[j].w) * g[j].w;
+        ((v4f *)(d + r * d_row))[4 * c + j] = v4f{o[4 * j + 0], o[4 * j + 1], o[4 * j + 2], o[4 * j + 3]};
+    }
+    quant16_q8k(o, aq + r * nc + 16 * c, ad + r * (nc >> 8) + (c >> 4), kbs + r * (nc >> 4) + c, c & 15);
+}
+
 // ---------------------------------------------------------------- cpy
 template <class TS, class TD> static __device__ __forceinline__ TD cvt(TS v);
 template <> __device__ __forceinline__ float  cvt<float, float>(float v) { return v; }
@@ -885,7 +906,13 @@ int mi355_qkv_finish(const mi355_qkv_finish_args * f, void * stream) {
 }
 
 static int launch_glu(int glu_op, const mi355_tensor * a, const mi355_tensor * b, const mi355_tensor * dst, int swapped,
-                      int8_t * aq, float * ads, void * stream, uint16_t * abf = nullptr);
+                      int8_t * aq, float * ads, void * stream, uint16_t * abf = nullptr, int16_t * kbs = nullptr);
+
+int mi355_glu_q8k_f32(int glu_op, const mi355_tensor * a, const mi355_tensor * b, const mi355_tensor * dst, int swapped,
+                      int8_t * act_q, float * act_d, int16_t * act_bsums, void * stream) {
+    if (!act_q || !act_d || !act_bsums) return MI355_E_NULL;
+    return launch_glu(glu_op, a, b, dst, swapped, act_q, act_d, stream, nullptr, act_bsums);
+}
 
 int mi355_glu_bf16_f32(int glu_op, const mi355_tensor * a, const mi355_tensor * b, const mi355_tensor * dst, int swapped,
                        uint16_t * act_bf16, void * stream) {
@@ -904,7 +931,7 @@ int mi355_glu_quant_f32(int glu_op, const mi355_tensor * a, const mi355_tensor *
 }
 
 static int launch_glu(int glu_op, const mi355_tensor * a, const mi355_tensor * b, const mi355_tensor * dst, int swapped,
-                      int8_t * aq, float * ads, void * stream, uint16_t * abf) {
+                      int8_t * aq, float * ads, void * stream, uint16_t * abf, int16_t * kbs) {
     CHECK_T(a); CHECK_T(dst);
     if (b && !b->data) return MI355_E_NULL;
     if (a->type != MI355_TYPE_F32 || dst->type != MI355_TYPE_F32 || (b && b->type != MI355_TYPE_F32)) return MI355_E_TYPE;
@@ -924,6 +951,15 @@ static int launch_glu(int glu_op, const mi355_tensor * a, const mi355_tensor * b
         const dim3 grid((unsigned)nrows(dst), (unsigned)((nc / 4 + 255) / 256));
         MI355_LAUNCH("glu_bf16", glu_bf16_kernel, grid, dim3(256), 0, (hipStream_t)stream, glu_op, ap, bp, a->nb[1],
                      b ? b->nb[1] : a->nb[1], (char *)dst->data, dst->nb[1], (int)nc, abf);
+        MI355_CHECK_LAUNCH();
+        return MI355_OK;
+    }
+    if (aq && kbs) {
+        const uintptr_t al = (uintptr_t)ap | (uintptr_t)bp | (uintptr_t)dst->data | (uintptr_t)a->nb[1] | (uintptr_t)(b ? b->nb[1] : a->nb[1]) | (uintptr_t)dst->nb[1] | (uintptr_t)aq;
+        if ((al & 15) || nc % 256 != 0 || nrows(dst) > 0x7fffffff) return MI355_E_UNSUPPORTED;
+        const dim3 grid((unsigned)nrows(dst), (unsigned)((nc / 16 + 255) / 256));
+        MI355_LAUNCH("glu_q8k", glu_q8k_kernel, grid, dim3(256), 0, (hipStream_t)stream, glu_op, ap, bp, a->nb[1],
+                     b ? b->nb[1] : a->nb[1], (char *)dst->data, dst->nb[1], (int)nc, aq, ads, kbs);
         MI355_CHECK_LAUNCH();
         return MI355_OK;
     }

@@ -849,6 +849,15 @@ def test_norm_q8k_form(ops, rows, n, with_add):
     assert torch.equal(q, rq.view(rows, n))
     assert torch.equal(d.view(torch.int32), rd.view(rows, n // 256).view(torch.int32))
     assert torch.equal(bs, rbs.view(rows, n // 16))
+    # the GLU producer of the same planes (ffn_down's input)
+    g0, g1 = torch.empty_like(x), torch.empty_like(x)
+    for op in (2, 1):
+        K.check(K.lib.mi355_glu_f32(op, T(x), T(y), T(g0), 0, s), "glu")
+        K.check(K.lib.mi355_glu_q8k_f32(op, T(x), T(y), T(g1), 0, q.data_ptr(), d.data_ptr(), bs.data_ptr(), s), "glu_q8k")
+        assert torch.equal(g0.view(torch.int32), g1.view(torch.int32))
+        rq, rd, rbs = ops.quantize_act_q8k(g1)
+        assert torch.equal(q, rq.view(rows, n)) and torch.equal(bs, rbs.view(rows, n // 16))
+        assert torch.equal(d.view(torch.int32), rd.view(rows, n // 256).view(torch.int32))
 
 
 @pytest.mark.parametrize("rows,n", [(1, 4096), (3, 1024), (8, 8192), (2, 96), (1, 4128)])
