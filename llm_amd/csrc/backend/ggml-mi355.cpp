@@ -2221,6 +2221,72 @@ static bool mi355_try_fuse_qkv_gemm(mi355_backend_ctx * ctx, ggml_cgraph * cgrap
     return true;
 }
 
+// Small-batch form (2..32 tokens on the skinny kernels): the three products go to scratch as one "plane" each and the same finish launch
+// rotates q and k and stores k and v -- 4 launches for the nodes' 7 (3 MUL_MAT, 2 ROPE, 2 CPY).  The products are the bits of the
+// separate MUL_MATs (same kernels, same activations), the finish launch adds nothing to a single plane: bit-identical.
+static bool small_mm_ok(const ggml_tensor * t) {
+    const ggml_tensor * w = t->src[0], * x = t->src[1];
+    if (!(t->op == GGML_OP_MUL_MAT && t->type == GGML_TYPE_F32 && x->type == GGML_TYPE_F32 && w->ne[2] == 1 && w->ne[3] == 1 && !tensor_is_split(w) &&
+          is_weight_type(w->type) && ggml_is_contiguous(t))) return false;
+    const int path = mi355_mul_mat_path(w, x);
+    return path == MM_SKINNY_K || path == MM_SKINNY;
+}
+
+static bool mi355_try_fuse_qkv_small(mi355_backend_ctx * ctx, ggml_cgraph * cgraph, int i, std::vector<char> & done) {
+    ggml_tensor * mq0 = ggml_graph_node(cgraph, i);
+    if (mq0->src[1]->ne[1] <= 1 || !small_mm_ok(mq0) || MI355_ENV_SET("GGML_MI355_NO_QKV_SMALL")) return false;
+    qkv_nodes q;
+    if (!qkv_match(cgraph, i, done, small_mm_ok, q)) return false;
+    const ggml_tensor * x = q.mq->src[1];
+    ggml_tensor * mm[3] = {q.mq, q.mk, q.mv};
+    const int64_t N = x->ne[1], hd = q.rq->ne[0];
+    const int64_t Mq = mm[0]->ne[0], Mk = mm[1]->ne[0], Mv = mm[2]->ne[0];
+    if (Mv % 4 || (N * Mv) % 4) return false;
+    size_t off[3], total = 0;
+    for (int m = 0; m < 3; m++) { off[m] = total; total += align_up((size_t)N * mm[m]->ne[0] * sizeof(float), 256); }
+    const ggml_tensor * outs[3] = {q.rq, q.ck, q.cv};
+    for (int a = 0; a < 3; a++) {
+        for (int b = 0; b < a; b++) if (ranges_overlap(outs[a]->data, ggml_nbytes(outs[a]), outs[b]->data, ggml_nbytes(outs[b]))) return false;
+        if (ranges_overlap(outs[a]->data, ggml_nbytes(outs[a]), q.rq->src[1]->data, ggml_nbytes(q.rq->src[1]))) return false;
+        if (ranges_overlap(outs[a]->data, ggml_nbytes(outs[a]), x->data, ggml_nbytes(x))) return false;
+    }
+    char * parts = (char *)ctx->get_scratch(3, total);
+    if (ctx->scratch_size[3] < total) return false;
+    float * kv_tmp = nullptr;
+    if (q.kv_q8) {
+        const size_t need = (size_t)N * (Mk + Mv) * sizeof(float);
+        kv_tmp = (float *)ctx->get_scratch(4, need);
+        if (ctx->scratch_size[4] < need) return false;
+    }
+    mi355_qkv_finish_args f;
+    memset(&f, 0, sizeof(f));
+    f.q_parts = (const float *)(parts + off[0]); f.k_parts = (const float *)(parts + off[1]); f.v_parts = (const float *)(parts + off[2]);
+    f.kz_q = f.kz_k = f.kz_v = 1;
+    f.m_q = Mq; f.m_k = Mk; f.m_v = Mv; f.n = N;
+    f.q_out = (float *)q.rq->data; f.k_out = q.ck->data; f.v_out = q.cv->data;
+    f.k_out_type = (int32_t)q.ck->type; f.v_out_type = (int32_t)q.cv->type;
+    if (kv_tmp) { f.k_out = kv_tmp; f.v_out = kv_tmp + N * Mk; f.k_out_type = f.v_out_type = (int32_t)GGML_TYPE_F32; }
+    f.pos = (const int32_t *)q.rq->src[1]->data; f.freq_factors = q.rq->src[2] ? (const float *)q.rq->src[2]->data : nullptr;
+    f.head_dim = (int32_t)hd;
+    float f6[6];
+    qkv_rope_params(q.rq, &f.n_dims, &f.mode, &f.n_ctx_orig, f6);
+    f.freq_base = f6[0]; f.freq_scale = f6[1]; f.ext_factor = f6[2]; f.attn_factor = f6[3]; f.beta_fast = f6[4]; f.beta_slow = f6[5];
+    // everything the finish launch could refuse, before anything is launched (mi355_qkv_finish's own checks)
+    if (hd <= 0 || (hd & 1) || f.n_dims > hd || (f.n_dims & 1) || Mq % hd || Mk % hd || (f.mode != 0 && f.mode != 2)) return false;
+    if ((f.k_out_type != (int32_t)GGML_TYPE_F16 && f.k_out_type != (int32_t)GGML_TYPE_F32) || (f.v_out_type != (int32_t)GGML_TYPE_F16 && f.v_out_type != (int32_t)GGML_TYPE_F32)) return false;
+    if (((uintptr_t)f.v_out & 15) || ((uintptr_t)f.q_out & 3) || ((uintptr_t)f.k_out & 3)) return false;
+    for (int m = 0; m < 3; m++) {
+        ggml_tensor t = *mm[m];              // the product of node m, into its plane instead of the node's own bytes
+        t.data = parts + off[m];
+        mi355_mul_mat(ctx, &t);
+    }
+    MI_CHECK(mi355_qkv_finish(&f, ctx->stream));
+    if (kv_tmp) MI_CHECK(mi355_kv_store_q8_0(kv_tmp, N * Mk, q.ck->data, kv_tmp + N * Mk, N * Mv, q.cv->data, nullptr, 0, ctx->stream));
+    for (int m = 1; m < 7; m++) done[q.idx[m]] = 1;
+    ctx->act_invalidate_if_written(q.rq);
+    return true;
+}
+
 // Decode form.  norm_idx >= 0: nodes norm_idx (RMS_NORM) and norm_idx + 1 (MUL by the norm weight, == x) come right before node i and
 // run in the launch's prologue (attn_norm of every layer): 9 nodes, one launch.
 static bool mi355_try_fuse_qkv_rope(mi355_backend_ctx * ctx, ggml_cgraph * cgraph, int i, std::vector<char> & done, int norm_idx = -1) {
@@ -2328,6 +2394,7 @@ static enum ggml_status mi355_issue_graph(mi355_backend_ctx * ctx, ggml_cgraph *
         if (fuse && node->op == GGML_OP_MUL_MAT && node->src[0]->type == GGML_TYPE_F32 && mi355_try_fuse_moe_router(ctx, cgraph, i, done)) continue;
         if (fuse && node->op == GGML_OP_MUL_MAT && mi355_try_fuse_qkv_rope(ctx, cgraph, i, done)) continue;
         if (fuse && node->op == GGML_OP_MUL_MAT && mi355_try_fuse_qkv_gemm(ctx, cgraph, i, done)) continue;
+        if (fuse && node->op == GGML_OP_MUL_MAT && mi355_try_fuse_qkv_small(ctx, cgraph, i, done)) continue;
         if (fuse && node->op == GGML_OP_MUL_MAT && mi355_try_fuse_gemm_add_norm(ctx, cgraph, i, done)) {
             i += 3;
             continue;

@@ -221,6 +221,31 @@ def test_gate_up_glu_gemm_is_bit_exact(tmp_path, ftype):
     assert np.array_equal(outs["fused"][0], outs["no_glu_gemm"][0])
 
 
+@pytest.mark.parametrize("kv", ["f16", "q8_0"])
+def test_small_batch_forms_are_bit_exact_and_run(tmp_path, kv):
+    """The 12-token batch of the parity sequence takes the skinny kernels: the norm and the GLU write the q8_K planes themselves
+    (mi355_rms_norm_mul_q8k_f32, mi355_glu_q8k_f32) and Q/K/V + 2 ROPE + 2 CPY run as three products and one mi355_qkv_finish.  Each
+    form can be switched off alone; the logits never change by a bit, the launch counts show the forms did run."""
+    import numpy as np
+    tool = os.path.join(ROOT, "tools", "run_llama_bench.sh")
+    outs = {}
+    for name, extra in (("fused", {}), ("no_q8k", {"GGML_MI355_NO_NORM_Q8K": "1"}), ("no_qkv_small", {"GGML_MI355_NO_QKV_SMALL": "1"}),
+                        ("nofuse", {"GGML_MI355_NO_FUSE": "1"})):
+        path = str(tmp_path / f"logits_{name}.bin")
+        env = dict(os.environ, GGML_MI355_KERNEL_TIMES="1", **extra)
+        r = subprocess.run([tool, "tiny", "Q4_K_M", "-ctk", kv, "-ctv", kv, "--dump-logits", path], capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stderr[-3000:]
+        cnt = {k: int(v) for k, v in re.findall(r"\[mi355\] kernel (\S+) (\d+) ", r.stderr)}
+        outs[name] = (np.fromfile(path, dtype=np.uint32), cnt)
+    for name in ("no_q8k", "no_qkv_small", "nofuse"):
+        assert np.array_equal(outs["fused"][0], outs[name][0]), name
+    c = {k: v[1] for k, v in outs.items()}
+    assert c["fused"].get("glu_q8k", 0) > 0 and c["no_q8k"].get("glu_q8k", 0) == 0 and c["nofuse"].get("glu_q8k", 0) == 0, c["fused"]
+    assert c["fused"].get("quantize_q8_K", 0) < c["no_q8k"].get("quantize_q8_K", 0)
+    assert c["fused"].get("qkv_finish", 0) > c["no_qkv_small"].get("qkv_finish", 0) and c["nofuse"].get("qkv_finish", 0) == 0
+    assert c["fused"].get("rope", 0) < c["no_qkv_small"].get("rope", 0)
+
+
 def test_fusions_are_bit_exact_with_a_q8_0_cache(tmp_path):
     """-ctk q8_0 -ctv q8_0: the fused Q/K/V launch leaves K and V as f32 rows in scratch and mi355_kv_store_q8_0 quantizes both into the
     cache -- the same bits as RMS_NORM, 3 MUL_MAT, 2 ROPE and 2 CPY f32 -> q8_0 launched one by one"""
