@@ -547,7 +547,7 @@ MI355_API int mi355_soft_max_f32(const mi355_tensor *x, const mi355_tensor *mask
 
 /* ---------------------------------------------------------------------------------------------
  * FLASH_ATTN_EXT (ggml.h:2012-2033): dst = softmax(scale * Q K^T [softcap] + slope * mask) V with
- * f16, q8_0 or q4_0 K/V (K and V of the same type), head size d in {64, 128, 256} (dk == dv).
+ * f16, bf16, q8_0 or q4_0 K/V (K and V of the same type), head size d in {64, 128, 256} (dk == dv).
  * Replaces ggml_cuda_flash_attn_ext (ggml/src/ggml-cuda/fattn.cu:271-346); oracle
  * ggml_compute_forward_flash_attn_ext_f16 (ggml/src/ggml-cpu/ops.cpp:7975-8192).
  *   q    f32 [d, n_q, n_head, ne3]      byte strides q_nb1..3 (rows contiguous, 16-byte aligned)

@@ -1178,13 +1178,13 @@ static void fattn_args_from(const ggml_tensor * dst, mi355_fattn_args * a) {
 static bool mi355_flash_attn_supported(const ggml_tensor * op) {
     const ggml_tensor * q = op->src[0], * k = op->src[1], * v = op->src[2], * mask = op->src[3];
     if (q->type != GGML_TYPE_F32 || op->type != GGML_TYPE_F32) return false;
-    if (k->type != v->type || (k->type != GGML_TYPE_F16 && k->type != GGML_TYPE_Q8_0 && k->type != GGML_TYPE_Q4_0)) return false;
+    if (k->type != v->type || (k->type != GGML_TYPE_F16 && k->type != GGML_TYPE_BF16 && k->type != GGML_TYPE_Q8_0 && k->type != GGML_TYPE_Q4_0)) return false;
     const int64_t d = q->ne[0];
     if ((d != 64 && d != 128 && d != 256) || k->ne[0] != d || v->ne[0] != d) return false;
     if (k->ne[3] != q->ne[3] || v->ne[3] != q->ne[3] || k->ne[2] != v->ne[2] || q->ne[2] % k->ne[2] != 0) return false;
     if (q->nb[0] != sizeof(float) || k->nb[0] != ggml_type_size(k->type) || v->nb[0] != ggml_type_size(v->type)) return false;
     if ((q->nb[1] | q->nb[2] | q->nb[3]) & 15) return false;
-    if (k->type == GGML_TYPE_F16 && ((k->nb[1] | k->nb[2] | k->nb[3] | v->nb[1] | v->nb[2] | v->nb[3]) & 15)) return false;
+    if ((k->type == GGML_TYPE_F16 || k->type == GGML_TYPE_BF16) && ((k->nb[1] | k->nb[2] | k->nb[3] | v->nb[1] | v->nb[2] | v->nb[3]) & 15)) return false;
     if (mask && (mask->type != GGML_TYPE_F16 || mask->nb[0] != sizeof(ggml_fp16_t))) return false;
     if (!ggml_is_contiguous(op)) return false;
     if (q->ne[1] > 65535 || q->ne[3] * 64 > 65535) return false;

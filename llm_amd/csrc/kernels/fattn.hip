@@ -56,6 +56,10 @@ static __device__ __forceinline__ void load8(const char * row, int j, float * ou
         const __half2 * h = (const __half2 *)&raw;
 #pragma unroll
         for (int i = 0; i < 4; i++) { const float2 f = __half22float2(h[i]); out[2 * i] = f.x; out[2 * i + 1] = f.y; }
+    } else if (TYPE == MI355_TYPE_BF16) {              // bf16 = the upper half of the f32 (ggml_compute_bf16_to_fp32, ggml-impl.h)
+        const v4i raw = *(const v4i *)(row + j * 16);
+#pragma unroll
+        for (int i = 0; i < 4; i++) { out[2 * i] = __int_as_float(raw[i] << 16); out[2 * i + 1] = __int_as_float(raw[i] & 0xffff0000); }
     } else if (TYPE == MI355_TYPE_Q8_0) {
         const char * blk = row + (j >> 2) * 34;
         const float d = h2f(*(const uint16_t *)blk);
@@ -112,6 +116,18 @@ template <int TK> struct FaQ {
     float f[8];
     __device__ __forceinline__ void set(const v4f q0, const v4f q1) { f[0] = q0.x; f[1] = q0.y; f[2] = q0.z; f[3] = q0.w; f[4] = q1.x; f[5] = q1.y; f[6] = q1.z; f[7] = q1.w; }
     __device__ __forceinline__ float dot(const FaRow<TK> & k) const {
+        float t = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 8; i++) t += f[i] * k.f[i];
+        return t;
+    }
+};
+// bf16 K: the query is rounded to bf16 first, as the CPU path does (Q is converted to the K type's vec_dot type, ops.cpp:8061-8066)
+template <> struct FaQ<MI355_TYPE_BF16> {
+    float f[8];
+    static __device__ __forceinline__ float r(float x) { return (float)(__bf16)x; }
+    __device__ __forceinline__ void set(const v4f q0, const v4f q1) { f[0] = r(q0.x); f[1] = r(q0.y); f[2] = r(q0.z); f[3] = r(q0.w); f[4] = r(q1.x); f[5] = r(q1.y); f[6] = r(q1.z); f[7] = r(q1.w); }
+    __device__ __forceinline__ float dot(const FaRow<MI355_TYPE_BF16> & k) const {
         float t = 0.0f;
 #pragma unroll
         for (int i = 0; i < 8; i++) t += f[i] * k.f[i];
@@ -888,6 +904,7 @@ static int dispatch_types(const FArgs & a, int tk, int tv, hipStream_t s) {
     if (tk == MI355_TYPE_F16 && tv == MI355_TYPE_F16)   return dispatch_r<D, MI355_TYPE_F16, MI355_TYPE_F16>(a, s);
     if (tk == MI355_TYPE_Q8_0 && tv == MI355_TYPE_Q8_0) return dispatch_r<D, MI355_TYPE_Q8_0, MI355_TYPE_Q8_0>(a, s);
     if (tk == MI355_TYPE_Q4_0 && tv == MI355_TYPE_Q4_0) return dispatch_r<D, MI355_TYPE_Q4_0, MI355_TYPE_Q4_0>(a, s);
+    if (tk == MI355_TYPE_BF16 && tv == MI355_TYPE_BF16) return dispatch_r<D, MI355_TYPE_BF16, MI355_TYPE_BF16>(a, s);
     return MI355_E_TYPE;
 }
 
@@ -929,8 +946,8 @@ static int fattn_run(const mi355_fattn_args * p, void * workspace, int64_t works
     if (p->n_q > 65535 || p->ne3 * 64 > 65535) return MI355_E_SHAPE;
     if (p->mask && (p->m_ne2 < 1 || p->m_ne3 < 1)) return MI355_E_SHAPE;
     if (((uintptr_t)p->q | (uintptr_t)p->q_nb1 | (uintptr_t)p->q_nb2 | (uintptr_t)p->q_nb3) & 15) return MI355_E_ALIGN;
-    if (p->type_k == MI355_TYPE_F16 && (((uintptr_t)p->k | (uintptr_t)p->k_nb1 | (uintptr_t)p->k_nb2 | (uintptr_t)p->k_nb3) & 15)) return MI355_E_ALIGN;
-    if (p->type_v == MI355_TYPE_F16 && (((uintptr_t)p->v | (uintptr_t)p->v_nb1 | (uintptr_t)p->v_nb2 | (uintptr_t)p->v_nb3) & 15)) return MI355_E_ALIGN;
+    if ((p->type_k == MI355_TYPE_F16 || p->type_k == MI355_TYPE_BF16) && (((uintptr_t)p->k | (uintptr_t)p->k_nb1 | (uintptr_t)p->k_nb2 | (uintptr_t)p->k_nb3) & 15)) return MI355_E_ALIGN;
+    if ((p->type_v == MI355_TYPE_F16 || p->type_v == MI355_TYPE_BF16) && (((uintptr_t)p->v | (uintptr_t)p->v_nb1 | (uintptr_t)p->v_nb2 | (uintptr_t)p->v_nb3) & 15)) return MI355_E_ALIGN;
     if ((act_q == nullptr) != (act_ds == nullptr)) return MI355_E_NULL;
     if (act_q && (((uintptr_t)act_q & 15) || ((uintptr_t)act_ds & 7))) return MI355_E_ALIGN;
     if (p->n_q == 0 || p->n_head == 0) return MI355_OK;

@@ -151,7 +151,7 @@ def mul_mat_id(t, as_, b, ids, m, n_expert):
 def flash_attn_ext(q, k, v, mask, type_kv, n_kv, scale, max_bias=0.0, logit_softcap=0.0, use_workspace=True, quant=False,
                    workspace_bytes=None, noalloc=False, bf16=False):
     """ggml_flash_attn_ext, batch 1.  q: [n_head, n_q, d] f32; k, v: [n_head_kv, n_kv, row_bytes] uint8 rows of
-    type_kv (F16 / Q8_0 / Q4_0); mask: [n_q_pad, n_kv] f16 bits (int16) or None -> [n_q, n_head, d] f32."""
+    type_kv (F16 / BF16 / Q8_0 / Q4_0); mask: [n_q_pad, n_kv] f16 bits (int16) or None -> [n_q, n_head, d] f32."""
     assert q.is_cuda and q.dtype == torch.float32 and q.is_contiguous() and k.is_contiguous() and v.is_contiguous()
     n_head, n_q, d = q.shape
     n_head_kv = k.shape[0]

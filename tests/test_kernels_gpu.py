@@ -990,6 +990,31 @@ def test_flash_attn_quantized_kv_vs_f64_oracle(ops, tkv, d, nh, nhkv, nq, nkv):
     assert np.isfinite(got).all() and O.nmse(ref, got) <= 5e-5, O.nmse(ref, got)
 
 
+@pytest.mark.parametrize("d,nh,nhkv,nq,nkv", [(128, 8, 2, 1, 300), (64, 4, 4, 33, 130), (128, 8, 2, 3, 5000), (256, 4, 2, 2, 100), (128, 32, 8, 70, 200)])
+def test_flash_attn_bf16_kv_vs_f64_oracle(ops, d, nh, nhkv, nq, nkv):
+    """bf16 KV cache (test-backend-ops.cpp:4866-4906 type_KV list; the vec kernel for any n_q): K / V values that both bf16 and f16
+    hold exactly, so the oracle's f64 evaluation on the f16 rows is the reference; the query is rounded to bf16 as the CPU path
+    does (ops.cpp:8061-8066), which is all the difference there is (NMSE <= 5e-5; the reference's own bar is 5e-4)."""
+    rng = np.random.default_rng(d + nq + nkv)
+    q = rng.standard_normal((nh, nq, d)).astype(np.float32)
+    k = (rng.integers(-64, 65, (nhkv, nkv, d)) / 32.0).astype(np.float32)
+    v = (rng.integers(-64, 65, (nhkv, nkv, d)) / 32.0).astype(np.float32)
+    kb, vb = ((x.view(np.uint32) >> 16).astype(np.uint16) for x in (k, v))
+    assert np.array_equal((kb.astype(np.uint32) << 16).view(np.float32), k)
+    nqp = (nq + 63) // 64 * 64
+    mask = np.zeros((nqp, nkv), np.float16)
+    off = nkv - nq
+    for i in range(nq):
+        mask[i, i + off + 1:] = -np.inf
+    scale = 1.0 / np.sqrt(d)
+    ku, vu = (x.view(np.uint8).reshape(nhkv, nkv, -1) for x in (kb, vb))
+    kh, vh = (x.astype(np.float16).view(np.uint8).reshape(nhkv, nkv, -1) for x in (k, v))
+    ref = O.flash_attn_ext(q, kh, vh, mask.view(np.uint16), O.F16, O.F16, d, d, nq, nkv, nh, nhkv, scale, exact=True)
+    for use_ws in (True, False):
+        got = ops.flash_attn_ext(dev(q), dev(ku), dev(vu), dev(mask.view(np.int16)), B.BF16, nkv, scale, use_workspace=use_ws).cpu().numpy()
+        assert np.isfinite(got).all() and O.nmse(ref, got) <= 5e-5, O.nmse(ref, got)
+
+
 @pytest.mark.parametrize("nq,nkv,use_ws", [(1, 300, True), (1, 300, False), (4, 4096, True), (8, 96, True)])
 def test_flash_attn_fused_q8_1_output(ops, nq, nkv, use_ws):
     """mi355_flash_attn_ext_quant: dst equals the plain call bit for bit and the fused q8_1 form equals
