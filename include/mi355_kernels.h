@@ -313,10 +313,11 @@ MI355_API int mi355_mul_mat_q(int type, const void *W, int64_t w_row_stride, con
  * Replaces the reference's large-batch path (mul_mat_q, or dequantize + hipBLAS GEMM: ggml-cuda.cu:1223-1340).
  *   act_bf16: n columns of k bf16, act_row_stride elements apart (multiple of 8)
  * Tiles: 128 weight rows x 256 columns, 8 multiplying + 4 dequantizing waves, activation tile by LDS-DMA.  A matrix with too few such
- * tiles for the chip (e.g. 4096 rows at n = 512) has K cut in 2 or 4 slices whose partial tiles are kept in a workspace the LIBRARY
- * owns per (device, stream) and are added in slice order (a fixed summation order, no atomics).  That workspace is the one
- * allocation this library makes inside a call: hipMalloc on first use / growth (with a device synchronisation when it grows), so
- * such a call must not sit under graph capture; MI355_MMDQ_KZ=0 in the environment keeps every launch on the paths without it. */
+ * tiles for the chip (e.g. 4096 rows at n = 512) has K cut in 2 or 4 slices whose partial tiles are kept in a workspace and are
+ * added in slice order (a fixed summation order, no atomics).  The workspace is the CALLER's (mi355_mul_mat_dq_slice_ws): no entry
+ * point of this library allocates or synchronises.  mi355_mul_mat_dq / mi355_mul_mat_dq_slice take no workspace and return
+ * MI355_E_WORKSPACE for a shape whose launch needs one (mi355_mul_mat_dq_workspace_bytes > 0); MI355_MMDQ_KZ=0 in the environment
+ * keeps every launch on the forms that need none. */
 MI355_API int mi355_act_bf16(const float *x, uint16_t *y, int64_t k, int64_t ne1, int64_t ne2, int64_t ne3,
                              int64_t nb1, int64_t nb2, int64_t nb3, void *stream);
 MI355_API int mi355_mul_mat_dq(int type, const void *W, int64_t w_row_stride, const uint16_t *act_bf16, int64_t act_row_stride,
@@ -327,8 +328,7 @@ MI355_API int mi355_mul_mat_dq(int type, const void *W, int64_t w_row_stride, co
 MI355_API int mi355_mul_mat_dq_slice(int type, const void *W, int64_t w_row_stride, const uint16_t *act_bf16, int64_t act_row_stride,
                                      float *dst, int64_t dst_col_stride, int64_t m, int64_t m_total, int64_t k, int64_t n, void *stream);
 /* same with the split-K workspace handed in by the caller: mi355_mul_mat_dq_workspace_bytes(m, m_total, k, n) bytes (0 when this shape
- * needs none), 16-byte aligned, private to the stream.  With it the call allocates nothing (capture-safe); workspace == NULL falls
- * back to the library's own.  MI355_E_WORKSPACE when it is too small. */
+ * needs none), 16-byte aligned, private to the stream.  MI355_E_WORKSPACE when the shape needs one and it is NULL or too small. */
 MI355_API int64_t mi355_mul_mat_dq_workspace_bytes(int64_t m, int64_t m_total, int64_t k, int64_t n);
 MI355_API int mi355_mul_mat_dq_slice_ws(int type, const void *W, int64_t w_row_stride, const uint16_t *act_bf16, int64_t act_row_stride,
                                         float *dst, int64_t dst_col_stride, int64_t m, int64_t m_total, int64_t k, int64_t n,

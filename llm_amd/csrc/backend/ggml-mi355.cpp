@@ -140,8 +140,7 @@ struct mi355_rccl {
     ncclResult_t (*GroupEnd)() = nullptr;
     const char * (*GetErrorString)(ncclResult_t) = nullptr;
     ncclComm_t comm[MI355_MAX_DEVICES] = {};
-    float * part[MI355_MAX_DEVICES] = {};  size_t part_size[MI355_MAX_DEVICES] = {};   // this device's slice, [cols][rows_max]
-    float * gath[MI355_MAX_DEVICES] = {};  size_t gath_size[MI355_MAX_DEVICES] = {};   // every device's slice, [ndev][cols][rows_max]
+    // (the staging buffers of the gather belong to the backend that drives it: mi355_backend_ctx::split_bufs)
 };
 static mi355_rccl & mi355_rccl_state() { static mi355_rccl r; return r; }
 
@@ -597,7 +596,23 @@ struct mi355_backend_ctx {
         void *      act = nullptr;
         size_t      act_size = 0;
         uint64_t    act_version = 0;
+        void *      gemm_ws = nullptr;      // split-K workspace of the prefill GEMM on this device's helper stream
+        size_t      gemm_ws_size = 0;
     } peers[MI355_MAX_DEVICES];
+    // RCCL form of the gather: per device d (this backend's own included) its slice [cols][rows_max] and everybody's slices
+    // [ndev][cols][rows_max].  They belong to THIS backend -- under -sm row the main device alternates by layer, so two
+    // backends' helper streams run on one GPU, and buffers shared between them would have no ordering.
+    struct split_buf_t { float * part = nullptr; size_t part_size = 0; float * gath = nullptr; size_t gath_size = 0; } split_bufs[MI355_MAX_DEVICES];
+    // device memory on `dev` that grows on demand, outside any capture (split graphs are never captured); `st`: the stream whose
+    // launches may still use the old block
+    static void grow_on(int dev, void ** buf, size_t * have, size_t need, hipStream_t st) {
+        if (*have >= need) return;
+        mi355_set_device(dev);
+        HIP_CHECK(hipStreamSynchronize(st));
+        if (*buf) HIP_CHECK(hipFree(*buf));
+        *have = (need + (8u << 20)) & ~((size_t)(1u << 20) - 1);
+        HIP_CHECK(hipMalloc(buf, *have));
+    }
     hipEvent_t ev_ready = nullptr;
     uint64_t   act_version = 0;     // bumped whenever scratch[0] receives new activations
 
@@ -642,6 +657,12 @@ struct mi355_backend_ctx {
         bool capturing = false, capture_failed = false;
         int  n_slots = 0;            // slots handed out during the capture in progress
         long n_replay = 0, n_capture = 0, n_eager = 0;       // GGML_MI355_GRAPH_STATS=1 prints them when the backend is freed
+        long n_dropped = 0;          // captured graphs thrown away because a scratch block they point into moved
+        hipEvent_t ring_ev[MI355_KV_RING] = {};    // recorded behind the table copy that reads ring slot i: the slot is reused only after it
+        void drop() {
+            if (exec) { HIP_CHECK(hipGraphExecDestroy(exec)); exec = nullptr; n_dropped++; }
+            sig.clear(); kv_nodes.clear(); recaptures = 0;
+        }
     } gc;
 
     void * get_scratch(int which, size_t need) {
@@ -653,6 +674,9 @@ struct mi355_backend_ctx {
         if (scratch[which]) {
             HIP_CHECK(hipStreamSynchronize(stream)); // earlier kernels may still read the old block
             HIP_CHECK(hipFree(scratch[which]));
+            // a captured decode graph has this block's address baked into its launches: drop it, so the next decode graph
+            // runs eagerly (first sighting) and is captured again against the new block
+            gc.drop();
         }
         if (which == 0) act_cache.valid = false;
         scratch_size[which] = (need + (8u << 20)) & ~((size_t)(1u << 20) - 1);
@@ -661,6 +685,10 @@ struct mi355_backend_ctx {
         if (which == 1) HIP_CHECK(hipMemsetAsync(scratch[which], 0, scratch_size[which], stream));
         return scratch[which];
     }
+
+    // split-K workspace of the prefill GEMM for helper device d's slice (the kernel library allocates nothing: every stream that
+    // launches a split-K GEMM brings its own)
+    void peer_gemm_ws(int d, const ggml_tensor * src0, const mi355_split_extra * extra, int64_t K, int64_t N, int path, void ** ws, int64_t * bytes);
 
     bool act_cached(const ggml_tensor * t, int fmt = 0) const {
         if (!act_cache.valid || act_cache.data != t->data || act_cache.fmt != fmt) return false;
@@ -705,7 +733,10 @@ static void mi355_backend_free(ggml_backend_t backend) {
     if (MI355_ENV_SET("GGML_MI355_GRAPH_STATS"))
         fprintf(stderr, "[mi355] %s decode graphs: %ld replays, %ld captures, %ld eager runs of capturable graphs%s\n", ctx->name.c_str(),
                 ctx->gc.n_replay, ctx->gc.n_capture, ctx->gc.n_eager, ctx->gc.disabled ? " (disabled)" : "");
+    if (MI355_ENV_SET("GGML_MI355_GRAPH_STATS") && ctx->gc.n_dropped)
+        fprintf(stderr, "[mi355] %s decode graphs dropped because a scratch block moved: %ld\n", ctx->name.c_str(), ctx->gc.n_dropped);
     if (ctx->gc.exec) HIP_CHECK(hipGraphExecDestroy(ctx->gc.exec));
+    for (hipEvent_t ev : ctx->gc.ring_ev) if (ev) HIP_CHECK(hipEventDestroy(ev));
     if (ctx->gc.kv_dev) HIP_CHECK(hipFree(ctx->gc.kv_dev));
     if (ctx->gc.kv_host) HIP_CHECK(hipHostFree(ctx->gc.kv_host));
     if (ctx->ev_ready) HIP_CHECK(hipEventDestroy(ctx->ev_ready));
@@ -715,8 +746,16 @@ static void mi355_backend_free(ggml_backend_t backend) {
         mi355_set_device(d);
         HIP_CHECK(hipStreamSynchronize(p.stream));
         if (p.act) HIP_CHECK(hipFree(p.act));
+        if (p.gemm_ws) HIP_CHECK(hipFree(p.gemm_ws));
         HIP_CHECK(hipEventDestroy(p.done));
         HIP_CHECK(hipStreamDestroy(p.stream));
+    }
+    for (int d = 0; d < MI355_MAX_DEVICES; d++) {
+        mi355_backend_ctx::split_buf_t & sb = ctx->split_bufs[d];
+        if (!sb.part && !sb.gath) continue;
+        mi355_set_device(d);
+        if (sb.part) HIP_CHECK(hipFree(sb.part));
+        if (sb.gath) HIP_CHECK(hipFree(sb.gath));
     }
     mi355_set_device(ctx->device);
     HIP_CHECK(hipStreamDestroy(ctx->stream));
@@ -810,12 +849,19 @@ enum mi355_mm_path { MM_VEC = 0, MM_DQ = 1, MM_SKINNY_K = 2, MM_SKINNY = 3, MM_Q
 // activation format each path consumes (act_cache.fmt): 0 q8_1 SoA, 1 bf16 rows, 2 q8_K planes
 static int mm_path_fmt(int path) { return path == MM_DQ ? 1 : path == MM_SKINNY_K ? 2 : 0; }
 
-static int mi355_mul_mat_path(const ggml_tensor * src0, const ggml_tensor * src1) {
+// dst: the MUL_MAT node when the caller has it (its op_params carry the precision request)
+static int mi355_mul_mat_path(const ggml_tensor * src0, const ggml_tensor * src1, const ggml_tensor * dst = nullptr) {
     static const bool int8_mmq = MI355_ENV_SET("GGML_MI355_MMQ_INT8");
     static const bool no_skinny = MI355_ENV_SET("GGML_MI355_NO_SKINNY");
     const int64_t K = src0->ne[0], N = src1->ne[1];
     const bool aligned = (((uintptr_t)src1->data | src1->nb[1] | src1->nb[2] | src1->nb[3]) & 15) == 0;
     if (is_float_weight_type(src0->type)) {
+        // The bf16 GEMM rounds both operands to bf16 (8 significant bits).  f32 weights, and products the graph asks f32
+        // precision for (GGML_PREC_F32: llama.cpp sets it on K*Q without flash attention, src/llama-graph.cpp build_attn_mha), stay
+        // on the exact f32-accumulating mat-vec whatever the batch -- the reference keeps f16 inputs with f32 accumulation there
+        // (ggml-cuda.cu:1205-1351) and ggml-cpu is f32 throughout.
+        if (src0->type == GGML_TYPE_F32) return MM_FLOAT;
+        if (dst && dst->op == GGML_OP_MUL_MAT && (enum ggml_prec)dst->op_params[0] == GGML_PREC_F32) return MM_FLOAT;
         return N > 16 && K % 64 == 0 && aligned && src1->type == GGML_TYPE_F32 ? MM_DQ : MM_FLOAT;
     }
     if (!is_weight_type(src0->type)) {      // q4_1 / q5_0 / q5_1
@@ -918,6 +964,18 @@ static void mi355_mul_mat_launch(const ggml_tensor * dst, const char * W, int64_
 
 static mi355_tensor to_mi355_tensor(const ggml_tensor * t);
 
+void mi355_backend_ctx::peer_gemm_ws(int d, const ggml_tensor * src0, const mi355_split_extra * extra, int64_t K, int64_t N, int path, void ** ws, int64_t * bytes) {
+    *ws = nullptr; *bytes = 0;
+    if (path != MM_DQ) return;
+    const int64_t own = extra->row_high[d] - extra->row_low[d];
+    const int64_t need = mi355_mul_mat_dq_workspace_bytes(own > 0 ? own : 0, src0->ne[1], K, N);
+    if (need <= 0) return;
+    peer_t & p = peer(d);
+    grow_on(d, &p.gemm_ws, &p.gemm_ws_size, (size_t)need, p.stream);
+    mi355_set_device(device);
+    *ws = p.gemm_ws; *bytes = need;
+}
+
 static void mi355_mul_mat(mi355_backend_ctx * ctx, ggml_tensor * dst) {
     const ggml_tensor * src0 = dst->src[0];
     const ggml_tensor * src1 = dst->src[1];
@@ -927,7 +985,7 @@ static void mi355_mul_mat(mi355_backend_ctx * ctx, ggml_tensor * dst) {
         MI_CHECK(mi355_mul_mat_f32(&ta, &tb, &td, ctx->stream));
         return;
     }
-    if (is_float_weight_type(src0->type) && mi355_mul_mat_path(src0, src1) == MM_FLOAT) {
+    if (is_float_weight_type(src0->type) && mi355_mul_mat_path(src0, src1, dst) == MM_FLOAT) {
         mi355_tensor ta = to_mi355_tensor(src0), tb = to_mi355_tensor(src1), td = to_mi355_tensor(dst);
         MI_CHECK(mi355_mul_mat_f(&ta, &tb, &td, ctx->stream));
         return;
@@ -939,7 +997,7 @@ static void mi355_mul_mat(mi355_backend_ctx * ctx, ggml_tensor * dst) {
 
     // Activations for all of src1 (strided / permuted src1 is handled by the converters), once per distinct src1 and
     // format: q8_1 for the mat-vec, q8_K for the K-quant skinny kernel, bf16 for the prefill GEMM.
-    const int path = mi355_mul_mat_path(src0, src1), fmt = mm_path_fmt(path);
+    const int path = mi355_mul_mat_path(src0, src1, dst), fmt = mm_path_fmt(path);
     const mi355_act_layout L = mi355_act_planes(path, K, rows);
     const size_t qb = L.total(), db = 0;
     char * ws = (char *)ctx->get_scratch(0, qb);
@@ -986,19 +1044,13 @@ static void mi355_mul_mat(mi355_backend_ctx * ctx, ggml_tensor * dst) {
         int64_t rows_max = 1;
         for (int d = 0; d < ndev; d++) rows_max = std::max(rows_max, extra->row_high[d] - extra->row_low[d]);
         const size_t slice = (size_t)rows * rows_max;                 // floats per device
-        auto grow = [&](float *& buf, size_t & have, size_t need, hipStream_t st) {
-            if (have >= need) return;
-            HIP_CHECK(hipStreamSynchronize(st));
-            if (buf) HIP_CHECK(hipFree(buf));
-            have = (need + (1u << 20)) & ~((size_t)(1u << 20) - 1);
-            HIP_CHECK(hipMalloc((void **)&buf, have));
-        };
         for (int d = 0; d < ndev; d++) {
             const bool main = d == ctx->device;
             hipStream_t st = main ? ctx->stream : ctx->peer(d).stream;
+            mi355_backend_ctx::split_buf_t & sb = ctx->split_bufs[d];
+            mi355_backend_ctx::grow_on(d, (void **)&sb.part, &sb.part_size, slice * sizeof(float), st);
+            mi355_backend_ctx::grow_on(d, (void **)&sb.gath, &sb.gath_size, slice * sizeof(float) * ndev, st);
             mi355_set_device(d);
-            grow(r.part[d], r.part_size[d], slice * sizeof(float), st);
-            grow(r.gath[d], r.gath_size[d], slice * sizeof(float) * ndev, st);
             const char * act = ws;
             if (!main) {
                 mi355_backend_ctx::peer_t & p = ctx->peers[d];
@@ -1024,14 +1076,16 @@ static void mi355_mul_mat(mi355_backend_ctx * ctx, ggml_tensor * dst) {
                 local.nb[1] = (size_t)rows_max * sizeof(float);
                 local.nb[2] = (size_t)N * local.nb[1];
                 local.nb[3] = (size_t)ne12 * local.nb[2];
-                local.data  = (char *)r.part[d] - extra->row_low[d] * (int64_t)sizeof(float);
-                mi355_mul_mat_launch(&local, (const char *)extra->data[d], extra->row_low[d], extra->row_high[d] - extra->row_low[d], act, path, st);
+                local.data  = (char *)sb.part - extra->row_low[d] * (int64_t)sizeof(float);
+                void * lws = gemm_ws; int64_t lws_bytes = gemm_ws_bytes;
+                if (!main) ctx->peer_gemm_ws(d, src0, extra, K, N, path, &lws, &lws_bytes);
+                mi355_mul_mat_launch(&local, (const char *)extra->data[d], extra->row_low[d], extra->row_high[d] - extra->row_low[d], act, path, st, lws, lws_bytes);
             }
         }
         RCCL_CHECK(r.GroupStart());
         for (int d = 0; d < ndev; d++) {
             mi355_set_device(d);
-            RCCL_CHECK(r.AllGather(r.part[d], r.gath[d], slice, ncclFloat, r.comm[d], d == ctx->device ? ctx->stream : ctx->peers[d].stream));
+            RCCL_CHECK(r.AllGather(ctx->split_bufs[d].part, ctx->split_bufs[d].gath, slice, ncclFloat, r.comm[d], d == ctx->device ? ctx->stream : ctx->peers[d].stream));
         }
         RCCL_CHECK(r.GroupEnd());
         mi355_set_device(ctx->device);
@@ -1039,7 +1093,7 @@ static void mi355_mul_mat(mi355_backend_ctx * ctx, ggml_tensor * dst) {
             const int64_t nr = extra->row_high[d] - extra->row_low[d];
             if (nr <= 0) continue;
             HIP_CHECK(hipMemcpy2DAsync((char *)dst->data + extra->row_low[d] * sizeof(float), dst->nb[1],
-                                       r.gath[ctx->device] + (size_t)d * slice, (size_t)rows_max * sizeof(float),
+                                       ctx->split_bufs[ctx->device].gath + (size_t)d * slice, (size_t)rows_max * sizeof(float),
                                        (size_t)nr * sizeof(float), (size_t)rows, hipMemcpyDeviceToDevice, ctx->stream));
         }
         return;
@@ -1060,8 +1114,11 @@ static void mi355_mul_mat(mi355_backend_ctx * ctx, ggml_tensor * dst) {
             mi355_copy_d2d_async(p.act, d, ws, ctx->device, qb + db, p.stream);
             p.act_version = ctx->act_version;
         }
+        void * lws = nullptr; int64_t lws_bytes = 0;
+        ctx->peer_gemm_ws(d, src0, extra, K, N, path, &lws, &lws_bytes);
+        mi355_set_device(d);
         mi355_mul_mat_launch(dst, (const char *)extra->data[d], extra->row_low[d], extra->row_high[d] - extra->row_low[d],
-                             (const char *)p.act, path, p.stream);
+                             (const char *)p.act, path, p.stream, lws, lws_bytes);
         HIP_CHECK(hipEventRecord(p.done, p.stream));
     }
     mi355_set_device(ctx->device);
@@ -1312,7 +1369,7 @@ static bool mi355_try_fuse_rms_norm_mul(mi355_backend_ctx * ctx, ggml_cgraph * c
         int fmt = -1;
         for (int j = i + 2; j < nn && j < i + 16 && fmt < 0; j++) {
             const ggml_tensor * t = ggml_graph_node(cgraph, j);
-            if (t->op == GGML_OP_MUL_MAT && t->src[1] == mul && !tensor_is_split(t->src[0])) fmt = mm_path_fmt(mi355_mul_mat_path(t->src[0], mul));
+            if (t->op == GGML_OP_MUL_MAT && t->src[1] == mul && !tensor_is_split(t->src[0])) fmt = mm_path_fmt(mi355_mul_mat_path(t->src[0], mul, t));
         }
         if (fmt == 2) {
             const mi355_act_layout L = mi355_act_planes(MM_SKINNY_K, K, rows);
@@ -2528,9 +2585,15 @@ static void mi355_graph_refresh_kv_table(mi355_backend_ctx * ctx, ggml_cgraph * 
     mi355_backend_ctx::graph_cache_t & gc = ctx->gc;
     if (gc.kv_nodes.empty()) return;
     void ** h = gc.kv_host + (size_t)gc.ring * MI355_KV_SLOTS * 2;
+    hipEvent_t & ev = gc.ring_ev[gc.ring];
+    // a caller may enqueue more than MI355_KV_RING decode graphs without a host sync (pipelined decode): the copy that read
+    // this slot must have run before the slot is rewritten
+    if (ev) HIP_CHECK(hipEventSynchronize(ev));
+    else    HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     gc.ring = (gc.ring + 1) % MI355_KV_RING;
     for (size_t j = 0; j < gc.kv_nodes.size(); j++) h[j] = ggml_graph_node(cgraph, gc.kv_nodes[j])->data;
     HIP_CHECK(hipMemcpyAsync(gc.kv_dev, h, gc.kv_nodes.size() * sizeof(void *), hipMemcpyHostToDevice, ctx->stream));
+    HIP_CHECK(hipEventRecord(ev, ctx->stream));
 }
 
 static enum ggml_status mi355_backend_graph_compute(ggml_backend_t backend, ggml_cgraph * cgraph) {
@@ -2603,6 +2666,9 @@ static enum ggml_status mi355_backend_graph_compute(ggml_backend_t backend, ggml
     HIP_CHECK(hipGraphInstantiate(&gc.exec, graph, nullptr, nullptr, 0));
     HIP_CHECK(hipGraphDestroy(graph));
     gc.n_capture++;
+    // the signature kept is the CAPTURED graph's (this one), not the first sighting's: a CPY that did not go through the
+    // table has this graph's destination baked in, and only an identical destination may replay it
+    gc.sig.swap(sig);
     for (int j : gc.kv_nodes) gc.sig[j].kv_dst = true;
     mi355_graph_refresh_kv_table(ctx, cgraph);
     HIP_CHECK(hipGraphLaunch(gc.exec, ctx->stream));

@@ -612,26 +612,6 @@ kz_sum_kernel(const float * part, float * dst, int64_t dst_col_stride, int m, in
     }
 }
 
-// workspace of the split-K launches (partial tiles), one per (device, stream) -- launches on different streams may overlap; grows
-// on demand: an allocation (and a device synchronisation when it grows) inside a call.  Prefill-sized MUL_MATs are not what a
-// caller captures into a graph, and MI355_MMDQ_KZ=0 keeps every launch on the paths that need none.
-static float * kz_workspace(size_t bytes, hipStream_t stream) {
-    struct Buf { float * p = nullptr; size_t have = 0; };
-    static std::mutex mu;
-    static std::map<std::pair<int, hipStream_t>, Buf> bufs;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-    std::lock_guard<std::mutex> lock(mu);
-    Buf & b = bufs[{dev, stream}];
-    if (b.have < bytes) {
-        if (b.p) { if (hipDeviceSynchronize() != hipSuccess) return nullptr; (void)hipFree(b.p); b.p = nullptr; b.have = 0; }
-        const size_t want = (bytes + (8u << 20)) & ~((size_t)(8u << 20) - 1);
-        if (hipMalloc((void **)&b.p, want) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-        b.have = want;
-    }
-    return b.p;
-}
-
 // f32 (4-D, strided rows) -> bf16 [rows][k], round to nearest even; one lane per 8 values
 __global__ void __launch_bounds__(256)
 act_bf16_kernel(const char * x, uint16_t * y, int k, int ne1, int ne2, int64_t nb1, int64_t nb2, int64_t nb3) {
@@ -699,7 +679,7 @@ static int launch(const DArgs & a_in, int64_t m_total, hipStream_t s, const char
     const int kzw = kzb > 1 ? kzb : kzs;
     if (kzw > 1 && dma_ok) {
         DArgs b = a;
-        if (!b.part) b.part = kz_workspace((size_t)kzw * a.n * a.m * sizeof(float), s);    // no workspace from the caller: the library's own
+        // the split-K forms need the caller's workspace (mi355_mul_mat_dq_workspace_bytes): this library allocates nothing
         if (!b.part) return MI355_E_WORKSPACE;
         if (kzb > 1) MI355_LAUNCH(tag, (mmdq_ws_kernel<TYPE, 128, 256>), dim3((unsigned)nb2, (unsigned)((a.m + 127) / 128), (unsigned)kzw), dim3(768), 0, s, b);
         else         MI355_LAUNCH(tag, (mmdq_ws_kernel<TYPE, 64, 128>), dim3((unsigned)nb, (unsigned)((a.m + 63) / 64), (unsigned)kzw), dim3(384), 0, s, b);

@@ -236,3 +236,23 @@ def check(code, where):
 for _which, _cls in enumerate((MmvqArgs, QkvRopeArgs, GluMatvecArgs, MoeDownArgs, FattnArgs, Tensor, QkvFinishArgs)):
     if lib.mi355_args_sizeof(_which) != C.sizeof(_cls):
         raise ImportError(f"{_cls.__name__}: ctypes mirror is {C.sizeof(_cls)} bytes, the library's struct {lib.mi355_args_sizeof(_which)}")
+
+
+_dq_ws = {}
+
+
+def mul_mat_dq(t, w, w_row_stride, x, x_row_stride, dst, dst_col_stride, m, k, n, stream, m_total=None):
+    """mi355_mul_mat_dq_slice_ws with the split-K workspace owned HERE, on the caller's side (a torch buffer per device, grown
+    on demand): the library itself allocates nothing.  Pointers are raw device addresses; returns the library's code."""
+    import torch
+    m_total = m if m_total is None else m_total
+    need = lib.mi355_mul_mat_dq_workspace_bytes(m, m_total, k, n)
+    ws = None
+    if need > 0:
+        dev = torch.cuda.current_device()
+        ws = _dq_ws.get(dev)
+        if ws is None or ws.numel() < need:
+            torch.cuda.synchronize()          # launches in flight may still use the old block
+            ws = _dq_ws[dev] = torch.empty(need + (8 << 20), dtype=torch.uint8, device="cuda")
+    return lib.mi355_mul_mat_dq_slice_ws(t, w, w_row_stride, x, x_row_stride, dst, dst_col_stride, m, m_total, k, n,
+                                         ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0, stream)

@@ -109,7 +109,7 @@ def mul_mat_dq(t, w, b, m):
     n, k = b.shape
     y = act_bf16(b)
     dst = torch.empty((n, m), dtype=torch.float32, device=b.device)
-    K.check(K.lib.mi355_mul_mat_dq(t, w.data_ptr(), B.row_size(t, k), y.data_ptr(), k, dst.data_ptr(), m, m, k, n,
+    K.check(K.mul_mat_dq(t, w.data_ptr(), B.row_size(t, k), y.data_ptr(), k, dst.data_ptr(), m, m, k, n,
                                    _stream()), "mi355_mul_mat_dq")
     return dst
 

@@ -218,7 +218,10 @@ def test_mmdq_split_k_workspace_from_the_caller(ops):
     ws = torch.empty(need, dtype=torch.uint8, device="cuda")
     a = torch.empty((n, m), device="cuda")
     b = torch.full((n, m), 7.0, device="cuda")
-    K.check(K.lib.mi355_mul_mat_dq_slice(t, w.data_ptr(), B.row_size(t, k), x.data_ptr(), k, a.data_ptr(), m, m, m, k, n, s), "dq_slice")
+    # without a workspace the library refuses a shape that needs one: it allocates nothing itself
+    assert K.lib.mi355_mul_mat_dq_slice(t, w.data_ptr(), B.row_size(t, k), x.data_ptr(), k, a.data_ptr(), m, m, m, k, n, s) == -5
+    assert K.lib.mi355_mul_mat_dq(t, w.data_ptr(), B.row_size(t, k), x.data_ptr(), k, a.data_ptr(), m, m, k, n, s) == -5
+    K.check(K.mul_mat_dq(t, w.data_ptr(), B.row_size(t, k), x.data_ptr(), k, a.data_ptr(), m, m, k, n, s), "dq (python-side workspace)")
     K.check(K.lib.mi355_mul_mat_dq_slice_ws(t, w.data_ptr(), B.row_size(t, k), x.data_ptr(), k, b.data_ptr(), m, m, m, k, n, ws.data_ptr(), need, s), "dq_slice_ws")
     assert torch.equal(a, b)
     rc = K.lib.mi355_mul_mat_dq_slice_ws(t, w.data_ptr(), B.row_size(t, k), x.data_ptr(), k, b.data_ptr(), m, m, m, k, n, ws.data_ptr(), need - 16, s)
@@ -243,8 +246,8 @@ def test_glu_mul_mat_dq_has_the_bits_of_the_three_launches(ops, t, op):
     s = torch.cuda.current_stream().cuda_stream
     rs = B.row_size(t, k)
     g = torch.empty((n, m), device="cuda"); u = torch.empty((n, m), device="cuda")
-    K.check(K.lib.mi355_mul_mat_dq(t, wa.data_ptr(), rs, x.data_ptr(), k, g.data_ptr(), m, m, k, n, s), "dq gate")
-    K.check(K.lib.mi355_mul_mat_dq(t, wb.data_ptr(), rs, x.data_ptr(), k, u.data_ptr(), m, m, k, n, s), "dq up")
+    K.check(K.mul_mat_dq(t, wa.data_ptr(), rs, x.data_ptr(), k, g.data_ptr(), m, m, k, n, s), "dq gate")
+    K.check(K.mul_mat_dq(t, wb.data_ptr(), rs, x.data_ptr(), k, u.data_ptr(), m, m, k, n, s), "dq up")
     h = torch.empty((n, m), device="cuda"); hb = torch.empty((n, m), dtype=torch.int16, device="cuda")
     K.check(K.lib.mi355_glu_bf16_f32(op, C.byref(K.Tensor.of(g)), C.byref(K.Tensor.of(u)), C.byref(K.Tensor.of(h)), 0, hb.data_ptr(), s), "glu")
     h2 = torch.full((n, m), 7.0, device="cuda"); hb2 = torch.full((n, m), 7, dtype=torch.int16, device="cuda")
@@ -282,7 +285,7 @@ def test_qkv_parts_and_finish_have_the_bits_of_the_separate_launches(ops, mq, mk
     for i, (m, t) in enumerate(zip(ms, ts)):
         w = dev(B.random_blocks(t, m, k, seed=40 + i)); ws.append(w)
         d = torch.empty((n, m), device="cuda")
-        K.check(K.lib.mi355_mul_mat_dq(t, w.data_ptr(), B.row_size(t, k), x.data_ptr(), k, d.data_ptr(), m, m, k, n, s), "dq")
+        K.check(K.mul_mat_dq(t, w.data_ptr(), B.row_size(t, k), x.data_ptr(), k, d.data_ptr(), m, m, k, n, s), "dq")
         want.append(d)
         nb = K.lib.mi355_mul_mat_dq_parts_bytes(m, m, k, n)
         assert nb >= n * m * 4
@@ -369,7 +372,7 @@ def test_gemm_planes_into_add_rms_norm_have_the_bits_of_the_separate_launches(op
     nw = dev((0.5 + rng.random(m)).astype(np.float32))
     T = lambda v: C.byref(K.Tensor.of(v))
     prod = torch.empty((n, m), device="cuda")
-    K.check(K.lib.mi355_mul_mat_dq(t, w.data_ptr(), B.row_size(t, k), x.data_ptr(), k, prod.data_ptr(), m, m, k, n, s), "dq")
+    K.check(K.mul_mat_dq(t, w.data_ptr(), B.row_size(t, k), x.data_ptr(), k, prod.data_ptr(), m, m, k, n, s), "dq")
     sum_a = torch.empty_like(prod); out_a = torch.empty_like(prod); bf_a = torch.empty((n, m), dtype=torch.int16, device="cuda")
     K.check(K.lib.mi355_rms_norm_mul_bf16_f32(T(prod), T(res), T(sum_a), nw.data_ptr(), T(out_a), 1e-5, bf_a.data_ptr(), s), "norm")
     nb = K.lib.mi355_mul_mat_dq_parts_bytes(m, m, k, n)

@@ -20,7 +20,7 @@ for t, m, k in ((B.Q4_K, 1024, 4096), (B.Q4_K, 4096, 4096), (B.Q4_K, 14336, 4096
     dst = torch.empty((n, mm), device="cuda")
     if which == "dq":
         y = ops.act_bf16(x)
-        run = lambda: K.check(K.lib.mi355_mul_mat_dq(t, w.data_ptr(), B.row_size(t, k), y.data_ptr(), k, dst.data_ptr(), mm, mm, k, n, s), "dq")
+        run = lambda: K.check(K.mul_mat_dq(t, w.data_ptr(), B.row_size(t, k), y.data_ptr(), k, dst.data_ptr(), mm, mm, k, n, s), "dq")
     elif which == "qk":
         if t not in (B.Q4_K, B.Q5_K): continue
         q8, d8, bs8 = ops.quantize_act_q8k(x)

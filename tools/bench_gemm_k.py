@@ -16,7 +16,7 @@ for k in (int(v) for v in sys.argv[4].split(",")):
         w = torch.from_numpy(B.random_blocks(t, m, k, seed=1)).cuda()
     y = ops.act_bf16(torch.randn((n, k), device="cuda"))
     dst = torch.empty((n, m), device="cuda")
-    run = lambda: K.check(K.lib.mi355_mul_mat_dq(t, w.data_ptr(), B.row_size(t, k), y.data_ptr(), k, dst.data_ptr(), m, m, k, n, s), "dq")
+    run = lambda: K.check(K.mul_mat_dq(t, w.data_ptr(), B.row_size(t, k), y.data_ptr(), k, dst.data_ptr(), m, m, k, n, s), "dq")
     for _ in range(3): run()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize(); e0.record()

@@ -11,8 +11,8 @@ s = torch.cuda.current_stream().cuda_stream
 rs = B.row_size(t, k)
 g = torch.empty((n, m), device='cuda'); u = torch.empty_like(g); h = torch.empty_like(g); hb = torch.empty((n, m), dtype=torch.int16, device='cuda')
 def three():
-    K.lib.mi355_mul_mat_dq(t, wa.data_ptr(), rs, x.data_ptr(), k, g.data_ptr(), m, m, k, n, s)
-    K.lib.mi355_mul_mat_dq(t, wb.data_ptr(), rs, x.data_ptr(), k, u.data_ptr(), m, m, k, n, s)
+    K.mul_mat_dq(t, wa.data_ptr(), rs, x.data_ptr(), k, g.data_ptr(), m, m, k, n, s)
+    K.mul_mat_dq(t, wb.data_ptr(), rs, x.data_ptr(), k, u.data_ptr(), m, m, k, n, s)
     K.lib.mi355_glu_bf16_f32(2, C.byref(K.Tensor.of(g)), C.byref(K.Tensor.of(u)), C.byref(K.Tensor.of(h)), 0, hb.data_ptr(), s)
 def one():
     K.lib.mi355_glu_mul_mat_dq(t, 2, wa.data_ptr(), rs, wb.data_ptr(), rs, x.data_ptr(), k, h.data_ptr(), m, hb.data_ptr(), m, k, n, s)

@@ -47,6 +47,6 @@ for t in types:
                                                              dst[c0:].data_ptr(), m, m, k, min(32, n - c0), s), "sk2")
                 res["skinny_k"] = timed(sk2, ["mmsk2_%s" % name, "mmsk6_%s" % name])
             if n > 8:
-                res["mmdq"] = timed(lambda: K.check(K.lib.mi355_mul_mat_dq(t, w.data_ptr(), rs, xb.data_ptr(), k, dst.data_ptr(), m, m, k, n, s), "dq"), ["mmdq_%s" % name, "mmdq_kz_sum"])
+                res["mmdq"] = timed(lambda: K.check(K.mul_mat_dq(t, w.data_ptr(), rs, xb.data_ptr(), k, dst.data_ptr(), m, m, k, n, s), "dq"), ["mmdq_%s" % name, "mmdq_kz_sum"])
             wb = m * rs
             print(f"{name:5s} {m:6d}x{k:6d} N={n:4d}  " + "  ".join(f"{kk} {v:8.2f} us ({wb / v / 1e3:6.0f} GB/s)" for kk, v in res.items()), flush=True)
