@@ -55,11 +55,11 @@ enum mi355_error {
 };
 
 /* library / device introspection */
-#define MI355_ABI_VERSION 4                             /* bumped on any signature or struct change */
+#define MI355_ABI_VERSION 5                             /* bumped on any signature or struct change */
 MI355_API int         mi355_abi_version(void);          /* == MI355_ABI_VERSION of the header the library was built from;
                                                          * the plugin and the Python binding refuse a library that differs */
 MI355_API int64_t     mi355_args_sizeof(int which);     /* sizeof of 0 mi355_mmvq_args, 1 qkv_rope, 2 glu_matvec, 3 moe_down,
-                                                         * 4 fattn_args, 5 mi355_tensor, 6 qkv_finish_args; -1 otherwise */
+                                                         * 4 fattn_args, 5 mi355_tensor, 6 qkv_finish_args, 7 decode_layer_args; -1 otherwise */
 MI355_API const char *mi355_error_string(int err);      /* MI355_E_* or hipGetErrorString */
 MI355_API int64_t     mi355_blck_size(int type);        /* elements per block, 0 if unknown */
 MI355_API int64_t     mi355_type_size(int type);        /* bytes per block, 0 if unknown */
@@ -253,6 +253,44 @@ typedef struct mi355_moe_down_args {
     const float *residual; float *residual_out;
 } mi355_moe_down_args;
 MI355_API int mi355_moe_down_matvec(const mi355_moe_down_args *args, void *stream);
+
+/* The body of one decode token's transformer layer in ONE persistent launch -- no counterpart in the reference, which runs a
+ * launch per node (ggml_cuda_mul_mat_vec_q, ggml-cuda/mmvq.cu:491-561; quantize_q8_1, quantize.cu:4-48; rms_norm_f32, norm.cu;
+ * binbcast.cu; rope.cu; cpy.cu) -- replacing, for n_tokens == 1, the node run of llm_build_llama (src/llama-model.cpp:4898-5052)
+ *     MUL_MAT(wo) ADD | RMS_NORM MUL MUL_MAT(gate) MUL_MAT(up) GLU | MUL_MAT(down) ADD | tail
+ * where the tail is the NEXT layer's RMS_NORM MUL MUL_MAT(wq) ROPE MUL_MAT(wk) ROPE MUL_MAT(wv) CPY CPY (MI355_TAIL_QKV: `qkv`, an
+ * mi355_qkv_rope_args whose norm_x is l_out), the model's RMS_NORM MUL MUL_MAT(output) (MI355_TAIL_ROWS: `out`, an mi355_mmvq_args
+ * whose src_f32 is l_out, with norm_w / norm_out), or nothing.  It is the four launches mi355_mul_mat_vec_q_group (+ residual),
+ * mi355_glu_matvec (+ norm), mi355_mul_mat_vec_q_group (+ residual), mi355_qkv_rope_matvec (+ norm) fused, and bit-identical
+ * to them: one workgroup per CU stays resident, the weight stream (LDS-DMA rings) runs on across the phase boundaries, and
+ * the three vectors that cross workgroups (ffn_inp, hidden, l_out) are handed over inside the launch through write-through
+ * stores, sharded arrival counters and L1-bypassing loads.
+ *   All matrices Q4_K / Q5_K / Q6_K; n_embd, k_o (columns of wo) and n_ff multiples of 256, >= 2048; n_embd <= 8192 and a
+ *   multiple of 4 x the workgroup count (the CU count, halved until it divides); otherwise MI355_E_UNSUPPORTED and the caller
+ *   runs the separate launches.  attn_q / attn_ds (mi355_quantize_act layout) or attn_f32: the attention output.  attn_out,
+ *   gate_out, up_out, down_out (the MUL_MAT nodes' own results) may be NULL.  All f32 pointers 16-byte aligned; no output may
+ *   overlap an input or another output, except that attn_out may equal ffn_inp and down_out may equal l_out (ADD in place).
+ *   sync: mi355_decode_layer_sync_bytes() bytes of device memory, 128-byte aligned, ZEROED by the caller before every call on
+ *   the same stream (hipMemsetAsync; one memset may clear the blocks of all of a token's calls) and not shared by calls that
+ *   can overlap.  Its last word receives a non-zero code if a wait inside the launch ran out (4 ms: a workgroup was not
+ *   resident, i.e. something else occupied the GPU): the launch then still ends, with undefined results. */
+enum { MI355_TAIL_NONE = 0, MI355_TAIL_QKV = 1, MI355_TAIL_ROWS = 2 };
+typedef struct mi355_decode_layer_args {
+    int32_t type_o, type_gu, type_d, glu_op, tail;
+    int64_t n_embd, k_o, n_ff;
+    const void *wo; int64_t wo_row_stride;                 /* [n_embd rows][k_o] */
+    const int8_t *attn_q; const float *attn_ds; const float *attn_f32;
+    const float *residual; float *attn_out; float *ffn_inp;
+    const float *ffn_norm_w; float *ffn_norm_out; float norm_eps;
+    const void *w_gate, *w_up; int64_t gu_row_stride;      /* [n_ff rows][n_embd] each */
+    float *gate_out, *up_out, *hidden;
+    const void *w_down; int64_t down_row_stride;           /* [n_embd rows][n_ff] */
+    float *down_out, *l_out;
+    mi355_qkv_rope_args qkv;                               /* MI355_TAIL_QKV */
+    mi355_mmvq_args out;                                   /* MI355_TAIL_ROWS */
+} mi355_decode_layer_args;
+MI355_API int64_t mi355_decode_layer_sync_bytes(void);
+MI355_API int mi355_decode_layer(const mi355_decode_layer_args *args, void *sync, void *stream);
 
 /* "Skinny" MUL_MAT, 1 <= n <= 32 activation columns per call, on the int8 matrix cores: same operands and
  * arithmetic contract as mi355_mul_mat_vec_q (one channel), but one v_mfma_i32_32x32x32_i8 covers 32 rows x 32 columns

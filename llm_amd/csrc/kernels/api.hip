@@ -15,6 +15,7 @@ int64_t mi355_args_sizeof(int which) {
         case 4: return (int64_t)sizeof(mi355_fattn_args);
         case 5: return (int64_t)sizeof(mi355_tensor);
         case 6: return (int64_t)sizeof(mi355_qkv_finish_args);
+        case 7: return (int64_t)sizeof(mi355_decode_layer_args);
     }
     return -1;
 }

@@ -17,7 +17,7 @@ lib = C.CDLL(LIB_PATH)
 
 _vp, _i64, _i32 = C.c_void_p, C.c_int64, C.c_int32
 
-ABI_VERSION = 4          # MI355_ABI_VERSION of include/mi355_kernels.h this binding mirrors
+ABI_VERSION = 5          # MI355_ABI_VERSION of include/mi355_kernels.h this binding mirrors
 
 EXPORTS = [
     "mi355_abi_version", "mi355_args_sizeof", "mi355_error_string", "mi355_blck_size", "mi355_type_size", "mi355_row_size",
@@ -26,6 +26,7 @@ EXPORTS = [
     "mi355_binary_f32", "mi355_rms_norm_f32", "mi355_rms_norm_mul_f32", "mi355_rms_norm_mul_quant_f32", "mi355_glu_quant_f32", "mi355_rms_norm_mul_bf16_f32", "mi355_glu_bf16_f32", "mi355_prefetch", "mi355_parts_add_rms_norm_mul_bf16_f32", "mi355_rms_norm_mul_q8k_f32", "mi355_glu_q8k_f32", "mi355_add_rms_norm_mul_f32", "mi355_mul_mat_vec_q_group", "mi355_qkv_rope_matvec", "mi355_glu_matvec", "mi355_moe_down_matvec", "mi355_rope_f32", "mi355_glu_f32", "mi355_cpy", "mi355_get_rows", "mi355_set_rows", "mi355_mul_mat_f",
     "mi355_scale_f32", "mi355_soft_max_f32", "mi355_flash_attn_ext_workspace_bytes", "mi355_flash_attn_ext", "mi355_flash_attn_ext_quant", "mi355_flash_attn_ext_bf16", "mi355_flash_attn_ext_noalloc_max_bytes", "mi355_flash_attn_ext_noalloc",
     "mi355_dequantize_row", "mi355_mul_mat_vec_q", "mi355_mul_mat_q", "mi355_mul_mat_skinny", "mi355_quantize_act_q8k", "mi355_mul_mat_skinny_k", "mi355_mul_mat_qk", "mi355_mul_mat_id_skinny_workspace_bytes", "mi355_mul_mat_id_skinny", "mi355_argsort_f32", "mi355_moe_router_f32", "mi355_sum_rows_f32", "mi355_mul_mat_f32", "mi355_mul_mat_dq", "mi355_mul_mat_dq_slice", "mi355_kv_store_q8_0", "mi355_mul_mat_dq_slice_ws", "mi355_glu_mul_mat_dq", "mi355_mul_mat_dq_parts_bytes", "mi355_mul_mat_dq_parts", "mi355_mul_mat_dq_parts_pair", "mi355_qkv_finish", "mi355_mul_mat_dq_workspace_bytes", "mi355_act_bf16", "mi355_mul_mat_id_dq_workspace_bytes", "mi355_mul_mat_id_dq", "mi355_mul_mat_workspace_bytes", "mi355_mul_mat",
+    "mi355_decode_layer_sync_bytes", "mi355_decode_layer",
 ]
 
 
@@ -118,6 +119,25 @@ class QkvFinishArgs(C.Structure):
     ]
 
 
+class DecodeLayerArgs(C.Structure):
+    """mi355_decode_layer_args (include/mi355_kernels.h)"""
+    _fields_ = [
+        ("type_o", _i32), ("type_gu", _i32), ("type_d", _i32), ("glu_op", _i32), ("tail", _i32),
+        ("n_embd", _i64), ("k_o", _i64), ("n_ff", _i64),
+        ("wo", _vp), ("wo_row_stride", _i64),
+        ("attn_q", _vp), ("attn_ds", _vp), ("attn_f32", _vp),
+        ("residual", _vp), ("attn_out", _vp), ("ffn_inp", _vp),
+        ("ffn_norm_w", _vp), ("ffn_norm_out", _vp), ("norm_eps", C.c_float),
+        ("w_gate", _vp), ("w_up", _vp), ("gu_row_stride", _i64),
+        ("gate_out", _vp), ("up_out", _vp), ("hidden", _vp),
+        ("w_down", _vp), ("down_row_stride", _i64),
+        ("down_out", _vp), ("l_out", _vp),
+        ("qkv", QkvRopeArgs), ("out", MmvqArgs),
+    ]
+
+
+TAIL_NONE, TAIL_QKV, TAIL_ROWS = 0, 1, 2
+
 lib.mi355_abi_version.restype = C.c_int
 lib.mi355_args_sizeof.restype = _i64
 lib.mi355_args_sizeof.argtypes = [C.c_int]
@@ -193,6 +213,9 @@ lib.mi355_mul_mat_skinny_k.argtypes = [C.c_int, _vp, _i64, _vp, _vp, _vp, _vp, _
 lib.mi355_mul_mat_qk.argtypes = [C.c_int, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp]
 lib.mi355_mul_mat_q.argtypes = [C.c_int, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp]
 lib.mi355_mul_mat.argtypes = [C.c_int, _vp, _i64, _vp, _vp, _i64, _i64, _i64, _vp, _i64, _vp]
+lib.mi355_decode_layer_sync_bytes.restype = _i64
+lib.mi355_decode_layer_sync_bytes.argtypes = []
+lib.mi355_decode_layer.argtypes = [C.POINTER(DecodeLayerArgs), _vp, _vp]
 
 
 lib.mi355_timing_enable.argtypes = [C.c_int]
@@ -233,7 +256,7 @@ def check(code, where):
 
 
 # the hand-kept ctypes mirrors must have the C structs' sizes (a stale library or binding would read struct tails as garbage)
-for _which, _cls in enumerate((MmvqArgs, QkvRopeArgs, GluMatvecArgs, MoeDownArgs, FattnArgs, Tensor, QkvFinishArgs)):
+for _which, _cls in enumerate((MmvqArgs, QkvRopeArgs, GluMatvecArgs, MoeDownArgs, FattnArgs, Tensor, QkvFinishArgs, DecodeLayerArgs)):
     if lib.mi355_args_sizeof(_which) != C.sizeof(_cls):
         raise ImportError(f"{_cls.__name__}: ctypes mirror is {C.sizeof(_cls)} bytes, the library's struct {lib.mi355_args_sizeof(_which)}")
 

@@ -257,6 +257,59 @@ def glu_matvec(t, w_gate, w_up, m, k, aq, ads, glu_op=2, quant=True, keep=True, 
     return dst, g, u, oq, ods
 
 
+_dl_sync = {}
+
+
+def decode_layer_sync(n_calls=1):
+    """A zeroed block of n_calls x mi355_decode_layer_sync_bytes() on the current device (memset on the current stream)."""
+    nb = K.lib.mi355_decode_layer_sync_bytes()
+    key = (torch.cuda.current_device(), n_calls)
+    buf = _dl_sync.get(key)
+    if buf is None:
+        buf = _dl_sync[key] = torch.empty(n_calls * nb, dtype=torch.uint8, device="cuda")
+    buf.zero_()
+    return buf, nb
+
+
+def decode_layer(types, w, n_embd, k_o, n_ff, attn, residual, ffn_norm_w, eps=1e-5, glu_op=2, tail=None, keep=True, sync=None):
+    """The persistent decode-layer launch (mi355_decode_layer).  types = (type_o, type_gu, type_d); w = (wo, w_gate, w_up, w_down)
+    uint8 block tensors; attn = f32 [k_o] or (act_q, act_ds); tail = None | ("qkv", QkvRopeArgs with everything but norm_x set) |
+    ("rows", MmvqArgs with everything but src_f32 set).  -> dict of the f32 outputs (+ "err": the sync block's error word)."""
+    dev = w[0].device
+    f = lambda n: torch.full((n,), float("nan"), dtype=torch.float32, device=dev)
+    o = {"ffn_inp": f(n_embd), "ffn_norm": f(n_embd), "hidden": f(n_ff), "l_out": f(n_embd)}
+    if keep:
+        o.update({"attn_out": f(n_embd), "gate": f(n_ff), "up": f(n_ff), "down": f(n_embd)})
+    a = K.DecodeLayerArgs()
+    a.type_o, a.type_gu, a.type_d, a.glu_op = types[0], types[1], types[2], glu_op
+    a.n_embd, a.k_o, a.n_ff = n_embd, k_o, n_ff
+    a.wo, a.wo_row_stride = _u8(w[0]).data_ptr(), B.row_size(types[0], k_o)
+    if isinstance(attn, tuple):
+        a.attn_q, a.attn_ds = attn[0].data_ptr(), attn[1].data_ptr()
+    else:
+        a.attn_f32 = attn.data_ptr()
+    a.residual, a.ffn_inp = residual.data_ptr(), o["ffn_inp"].data_ptr()
+    a.ffn_norm_w, a.ffn_norm_out, a.norm_eps = ffn_norm_w.data_ptr(), o["ffn_norm"].data_ptr(), eps
+    a.w_gate, a.w_up, a.gu_row_stride = _u8(w[1]).data_ptr(), _u8(w[2]).data_ptr(), B.row_size(types[1], n_embd)
+    a.hidden = o["hidden"].data_ptr()
+    a.w_down, a.down_row_stride = _u8(w[3]).data_ptr(), B.row_size(types[2], n_ff)
+    a.l_out = o["l_out"].data_ptr()
+    if keep:
+        a.attn_out, a.gate_out, a.up_out, a.down_out = (o[n].data_ptr() for n in ("attn_out", "gate", "up", "down"))
+    a.tail = K.TAIL_NONE
+    if tail is not None and tail[0] == "qkv":
+        a.tail, a.qkv = K.TAIL_QKV, tail[1]
+        a.qkv.norm_x = o["l_out"].data_ptr()
+    elif tail is not None:
+        a.tail, a.out = K.TAIL_ROWS, tail[1]
+        a.out.src_f32 = o["l_out"].data_ptr()
+    if sync is None:
+        sync = decode_layer_sync()[0]
+    K.check(K.lib.mi355_decode_layer(a, sync.data_ptr(), _stream()), "mi355_decode_layer")
+    o["sync"] = sync
+    return o
+
+
 def moe_down_matvec(t, w, m, k, n_expert, aq, ads, ids, weights, residual=None, in_place=False):
     """Fused expert feed-forward output of one decode token (mi355_moe_down_matvec): w = [n_expert][m rows] blocks, aq / ads =
     q8_1 of the [n_slots, k] activations, ids int32 [n_slots], weights f32 [n_slots]
