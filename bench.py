@@ -36,6 +36,7 @@ def parse():
     ap.add_argument("--model", default="llama3-8b")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the llama-bench style tg128 / pp512 leg")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the llama-bench legs of BASELINE.json's configs 3-5 (Q8_0 pp2048 with a q8_0 cache, 70B, 8x7B)")
     ap.add_argument("--no-group", action="store_true", help="one launch per matrix instead of grouped QKV / gate+up launches")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
     ap.add_argument("--no-glu-fuse", action="store_true", help="grouped gate+up mat-vec and a separate quantization instead of mi355_glu_matvec")
@@ -143,6 +144,50 @@ def end_to_end(budget_s):
             "pp512_tps": round(j["pp_avg_ts"], 1), "pp512_stddev": round(j["pp_stddev_ts"], 1),
             "tg128_frac_of_hbm_bound": round(j["tg_avg_ts"] * bytes_per_token / (HBM_PEAK_GBPS * 1e9), 4),
             "seconds": round(time.perf_counter() - t0, 1)}
+
+
+def other_configs(budget_s):
+    """BASELINE.json configs 3-5 on ONE GPU through the reference's own llama-bench + plugin (random-weight GGUFs written to /tmp
+    and removed again): 8B Q8_0 pp2048 with a q8_0 KV cache; 70B Q4_K_M pp512 / tg64 (its 1-GPU row; the 2/4/8-GPU rows need a
+    multi-GPU node); Mixtral-8x7B-shaped Q4_K_M batched decode pp8..64 and tg64.  Every leg has its own time limit and the legs
+    stop when the budget is used up, so the default run stays within minutes."""
+    ref = os.path.join(ROOT, "oracle", "_ref")
+    plugin = os.path.join(ROOT, "llm_amd", "lib", "libggml-mi355.so")
+    exe, mk = os.path.join(ref, "llama-bench"), os.path.join(ref, "make-random-gguf")
+    if not all(os.path.exists(x) for x in (exe, mk, plugin)):
+        return {"error": "oracle/_ref/llama-bench, make-random-gguf or the plugin is not built"}
+    legs = [("config3_8b_q8_0_q8kv", "8b", "Q8_0", ["-p", "2048", "-n", "0", "-ctk", "q8_0", "-ctv", "q8_0"]),
+            ("config5_8x7b_q4km", "8x7b", "Q4_K_M", ["-p", "8,16,32,64", "-n", "64"]),
+            ("config4_70b_q4km_1gpu", "70b", "Q4_K_M", ["-p", "512", "-n", "64"])]
+    out, t_all = {}, time.perf_counter()
+    for name, model, ftype, extra in legs:
+        left = budget_s - (time.perf_counter() - t_all)
+        if left < 45:
+            out[name] = {"skipped": "time budget of the default run used up"}
+            continue
+        gguf = f"/tmp/random-{model}-{ftype}.gguf"
+        t0 = time.perf_counter()
+        try:
+            if not os.path.exists(gguf):
+                subprocess.run([mk, gguf, model, ftype], check=True, capture_output=True, timeout=left)
+            r = subprocess.run([exe, "-m", gguf, "-ngl", "99", "-fa", "1", "-r", "2", "-o", "json"] + extra, capture_output=True, text=True,
+                               timeout=max(30, left - (time.perf_counter() - t0)), env=dict(os.environ, GGML_BACKEND_PATH=plugin))
+            rows = json.loads(r.stdout)
+            res = {}
+            for x in rows:
+                key = f"pp{x['n_prompt']}" if x["n_gen"] == 0 else f"tg{x['n_gen']}"
+                res[key + "_tps"] = round(x["avg_ts"], 1)
+            res["seconds"] = round(time.perf_counter() - t0, 1)
+            out[name] = res
+        except Exception as e:  # noqa: BLE001
+            out[name] = {"error": f"{type(e).__name__}: {e}"[:200]}
+        finally:
+            try:
+                os.remove(gguf)
+            except OSError:
+                pass
+    out["harness"] = "the reference's llama-bench (unmodified) + reference libllama + plugin, 2 reps, random-init GGUFs (tools/make_random_gguf.cpp), flash attention"
+    return out
 
 
 def main():
@@ -447,6 +492,58 @@ def main():
                 "traffic": traffic, "traffic_source": "profiles/r02_bench_traffic.json (rocprofv3 --pmc FETCH_SIZE x2, separate pass)" if traffic else None,
                 "launches": n_launch, "avg_launch_us": round(avg_us, 3),
                 "algorithmic_bytes_per_launch": round(q4k_bytes / n_launch), "all_kernels": kernels}
+    # ---- the two denominators: the data sheet's 8 TB/s and what this box streams.  The ceiling is measured with the weight
+    # stream's own instruction (LDS-DMA, non-temporal: mi355_stream_read) over 2 GiB, i.e. cold with respect to the 256 MiB Infinity Cache.
+    ceiling = None
+    single_op = []
+    if world == 1:
+        def timed(fn, reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            fn()
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) * 1e3 / reps      # us
+        big = torch.empty(2 << 30, dtype=torch.uint8, device="cuda")
+        big.random_(0, 256)
+        stream0 = torch.cuda.current_stream().cuda_stream
+        best = 0.0
+        for wgs in (256, 512):
+            us = timed(lambda: K.check(K.lib.mi355_stream_read(big.data_ptr(), big.numel(), wgs, stream0), "mi355_stream_read"), 5)
+            best = max(best, big.numel() / us * 1e-3)
+        ceiling = {"value": round(best, 1), "unit": "GB/s", "what": "mi355_stream_read: 2 GiB read once by LDS-DMA (global_load_lds_dwordx4 nt, 8 KiB in "
+                   "flight per wave, 16 waves per CU), best of 256 / 512 workgroups", "frac_of_8TBps": round(best / HBM_PEAK_GBPS, 4)}
+        del big
+        # single-op Q4_K mat-vec, cold (rotating over >= 1 GB of matrices), eager launches back to back: per launch, launch cost included
+        def single(m, k, pool):
+            outv = torch.empty((1, m), dtype=torch.float32, device="cuda")
+            x1 = torch.randn((1, k), device="cuda", generator=gen)
+            aq1, ads1 = ops.quantize_act(x1)
+            args = []
+            for w in pool:
+                a = K.MmvqArgs()
+                a.type, a.W, a.w_row_stride, a.w_ch_stride = B.Q4_K, w.data_ptr(), B.row_size(B.Q4_K, k), 0
+                a.act_q, a.act_ds, a.act_ch_stride = aq1.data_ptr(), ads1.data_ptr(), 0
+                a.dst, a.dst_col_stride, a.dst_ch_stride = outv.data_ptr(), m, 0
+                a.m, a.k, a.ncols, a.nchannels, a.ch_ratio = m, k, 1, 1, 1
+                args.append(a)
+            def sweep():
+                for a in args:
+                    K.check(K.lib.mi355_mul_mat_vec_q(a, stream0), "mi355_mul_mat_vec_q")
+            us = timed(sweep, 5) / len(args)
+            gbps = B.matvec_bytes(B.Q4_K, m, k) / us * 1e-3
+            return {"shape": f"q4_K {m}x{k} n=1", "us": round(us, 2), "GB/s": round(gbps, 1), "frac_of_8TBps": round(gbps / HBM_PEAK_GBPS, 4),
+                    "frac_of_measured_ceiling": round(gbps / best, 4), "cold_pool_MB": round(len(pool) * B.row_size(B.Q4_K, k) * m / 1e6)}
+        gates = [weights[i] for i, mt in enumerate(mats) if mt.name.endswith("ffn_gate") and mt.type == B.Q4_K]
+        single_op.append(single(dims.n_ff, dims.n_embd, gates))
+        pool2 = [make_weights(torch, B, B.Q4_K, 28672, 8192, gen) for _ in range(8)]
+        single_op.append(single(28672, 8192, pool2))
+        del pool2
+        roofline["peak_measured"] = ceiling["value"]
+        roofline["frac_of_measured"] = round(achieved / best, 4)
     n_launches = sum(1 for p in plan) + sum(1 for p in plan if p[0] is not None)
 
     if rank == 0:
@@ -467,10 +564,16 @@ def main():
                        "decode_tokens_per_s_matvec_only": round(1e3 / ms_per_step, 1)},
             "roofline": roofline,
         }
+        if ceiling is not None:
+            line["stream_ceiling"] = ceiling
+            line["single_op"] = single_op
+            line["config"]["pct_of_measured_ceiling"] = round(value / ceiling["value"] * 100, 2)
         if base is not None:
             line["cpu_baseline"] = base
         if world == 1 and not args.no_e2e:
             line["e2e"] = end_to_end(240)      # a child process with its own copy of the model (288 GB of HBM: no contention)
+            if not args.no_other_configs:
+                line["e2e_other_configs"] = other_configs(300)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -524,6 +524,10 @@ MI355_API int mi355_parts_add_rms_norm_mul_bf16_f32(const float *a_parts, int kz
  * ahead of the launch that streams it, from a second stream beside the previous launch.  No counterpart in the reference; measured
  * in bench.py (BENCH_PREFETCH_MB), see DESIGN.md section 8. */
 MI355_API int mi355_prefetch(const void *p, int64_t bytes, int workgroups, void *stream);
+/* Measurement aid, not part of the hot path: reads bytes (rounded down to whole KiB) from p once with the weight stream's own
+ * instruction (LDS-DMA, non-temporal, 8 KiB in flight per wave, 16 waves per workgroup) and discards them -- the streaming rate
+ * this box reaches, which bench.py reports beside the 8 TB/s of the data sheet.  workgroups: the grid (256 = one per CU). */
+MI355_API int mi355_stream_read(const void *p, int64_t bytes, int workgroups, void *stream);
 
 /* copy / convert with arbitrary strides and equal element counts (ggml_cpy, ggml_cont, ggml_dup):
  * f32 -> f32 | f16 | q8_0, f16 -> f16 | f32.  The q8_0 destination follows quantize_row_q8_0_ref

@@ -69,7 +69,7 @@ struct KLayer {
     DLMat t30, t31, t32; int pe0, pe1, pe2; int ppw, pw3, rpw3;   // ppw: consecutive rotated pairs per stream wave; pw3 / rpw3: rows per workgroup / wave (tail 2)    // ppw: rotated pairs per workgroup, pw3: rows per workgroup (tail 2)
     float * q_out; void * k_out, * v_out; int k_f16, v_f16;
     const int32_t * pos; const float * ff; RopeP rp; void * const * kv_tab; int kv_slot;
-    unsigned * sync;
+    unsigned * sync; int prio_mode;
     unsigned long long * stamps;                // lab: 16 s_memrealtime stamps per wave (mi355_decode_layer_debug_stamps), or null
 };
 
@@ -192,6 +192,7 @@ static __device__ __forceinline__ void stream_waves(const KLayer & a, uint8_t * 
         ss.s3 = SSeg{a.wo.w, 0, 0, 0, 16, MI355_TYPE_Q4_K};
     }
     ss.init(lds_addr(lds) + a.ring_off + sw * D * a.pitch, (unsigned)a.pitch, a.tail ? 4 : 3);
+    ss.prio_balance = a.prio_mode != 0;
     ss.prime();
     DL_STAMP(a, 0);
 
@@ -468,6 +469,7 @@ decode_layer_kernel(const KLayer a) {
     __syncthreads();                // the only workgroup barrier, before anything is in flight
     Bail bl{&ctr[4], a.sync + DL_ERR_WORD};
     if (wave_id() < DL_COMM) DL_STAMP(a, 0);
+    if (wave_id() < DL_COMM && a.prio_mode) __builtin_amdgcn_s_setprio(3);      // the hand-offs are on every phase's critical path
     if (wave_id() < DL_COMM) comm_waves(a, lds, ctr, (lds_f32 *)wsum_, bl);
     else                     stream_waves<D>(a, lds, ctr, bl);
 }
@@ -603,6 +605,7 @@ extern "C" int mi355_decode_layer(const mi355_decode_layer_args * p, void * sync
     if (total <= 82 * 1024) total = 82 * 1024;                      // never two workgroups on one CU: the grid must be resident at once
     a.sync = (unsigned *)sync;
     a.stamps = g_dl_stamps;
+    { static const int pm = [] { const char * e = getenv("MI355_DL_PRIO"); return e ? atoi(e) : 0; }(); a.prio_mode = pm; }
     if (depth == 3) {
         hipError_t e = allow_lds(decode_layer_kernel<3>, total);
         if (e != hipSuccess) return (int)e;

@@ -66,6 +66,7 @@ struct SStream {
     unsigned vo[4], vl[4];                  // per-lane source offsets of the P fetches of a full / a row's last step
     // consuming cursor
     int cslot, consumed;
+    bool prio_balance = false;
 
     static __device__ __forceinline__ int steps_of(const SSeg & s) { return s.nrows * ((s.nb + 15) >> 4); }
     __device__ __forceinline__ void load_seg(int i) {
@@ -142,6 +143,14 @@ struct SStream {
         float out = 0.0f;
         for (int r = 0; r < sg.nrows; r++) {
             float acc = 0.0f;
+            if (prio_balance) {
+                // The SIMD's arbiter serves its oldest wave first (memory requests included), so with equal shares the youngest
+                // waves of a workgroup finish a phase ~30 % after the oldest.  A wave that is behind asks for more: priority
+                // 3 in the first quarter of its rows, 0 in the last.
+                const int lvl = (4 * r) / sg.nrows;
+                if (lvl == 0) __builtin_amdgcn_s_setprio(3); else if (lvl == 1) __builtin_amdgcn_s_setprio(2);
+                else if (lvl == 2) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+            }
             for (int it = 0; it < nit; it++) {
                 wait_step<P>(seg);
                 issue_step();                                       // step i + D - 1 into the slot step i - 1 was read from

@@ -1114,6 +1114,40 @@ def test_mul_mat_id_skinny(ops, t, m, k, n_exp, n_used, n_tok, b1):
     assert O.nmse(vec, got) <= 5e-4
 
 
+@pytest.mark.parametrize("t", [B.Q4_K, B.Q6_K])
+@pytest.mark.parametrize("m,k", [(14336, 4096), (4096, 14336)])
+@pytest.mark.parametrize("n_tok", [8, 32, 64])
+def test_mul_mat_id_skinny_mixtral_shapes(ops, t, m, k, n_tok):
+    """BASELINE.json config 5 at FULL size on its batched path: Mixtral-8x7B's expert matrices (8 x 14336 x 4096 gate / up,
+    8 x 4096 x 14336 down), 2 experts per token, T = 8 / 32 / 64 tokens through mi355_mul_mat_id_skinny (device-side bucketing,
+    col_map, K split, the q6_K mmsk6 kernel in IDS mode).  Checked against exact dequant(as[ids]) . b in f64 on a random subset
+    of rows of every expert (the oracle's dequantizer on those rows), and against the per-pair mat-vec path on all rows."""
+    from test_decode_layer_gpu import gpu_blocks
+    n_exp, n_used = 8, 2
+    rng = np.random.default_rng(m + n_tok + t)
+    w = gpu_blocks(t, n_exp * m, k, seed=40 + t)
+    b = rng.standard_normal((n_tok, 1, k)).astype(np.float32)
+    ids = np.stack([rng.permutation(n_exp)[:n_used] for _ in range(n_tok)]).astype(np.int32)
+    ids[: n_tok // 2, 0] = 3; ids[: n_tok // 2, 1] = (4 + np.arange(n_tok // 2)) % n_exp       # expert 3 takes more than its share
+    ids[: n_tok // 2, 1][ids[: n_tok // 2, 1] == 3] = 0
+    got = ops.mul_mat_id_skinny(t, w, dev(b), dev(ids), m, n_exp).cpu().numpy()
+    assert got.shape == (n_tok, n_used, m) and np.isfinite(got).all()
+    rows = np.sort(rng.choice(m, size=48, replace=False))
+    rs = B.row_size(t, k)
+    num = den = 0.0
+    for e in range(n_exp):
+        sub = w.view(n_exp, m, rs)[e][torch.from_numpy(rows).cuda()].cpu().numpy()
+        wf = O.dequantize_row(t, np.ascontiguousarray(sub), len(rows) * k).reshape(len(rows), k).astype(np.float64)
+        for tt in range(n_tok):
+            for s_ in range(n_used):
+                if ids[tt, s_] == e:
+                    ref = wf @ b[tt, 0].astype(np.float64)
+                    num += float(((got[tt, s_, rows] - ref) ** 2).sum()); den += float((ref ** 2).sum())
+    assert den > 0 and num / den < 5e-4, num / den
+    vec = ops.mul_mat_id(t, w, dev(b), dev(ids), m, n_exp).cpu().numpy()
+    assert O.nmse(vec, got) <= 5e-4
+
+
 def test_errors_are_reported_not_launched(ops):
     import llm_amd.kernels as K
     w = torch.zeros(144 * 4 + 16, dtype=torch.uint8, device="cuda")
