@@ -36,9 +36,13 @@ enum mi355_type {
     MI355_TYPE_Q5_1 = 7,
     MI355_TYPE_Q8_0 = 8,
     MI355_TYPE_Q8_1 = 9,
+    MI355_TYPE_Q2_K = 10,
+    MI355_TYPE_Q3_K = 11,
     MI355_TYPE_Q4_K = 12,
     MI355_TYPE_Q5_K = 13,
     MI355_TYPE_Q6_K = 14,
+    MI355_TYPE_IQ4_NL = 20,
+    MI355_TYPE_IQ4_XS = 23,
     MI355_TYPE_I32  = 26,
     MI355_TYPE_I64  = 27,
     MI355_TYPE_BF16 = 30,

@@ -819,9 +819,11 @@ static bool is_weight_type(enum ggml_type t) {
     return t == GGML_TYPE_Q4_0 || t == GGML_TYPE_Q8_0 || t == GGML_TYPE_Q4_K || t == GGML_TYPE_Q5_K || t == GGML_TYPE_Q6_K;
 }
 
-// MUL_MAT also takes the rest of the 32-value block types (mat-vec + bf16 GEMM, no fused / skinny kernels) and float weights
+// MUL_MAT also takes the rest of the 32-value block types, the 2- / 3-bit K-quants and the non-linear 4-bit types (mat-vec + bf16
+// GEMM, no fused / skinny kernels) and float weights
 static bool is_block_weight_type(enum ggml_type t) {
-    return is_weight_type(t) || t == GGML_TYPE_Q4_1 || t == GGML_TYPE_Q5_0 || t == GGML_TYPE_Q5_1;
+    return is_weight_type(t) || t == GGML_TYPE_Q4_1 || t == GGML_TYPE_Q5_0 || t == GGML_TYPE_Q5_1 ||
+           t == GGML_TYPE_Q2_K || t == GGML_TYPE_Q3_K || t == GGML_TYPE_IQ4_NL || t == GGML_TYPE_IQ4_XS;
 }
 static bool is_float_weight_type(enum ggml_type t) { return t == GGML_TYPE_F32 || t == GGML_TYPE_F16 || t == GGML_TYPE_BF16; }
 
@@ -864,7 +866,7 @@ static int mi355_mul_mat_path(const ggml_tensor * src0, const ggml_tensor * src1
         if (dst && dst->op == GGML_OP_MUL_MAT && (enum ggml_prec)dst->op_params[0] == GGML_PREC_F32) return MM_FLOAT;
         return N > 16 && K % 64 == 0 && aligned && src1->type == GGML_TYPE_F32 ? MM_DQ : MM_FLOAT;
     }
-    if (!is_weight_type(src0->type)) {      // q4_1 / q5_0 / q5_1
+    if (!is_weight_type(src0->type)) {      // q4_1 / q5_0 / q5_1 / q2_K / q3_K / iq4_nl / iq4_xs
         return N > 8 && K % 64 == 0 && aligned ? MM_DQ : MM_VEC;
     }
     if (!no_skinny && K % 256 == 0 && aligned && !(N > 8 && int8_mmq)) {

@@ -37,8 +37,8 @@ const char * mi355_error_string(int err) {
 int64_t mi355_blck_size(int type) {
     switch (type) {
         case MI355_TYPE_F32: case MI355_TYPE_F16: case MI355_TYPE_BF16: return 1;
-        case MI355_TYPE_Q4_0: case MI355_TYPE_Q4_1: case MI355_TYPE_Q5_0: case MI355_TYPE_Q5_1: case MI355_TYPE_Q8_0: case MI355_TYPE_Q8_1: return QK;
-        case MI355_TYPE_Q4_K: case MI355_TYPE_Q5_K: case MI355_TYPE_Q6_K: return QK_K;
+        case MI355_TYPE_Q4_0: case MI355_TYPE_Q4_1: case MI355_TYPE_Q5_0: case MI355_TYPE_Q5_1: case MI355_TYPE_Q8_0: case MI355_TYPE_Q8_1: case MI355_TYPE_IQ4_NL: return QK;
+        case MI355_TYPE_Q4_K: case MI355_TYPE_Q5_K: case MI355_TYPE_Q6_K: case MI355_TYPE_Q2_K: case MI355_TYPE_Q3_K: case MI355_TYPE_IQ4_XS: return QK_K;
     }
     return 0;
 }
@@ -57,6 +57,10 @@ int64_t mi355_type_size(int type) {
         case MI355_TYPE_Q4_K: return 144;
         case MI355_TYPE_Q5_K: return 176;
         case MI355_TYPE_Q6_K: return 210;
+        case MI355_TYPE_Q2_K: return 84;
+        case MI355_TYPE_Q3_K: return 110;
+        case MI355_TYPE_IQ4_NL: return 18;
+        case MI355_TYPE_IQ4_XS: return 136;
     }
     return 0;
 }

@@ -1,5 +1,5 @@
 // deq_elem.h -- one dequantized element of a GGUF block row, bit-exact with the reference's
-// dequantize_row_* (ggml/src/ggml-quants.c:249-267,343-357,1274-1296,1476-1501,1684-1713).
+// dequantize_row_* (ggml/src/ggml-quants.c:249-267,343-357,706-735,1050-1099,1274-1296,1476-1501,1684-1713,2428-2468).
 // Every product / difference is an explicit single-rounding intrinsic (no FMA contraction).
 #pragma once
 #include "common.h"
@@ -8,6 +8,12 @@ static __device__ __forceinline__ void scale_min_k4(int j, const uint8_t * q, in
     // get_scale_min_k4, ggml-quants.c:625-632
     if (j < 4) { sc = q[j] & 63; m = q[j + 4] & 63; }
     else       { sc = (q[j + 4] & 0xF) | ((q[j - 4] >> 6) << 4); m = (q[j + 4] >> 4) | ((q[j] >> 6) << 4); }
+}
+
+// kvalues_iq4nl, ggml-common.h:1077-1079
+static __device__ __forceinline__ float iq4nl_value(int code) {
+    constexpr uint64_t LO = 0xF6EADDCFBFAD9881ull, HI = 0x7159453526190D01ull;
+    return (float)(int8_t)(((code & 8) ? HI : LO) >> (8 * (code & 7)));
 }
 
 template <int TYPE>
@@ -76,6 +82,39 @@ static __device__ __forceinline__ float deq_elem(const uint8_t * __restrict__ ba
         const int nib = (g & 2) ? (lo >> 4) : (lo & 0xF);
         const int q = (int)(int8_t)(nib | (((qh[l] >> (2 * g)) & 3) << 4)) - 32;
         return __fmul_rn(__fmul_rn(d, (float)sc[l / 16 + 2 * g]), (float)q);
+    } else if (TYPE == MI355_TYPE_Q2_K) {
+        // dequantize_row_q2_K, ggml-quants.c:706-735: element 128 n + 32 j + 16 h + l
+        const uint8_t * b = base + (i / QK_K) * 84;
+        const int e = i % QK_K, n = e / 128, j = (e % 128) / 32, h = (e % 32) / 16, l = e % 16;
+        const int sc = b[8 * n + 2 * j + h];
+        const float dl = __fmul_rn(h2f(*(const uint16_t *)(b + 80)), (float)(sc & 0xF));
+        const float ml = __fmul_rn(h2f(*(const uint16_t *)(b + 82)), (float)(sc >> 4));
+        const int q = (b[16 + 32 * n + 16 * h + l] >> (2 * j)) & 3;
+        return __fsub_rn(__fmul_rn(dl, (float)q), ml);
+    } else if (TYPE == MI355_TYPE_Q3_K) {
+        // dequantize_row_q3_K, ggml-quants.c:1050-1099
+        const uint8_t * b = base + (i / QK_K) * 110;
+        const int e = i % QK_K, n = e / 128, j = (e % 128) / 32, h = (e % 32) / 16, l = e % 16;
+        const int is = 8 * n + 2 * j + h;
+        const int sc = ((b[96 + (is & 7)] >> (4 * (is >> 3))) & 0xF) | (((b[104 + (is & 3)] >> (2 * (is >> 2))) & 3) << 4);
+        const float dl = __fmul_rn(h2f(*(const uint16_t *)(b + 108)), (float)(sc - 32));
+        const int q = ((b[32 + 32 * n + 16 * h + l] >> (2 * j)) & 3) - ((b[16 * h + l] >> (4 * n + j)) & 1 ? 0 : 4);
+        return __fmul_rn(dl, (float)q);
+    } else if (TYPE == MI355_TYPE_IQ4_NL) {
+        // dequantize_row_iq4_nl, ggml-quants.c:2428-2444
+        const uint8_t * b = base + (i / QK) * 18;
+        const int j = i % QK;
+        const int code = j < 16 ? (b[2 + j] & 0x0F) : (b[2 + j - 16] >> 4);
+        return __fmul_rn(h2f(*(const uint16_t *)b), iq4nl_value(code));
+    } else if (TYPE == MI355_TYPE_IQ4_XS) {
+        // dequantize_row_iq4_xs, ggml-quants.c:2446-2468
+        const uint8_t * b = base + (i / QK_K) * 136;
+        const int e = i % QK_K, ib = e / 32, j = e % 32;
+        const int sh = *(const uint16_t *)(b + 2);
+        const int ls = ((b[4 + ib / 2] >> (4 * (ib % 2))) & 0xF) | (((sh >> (2 * ib)) & 3) << 4);
+        const float dl = __fmul_rn(h2f(*(const uint16_t *)b), (float)(ls - 32));
+        const int code = j < 16 ? (b[8 + 16 * ib + j] & 0x0F) : (b[8 + 16 * ib + j - 16] >> 4);
+        return __fmul_rn(dl, iq4nl_value(code));
     } else if (TYPE == MI355_TYPE_F16) {
         return h2f(((const uint16_t *)base)[i]);
     } else if (TYPE == MI355_TYPE_BF16) {

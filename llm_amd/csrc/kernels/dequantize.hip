@@ -48,6 +48,10 @@ extern "C" int mi355_dequantize_row(int type, const void * blocks, float * y, in
         case MI355_TYPE_Q4_K: return launch_deq<MI355_TYPE_Q4_K>(blocks, y, n, s);
         case MI355_TYPE_Q5_K: return launch_deq<MI355_TYPE_Q5_K>(blocks, y, n, s);
         case MI355_TYPE_Q6_K: return launch_deq<MI355_TYPE_Q6_K>(blocks, y, n, s);
+        case MI355_TYPE_Q2_K: return launch_deq<MI355_TYPE_Q2_K>(blocks, y, n, s);
+        case MI355_TYPE_Q3_K: return launch_deq<MI355_TYPE_Q3_K>(blocks, y, n, s);
+        case MI355_TYPE_IQ4_NL: return launch_deq<MI355_TYPE_IQ4_NL>(blocks, y, n, s);
+        case MI355_TYPE_IQ4_XS: return launch_deq<MI355_TYPE_IQ4_XS>(blocks, y, n, s);
     }
     return MI355_E_TYPE;
 }

@@ -1069,6 +1069,10 @@ int mi355_get_rows(const mi355_tensor * src, const mi355_tensor * ids, const mi3
         case MI355_TYPE_Q4_K: GR(MI355_TYPE_Q4_K);
         case MI355_TYPE_Q5_K: GR(MI355_TYPE_Q5_K);
         case MI355_TYPE_Q6_K: GR(MI355_TYPE_Q6_K);
+        case MI355_TYPE_Q2_K: GR(MI355_TYPE_Q2_K);
+        case MI355_TYPE_Q3_K: GR(MI355_TYPE_Q3_K);
+        case MI355_TYPE_IQ4_NL: GR(MI355_TYPE_IQ4_NL);
+        case MI355_TYPE_IQ4_XS: GR(MI355_TYPE_IQ4_XS);
         default: return MI355_E_TYPE;
     }
 #undef GR

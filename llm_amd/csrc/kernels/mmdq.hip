@@ -66,6 +66,10 @@ template <> struct Raw<MI355_TYPE_Q4_0> { v4i qs; uint16_t d; };
 template <> struct Raw<MI355_TYPE_Q4_1> { v4i qs; uint16_t d, m; };
 template <> struct Raw<MI355_TYPE_Q5_0> { v4i qs; uint32_t qh; uint16_t d; };
 template <> struct Raw<MI355_TYPE_Q5_1> { v4i qs; uint32_t qh; uint16_t d, m; };
+template <> struct Raw<MI355_TYPE_Q2_K> { v4i q0, q1; uint16_t sc, d, dmin; };
+template <> struct Raw<MI355_TYPE_Q3_K> { v4i q0, q1, h0, h1; uint16_t sl, sh, d; };
+template <> struct Raw<MI355_TYPE_IQ4_NL> { v4i qs; uint16_t d; };
+template <> struct Raw<MI355_TYPE_IQ4_XS> { v4i qs; uint16_t d, sh, sl; };
 // float weights (an unquantized GGUF; K / V of a graph without flash attention): "dequantization" is the conversion to bf16
 template <> struct Raw<MI355_TYPE_F16>  { v4i q[4]; };
 template <> struct Raw<MI355_TYPE_BF16> { v4i q[4]; };
@@ -119,6 +123,35 @@ static __device__ __forceinline__ Raw<TYPE> load_raw(const uint8_t * wrow, int k
         const uint8_t * blk = wrow + (int64_t)(k >> 5) * 24;
         r.qs = ld16_a2(blk + 8);
         r.d  = ld_u16(blk); r.m = ld_u16(blk + 2); r.qh = (uint32_t)ld_u16(blk + 4) | ((uint32_t)ld_u16(blk + 6) << 16);
+    } else if constexpr (TYPE == MI355_TYPE_Q2_K) {
+        // the 32 values at 128 n + 32 j: (qs[32 n + l] >> 2 j) & 3, scale bytes 8 n + 2 j (l < 16) and + 1 (ggml-quants.c:706-735)
+        const uint8_t * blk = wrow + (int64_t)(k >> 8) * 84;
+        const int n = (k >> 7) & 1, j = (k >> 5) & 3;
+        r.q0 = ld16_a2(blk + 16 + 32 * n);
+        r.q1 = ld16_a2(blk + 32 + 32 * n);
+        r.sc = ld_u16(blk + 8 * n + 2 * j);
+        r.d  = ld_u16(blk + 80); r.dmin = ld_u16(blk + 82);
+    } else if constexpr (TYPE == MI355_TYPE_Q3_K) {
+        // as q2_K plus bit 4 n + j of hmask[l]; scales is = 8 n + 2 j and is + 1: low nibbles in bytes is & 7 (and + 1), shifted by
+        // 4 (is >> 3); high bits in bytes 8 + (is & 3) (and + 1), shifted by 2 (is >> 2) (ggml-quants.c:1050-1099)
+        const uint8_t * blk = wrow + (int64_t)(k >> 8) * 110;
+        const int n = (k >> 7) & 1, j = (k >> 5) & 3, is = 8 * n + 2 * j;
+        r.q0 = ld16_a2(blk + 32 + 32 * n);
+        r.q1 = ld16_a2(blk + 48 + 32 * n);
+        r.h0 = ld16_a2(blk);
+        r.h1 = ld16_a2(blk + 16);
+        r.sl = ld_u16(blk + 96 + (is & 7));
+        r.sh = ld_u16(blk + 104 + (is & 3));
+        r.d  = ld_u16(blk + 108);
+    } else if constexpr (TYPE == MI355_TYPE_IQ4_NL) {
+        const uint8_t * blk = wrow + (int64_t)(k >> 5) * 18;
+        r.qs = ld16_a2(blk + 2);
+        r.d  = ld_u16(blk);
+    } else if constexpr (TYPE == MI355_TYPE_IQ4_XS) {
+        const uint8_t * blk = wrow + (int64_t)(k >> 8) * 136;
+        const int ib = (k >> 5) & 7;
+        r.qs = ld16_a2(blk + 8 + 16 * ib);
+        r.d  = ld_u16(blk); r.sh = ld_u16(blk + 2); r.sl = ld_u16(blk + 4 + (ib >> 2) * 2);
     } else if constexpr (TYPE == MI355_TYPE_F32) {
 #pragma unroll
         for (int i = 0; i < 8; i++) r.q[i] = ld16_a2(wrow + (int64_t)k * 4 + 16 * i);
@@ -146,6 +179,11 @@ static __device__ __forceinline__ void k4_one(const v4i hdr, int j, float & dsc,
 }
 
 static __device__ __forceinline__ float ubyte(int w, int i) { return (float)((w >> (8 * i)) & 0xff); }
+// kvalues_iq4nl, ggml-common.h:1077-1079
+static __device__ __forceinline__ float iq4nl_f(int code) {
+    constexpr uint64_t LO = 0xF6EADDCFBFAD9881ull, HI = 0x7159453526190D01ull;
+    return (float)(int8_t)(((code & 8) ? HI : LO) >> (8 * (code & 7)));
+}
 
 // dequantize the 32 weights to f32 (same formulas as dequantize_row_*, ggml-quants.c)
 template <int TYPE>
@@ -208,6 +246,45 @@ static __device__ __forceinline__ void dequant32(const Raw<TYPE> & r, int k, flo
                 const float hi = ubyte((r.qs[w] >> 4) & 0x0f0f0f0f, i) + (float)(((qh >> (e + 16)) & 1u) << 4);
                 f[e]      = d * (lo - off) + m;
                 f[16 + e] = d * (hi - off) + m;
+            }
+        }
+    } else if constexpr (TYPE == MI355_TYPE_Q2_K) {
+        const int j = (k >> 5) & 3;
+        const float d = h2f(r.d), dmin = h2f(r.dmin);
+        const float d0 = d * (float)(r.sc & 0xf), m0 = dmin * (float)((r.sc >> 4) & 0xf);
+        const float d1 = d * (float)((r.sc >> 8) & 0xf), m1 = dmin * (float)(r.sc >> 12);
+#pragma unroll
+        for (int w = 0; w < 8; w++) {
+            const int q = ((w < 4 ? r.q0[w] : r.q1[w - 4]) >> (2 * j)) & 0x03030303;
+#pragma unroll
+            for (int i = 0; i < 4; i++) f[4 * w + i] = (w < 4 ? d0 : d1) * ubyte(q, i) - (w < 4 ? m0 : m1);
+        }
+    } else if constexpr (TYPE == MI355_TYPE_Q3_K) {
+        const int n = (k >> 7) & 1, j = (k >> 5) & 3, is = 8 * n + 2 * j;
+        const float d = h2f(r.d);
+        const int lsh = 4 * (is >> 3), hsh = 2 * (is >> 2);
+        const int s0 = (int)(((r.sl >> lsh) & 0xf) | (((r.sh >> hsh) & 3) << 4)) - 32;
+        const int s1 = (int)(((r.sl >> (8 + lsh)) & 0xf) | (((r.sh >> (8 + hsh)) & 3) << 4)) - 32;
+        const float d0 = d * (float)s0, d1 = d * (float)s1;
+#pragma unroll
+        for (int w = 0; w < 8; w++) {
+            const int q = (((w < 4 ? r.q0[w] : r.q1[w - 4]) >> (2 * j)) & 0x03030303) | ((((w < 4 ? r.h0[w] : r.h1[w - 4]) >> (4 * n + j)) & 0x01010101) << 2);
+#pragma unroll
+            for (int i = 0; i < 4; i++) f[4 * w + i] = (w < 4 ? d0 : d1) * (ubyte(q, i) - 4.0f);
+        }
+    } else if constexpr (TYPE == MI355_TYPE_IQ4_NL || TYPE == MI355_TYPE_IQ4_XS) {
+        float d = h2f(r.d);
+        if constexpr (TYPE == MI355_TYPE_IQ4_XS) {
+            const int ib = (k >> 5) & 7;
+            const int ls = (int)(((r.sl >> (4 * (ib & 3))) & 0xf) | (((r.sh >> (2 * ib)) & 3) << 4));
+            d *= (float)(ls - 32);
+        }
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                f[4 * w + i]      = d * iq4nl_f((r.qs[w] >> (8 * i)) & 0xf);
+                f[16 + 4 * w + i] = d * iq4nl_f((r.qs[w] >> (8 * i + 4)) & 0xf);
             }
         }
     } else if constexpr (TYPE == MI355_TYPE_F16) {
@@ -827,6 +904,10 @@ static int dq_run(int type, const void * W, int64_t w_row_stride, const uint16_t
         case MI355_TYPE_Q4_1: return launch<MI355_TYPE_Q4_1>(a, m_total, s, "mmdq_q4_1", parts_kz);
         case MI355_TYPE_Q5_0: return launch<MI355_TYPE_Q5_0>(a, m_total, s, "mmdq_q5_0", parts_kz);
         case MI355_TYPE_Q5_1: return launch<MI355_TYPE_Q5_1>(a, m_total, s, "mmdq_q5_1", parts_kz);
+        case MI355_TYPE_Q2_K: return launch<MI355_TYPE_Q2_K>(a, m_total, s, "mmdq_q2_K", parts_kz);
+        case MI355_TYPE_Q3_K: return launch<MI355_TYPE_Q3_K>(a, m_total, s, "mmdq_q3_K", parts_kz);
+        case MI355_TYPE_IQ4_NL: return launch<MI355_TYPE_IQ4_NL>(a, m_total, s, "mmdq_iq4_nl", parts_kz);
+        case MI355_TYPE_IQ4_XS: return launch<MI355_TYPE_IQ4_XS>(a, m_total, s, "mmdq_iq4_xs", parts_kz);
         case MI355_TYPE_F16:  return launch<MI355_TYPE_F16>(a, m_total, s, "mmdq_f16", parts_kz);
         case MI355_TYPE_BF16: return launch<MI355_TYPE_BF16>(a, m_total, s, "mmdq_bf16", parts_kz);
         case MI355_TYPE_F32:  return launch<MI355_TYPE_F32>(a, m_total, s, "mmdq_f32", parts_kz);

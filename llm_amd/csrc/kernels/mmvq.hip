@@ -901,6 +901,7 @@ static const char * type_name(int t) {
         case MI355_TYPE_Q4_0: return "q4_0"; case MI355_TYPE_Q8_0: return "q8_0"; case MI355_TYPE_Q4_K: return "q4_K";
         case MI355_TYPE_Q5_K: return "q5_K"; case MI355_TYPE_Q6_K: return "q6_K";
         case MI355_TYPE_Q4_1: return "q4_1"; case MI355_TYPE_Q5_0: return "q5_0"; case MI355_TYPE_Q5_1: return "q5_1";
+        case MI355_TYPE_Q2_K: return "q2_K"; case MI355_TYPE_Q3_K: return "q3_K"; case MI355_TYPE_IQ4_NL: return "iq4_nl"; case MI355_TYPE_IQ4_XS: return "iq4_xs";
     }
     return "?";
 }
@@ -1060,6 +1061,10 @@ extern "C" int mi355_mul_mat_vec_q(const mi355_mmvq_args * p, void * stream) {
         case MI355_TYPE_Q4_1: return dispatch_cols<MI355_TYPE_Q4_1>(a, p->ncols, p->nchannels, s);
         case MI355_TYPE_Q5_0: return dispatch_cols<MI355_TYPE_Q5_0>(a, p->ncols, p->nchannels, s);
         case MI355_TYPE_Q5_1: return dispatch_cols<MI355_TYPE_Q5_1>(a, p->ncols, p->nchannels, s);
+        case MI355_TYPE_Q2_K: return dispatch_cols<MI355_TYPE_Q2_K>(a, p->ncols, p->nchannels, s);
+        case MI355_TYPE_Q3_K: return dispatch_cols<MI355_TYPE_Q3_K>(a, p->ncols, p->nchannels, s);
+        case MI355_TYPE_IQ4_NL: return dispatch_cols<MI355_TYPE_IQ4_NL>(a, p->ncols, p->nchannels, s);
+        case MI355_TYPE_IQ4_XS: return dispatch_cols<MI355_TYPE_IQ4_XS>(a, p->ncols, p->nchannels, s);
     }
     return MI355_E_TYPE;
 }
@@ -1129,6 +1134,10 @@ extern "C" int mi355_mul_mat_vec_q_group(const mi355_mmvq_args * p, int n_mats, 
             case MI355_TYPE_Q4_1: return launch_stream<MI355_TYPE_Q4_1>(b, s);
             case MI355_TYPE_Q5_0: return launch_stream<MI355_TYPE_Q5_0>(b, s);
             case MI355_TYPE_Q5_1: return launch_stream<MI355_TYPE_Q5_1>(b, s);
+            case MI355_TYPE_Q2_K: return launch_stream<MI355_TYPE_Q2_K>(b, s);
+            case MI355_TYPE_Q3_K: return launch_stream<MI355_TYPE_Q3_K>(b, s);
+            case MI355_TYPE_IQ4_NL: return launch_stream<MI355_TYPE_IQ4_NL>(b, s);
+            case MI355_TYPE_IQ4_XS: return launch_stream<MI355_TYPE_IQ4_XS>(b, s);
         }
         return MI355_E_TYPE;
     }
@@ -1142,6 +1151,10 @@ extern "C" int mi355_mul_mat_vec_q_group(const mi355_mmvq_args * p, int n_mats, 
         case MI355_TYPE_Q4_1: return dispatch_group_cols<MI355_TYPE_Q4_1>(a, p[0].ncols, s);
         case MI355_TYPE_Q5_0: return dispatch_group_cols<MI355_TYPE_Q5_0>(a, p[0].ncols, s);
         case MI355_TYPE_Q5_1: return dispatch_group_cols<MI355_TYPE_Q5_1>(a, p[0].ncols, s);
+        case MI355_TYPE_Q2_K: return dispatch_group_cols<MI355_TYPE_Q2_K>(a, p[0].ncols, s);
+        case MI355_TYPE_Q3_K: return dispatch_group_cols<MI355_TYPE_Q3_K>(a, p[0].ncols, s);
+        case MI355_TYPE_IQ4_NL: return dispatch_group_cols<MI355_TYPE_IQ4_NL>(a, p[0].ncols, s);
+        case MI355_TYPE_IQ4_XS: return dispatch_group_cols<MI355_TYPE_IQ4_XS>(a, p[0].ncols, s);
     }
     return MI355_E_TYPE;
 }

@@ -370,6 +370,186 @@ template <> struct Unit<MI355_TYPE_Q5_1> {
     }
 };
 
+// ---- the third batch (the remainder): q2_K, q3_K, iq4_nl, iq4_xs -------------------------------------------------
+// kvalues_iq4nl (ggml-common.h:1077-1079) packed four to a dword; iq4nl_lut4 maps the four 4-bit codes in the bytes of `idx`
+// (each 0..15) to their int8 values with three v_perm_b32: entries 0..7, entries 8..15, then a per-byte pick by bit 3.
+static __device__ __forceinline__ int iq4nl_lut4(uint32_t idx) {
+    constexpr uint32_t T0 = 0xBFAD9881u, T1 = 0xF6EADDCFu, T2 = 0x26190D01u, T3 = 0x71594535u;
+    const uint32_t sel = idx & 0x07070707u;
+    const uint32_t lo = __builtin_amdgcn_perm(T1, T0, sel), hi = __builtin_amdgcn_perm(T3, T2, sel);
+    return (int)__builtin_amdgcn_perm(hi, lo, 0x03020100u | ((idx >> 1) & 0x04040404u));
+}
+
+// ---- IQ4_NL: 18 B = {half d, u8 qs[16]} (ggml-common.h:405-410); as q4_0 with the nibble looked up in the code book
+// (dequantize_row_iq4_nl, ggml-quants.c:2428-2444)
+template <> struct Unit<MI355_TYPE_IQ4_NL> {
+    static constexpr int ELEMS = 32;
+    struct Raw { v4i qs; uint16_t d; };
+    struct Dec { v4i lo, hi; float d; };
+    typedef Unit<MI355_TYPE_Q8_0>::Act Act;
+    static __device__ __forceinline__ Raw load(const uint8_t * row, int u) {
+        const uint8_t * blk = row + (int64_t)u * 18;
+        Raw r;
+        r.qs = ld16_a2(blk + 2);
+        r.d  = ld_u16(blk);
+        return r;
+    }
+    static __device__ __forceinline__ Dec decode(const Raw & r, int) {
+        Dec d;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            d.lo[j] = iq4nl_lut4((uint32_t)r.qs[j] & 0x0f0f0f0fu);
+            d.hi[j] = iq4nl_lut4(((uint32_t)r.qs[j] >> 4) & 0x0f0f0f0fu);
+        }
+        d.d = h2f(r.d);
+        return d;
+    }
+    template <class AP> static __device__ __forceinline__ Act load_act(const AP a, int u) { return Unit<MI355_TYPE_Q8_0>::load_act(a, u); }
+    static __device__ __forceinline__ float dot(const Dec & w, const Act & a) {
+        int s = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) { s = dot4(w.lo[j], a.q0[j], s); s = dot4(w.hi[j], a.q1[j], s); }
+        return w.d * a.d * (float)s;
+    }
+};
+
+// ---- IQ4_XS: 136 B = {half d, u16 scales_h, u8 scales_l[4], u8 qs[128]} (ggml-common.h:412-418).  Sub-block ib (32 values): qs[16 ib ..],
+// low nibbles first; its 6-bit scale is nibble ib of scales_l | bits 2 ib.. of scales_h << 4, minus 32 (dequantize_row_iq4_xs,
+// ggml-quants.c:2446-2468).  unit = sub-blocks 2g, 2g + 1 of block b.
+template <> struct Unit<MI355_TYPE_IQ4_XS> {
+    static constexpr int ELEMS = 64;
+    struct Raw { v4i q0, q1; v2i hdr; };
+    struct Dec { v4i lo0, hi0, lo1, hi1; float d0, d1; };
+    typedef Act64 Act;
+    static __device__ __forceinline__ Raw load(const uint8_t * row, int u) {
+        const uint8_t * blk = row + (int64_t)(u >> 2) * 136;
+        Raw r;
+        r.q0  = ld16_a2(blk + 8 + (u & 3) * 32);
+        r.q1  = ld16_a2(blk + 24 + (u & 3) * 32);
+        r.hdr = ((const v2i_a2 *)blk)->v;
+        return r;
+    }
+    static __device__ __forceinline__ Dec decode(const Raw & r, int u) {
+        const int g = u & 3;
+        Dec d;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            d.lo0[j] = iq4nl_lut4((uint32_t)r.q0[j] & 0x0f0f0f0fu); d.hi0[j] = iq4nl_lut4(((uint32_t)r.q0[j] >> 4) & 0x0f0f0f0fu);
+            d.lo1[j] = iq4nl_lut4((uint32_t)r.q1[j] & 0x0f0f0f0fu); d.hi1[j] = iq4nl_lut4(((uint32_t)r.q1[j] >> 4) & 0x0f0f0f0fu);
+        }
+        const uint32_t sl = ((uint32_t)r.hdr.y >> (8 * g)) & 0xffu, sh = ((uint32_t)r.hdr.x >> (16 + 4 * g)) & 0xfu;
+        const int ls0 = (int)((sl & 0xfu) | ((sh & 3u) << 4)), ls1 = (int)((sl >> 4) | ((sh >> 2) << 4));
+        const float dd = h2f((uint16_t)((uint32_t)r.hdr.x & 0xffffu));
+        d.d0 = dd * (float)(ls0 - 32); d.d1 = dd * (float)(ls1 - 32);
+        return d;
+    }
+    template <class AP> static __device__ __forceinline__ Act load_act(const AP a, int u) { return load_act64(a, u); }
+    static __device__ __forceinline__ float dot(const Dec & w, const Act & a) {
+        int s0 = 0, s1 = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            s0 = dot4(w.lo0[j], a.q[0][j], s0); s0 = dot4(w.hi0[j], a.q[1][j], s0);
+            s1 = dot4(w.lo1[j], a.q[2][j], s1); s1 = dot4(w.hi1[j], a.q[3][j], s1);
+        }
+        return w.d0 * a.ds.x * (float)s0 + w.d1 * a.ds.z * (float)s1;
+    }
+};
+
+// ---- Q2_K: 84 B = {u8 scales[16], u8 qs[64], half d, half dmin} (ggml-common.h:256-267).  Element 128 n + 32 j + 16 h + l is
+// (qs[32 n + 16 h + l] >> 2 j) & 3 with scale byte 8 n + 2 j + h: low nibble * d the scale, high nibble * dmin the minimum
+// (dequantize_row_q2_K, ggml-quants.c:706-735).  unit (b, n, h) as for q6_K: 16 bytes of qs -> 4 groups (j) of 16 weights.
+// A minimum applies to 16 values, half a q8_1 block, so the activations' sum is taken here (4 dot4 with ones per group).
+typedef Unit<MI355_TYPE_Q6_K>::Act ActK16;
+template <> struct Unit<MI355_TYPE_Q2_K> {
+    static constexpr int ELEMS = 64;
+    struct Raw { v4i qs; v2i sc; uint16_t d, dmin; };
+    struct Dec { v4i q[4]; float dl[4], ml[4]; };
+    typedef ActK16 Act;
+    static __device__ __forceinline__ Raw load(const uint8_t * row, int u) {
+        const uint8_t * blk = row + (int64_t)(u >> 2) * 84;
+        const int n = (u >> 1) & 1, h = u & 1;
+        Raw r;
+        r.qs = ld16_a2(blk + 16 + 32 * n + 16 * h);
+        r.sc = ((const v2i_a2 *)(blk + 8 * n))->v;
+        r.d = ld_u16(blk + 80); r.dmin = ld_u16(blk + 82);
+        return r;
+    }
+    static __device__ __forceinline__ Dec decode(const Raw & r, int u) {
+        const int h = u & 1;
+        Dec d;
+        const float dd = h2f(r.d), dm = h2f(r.dmin);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            d.q[j] = (r.qs >> (2 * j)) & 0x03030303;
+            const uint32_t s = ((uint32_t)(j < 2 ? r.sc.x : r.sc.y) >> (8 * h + 16 * (j & 1))) & 0xffu;
+            d.dl[j] = dd * (float)(s & 0xfu); d.ml[j] = dm * (float)(s >> 4);
+        }
+        return d;
+    }
+    template <class AP> static __device__ __forceinline__ Act load_act(const AP a, int u) { return Unit<MI355_TYPE_Q6_K>::load_act(a, u); }
+    static __device__ __forceinline__ float dot(const Dec & w, const Act & a) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            int s = 0, t = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) { s = dot4(w.q[i][j], a.q[i][j], s); t = dot4(0x01010101, a.q[i][j], t); }
+            acc += a.d[i] * (w.dl[i] * (float)s - w.ml[i] * (float)t);
+        }
+        return acc;
+    }
+};
+
+// ---- Q3_K: 110 B = {u8 hmask[32], u8 qs[64], u8 scales[12], half d} (ggml-common.h:273-279).  Element 128 n + 32 j + 16 h + l is
+// ((qs[32 n + 16 h + l] >> 2 j) & 3) - (bit 4 n + j of hmask[16 h + l] ? 0 : 4), scale 8 n + 2 j + h of sixteen 6-bit values
+// (low 4 bits: nibble (is >> 3) of byte is & 7; high 2 bits: bits 2 (is >> 2).. of byte 8 + (is & 3)), minus 32
+// (dequantize_row_q3_K, ggml-quants.c:1050-1099).  unit (b, n, h): 16 bytes of qs + 16 of hmask -> 4 groups of 16 weights.
+template <> struct Unit<MI355_TYPE_Q3_K> {
+    static constexpr int ELEMS = 64;
+    struct Raw { v4i qs, hm; uint32_t s0, s1, s2; uint16_t d; };
+    struct Dec { v4i q[4]; float dl[4]; };
+    typedef ActK16 Act;
+    static __device__ __forceinline__ uint32_t ld_u32_a2(const uint8_t * p) { return (uint32_t)ld_u16(p) | ((uint32_t)ld_u16(p + 2) << 16); }
+    static __device__ __forceinline__ Raw load(const uint8_t * row, int u) {
+        const uint8_t * blk = row + (int64_t)(u >> 2) * 110;
+        const int n = (u >> 1) & 1, h = u & 1;
+        Raw r;
+        r.qs = ld16_a2(blk + 32 + 32 * n + 16 * h);
+        r.hm = ld16_a2(blk + 16 * h);
+        r.s0 = ld_u32_a2(blk + 96); r.s1 = ld_u32_a2(blk + 100); r.s2 = ld_u32_a2(blk + 104);
+        r.d  = ld_u16(blk + 108);
+        return r;
+    }
+    static __device__ __forceinline__ Dec decode(const Raw & r, int u) {
+        const int n = (u >> 1) & 1, h = u & 1;
+        Dec d;
+        const float dd = h2f(r.d);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const v4i v = ((r.qs >> (2 * j)) & 0x03030303) | (((r.hm >> (4 * n + j)) & 0x01010101) << 2);
+#pragma unroll
+            for (int c = 0; c < 4; c++) d.q[j][c] = sub_bytes(v[c], 0x04040404);
+            const int is = 8 * n + 2 * j + h;
+            const uint32_t lo = ((is & 4 ? r.s1 : r.s0) >> (8 * (is & 3) + 4 * (is >> 3))) & 0xfu;
+            const uint32_t hi = (r.s2 >> (8 * (is & 3) + 2 * (is >> 2))) & 3u;
+            d.dl[j] = dd * (float)((int)(lo | (hi << 4)) - 32);
+        }
+        return d;
+    }
+    template <class AP> static __device__ __forceinline__ Act load_act(const AP a, int u) { return Unit<MI355_TYPE_Q6_K>::load_act(a, u); }
+    static __device__ __forceinline__ float dot(const Dec & w, const Act & a) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            int s = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) s = dot4(w.q[i][j], a.q[i][j], s);
+            acc += w.dl[i] * a.d[i] * (float)s;
+        }
+        return acc;
+    }
+};
+
 static __device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 
 typedef __attribute__((address_space(3))) uint8_t lds_u8;

@@ -202,6 +202,7 @@ lib.mi355_glu_bf16_f32.argtypes = [C.c_int, _T, _T, _T, C.c_int, _vp, _vp]
 lib.mi355_rms_norm_mul_bf16_f32.argtypes = [_T, _T, _T, _vp, _T, C.c_float, _vp, _vp]
 lib.mi355_cpy.argtypes = [_T, _T, _vp]
 lib.mi355_set_rows.argtypes = [_T, _T, _T, _vp]
+lib.mi355_get_rows.argtypes = [_T, _T, _T, _vp]
 lib.mi355_mul_mat_f.argtypes = [_T, _T, _T, _vp]
 lib.mi355_rope_f32.argtypes = [C.POINTER(Tensor), _vp, _vp, C.POINTER(Tensor), C.c_int, C.c_int, C.c_int] + [C.c_float] * 6 + [_vp]
 lib.mi355_qkv_rope_matvec.argtypes = [C.POINTER(QkvRopeArgs), _vp]

@@ -436,6 +436,20 @@ def mul_mat_f(type_a, a, b, type_b=B.F32):
     return dst
 
 
+def get_rows(t, w, ids, k):
+    """GGML_OP_GET_ROWS (mi355_get_rows): w uint8 [nrows, row_bytes] blocks of type t (k values per row), ids int32 [n] or
+    [b, n] -> f32 [.., n, k], row ids[.., i] dequantized."""
+    assert w.is_cuda and ids.is_cuda and ids.dtype == torch.int32 and w.dtype == torch.uint8 and w.dim() == 2
+    dst = torch.empty(list(ids.shape) + [k], dtype=torch.float32, device=w.device)
+    ts = K.Tensor()
+    ts.data, ts.type = w.data_ptr(), t
+    ts.ne[0], ts.ne[1], ts.ne[2], ts.ne[3] = k, w.shape[0], 1, 1
+    ts.nb[0], ts.nb[1] = B.TYPE_SIZE[t], w.stride(0)
+    ts.nb[2] = ts.nb[3] = 0 if ids.dim() > 1 else w.stride(0) * w.shape[0]     # one table for every batch of ids
+    K.check(K.lib.mi355_get_rows(ts, _desc(ids, B.I32), _desc(dst, B.F32), _stream()), "mi355_get_rows")
+    return dst
+
+
 def set_rows(src, ids, dst, type_dst):
     """GGML_OP_SET_ROWS (mi355_set_rows): src f32 [.., n, k], ids int64 [.., n], dst rows of type_dst (f32 / f16 tensors,
     or uint8 rows of q8_0 blocks); writes into dst and returns it."""

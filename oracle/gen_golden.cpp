@@ -78,6 +78,8 @@ static const ggml_type WTYPES[] = {GGML_TYPE_Q4_0, GGML_TYPE_Q8_0, GGML_TYPE_Q4_
 // second batch: the remaining 32-value block types; their fixtures go to files of their own so that the
 // first batch's files stay byte-identical
 static const ggml_type WTYPES2[] = {GGML_TYPE_Q4_1, GGML_TYPE_Q5_0, GGML_TYPE_Q5_1};
+// third batch (the remainder): the 2- and 3-bit K-quants and the non-linear 4-bit types
+static const ggml_type WTYPES3[] = {GGML_TYPE_Q2_K, GGML_TYPE_Q3_K, GGML_TYPE_IQ4_NL, GGML_TYPE_IQ4_XS};
 
 // random *bytes* as blocks, with the fp16 scale fields forced to finite, moderate values so that
 // every packed-scale bit pattern is covered without inf/nan
@@ -105,6 +107,15 @@ static std::vector<uint8_t> random_blocks(ggml_type t, size_t nblocks, uint32_t 
                 h = half(1e-4f, 0.01f); memcpy(p + 2, &h, 2); break;
             case GGML_TYPE_Q6_K:
                 h = half(1e-5f, 1e-3f); memcpy(p + 208, &h, 2); break;
+            case GGML_TYPE_Q2_K:
+                h = half(1e-3f, 0.05f); memcpy(p + 80, &h, 2);
+                h = half(1e-3f, 0.05f); memcpy(p + 82, &h, 2); break;
+            case GGML_TYPE_Q3_K:
+                h = half(1e-4f, 0.01f); memcpy(p + 108, &h, 2); break;
+            case GGML_TYPE_IQ4_NL:
+                h = half(1e-4f, 0.01f); memcpy(p, &h, 2); break;
+            case GGML_TYPE_IQ4_XS:
+                h = half(1e-5f, 1e-3f); memcpy(p, &h, 2); break;
             default: break;
         }
     }
@@ -177,6 +188,24 @@ static void gen_dequant2(const std::string & dir) {
     }
     g.f32("quant.src", src);
     g.write(dir + "/dequantize2.gold");
+}
+
+static void gen_dequant3(const std::string & dir) {
+    Gold g;
+    const std::vector<float> src = uniform(2048, 4321);
+    for (ggml_type t : WTYPES3) {
+        const std::string tn = ggml_type_name(t);
+        const size_t n = 2048;
+        auto rb = random_blocks(t, n / ggml_blck_size(t), 7 + (uint32_t)t);
+        g.u8("rand.blocks." + tn, rb);
+        g.f32("rand.deq." + tn, dequant(t, rb, n));
+        std::vector<uint8_t> qb(ggml_row_size(t, n));
+        ggml_quantize_chunk(t, src.data(), qb.data(), 0, 1, n, nullptr);
+        g.u8("quant.blocks." + tn, qb);
+        g.f32("quant.deq." + tn, dequant(t, qb, n));
+    }
+    g.f32("quant.src", src);
+    g.write(dir + "/dequantize3.gold");
 }
 
 // ---- 3. ops on the ggml-cpu backend ------------------------------------------------------------
@@ -260,6 +289,35 @@ static void gen_mul_mat2(const std::string & dir) {
         }
     }
     g.write(dir + "/mul_mat2.gold");
+}
+
+static void gen_mul_mat3(const std::string & dir) {
+    Gold g;
+    struct Shape { int64_t m, k, n; };
+    const Shape shapes[] = {{16, 256, 1}, {33, 512, 3}, {64, 1024, 8}, {24, 256, 17}, {40, 96, 2}};
+    int si = 0;
+    for (ggml_type t : WTYPES3) {
+        for (const Shape & s : shapes) {
+            if (s.k % ggml_blck_size(t) != 0) continue;
+            Ctx cx;
+            const std::string tag = std::string(ggml_type_name(t)) + "." + std::to_string(s.m) + "x" + std::to_string(s.k) + "x" + std::to_string(s.n);
+            auto wf = uniform(s.m * s.k, 500 + si), xf = uniform(s.k * s.n, 600 + si);
+            si++;
+            auto wq = quantize_w(t, wf, s.m, s.k);
+            ggml_tensor * a = ggml_new_tensor_2d(cx.c, t, s.k, s.m);
+            ggml_tensor * b = ggml_new_tensor_2d(cx.c, GGML_TYPE_F32, s.k, s.n);
+            memcpy(a->data, wq.data(), wq.size());
+            memcpy(b->data, xf.data(), xf.size() * 4);
+            ggml_tensor * d = ggml_mul_mat(cx.c, a, b);
+            compute(cx.c, d);
+            std::vector<float> out((float *)d->data, (float *)d->data + s.m * s.n);
+            g.i32("shape." + tag, {(int32_t)t, (int32_t)s.m, (int32_t)s.k, (int32_t)s.n});
+            g.u8("w." + tag, wq);
+            g.f32("x." + tag, xf);
+            g.f32("dst." + tag, out);
+        }
+    }
+    g.write(dir + "/mul_mat3.gold");
 }
 
 static void gen_mul_mat_id(const std::string & dir) {
@@ -379,5 +437,7 @@ int main(int argc, char ** argv) {
     gen_flash_attn(dir);
     gen_dequant2(dir);
     gen_mul_mat2(dir);
+    gen_dequant3(dir);
+    gen_mul_mat3(dir);
     return 0;
 }

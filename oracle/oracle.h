@@ -31,10 +31,14 @@ enum {
     ORC_TYPE_Q5_1 = 7,
     ORC_TYPE_Q8_0 = 8,
     ORC_TYPE_Q8_1 = 9,
+    ORC_TYPE_Q2_K = 10,
+    ORC_TYPE_Q3_K = 11,
     ORC_TYPE_Q4_K = 12,
     ORC_TYPE_Q5_K = 13,
     ORC_TYPE_Q6_K = 14,
     ORC_TYPE_Q8_K = 15,
+    ORC_TYPE_IQ4_NL = 20,
+    ORC_TYPE_IQ4_XS = 23,
     ORC_TYPE_BF16 = 30,
 };
 

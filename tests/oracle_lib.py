@@ -14,10 +14,13 @@ _SO = os.path.join(_ROOT, "oracle", "liboracle.so")
 
 F32, F16, Q4_0, Q8_0, Q8_1, Q4_K, Q5_K, Q6_K, Q8_K = 0, 1, 2, 8, 9, 12, 13, 14, 15
 Q4_1, Q5_0, Q5_1, BF16 = 3, 6, 7, 30
+Q2_K, Q3_K, IQ4_NL, IQ4_XS = 10, 11, 20, 23
 TYPE_NAMES = {F32: "f32", F16: "f16", Q4_0: "q4_0", Q8_0: "q8_0", Q8_1: "q8_1", Q4_K: "q4_K",
-              Q5_K: "q5_K", Q6_K: "q6_K", Q8_K: "q8_K", Q4_1: "q4_1", Q5_0: "q5_0", Q5_1: "q5_1", BF16: "bf16"}
+              Q5_K: "q5_K", Q6_K: "q6_K", Q8_K: "q8_K", Q4_1: "q4_1", Q5_0: "q5_0", Q5_1: "q5_1", BF16: "bf16",
+              Q2_K: "q2_K", Q3_K: "q3_K", IQ4_NL: "iq4_nl", IQ4_XS: "iq4_xs"}
 WEIGHT_TYPES = (Q4_0, Q8_0, Q4_K, Q5_K, Q6_K)
 WEIGHT_TYPES2 = (Q4_1, Q5_0, Q5_1)          # second batch, fixtures in *2.gold
+WEIGHT_TYPES3 = (Q2_K, Q3_K, IQ4_NL, IQ4_XS)  # third batch (the remainder), fixtures in *3.gold
 FLOAT_WEIGHT_TYPES = (F16, BF16, F32)
 
 

@@ -162,7 +162,8 @@ def test_moe_layers_are_as_close_to_the_exact_twin_as_ggml_cpu(tmp_path):
             assert eb / n <= 1.25 * ea / n + 1e-3, (kind, layer, ea / n, eb / n)
 
 
-@pytest.mark.parametrize("ftype,ctk", [("Q4_K_M", "f16"), ("Q8_0", "q8_0"), ("Q4_0", "f16"), ("Q4_1", "f16"), ("Q5_0", "f16"), ("Q5_1", "f16"), ("F16", "f16")])
+@pytest.mark.parametrize("ftype,ctk", [("Q4_K_M", "f16"), ("Q8_0", "q8_0"), ("Q4_0", "f16"), ("Q4_1", "f16"), ("Q5_0", "f16"), ("Q5_1", "f16"), ("F16", "f16"),
+                                       ("Q2_K", "f16"), ("Q3_K", "f16"), ("IQ4_NL", "f16"), ("IQ4_XS", "f16")])
 def test_llama_logits_match_ggml_cpu(ftype, ctk, tmp_path):
     """Whole-graph parity (covers the backend's fusions, which test-backend-ops cannot see): logits of a 48-token prefill, 6 decode
     steps and batches of 3, 2, 12 and 160 tokens on MI355_0 vs the same model on the reference's ggml-cpu.  Both round the activations

@@ -45,6 +45,17 @@ def test_dequantize2_bit_exact(src, t):
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
 
 
+@pytest.mark.parametrize("src", ["rand", "quant"])
+@pytest.mark.parametrize("t", O.WEIGHT_TYPES3)
+def test_dequantize3_bit_exact(src, t):
+    """q2_K / q3_K / iq4_nl / iq4_xs (ggml-quants.c:706-735, 1050-1099, 2428-2468)"""
+    g = load_gold("dequantize3.gold")
+    tn = O.TYPE_NAMES[t]
+    want = g[f"{src}.deq.{tn}"]
+    got = O.dequantize_row(t, g[f"{src}.blocks.{tn}"], want.size)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
 def test_fp16_roundtrip_all_values():
     # every finite half: to_fp32 then back is the identity; also spot-check RNE on midpoints
     import ctypes as C
@@ -96,6 +107,23 @@ def test_mul_mat2_vs_ggml_cpu(tag):
     if t in O.WEIGHT_TYPES2:
         got81 = O.mul_mat(t, g["w." + tag], g["x." + tag], m, k, n, "q8_1")
         assert O.nmse(want, got81) < 2e-4
+
+
+def _mm3_cases():
+    g = load_gold("mul_mat3.gold")
+    return [k[len("shape."):] for k in g if k.startswith("shape.")]
+
+
+@pytest.mark.parametrize("tag", _mm3_cases())
+def test_mul_mat3_vs_ggml_cpu(tag):
+    """q2_K / q3_K / iq4_xs (q8_K activations) and iq4_nl (q8_0): restated generic vec_dot against the ggml-cpu backend"""
+    g = load_gold("mul_mat3.gold")
+    t, m, k, n = (int(x) for x in g["shape." + tag])
+    want = g["dst." + tag].reshape(n, m)
+    got = O.mul_mat(t, g["w." + tag], g["x." + tag], m, k, n, "cpu")
+    assert O.nmse(want, got) < 1e-6
+    got81 = O.mul_mat(t, g["w." + tag], g["x." + tag], m, k, n, "q8_1")
+    assert O.nmse(want, got81) < 2e-4
 
 
 def _mmid_cases():

@@ -4,7 +4,8 @@
 // src/llama-model.cpp:447-596; type map per src/llama-quant.cpp:178-404; tokenizer "no_vocab"
 // (src/llama-vocab.cpp:1383-1403).  Weights are random *valid* blocks (random quants, finite fp16
 // scales), norms are 1.0.
-//   make-random-gguf <out.gguf> <8b|70b|8x7b|tiny|tinymoe> [Q4_K_M|Q8_0|Q4_0|Q4_1|Q5_0|Q5_1|F16] [vocab.gguf]
+//   make-random-gguf <out.gguf> <8b|70b|8x7b|tiny|tinymoe> [Q4_K_M|Q8_0|Q4_0|Q4_1|Q5_0|Q5_1|Q2_K|Q3_K|IQ4_NL|IQ4_XS|F16] [vocab.gguf]
+// (Q2_K / Q3_K / IQ4_NL / IQ4_XS: every matrix in that one type -- "pure" -- not llama-quant's mixtures of the same names)
 // 8x7b / tinymoe are Mixtral-style (llama architecture with 8 experts, 2 used): ffn_gate_inp f32, ffn_*_exps 3-D;
 // Q4_K_M for 8 experts bumps attn_k / attn_v to Q8_0 and attn_output to Q5_K (llama-quant.cpp:300-311,370-378).
 #include "ggml.h"
@@ -61,13 +62,25 @@ static void fill_blocks(ggml_tensor * t) {
                 break;
             }
             case GGML_TYPE_Q6_K: put_half(blk + 208, 0.00002f, 0.0001f, true); break;
+            case GGML_TYPE_Q2_K:
+                // w = d (sc & 15) q - dmin (sc >> 4), q uniform in 0..3: centred when every minimum nibble equals its scale nibble and dmin = 1.5 d
+                for (int j = 0; j < 16; j++) blk[j] = (uint8_t)((blk[j] & 0x0F) * 0x11);
+                {
+                    const ggml_fp16_t h = ggml_fp32_to_fp16(0.0015f + 0.002f * (float)(rnd() >> 40) * (1.0f / 16777216.0f));
+                    const ggml_fp16_t hm = ggml_fp32_to_fp16(1.5f * ggml_fp16_to_fp32(h));
+                    memcpy(blk + 80, &h, 2); memcpy(blk + 82, &hm, 2);
+                }
+                break;
+            case GGML_TYPE_Q3_K:   put_half(blk + 108, 0.0003f, 0.0007f, true); break;
+            case GGML_TYPE_IQ4_NL: put_half(blk, 0.0002f, 0.0004f, true); break;
+            case GGML_TYPE_IQ4_XS: put_half(blk, 0.00001f, 0.00003f, true); break;
             default: break;
         }
     }
 }
 
 int main(int argc, char ** argv) {
-    if (argc < 3) { fprintf(stderr, "usage: %s out.gguf 8b|70b|8x7b|tiny|tinymoe [Q4_K_M|Q8_0|Q4_0|Q4_1|Q5_0|Q5_1|F16] [vocab.gguf]\n", argv[0]); return 2; }
+    if (argc < 3) { fprintf(stderr, "usage: %s out.gguf 8b|70b|8x7b|tiny|tinymoe [Q4_K_M|Q8_0|Q4_0|Q4_1|Q5_0|Q5_1|Q2_K|Q3_K|IQ4_NL|IQ4_XS|F16] [vocab.gguf]\n", argv[0]); return 2; }
     const std::string out = argv[1], model = argv[2];
     std::string ftype = argc > 3 ? argv[3] : "Q4_K_M";
     // "<ftype>+F32": the same random blocks, stored dequantized as F32 -- the model's exact twin, against which both ggml-cpu's and
@@ -86,7 +99,9 @@ int main(int argc, char ** argv) {
     else if (model == "tinymoe") { d = {1024, 4, 8, 2, 2816, 32000, false};    d.n_expert = 8; d.n_expert_used = 2; }
     else { fprintf(stderr, "unknown model %s\n", model.c_str()); return 2; }
     const ggml_type base = ftype == "Q8_0" ? GGML_TYPE_Q8_0 : ftype == "Q4_0" ? GGML_TYPE_Q4_0 : ftype == "Q4_1" ? GGML_TYPE_Q4_1 :
-                           ftype == "Q5_0" ? GGML_TYPE_Q5_0 : ftype == "Q5_1" ? GGML_TYPE_Q5_1 : ftype == "F16" ? GGML_TYPE_F16 : GGML_TYPE_Q4_K;
+                           ftype == "Q5_0" ? GGML_TYPE_Q5_0 : ftype == "Q5_1" ? GGML_TYPE_Q5_1 : ftype == "F16" ? GGML_TYPE_F16 :
+                           ftype == "Q2_K" ? GGML_TYPE_Q2_K : ftype == "Q3_K" ? GGML_TYPE_Q3_K : ftype == "IQ4_NL" ? GGML_TYPE_IQ4_NL :
+                           ftype == "IQ4_XS" ? GGML_TYPE_IQ4_XS : GGML_TYPE_Q4_K;
     const bool km = ftype == "Q4_K_M";
     const int head_dim = d.n_embd / d.n_head, kv_dim = head_dim * d.n_head_kv;
 
@@ -128,7 +143,8 @@ int main(int argc, char ** argv) {
     gguf_set_val_f32(g, "llama.rope.freq_base", 500000.0f);
     gguf_set_val_u32(g, "llama.vocab_size", d.n_vocab);
     gguf_set_val_u32(g, "general.file_type", exact ? 0 : km ? 15 : base == GGML_TYPE_Q8_0 ? 7 : base == GGML_TYPE_F16 ? 1 : base == GGML_TYPE_Q4_1 ? 3 :
-                                               base == GGML_TYPE_Q5_0 ? 8 : base == GGML_TYPE_Q5_1 ? 9 : 2);
+                                               base == GGML_TYPE_Q5_0 ? 8 : base == GGML_TYPE_Q5_1 ? 9 : base == GGML_TYPE_Q2_K ? 10 : base == GGML_TYPE_Q3_K ? 11 :
+                                               base == GGML_TYPE_IQ4_NL ? 25 : base == GGML_TYPE_IQ4_XS ? 30 : 2);
     if (!vocab_path) gguf_set_val_str(g, "tokenizer.ggml.model", "no_vocab");
     if (d.n_expert) {
         gguf_set_val_u32(g, "llama.expert_count", d.n_expert);
