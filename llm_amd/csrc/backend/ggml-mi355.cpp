@@ -1153,7 +1153,7 @@ static void mi355_mul_mat_id(mi355_backend_ctx * ctx, ggml_tensor * dst) {
     const bool dense_dst = dst->nb[1] == (size_t)M * sizeof(float) && dst->nb[2] == (size_t)M * n_used * sizeof(float) &&
                            ((((uintptr_t)b->data) | b->nb[1] | b->nb[2]) & 15) == 0;
     // (measured on 8x7B Q4_K_M: below ~20 pairs the per-pair mat-vec wins -- 16 pairs: 548 vs 521 t/s -- above 256 the GEMM)
-    if (n_tokens * n_used >= sk_min && n_tokens * n_used <= sk_max && K % 256 == 0 && n_expert <= 256 && dense_dst &&
+    if (n_tokens * n_used >= sk_min && n_tokens * n_used <= sk_max && K % 256 == 0 && n_expert <= 256 && dense_dst && is_weight_type(as->type) &&
         !MI355_ENV_SET("GGML_MI355_NO_SKINNY")) {
         const int64_t need = mi355_mul_mat_id_skinny_workspace_bytes((int)as->type, K, n_tokens, b_ne1, n_used, n_expert);
         void * ws = ctx->get_scratch(0, (size_t)need);
@@ -2535,7 +2535,11 @@ static bool mi355_graph_capturable(ggml_cgraph * cgraph) {
     for (int i = 0; i < n; i++) {
         const ggml_tensor * t = ggml_graph_node((ggml_cgraph *)cgraph, i);
         if (t->op == GGML_OP_MUL_MAT || t->op == GGML_OP_MUL_MAT_ID) {
-            if (ggml_nelements(t->src[1]) != t->src[1]->ne[0] * (t->op == GGML_OP_MUL_MAT_ID ? t->src[1]->ne[1] : 1)) return false;
+            // GGML_MI355_GRAPH_COLS=n (lab switch): also steps of up to n tokens (batched / speculative decoding: the same small graph
+            // step after step) -- default 1
+            static const int64_t max_cols = [] { const char * e = getenv("GGML_MI355_GRAPH_COLS"); return e ? atoll(e) : 1; }();
+            const int64_t cols = ggml_nelements(t->src[1]) / (t->src[1]->ne[0] * (t->op == GGML_OP_MUL_MAT_ID ? t->src[1]->ne[1] : 1));
+            if (cols > max_cols) return false;
             if (t->op == GGML_OP_MUL_MAT && ggml_is_quantized(t->src[0]->type)) any = true;
         }
         for (int k = 0; k < GGML_MAX_SRC; k++) if (t->src[k] && tensor_is_split(t->src[k])) return false;
@@ -2813,7 +2817,7 @@ static bool mi355_dev_supports_op(ggml_backend_dev_t dev, const ggml_tensor * op
             const ggml_tensor * a = op->src[0];
             const ggml_tensor * b = op->src[1];
             const ggml_tensor * ids = op->src[2];
-            if (!is_weight_type(a->type) || b->type != GGML_TYPE_F32 || op->type != GGML_TYPE_F32 || ids->type != GGML_TYPE_I32) return false;
+            if (!is_block_weight_type(a->type) || b->type != GGML_TYPE_F32 || op->type != GGML_TYPE_F32 || ids->type != GGML_TYPE_I32) return false;
             if (a->nb[0] != ggml_type_size(a->type) || b->nb[0] != sizeof(float) || ids->nb[0] != sizeof(int32_t)) return false;
             if (!ggml_is_contiguous(op) || a->ne[3] != 1 || b->ne[3] != 1) return false;
             if (b->ne[1] != 1 && b->ne[1] != ids->ne[0]) return false;

@@ -1056,6 +1056,13 @@ extern "C" int mi355_mul_mat_id_dq(int type, const void * as, int64_t w_row_stri
         case MI355_TYPE_Q4_K: return launch_ids<MI355_TYPE_Q4_K>(a, max_tiles, s, "mmdq_id_q4_K");
         case MI355_TYPE_Q5_K: return launch_ids<MI355_TYPE_Q5_K>(a, max_tiles, s, "mmdq_id_q5_K");
         case MI355_TYPE_Q6_K: return launch_ids<MI355_TYPE_Q6_K>(a, max_tiles, s, "mmdq_id_q6_K");
+        case MI355_TYPE_Q4_1: return launch_ids<MI355_TYPE_Q4_1>(a, max_tiles, s, "mmdq_id_q4_1");
+        case MI355_TYPE_Q5_0: return launch_ids<MI355_TYPE_Q5_0>(a, max_tiles, s, "mmdq_id_q5_0");
+        case MI355_TYPE_Q5_1: return launch_ids<MI355_TYPE_Q5_1>(a, max_tiles, s, "mmdq_id_q5_1");
+        case MI355_TYPE_Q2_K: return launch_ids<MI355_TYPE_Q2_K>(a, max_tiles, s, "mmdq_id_q2_k");
+        case MI355_TYPE_Q3_K: return launch_ids<MI355_TYPE_Q3_K>(a, max_tiles, s, "mmdq_id_q3_k");
+        case MI355_TYPE_IQ4_NL: return launch_ids<MI355_TYPE_IQ4_NL>(a, max_tiles, s, "mmdq_id_iq4_nl");
+        case MI355_TYPE_IQ4_XS: return launch_ids<MI355_TYPE_IQ4_XS>(a, max_tiles, s, "mmdq_id_iq4_xs");
     }
     return MI355_E_TYPE;
 }

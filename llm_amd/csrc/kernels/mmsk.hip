@@ -384,6 +384,11 @@ mmsk2_kernel(const S2Args a) {
         woff[i] = v ? (uint32_t)rr * (uint32_t)a.w_row_stride + wc_ * 16 : 0u;
         wlds[i] = v ? r * BS + wc_ * 16 : WBYTES + ABYTES;
     }
+    // Only the columns that exist are staged, four per load instruction: the activations of a super-step are 8 KB for 32 columns
+    // against 4.6 KB of weights, and both go through the CU's load path -- at 8 columns they are 2 KB.  Lanes of the MFMA's other
+    // columns read column 0 from LDS (finite values, results never stored).
+    const int na = __builtin_amdgcn_readfirstlane((cm.ncol + 3) >> 2);
+    const int lrc = lr < 4 * na ? lr : 0;
     uint32_t aoff[8];
 #pragma unroll
     for (int i = 0; i < 8; i++) {
@@ -420,7 +425,7 @@ mmsk2_kernel(const S2Args a) {
         StageA r;
         const int8_t * ab = a.aq + (int64_t)sb_ * 256;
 #pragma unroll
-        for (int i = 0; i < 8; i++) r.q[i] = *(const v4i *)(ab + aoff[i]);
+        for (int i = 0; i < 8; i++) if (i < na) r.q[i] = *(const v4i *)(ab + aoff[i]);
         r.s = *(const v4i *)((const uint8_t *)a.bs + (int64_t)sb_ * 32 + soff);
         r.d = *(const float *)((const uint8_t *)a.ad + (int64_t)sb_ * 4 + doff);
         return r;
@@ -434,7 +439,7 @@ mmsk2_kernel(const S2Args a) {
 #pragma unroll
         for (int i = 0; i < NI; i++) *(v4i *)(Lw + wlds[i]) = sw.w[i];
 #pragma unroll
-        for (int i = 0; i < 8; i++) *(v4i *)(La + (i * 4 + (lane >> 4)) * APITCH + (lane & 15) * 16) = sa.q[i];
+        for (int i = 0; i < 8; i++) if (i < na) *(v4i *)(La + (i * 4 + (lane >> 4)) * APITCH + (lane & 15) * 16) = sa.q[i];
         const float d8 = sa.d;
         const v4i sv = sa.s;
         __builtin_amdgcn_wave_barrier();
@@ -475,7 +480,7 @@ mmsk2_kernel(const S2Args a) {
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             const v4i x = T::frag(cur, j, lh, 0);
-            const v4i bq = *(const v4i *)(La + lr * APITCH + j * 32 + lh * 16);
+            const v4i bq = *(const v4i *)(La + lrc * APITCH + j * 32 + lh * 16);
 #pragma unroll
             for (int p = 0; p < P; p++) {
                 const int rep = (int)__builtin_amdgcn_perm(0u, digw[p][j >> 2], 0x0c000c00u | (uint32_t)(j & 3) | ((uint32_t)(j & 3) << 16));
@@ -576,6 +581,8 @@ mmsk6_kernel(const S2Args a) {
         woff[i] = v ? (uint32_t)rr * (uint32_t)a.w_row_stride + (wc_ < 13 ? wc_ * 16 : 194) : 0u;
         wlds[i] = v ? r * IMG + wc_ * 16 : WBYTES + ABYTES;
     }
+    const int na = __builtin_amdgcn_readfirstlane((cm.ncol + 3) >> 2);      // only the columns that exist are staged (see mmsk2_kernel)
+    const int lrc = lr < 4 * na ? lr : 0;
     uint32_t aoff[8];
 #pragma unroll
     for (int i = 0; i < 8; i++) aoff[i] = (uint32_t)s_row[i * 4 + (lane >> 4)] * (uint32_t)a.k + (lane & 15) * 16;
@@ -603,7 +610,7 @@ mmsk6_kernel(const S2Args a) {
         StageA r;
         const int8_t * ab = a.aq + (int64_t)sb_ * 256;
 #pragma unroll
-        for (int i = 0; i < 8; i++) r.q[i] = *(const v4i *)(ab + aoff[i]);
+        for (int i = 0; i < 8; i++) if (i < na) r.q[i] = *(const v4i *)(ab + aoff[i]);
         r.d = *(const float *)((const uint8_t *)a.ad + (int64_t)sb_ * 4 + doff);
         return r;
     };
@@ -616,14 +623,14 @@ mmsk6_kernel(const S2Args a) {
 #pragma unroll
         for (int i = 0; i < NI; i++) *(v4i *)(Lw + wlds[i]) = sw.w[i];
 #pragma unroll
-        for (int i = 0; i < 8; i++) *(v4i *)(La + (i * 4 + (lane >> 4)) * APITCH + (lane & 15) * 16) = sa.q[i];
+        for (int i = 0; i < 8; i++) if (i < na) *(v4i *)(La + (i * 4 + (lane >> 4)) * APITCH + (lane & 15) * 16) = sa.q[i];
         if (lh == 0) d8s[wave][lr] = sa.d;
         __builtin_amdgcn_wave_barrier();
         sa = fetch_a(clampsb(sb + 1));
         sw = fetch_w(clampsb(sb + 1));
 
         const uint8_t * wl = Lw + lr * IMG;          // this lane's weight row (both lane halves: its two 8-weight halves of a sub-block)
-        const uint8_t * al = La + lr * APITCH + 8 * lh;   // ... and, as the A operand, activation column lr
+        const uint8_t * al = La + lrc * APITCH + 8 * lh;  // ... and, as the A operand, activation column lr
         const v4i scv = *(const v4i *)(wl + 192);
         const float d = h2f(*(const uint16_t *)(wl + 222));
         int acc_i[16];
