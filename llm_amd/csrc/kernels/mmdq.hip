@@ -204,21 +204,24 @@ static __device__ __forceinline__ void dequant32(const Raw<TYPE> & r, int k, flo
         const int i2 = (k >> 5) & 3;
         const float d = h2f(r.d);
         const float s0 = d * (float)(int8_t)(r.sc & 0xff), s1 = d * (float)(int8_t)(r.sc >> 8);
+        const float o0 = -32.0f * s0, o1 = -32.0f * s1;       // s (q - 32) as one fma per weight: s q - 32 s (exact: 32 s is a power-of-two multiple)
 #pragma unroll
         for (int w = 0; w < 8; w++) {
             const int ql = ((w < 4 ? r.l0[w] : r.l1[w - 4]) >> (4 * (i2 >> 1))) & 0x0f0f0f0f;
             const int qh = (((w < 4 ? r.h0[w] : r.h1[w - 4]) >> (2 * i2)) & 0x03030303) << 4;
             const int q = ql | qh;
 #pragma unroll
-            for (int i = 0; i < 4; i++) f[4 * w + i] = (w < 4 ? s0 : s1) * (ubyte(q, i) - 32.0f);
+            for (int i = 0; i < 4; i++) f[4 * w + i] = (w < 4 ? s0 : s1) * ubyte(q, i) + (w < 4 ? o0 : o1);
         }
     } else if constexpr (TYPE == MI355_TYPE_Q8_0) {
-        const float d = h2f(r.d);
+        // d q with q signed: the byte read as unsigned is q + 128 (after flipping the sign bits), and v_cvt_f32_ubyteN converts it in one
+        // instruction where a signed byte takes a bit-field extract and a convert: d (q + 128) - 128 d, one fma per weight
+        const float d = h2f(r.d), o = -128.0f * d;
 #pragma unroll
         for (int w = 0; w < 8; w++) {
-            const int q = w < 4 ? r.q0[w] : r.q1[w - 4];
+            const int q = (w < 4 ? r.q0[w] : r.q1[w - 4]) ^ (int)0x80808080;
 #pragma unroll
-            for (int i = 0; i < 4; i++) f[4 * w + i] = d * (float)(int8_t)(q >> (8 * i));
+            for (int i = 0; i < 4; i++) f[4 * w + i] = d * ubyte(q, i) + o;
         }
     } else if constexpr (TYPE == MI355_TYPE_Q4_0) {
         const float d = h2f(r.d);
