@@ -272,8 +272,11 @@ MI355_API int mi355_moe_down_matvec(const mi355_moe_down_args *args, void *strea
  *   All matrices Q4_K / Q5_K / Q6_K; n_embd, k_o (columns of wo) and n_ff multiples of 256, >= 2048; n_embd <= 8192 and a
  *   multiple of 4 x the workgroup count (the CU count, halved until it divides); otherwise MI355_E_UNSUPPORTED and the caller
  *   runs the separate launches.  attn_q / attn_ds (mi355_quantize_act layout) or attn_f32: the attention output.  attn_out,
- *   gate_out, up_out, down_out (the MUL_MAT nodes' own results) may be NULL.  All f32 pointers 16-byte aligned; no output may
- *   overlap an input or another output, except that attn_out may equal ffn_inp and down_out may equal l_out (ADD in place).
+ *   gate_out, up_out, down_out (the MUL_MAT nodes' own results) may be NULL.  All f32 pointers 16-byte aligned.  attn_out may equal
+ *   ffn_inp and down_out may equal l_out (ADD in place).  Beyond that the launch keeps the node order's guarantees for memory that
+ *   ggml-alloc reuses: an output may lie on the bytes of an output or input of an EARLIER node of the run (l_out on ffn_norm_out, the
+ *   tail's q_out on gate_out, the tail's norm_out on residual, ...) and then holds the later node's values; outputs of the same node
+ *   group (gate_out / up_out / hidden; q_out / k_out / v_out) and the weights must not overlap anything written.
  *   sync: mi355_decode_layer_sync_bytes() bytes of device memory, 128-byte aligned, ZEROED by the caller before every call on
  *   the same stream (hipMemsetAsync; one memset may clear the blocks of all of a token's calls) and not shared by calls that
  *   can overlap.  Its last word receives a non-zero code if a wait inside the launch ran out (4 ms: a workgroup was not

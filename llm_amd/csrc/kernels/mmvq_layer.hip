@@ -316,7 +316,11 @@ static __device__ __forceinline__ void publish_rows(const KLayer & a, int e, con
     DL_STAMP(a, 2 + 4 * e);
     if (has) {
         const v4f o = *(const __attribute__((address_space(3))) v4f *)(res + 4 * lane);
-        if (dst && dst != sum) *(v4f *)(dst + row0 + 4 * lane) = o;
+        // Every store of phases 0..2 is write-through, also those nothing in this launch reads: ggml-alloc places tensors of later
+        // nodes on the bytes of dead earlier ones (in a llama layer: l_out on ffn_norm's, the next layer's Qcur on ffn_gate's), and a
+        // line left DIRTY in one XCD's L2 by an early phase would be written back at the end of the launch over what another XCD
+        // stored there in a later phase.
+        if (dst && dst != sum) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, o), make_rsrc(dst, m * 4), (row0 + 4 * lane) * 4, 0, 16);
         const v4f s = o + r;
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, s), rs_sum, (row0 + 4 * lane) * 4, 0, 16);
     }
@@ -373,6 +377,7 @@ static __device__ __forceinline__ void stage_norm(const KLayer & a, const float 
     for (int i = 1; i < nsw; i++) tot += ((volatile lds_f32 *)wsum)[i];
     const float scale = 1.0f / sqrtf(tot / (float)k + eps);
     const bool store = blockIdx.x == 0;
+    const __amdgpu_buffer_rsrc_t rs_n = make_rsrc(nout, k * 4);
 #pragma unroll
     for (int p = 0; p < 2; p++) {
         const int t = ct + DL_CT * p;
@@ -382,12 +387,13 @@ static __device__ __forceinline__ void stage_norm(const KLayer & a, const float 
             for (int q = 0; q < 4; q++) {
                 v4f xx = v[p][q];
                 xx = xx * scale; xx = xx * wv[p][q];
-                if (store) ((v4f *)nout)[4 * t + q] = xx;
+                if (store) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, xx), rs_n, (4 * t + q) * 16, 0, 16);      // write-through (publish_rows)
                 o[4 * q] = xx.x; o[4 * q + 1] = xx.y; o[4 * q + 2] = xx.z; o[4 * q + 3] = xx.w;
             }
             quant16_soa(o, (int8_t *)lds + 16 * t, (float *)(lds + (size_t)k) + (t >> 1) * 2, (t & 1) == 0);
         }
     }
+    if (store) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // ... and at memory before this workgroup's next arrival can be counted
     lds_signal(&ctr[0]);
     DL_STAMP(a, 5 + 4 * e);
 }
@@ -433,8 +439,8 @@ static __device__ __forceinline__ void comm_waves(const KLayer & a, uint8_t * ld
         if (4 * lane < a.pw1) {
             const v4f gv = *(const __attribute__((address_space(3))) v4f *)(res + DL_RES + 4 * lane);
             const v4f uv = *(const __attribute__((address_space(3))) v4f *)(res + 2 * DL_RES + 4 * lane);
-            if (a.gate_out) *(v4f *)(a.gate_out + o0 + 4 * lane) = gv;
-            if (a.up_out)   *(v4f *)(a.up_out + o0 + 4 * lane)   = uv;
+            if (a.gate_out) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, gv), make_rsrc(a.gate_out, a.k2 * 4), (o0 + 4 * lane) * 4, 0, 16);
+            if (a.up_out)   __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, uv), make_rsrc(a.up_out, a.k2 * 4), (o0 + 4 * lane) * 4, 0, 16);
             v4f hv;
             hv.x = glu_act_dl(a.glu_op, gv.x) * uv.x; hv.y = glu_act_dl(a.glu_op, gv.y) * uv.y;
             hv.z = glu_act_dl(a.glu_op, gv.z) * uv.z; hv.w = glu_act_dl(a.glu_op, gv.w) * uv.w;

@@ -271,15 +271,17 @@ def decode_layer_sync(n_calls=1):
     return buf, nb
 
 
-def decode_layer(types, w, n_embd, k_o, n_ff, attn, residual, ffn_norm_w, eps=1e-5, glu_op=2, tail=None, keep=True, sync=None):
+def decode_layer(types, w, n_embd, k_o, n_ff, attn, residual, ffn_norm_w, eps=1e-5, glu_op=2, tail=None, keep=True, sync=None, bufs=None):
     """The persistent decode-layer launch (mi355_decode_layer).  types = (type_o, type_gu, type_d); w = (wo, w_gate, w_up, w_down)
     uint8 block tensors; attn = f32 [k_o] or (act_q, act_ds); tail = None | ("qkv", QkvRopeArgs with everything but norm_x set) |
-    ("rows", MmvqArgs with everything but src_f32 set).  -> dict of the f32 outputs (+ "err": the sync block's error word)."""
+    ("rows", MmvqArgs with everything but src_f32 set).  bufs: output tensors to use instead of fresh ones, by name (tests place
+    them on top of each other the way ggml-alloc does).  -> dict of the f32 outputs (+ "sync": the sync block, error word last)."""
     dev = w[0].device
-    f = lambda n: torch.full((n,), float("nan"), dtype=torch.float32, device=dev)
-    o = {"ffn_inp": f(n_embd), "ffn_norm": f(n_embd), "hidden": f(n_ff), "l_out": f(n_embd)}
+    bufs = bufs or {}
+    f = lambda name, n: bufs[name] if name in bufs else torch.full((n,), float("nan"), dtype=torch.float32, device=dev)
+    o = {"ffn_inp": f("ffn_inp", n_embd), "ffn_norm": f("ffn_norm", n_embd), "hidden": f("hidden", n_ff), "l_out": f("l_out", n_embd)}
     if keep:
-        o.update({"attn_out": f(n_embd), "gate": f(n_ff), "up": f(n_ff), "down": f(n_embd)})
+        o.update({"attn_out": f("attn_out", n_embd), "gate": f("gate", n_ff), "up": f("up", n_ff), "down": f("down", n_embd)})
     a = K.DecodeLayerArgs()
     a.type_o, a.type_gu, a.type_d, a.glu_op = types[0], types[1], types[2], glu_op
     a.n_embd, a.k_o, a.n_ff = n_embd, k_o, n_ff

@@ -247,6 +247,36 @@ def test_small_batch_forms_are_bit_exact_and_run(tmp_path, kv):
     assert c["fused"].get("rope", 0) < c["no_qkv_small"].get("rope", 0)
 
 
+@pytest.mark.parametrize("kv", ["f16", "q8_0"])
+def test_decode_layer_launch_is_bit_exact_and_runs(tmp_path, kv):
+    """GGML_MI355_DECODE_LAYER=1: MUL_MAT(wo) ADD RMS_NORM MUL MUL_MAT MUL_MAT GLU MUL_MAT ADD and the next layer's RMS_NORM MUL + Q/K/V +
+    2 ROPE + 2 CPY of every decode token run as ONE persistent launch per layer (mi355_decode_layer; on by default from n_embd 8192).
+    A 3-layer model of 2048 x 5120 matrices, 230 decode steps (graph replay, the KV rows through the pointer table, a re-capture at the
+    256-row boundary): logits equal, bit for bit, to the unfused graph's and to the four-launch fusions'; the launch did run (one per
+    token for every layer but the last -- llama.cpp puts the GET_ROWS of the output rows between its wo and the residual ADD -- and the
+    Q/K/V launch only for the first layer; with a q8_0 cache the launch ends at l_out and Q/K/V keep theirs)."""
+    import numpy as np
+    tool = os.path.join(ROOT, "tools", "run_llama_bench.sh")
+    outs = {}
+    for name, extra in (("layer", {"GGML_MI355_DECODE_LAYER": "1"}), ("four", {"GGML_MI355_DECODE_LAYER": "0"}), ("nofuse", {"GGML_MI355_NO_FUSE": "1"}),
+                        ("layer_counted", {"GGML_MI355_DECODE_LAYER": "1", "GGML_MI355_KERNEL_TIMES": "1"})):
+        path = str(tmp_path / f"logits_{name}.bin")
+        r = subprocess.run([tool, "mid", "Q4_K_M", "-ctk", kv, "-ctv", kv, "--dump-logits", path, "--decode-steps", "230"], capture_output=True, text=True,
+                           timeout=600, env=dict(os.environ, GGML_MI355_GRAPH_STATS="1", **extra))
+        assert r.returncode == 0, r.stderr[-3000:]
+        cnt = {k: int(v) for k, v in re.findall(r"\[mi355\] kernel (\S+) (\d+) ", r.stderr)}
+        m = re.search(r"decode graphs: (\d+) replays", r.stderr)
+        outs[name] = (np.fromfile(path, dtype=np.uint32), cnt, int(m.group(1)) if m else 0)
+    assert np.array_equal(outs["layer"][0], outs["nofuse"][0])
+    assert np.array_equal(outs["layer"][0], outs["four"][0])
+    assert np.array_equal(outs["layer"][0], outs["layer_counted"][0])
+    assert outs["layer"][2] >= 200, "the decode steps were not replayed from the captured graph"
+    c = outs["layer_counted"][1]
+    assert c.get("decode_layer", 0) >= 2 * 230, c
+    if kv == "f16":
+        assert c.get("mmvq_qkv_rope", 0) <= c["decode_layer"] // 2 + 8, c          # the first layer's only
+
+
 def test_fusions_are_bit_exact_with_a_q8_0_cache(tmp_path):
     """-ctk q8_0 -ctv q8_0: the fused Q/K/V launch leaves K and V as f32 rows in scratch and mi355_kv_store_q8_0 quantizes both into the
     cache -- the same bits as RMS_NORM, 3 MUL_MAT, 2 ROPE and 2 CPY f32 -> q8_0 launched one by one"""

@@ -140,6 +140,67 @@ def test_decode_layer_has_the_bits_of_the_four_launches(ops, n_embd, k_o, n_ff, 
             assert torch.isfinite(logits1).all() and torch.equal(bits(logits1), bits(logits0)), f"logits differ (rep {rep})"
 
 
+@pytest.mark.parametrize("n_embd,n_ff,heads", [(4096, 14336, (32, 8, 128)), (8192, 28672, (64, 8, 128)), (2048, 5120, (16, 4, 128))])
+def test_decode_layer_on_buffers_placed_like_ggml_alloc(ops, n_embd, n_ff, heads):
+    """ggml-alloc puts the tensors of later nodes on the bytes of dead earlier ones.  In a llama decode graph (GGML_MI355_DUMP_GRAPH):
+    ffn_inp in place on attn_out; ffn_out (down) and l_out on ffn_norm's bytes; the next layer's rotated Qcur on ffn_gate's bytes; the
+    next layer's attn_norm on the bytes of this layer's residual input.  Inside ONE launch those are stores of different phases,
+    from different XCDs, to the same addresses: whatever survives must still carry the bits of the separate launches."""
+    import llm_amd.kernels as K
+    types, tt = (B.Q4_K, B.Q4_K, B.Q6_K), (B.Q4_K, B.Q6_K)
+    nh, nkv, hd = heads
+    wo = gpu_blocks(types[0], n_embd, n_embd, 1)
+    wg, wu = gpu_blocks(types[1], n_ff, n_embd, 2), gpu_blocks(types[1], n_ff, n_embd, 3)
+    wd = gpu_blocks(types[2], n_embd, n_ff, 4)
+    wq, wk, wv = gpu_blocks(tt[0], nh * hd, n_embd, 5), gpu_blocks(tt[0], nkv * hd, n_embd, 6), gpu_blocks(tt[1], nkv * hd, n_embd, 7)
+    eps = 1e-5
+    pos = torch.tensor([7], dtype=torch.int32, device="cuda")
+    buf_a = torch.empty(n_embd, device="cuda")       # ffn_norm, then ffn_out / l_out
+    buf_b = torch.empty(n_embd, device="cuda")       # attn_out / ffn_inp
+    buf_g = torch.empty(n_ff, device="cuda")         # ffn_gate, then the next layer's Qcur
+    for rep in range(4):
+        g = torch.Generator(device="cuda")
+        g.manual_seed(500 + rep)
+        attn = torch.randn(n_embd, device="cuda", generator=g)
+        x = torch.randn(n_embd, device="cuda", generator=g)          # the residual input, then the next layer's attn_norm
+        nw1 = torch.rand(n_embd, device="cuda", generator=g) + 0.5
+        nw3 = torch.rand(n_embd, device="cuda", generator=g) + 0.5
+        aq, ads = ops.quantize_act(attn.view(1, -1))
+        ffn_inp0 = torch.empty(1, n_embd, device="cuda")
+        ops.mul_mat_vec_q(types[0], wo, n_embd, n_embd, aq, ads, 1, residual=x.view(1, -1), sum_out=ffn_inp0)
+        n1_0 = torch.empty(n_embd, device="cuda")
+        h0, g0, u0, hq, hds = ops.glu_matvec(types[1], wg, wu, n_ff, n_embd, None, None, glu_op=2, quant=True, keep=True, norm=(ffn_inp0, nw1, eps, n1_0))
+        l_out0 = torch.empty(1, n_embd, device="cuda")
+        ops.mul_mat_vec_q(types[2], wd, n_embd, n_ff, hq.view(1, -1), hds.view(1, -1, 2), 1, residual=ffn_inp0, sum_out=l_out0)
+        n3_0 = torch.full((n_embd,), float("nan"), device="cuda")
+        q0, k0, v0 = ops.qkv_rope_matvec(tt[0], tt[1], wq, wk, wv, nh * hd, nkv * hd, nkv * hd, n_embd, None, None, pos, hd, hd, 0,
+                                         freq_base=500000.0, norm=(l_out0.view(-1), nw3, eps, n3_0))
+        k1 = torch.zeros(nkv * hd, dtype=torch.float16, device="cuda")
+        v1 = torch.zeros(nkv * hd, dtype=torch.float16, device="cuda")
+        a = K.QkvRopeArgs()
+        a.type_qk, a.type_v, a.wq, a.wk, a.wv = tt[0], tt[1], wq.data_ptr(), wk.data_ptr(), wv.data_ptr()
+        a.wq_row_stride = a.wk_row_stride = B.row_size(tt[0], n_embd)
+        a.wv_row_stride = B.row_size(tt[1], n_embd)
+        a.m_q, a.m_k, a.m_v, a.k = nh * hd, nkv * hd, nkv * hd, n_embd
+        a.q_out, a.k_out, a.v_out = buf_g.data_ptr(), k1.data_ptr(), v1.data_ptr()
+        a.k_out_type = a.v_out_type = B.F16
+        a.pos = pos.data_ptr()
+        a.head_dim, a.n_dims, a.mode, a.n_ctx_orig = hd, hd, 0, 8192
+        a.freq_base, a.freq_scale, a.ext_factor, a.attn_factor, a.beta_fast, a.beta_slow = 500000.0, 1.0, 0.0, 1.0, 32.0, 1.0
+        a.norm_w, a.norm_out, a.norm_eps = nw3.data_ptr(), x.data_ptr(), eps
+        for t in (buf_a, buf_b, buf_g):
+            t.fill_(float("nan"))
+        o = ops.decode_layer(types, (wo, wg, wu, wd), n_embd, n_embd, n_ff, (aq, ads), x, nw1, eps=eps, glu_op=2, tail=("qkv", a), keep=True,
+                             bufs={"ffn_norm": buf_a, "down": buf_a, "l_out": buf_a, "attn_out": buf_b, "ffn_inp": buf_b, "gate": buf_g})
+        torch.cuda.synchronize()
+        err = int(o["sync"].view(torch.int32)[-32].item())
+        assert err == 0, f"a wait inside the launch ran out: code {err:#x}"
+        for name, got, ref in (("ffn_inp", buf_b, ffn_inp0), ("up", o["up"], u0), ("hidden", o["hidden"], h0), ("l_out", buf_a, l_out0),
+                               ("attn_norm of the next layer", x, n3_0), ("q", buf_g[:nh * hd], q0), ("k", k1, k0), ("v", v1, v0)):
+            assert torch.equal(bits(got), bits(ref)), f"{name} differs (rep {rep})"
+        assert torch.equal(bits(buf_g[nh * hd:]), bits(g0.view(-1)[nh * hd:])), "the rest of ffn_gate differs"
+
+
 def test_decode_layer_argument_errors(ops):
     import llm_amd.kernels as K
     a = K.DecodeLayerArgs()
