@@ -1151,10 +1151,11 @@ static void mi355_mul_mat_id(mi355_backend_ctx * ctx, ggml_tensor * dst) {
     // a few to a few hundred pairs (SURVEY config 5, T = 8..64): bucket by expert on the device, then every expert's matrix
     // is streamed once per 32 of its columns through the skinny int8-MFMA kernels
     static const int64_t sk_max = getenv("GGML_MI355_MOE_SKINNY_MAX") ? atoll(getenv("GGML_MI355_MOE_SKINNY_MAX")) : 256;
-    static const int64_t sk_min = getenv("GGML_MI355_MOE_SKINNY_MIN") ? atoll(getenv("GGML_MI355_MOE_SKINNY_MIN")) : 20;
+    static const int64_t sk_min = getenv("GGML_MI355_MOE_SKINNY_MIN") ? atoll(getenv("GGML_MI355_MOE_SKINNY_MIN")) : 12;
     const bool dense_dst = dst->nb[1] == (size_t)M * sizeof(float) && dst->nb[2] == (size_t)M * n_used * sizeof(float) &&
                            ((((uintptr_t)b->data) | b->nb[1] | b->nb[2]) & 15) == 0;
-    // (measured on 8x7B Q4_K_M: below ~20 pairs the per-pair mat-vec wins -- 16 pairs: 548 vs 521 t/s -- above 256 the GEMM)
+    // (measured on 8x7B Q4_K_M, profiles/r03_moe_skinny_min.txt: 16 pairs 642 t/s here against 605 on the per-pair mat-vec since the
+    // skinny kernels stage only the columns that exist -- it was 521 against 548 before --, 8 pairs 371 against 444; above 256 the GEMM)
     if (n_tokens * n_used >= sk_min && n_tokens * n_used <= sk_max && K % 256 == 0 && n_expert <= 256 && dense_dst && is_weight_type(as->type) &&
         !MI355_ENV_SET("GGML_MI355_NO_SKINNY")) {
         const int64_t need = mi355_mul_mat_id_skinny_workspace_bytes((int)as->type, K, n_tokens, b_ne1, n_used, n_expert);
