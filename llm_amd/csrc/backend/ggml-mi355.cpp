@@ -221,15 +221,34 @@ static void mi355_buffer_memset_tensor(ggml_backend_buffer_t buffer, ggml_tensor
     HIP_CHECK(hipDeviceSynchronize());
 }
 
+// GGML_MI355_TIME_GRAPH=1 (diagnostics): host time spent in the synchronous copies between graphs, printed with the graph times.
+// (Measured with it: a decode token's four input uploads -- embedding row, positions, mask, output ids, 82 KB -- cost 65 us of host
+// time, 10-16 us each whatever the size (lab/h2d_lab.cpp).  Moving them to a pinned ring and an upload stream that the compute stream
+// waits on cut the host time to 13 us and the token rate not at all (512 vs 510 t/s): the four copies then queue in front of the
+// graph on the device instead.  Not kept.)
+struct mi355_copy_stats { double us[2] = {0, 0}; long n[2] = {0, 0}; size_t bytes[2] = {0, 0}; };
+static mi355_copy_stats g_copy_stats;
+struct mi355_copy_timer {
+    int which; size_t size; bool on; std::chrono::steady_clock::time_point t0;
+    mi355_copy_timer(int w, size_t sz) : which(w), size(sz), on(getenv("GGML_MI355_TIME_GRAPH") != nullptr) { if (on) t0 = std::chrono::steady_clock::now(); }
+    ~mi355_copy_timer() {
+        if (!on) return;
+        g_copy_stats.us[which] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+        g_copy_stats.n[which]++; g_copy_stats.bytes[which] += size;
+    }
+};
+
 // set/get are synchronous host<->device copies (ggml-cuda.cu:604-618)
 static void mi355_buffer_set_tensor(ggml_backend_buffer_t buffer, ggml_tensor * tensor, const void * data, size_t offset, size_t size) {
     mi355_buffer_ctx * ctx = (mi355_buffer_ctx *)buffer->context;
+    mi355_copy_timer tm(0, size);
     mi355_set_device(ctx->device);
     HIP_CHECK(hipMemcpy((char *)tensor->data + offset, data, size, hipMemcpyHostToDevice));
 }
 
 static void mi355_buffer_get_tensor(ggml_backend_buffer_t buffer, const ggml_tensor * tensor, void * data, size_t offset, size_t size) {
     mi355_buffer_ctx * ctx = (mi355_buffer_ctx *)buffer->context;
+    mi355_copy_timer tm(1, size);
     mi355_set_device(ctx->device);
     HIP_CHECK(hipMemcpy(data, (const char *)tensor->data + offset, size, hipMemcpyDeviceToHost));
 }
@@ -2707,30 +2726,33 @@ static bool mi355_graph_capturable(ggml_cgraph * cgraph) {
     return any;
 }
 
+static void mi355_node_signature(const ggml_tensor * t, mi355_backend_ctx::node_sig & s) {
+    s.op = (int32_t)t->op; s.type = (int32_t)t->type; s.flags = t->flags; s.data = t->data; s.kv_dst = false;
+    for (int k = 0; k < 4; k++) { s.ne[k] = t->ne[k]; s.nb[k] = t->nb[k]; }
+    for (int k = 0; k < GGML_MAX_SRC; k++) s.src[k] = t->src[k] ? t->src[k]->data : nullptr;
+    memcpy(s.params, t->op_params, sizeof(s.params));
+}
+
 static void mi355_graph_signature(ggml_cgraph * cgraph, std::vector<mi355_backend_ctx::node_sig> & sig) {
     const int n = ggml_graph_n_nodes(cgraph);
     sig.resize(n);
-    for (int i = 0; i < n; i++) {
-        const ggml_tensor * t = ggml_graph_node((ggml_cgraph *)cgraph, i);
-        mi355_backend_ctx::node_sig & s = sig[i];
-        s.op = (int32_t)t->op; s.type = (int32_t)t->type; s.flags = t->flags; s.data = t->data; s.kv_dst = false;
-        for (int k = 0; k < 4; k++) { s.ne[k] = t->ne[k]; s.nb[k] = t->nb[k]; }
-        for (int k = 0; k < GGML_MAX_SRC; k++) s.src[k] = t->src[k] ? t->src[k]->data : nullptr;
-        memcpy(s.params, t->op_params, sizeof(s.params));
-    }
+    for (int i = 0; i < n; i++) mi355_node_signature(ggml_graph_node((ggml_cgraph *)cgraph, i), sig[i]);
 }
 
 // same graph as the cached one?  View nodes compute nothing (their addresses count through their consumers' sources);
 // a CPY whose destination goes through the table may move.
 // `captured`: the cached signature belongs to an instantiated graph (only the CPYs it routed through the table may move);
 // before that every CPY destination may move -- whether the launches can follow it is decided at capture time.
-static bool mi355_graph_same(const std::vector<mi355_backend_ctx::node_sig> & a, const std::vector<mi355_backend_ctx::node_sig> & cached,
-                             ggml_cgraph * cgraph, bool captured) {
+// (the graph's signature is taken node by node on the stack: the replay path -- every decode token -- allocates nothing)
+static bool mi355_graph_same(const std::vector<mi355_backend_ctx::node_sig> & cached, ggml_cgraph * cgraph, bool captured) {
     static const bool dbg = getenv("GGML_MI355_GRAPH_DEBUG") != nullptr;
-    if (a.size() != cached.size()) { if (dbg) fprintf(stderr, "[mi355] graph: %zu nodes, cached %zu\n", a.size(), cached.size()); return false; }
-    for (size_t i = 0; i < a.size(); i++) {
-        const mi355_backend_ctx::node_sig & x = a[i], & c = cached[i];
+    const size_t n = (size_t)ggml_graph_n_nodes(cgraph);
+    if (n != cached.size()) { if (dbg) fprintf(stderr, "[mi355] graph: %zu nodes, cached %zu\n", n, cached.size()); return false; }
+    for (size_t i = 0; i < n; i++) {
         const ggml_tensor * t = ggml_graph_node(cgraph, (int)i);
+        mi355_backend_ctx::node_sig x;
+        mi355_node_signature(t, x);
+        const mi355_backend_ctx::node_sig & c = cached[i];
         bool ok = x.op == c.op && x.type == c.type && !memcmp(x.ne, c.ne, sizeof(x.ne)) && !memcmp(x.nb, c.nb, sizeof(x.nb));
         // view nodes compute nothing: where they point (their op_params hold the offset) counts through their consumers' sources
         if (ok && node_computes(t)) ok = x.flags == c.flags && !memcmp(x.params, c.params, sizeof(x.params));
@@ -2779,6 +2801,9 @@ static enum ggml_status mi355_backend_graph_compute(ggml_backend_t backend, ggml
             last_end = now; calls++;
             if (calls % 64 == 0) {
                 fprintf(stderr, "[mi355] graph_compute host time: %.1f us avg over 64 calls (%d nodes), %.1f us between calls\n", tot / 64, n, between / 64);
+                fprintf(stderr, "[mi355]   per graph: %.1f set_tensor calls %.1f us %.0f bytes, %.1f get_tensor calls %.1f us %.0f bytes\n",
+                        g_copy_stats.n[0] / 64.0, g_copy_stats.us[0] / 64, g_copy_stats.bytes[0] / 64.0, g_copy_stats.n[1] / 64.0, g_copy_stats.us[1] / 64, g_copy_stats.bytes[1] / 64.0);
+                g_copy_stats = mi355_copy_stats();
                 tot = between = 0;
             }
         }
@@ -2788,9 +2813,7 @@ static enum ggml_status mi355_backend_graph_compute(ggml_backend_t backend, ggml
     static const bool graphs_off = getenv("GGML_MI355_NO_GRAPHS") != nullptr || MI355_ENV_SET("GGML_MI355_KERNEL_TIMES");
     if (graphs_off || gc.disabled || !mi355_graph_capturable(cgraph)) return mi355_issue_graph(ctx, cgraph);
 
-    std::vector<mi355_backend_ctx::node_sig> sig;
-    mi355_graph_signature(cgraph, sig);
-    const bool same = mi355_graph_same(sig, gc.sig, cgraph, gc.exec != nullptr);
+    const bool same = mi355_graph_same(gc.sig, cgraph, gc.exec != nullptr);
     if (same && gc.exec) {                         // replay
         gc.recaptures = 0; gc.n_replay++;
         mi355_graph_refresh_kv_table(ctx, cgraph);
@@ -2800,7 +2823,7 @@ static enum ggml_status mi355_backend_graph_compute(ggml_backend_t backend, ggml
     if (!same) {
         // first sighting of this graph: run it eagerly (this also sizes the scratch buffers); a second identical one is captured
         if (gc.exec) { HIP_CHECK(hipGraphExecDestroy(gc.exec)); gc.exec = nullptr; }
-        gc.sig.swap(sig);
+        mi355_graph_signature(cgraph, gc.sig);
         gc.kv_nodes.clear();
         if (++gc.recaptures > 8) {                 // a graph that never settles (ggml-cuda.cu:2674-2690 gives up the same way)
             gc.disabled = true;
@@ -2810,6 +2833,8 @@ static enum ggml_status mi355_backend_graph_compute(ggml_backend_t backend, ggml
         return mi355_issue_graph(ctx, cgraph);
     }
     // second identical graph: capture
+    std::vector<mi355_backend_ctx::node_sig> sig;
+    mi355_graph_signature(cgraph, sig);
     if (!gc.kv_dev) {
         HIP_CHECK(hipMalloc((void **)&gc.kv_dev, MI355_KV_SLOTS * 2 * sizeof(void *)));
         HIP_CHECK(hipHostMalloc((void **)&gc.kv_host, (size_t)MI355_KV_RING * MI355_KV_SLOTS * 2 * sizeof(void *), hipHostMallocDefault));
