@@ -479,17 +479,18 @@ def main():
     kernels = {t_: {"launches": n, "avg_us": round(us / n, 3)} for t_, (n, us) in K.timing_report().items() if n}
     # HBM bytes per launch of that kernel from the PMC counters: collected in a run of its own (rocprofv3 --pmc cannot be
     # combined with this timed run) by tools/pmc_traffic.sh on this same workload and committed under profiles/.
-    traffic = None
+    traffic, tr_name = None, ""
     if world == 1 and not args.no_group:
         try:
-            tr = json.load(open(os.path.join(ROOT, "profiles", "r02_bench_traffic.json")))
+            tr_name = "r03_bench_traffic.json" if os.path.exists(os.path.join(ROOT, "profiles", "r03_bench_traffic.json")) else "r02_bench_traffic.json"
+            tr = json.load(open(os.path.join(ROOT, "profiles", tr_name)))
             if tr["kernel"].startswith("mmvq_glu") == bool(fused_idx):
                 traffic = tr["traffic_bytes_per_launch"]
         except (OSError, KeyError, ValueError):
             traffic = None
     roofline = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
-                "traffic": traffic, "traffic_source": "profiles/r02_bench_traffic.json (rocprofv3 --pmc FETCH_SIZE x2, separate pass)" if traffic else None,
+                "traffic": traffic, "traffic_source": f"profiles/{tr_name} (rocprofv3 --pmc FETCH_SIZE x2, separate pass)" if traffic else None,
                 "launches": n_launch, "avg_launch_us": round(avg_us, 3),
                 "algorithmic_bytes_per_launch": round(q4k_bytes / n_launch), "all_kernels": kernels}
     # ---- the two denominators: the data sheet's 8 TB/s and what this box streams.  The ceiling is measured with the weight
@@ -535,8 +536,16 @@ def main():
                     K.check(K.lib.mi355_mul_mat_vec_q(a, stream0), "mi355_mul_mat_vec_q")
             us = timed(sweep, 5) / len(args)
             gbps = B.matvec_bytes(B.Q4_K, m, k) / us * 1e-3
+            # the same launches as pure reads: mi355_stream_read over each matrix's bytes, same pool, same order -- what a launch of
+            # this size can stream at all, its launch cost and ramp included
+            wb = B.row_size(B.Q4_K, k) * m
+            def sweep_read():
+                for w in pool:
+                    K.check(K.lib.mi355_stream_read(w.data_ptr(), wb, 256, stream0), "mi355_stream_read")
+            us_r = timed(sweep_read, 5) / len(pool)
             return {"shape": f"q4_K {m}x{k} n=1", "us": round(us, 2), "GB/s": round(gbps, 1), "frac_of_8TBps": round(gbps / HBM_PEAK_GBPS, 4),
-                    "frac_of_measured_ceiling": round(gbps / best, 4), "cold_pool_MB": round(len(pool) * B.row_size(B.Q4_K, k) * m / 1e6)}
+                    "frac_of_measured_ceiling": round(gbps / best, 4), "cold_pool_MB": round(len(pool) * wb / 1e6),
+                    "read_only_launch_us": round(us_r, 2), "read_only_GB/s": round(wb / us_r * 1e-3, 1), "frac_of_read_only_launch": round(us_r / us, 4)}
         gates = [weights[i] for i, mt in enumerate(mats) if mt.name.endswith("ffn_gate") and mt.type == B.Q4_K]
         single_op.append(single(dims.n_ff, dims.n_embd, gates))
         pool2 = [make_weights(torch, B, B.Q4_K, 28672, 8192, gen) for _ in range(8)]

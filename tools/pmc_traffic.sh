@@ -6,5 +6,5 @@
 out=${1:-pmc_bench}
 ROOT=$PWD
 cd /tmp && export TMPDIR=/tmp
-timeout -s KILL 280 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $ROOT/gpurun_out/$out -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-graph --no-cpu-baseline --no-e2e > $ROOT/gpurun_out/$out.log 2>&1
+timeout -s KILL 280 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $ROOT/gpurun_out/$out -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-graph --no-cpu-baseline --no-e2e --no-other-configs > $ROOT/gpurun_out/$out.log 2>&1
 ls $ROOT/gpurun_out/$out/*/ | head
