@@ -345,10 +345,14 @@ static __device__ __forceinline__ int pk_bytes_mul(int x, int rep) {
 // 256 bytes of activations per instruction -- and reads the operands back row-per-lane with ds_read_b128 (pitches
 // 144 / 176 / 272 bytes: conflict-free).  The region is private to the wave: LDS operations of one wave execute in
 // order, so no workgroup barrier is involved.  Each wave takes a CONTIGUOUS range of super-blocks.
-template <int TYPE, int WAVES>
+// TPW: row tiles per workgroup.  With K = 4096 a wave of an 8-wave tile has TWO super-steps between a ~1900-cycle setup and a
+// ~2700-cycle reduction (stamps, lab/mmsk_stamps.hip), and 448 tiles of 14336 rows are 1.75 rounds on 256 CUs.  TPW = 2 gives each tile
+// WAVES / 2 waves with twice the steps: the fixed costs are paid once per 64 rows and the launch is one round.
+template <int TYPE, int WAVES, int TPW = 1>
 __global__ void __launch_bounds__(WAVES * 64)
 mmsk2_kernel(const S2Args a) {
     typedef SK<TYPE> T;
+    constexpr int WK = WAVES / TPW;            // waves that split a tile's K
     constexpr int P = TYPE == MI355_TYPE_Q4_K ? 2 : 3, B = TYPE == MI355_TYPE_Q4_K ? 3 : 2;
     constexpr int BS = T::BS, QO = T::QO;
     constexpr int CH = BS / 16, RPI = 64 / CH, NI = (32 + RPI - 1) / RPI;      // 16-byte chunks per row; rows per load; loads
@@ -359,7 +363,9 @@ mmsk2_kernel(const S2Args a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // scalar: everything derived from it stays in SGPRs
     const int lr = lane & 31, lh = lane >> 5;
-    const int m0 = blockIdx.x * 32;
+    const int tile = wave / WK, kw = wave % WK;
+    const int m0 = ((int)blockIdx.x * TPW + tile) * 32;
+    const bool tile_ok = m0 < a.m;              // (an odd number of 32-row tiles: the last workgroup's second tile is empty)
     uint8_t * Lw = lds + wave * REGION, * La = Lw + WBYTES;
     __shared__ int s_row[32], s_pair[32];
     ColMap cm;
@@ -380,7 +386,7 @@ mmsk2_kernel(const S2Args a) {
     for (int i = 0; i < NI; i++) {
         const int r = i * RPI + wr_;
         const bool v = lane < RPI * CH && r < 32;
-        const int rr = m0 + r < a.m ? r : a.m - 1 - m0;      // rows past the end repeat the last row (never stored)
+        const int rr = !tile_ok ? 0 : (m0 + r < a.m ? r : a.m - 1 - m0);      // rows past the end repeat the last row (never stored)
         woff[i] = v ? (uint32_t)rr * (uint32_t)a.w_row_stride + wc_ * 16 : 0u;
         wlds[i] = v ? r * BS + wc_ * 16 : WBYTES + ABYTES;
     }
@@ -401,8 +407,8 @@ mmsk2_kernel(const S2Args a) {
     // super-blocks of this workgroup (K split over gridDim.y workgroups) and, contiguously, of this wave
     const int nsb = a.k / 256, per = (nsb + cm.ky_cnt - 1) / cm.ky_cnt;
     const int sb0 = cm.ky_idx * per, sb1 = sb0 + per < nsb ? sb0 + per : nsb;
-    const int perw = (sb1 - sb0 + WAVES - 1) / WAVES;
-    const int my0 = sb0 + wave * perw, my1 = my0 + perw < sb1 ? my0 + perw : sb1;
+    const int perw = (sb1 - sb0 + WK - 1) / WK;
+    const int my0 = sb0 + kw * perw, my1 = !tile_ok ? my0 : (my0 + perw < sb1 ? my0 + perw : sb1);
 
     v16f acc;
 #pragma unroll
@@ -522,12 +528,12 @@ mmsk2_kernel(const S2Args a) {
 #pragma unroll
     for (int r = 0; r < 16; r++) red[(wave * 16 + r) * 64 + lane] = acc[r];
     __syncthreads();
-    for (int e = tid; e < 16 * 64; e += WAVES * 64) {
-        const int r = e >> 6, l = e & 63;
+    for (int e = tid; e < TPW * 16 * 64; e += WAVES * 64) {
+        const int tl = e >> 10, r = (e >> 6) & 15, l = e & 63;
         float s = 0.0f;
 #pragma unroll
-        for (int w = 0; w < WAVES; w++) s += red[(w * 16 + r) * 64 + l];
-        const int orow = m0 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), ocol = l & 31;
+        for (int w = 0; w < WK; w++) s += red[((tl * WK + w) * 16 + r) * 64 + l];
+        const int orow = ((int)blockIdx.x * TPW + tl) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), ocol = l & 31;
         if (orow < a.m && ocol < cm.ncol) {
             float * o = a.dst + (int64_t)s_pair[ocol] * a.dst_col_stride + orow;
             if (cm.ky_cnt > 1) atomicAdd(o, s); else *o = s;
@@ -553,9 +559,10 @@ mmsk2_kernel(const S2Args a) {
 // conversion per super-block: acc[r] += (d_row * d8_col) * float(acc_i[r]).  No digit split, no bsums, no per-sub-block float work.
 // Staging as in mmsk2_kernel (coalesced loads into a wave-private LDS region); the 210-byte block is laid out as a 224-byte image:
 // chunks 0..12 = bytes 0..207, chunk 13 = bytes 194..209 (so d sits at image offset 222).
-template <int WAVES>
+template <int WAVES, int TPW = 1>
 __global__ void __launch_bounds__(WAVES * 64)
 mmsk6_kernel(const S2Args a) {
+    constexpr int WK = WAVES / TPW;            // waves that split a tile's K (see mmsk2_kernel)
     constexpr int BLK = 210, IMG = 224, CH = 14, RPI = 64 / CH, NI = (32 + RPI - 1) / RPI;
     constexpr int APITCH = 272, WBYTES = 32 * IMG, ABYTES = 32 * APITCH, REGION = WBYTES + ABYTES + 16;   // + a dump slot
     static_assert(REGION >= 16 * 64 * 4, "the staging region doubles as the reduction buffer");
@@ -564,7 +571,9 @@ mmsk6_kernel(const S2Args a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 31, lh = lane >> 5;
-    const int m0 = blockIdx.x * 32;
+    const int tile = wave / WK, kw = wave % WK;
+    const int m0 = ((int)blockIdx.x * TPW + tile) * 32;
+    const bool tile_ok = m0 < a.m;
     uint8_t * Lw = lds + wave * REGION, * La = Lw + WBYTES;
     __shared__ int s_row[32], s_pair[32];
     ColMap cm;
@@ -577,7 +586,7 @@ mmsk6_kernel(const S2Args a) {
     for (int i = 0; i < NI; i++) {
         const int r = i * RPI + wr_;
         const bool v = lane < RPI * CH && r < 32;
-        const int rr = m0 + r < a.m ? r : a.m - 1 - m0;      // rows past the end repeat the last row (never stored)
+        const int rr = !tile_ok ? 0 : (m0 + r < a.m ? r : a.m - 1 - m0);      // rows past the end repeat the last row (never stored)
         woff[i] = v ? (uint32_t)rr * (uint32_t)a.w_row_stride + (wc_ < 13 ? wc_ * 16 : 194) : 0u;
         wlds[i] = v ? r * IMG + wc_ * 16 : WBYTES + ABYTES;
     }
@@ -590,8 +599,8 @@ mmsk6_kernel(const S2Args a) {
 
     const int nsb = a.k / 256, per = (nsb + cm.ky_cnt - 1) / cm.ky_cnt;
     const int sb0 = cm.ky_idx * per, sb1 = sb0 + per < nsb ? sb0 + per : nsb;
-    const int perw = (sb1 - sb0 + WAVES - 1) / WAVES;
-    const int my0 = sb0 + wave * perw, my1 = my0 + perw < sb1 ? my0 + perw : sb1;
+    const int perw = (sb1 - sb0 + WK - 1) / WK;
+    const int my0 = sb0 + kw * perw, my1 = !tile_ok ? my0 : (my0 + perw < sb1 ? my0 + perw : sb1);
 
     float acc[16];
 #pragma unroll
@@ -679,12 +688,12 @@ mmsk6_kernel(const S2Args a) {
 #pragma unroll
     for (int r = 0; r < 16; r++) red[(wave * 16 + r) * 64 + lane] = acc[r];
     __syncthreads();
-    for (int e = tid; e < 16 * 64; e += WAVES * 64) {
-        const int r = e >> 6, l = e & 63;
+    for (int e = tid; e < TPW * 16 * 64; e += WAVES * 64) {
+        const int tl = e >> 10, r = (e >> 6) & 15, l = e & 63;
         float s = 0.0f;
 #pragma unroll
-        for (int w = 0; w < WAVES; w++) s += red[(w * 16 + r) * 64 + l];
-        const int orow = m0 + (l & 31), ocol = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+        for (int w = 0; w < WK; w++) s += red[((tl * WK + w) * 16 + r) * 64 + l];
+        const int orow = ((int)blockIdx.x * TPW + tl) * 32 + (l & 31), ocol = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
         if (orow < a.m && ocol < cm.ncol) {
             float * o = a.dst + (int64_t)s_pair[ocol] * a.dst_col_stride + orow;
             if (cm.ky_cnt > 1) atomicAdd(o, s); else *o = s;
@@ -692,8 +701,20 @@ mmsk6_kernel(const S2Args a) {
     }
 }
 
+// two row tiles per workgroup where one per workgroup is more than a round and a half of the chip and K is short (few steps per wave)
+static int sk_tpw(int64_t m, int64_t k) {
+    static const int v = [] { const char * e = getenv("MI355_SK_TPW"); return e ? atoi(e) : 0; }();
+    if (v) return v == 2 ? 2 : 1;
+    return (m + 31) / 32 >= 384 && k <= 8192 ? 2 : 1;
+}
+
 static int launch6(const S2Args & a, hipStream_t s, const char * tag) {
     const unsigned nb = (unsigned)((a.m + 31) / 32);
+    if (sk_tpw(a.m, a.k) == 2) {
+        MI355_LAUNCH(tag, (mmsk6_kernel<8, 2>), dim3((nb + 1) / 2, 1), dim3(512), 0, s, a);
+        MI355_CHECK_LAUNCH();
+        return MI355_OK;
+    }
     const unsigned ky = nb < 256 && a.k >= 2048 ? 2 : 1;
     if (ky > 1) {
         hipError_t e = a.dst_col_stride == a.m
@@ -709,6 +730,11 @@ static int launch6(const S2Args & a, hipStream_t s, const char * tag) {
 template <int TYPE>
 static int launch2(const S2Args & a, hipStream_t s, const char * tag) {
     const unsigned nb = (unsigned)((a.m + 31) / 32);
+    if (sk_tpw(a.m, a.k) == 2) {
+        MI355_LAUNCH(tag, (mmsk2_kernel<TYPE, 8, 2>), dim3((nb + 1) / 2, 1), dim3(512), 0, s, a);
+        MI355_CHECK_LAUNCH();
+        return MI355_OK;
+    }
     const unsigned ky = nb < 256 && a.k >= 2048 ? 2 : 1;
     if (ky > 1) {
         hipError_t e = a.dst_col_stride == a.m
@@ -888,7 +914,13 @@ extern "C" int mi355_mul_mat_id_skinny(int type, const void * as, int64_t w_row_
         S2Args a = {};
         a.W = (const uint8_t *)as; a.w_row_stride = w_row_stride; a.aq = (const int8_t *)ws; a.ad = (const float *)(ws + b0);
         a.bs = (const int16_t *)(ws + b0 + b1); a.dst = dst; a.dst_col_stride = m; a.m = (int)m; a.n = 32; a.k = (int)k; a.ids = I;
-        if (type == MI355_TYPE_Q4_K)      MI355_LAUNCH("mmsk2_id_q4_K", (mmsk2_kernel<MI355_TYPE_Q4_K, 8>), dim3(nb, max_tiles), dim3(512), 0, s, a);
+        if (sk_tpw(m, k) == 2) {
+            const unsigned nb2 = (nb + 1) / 2;
+            if (type == MI355_TYPE_Q4_K)      MI355_LAUNCH("mmsk2_id_q4_K", (mmsk2_kernel<MI355_TYPE_Q4_K, 8, 2>), dim3(nb2, max_tiles), dim3(512), 0, s, a);
+            else if (type == MI355_TYPE_Q5_K) MI355_LAUNCH("mmsk2_id_q5_K", (mmsk2_kernel<MI355_TYPE_Q5_K, 8, 2>), dim3(nb2, max_tiles), dim3(512), 0, s, a);
+            else                              MI355_LAUNCH("mmsk6_id_q6_K", (mmsk6_kernel<8, 2>), dim3(nb2, max_tiles), dim3(512), 0, s, a);
+        }
+        else if (type == MI355_TYPE_Q4_K) MI355_LAUNCH("mmsk2_id_q4_K", (mmsk2_kernel<MI355_TYPE_Q4_K, 8>), dim3(nb, max_tiles), dim3(512), 0, s, a);
         else if (type == MI355_TYPE_Q5_K) MI355_LAUNCH("mmsk2_id_q5_K", (mmsk2_kernel<MI355_TYPE_Q5_K, 8>), dim3(nb, max_tiles), dim3(512), 0, s, a);
         else                              MI355_LAUNCH("mmsk6_id_q6_K", (mmsk6_kernel<8>), dim3(nb, max_tiles), dim3(512), 0, s, a);
     } else {

@@ -11,6 +11,7 @@ namespace mi355 { bool timing_on() { return false; } void timing_events(const ch
 
 int main(int argc, char ** argv) {
     const int m = argc > 1 ? atoi(argv[1]) : 14336, k = argc > 2 ? atoi(argv[2]) : 4096, n = argc > 3 ? atoi(argv[3]) : 8;
+    const int tpw = argc > 4 ? atoi(argv[4]) : 1;       // row tiles per workgroup
     const int WAVES = 8;
     const int64_t rs = (int64_t)k / 256 * 144;
     std::vector<uint8_t> hw((size_t)m * rs);
@@ -23,13 +24,14 @@ int main(int argc, char ** argv) {
     hipMalloc(&ad, (size_t)32 * (k / 256) * 4); hipMemset(ad, 0, (size_t)32 * (k / 256) * 4);
     hipMalloc(&bs, (size_t)32 * (k / 16) * 2); hipMemset(bs, 0, (size_t)32 * (k / 16) * 2);
     hipMalloc(&dst, (size_t)32 * m * 4);
-    const unsigned nb = (m + 31) / 32, ky = nb < 256 && k >= 2048 ? 2 : 1;
+    const unsigned nb = tpw == 2 ? (m + 63) / 64 : (m + 31) / 32, ky = tpw == 1 && nb < 256 && k >= 2048 ? 2 : 1;
     const size_t nst = (size_t)nb * ky * WAVES * 8;
     hipMalloc(&stamps, nst * 8);
     S2Args a = {}; a.W = W; a.w_row_stride = rs; a.aq = aq; a.ad = ad; a.bs = bs; a.dst = dst; a.dst_col_stride = m; a.m = m; a.n = n; a.k = k; a.stamps = stamps;
     for (int it = 0; it < 5; it++) {
         hipMemset(dst, 0, (size_t)32 * m * 4);
-        hipLaunchKernelGGL((mmsk2_kernel<MI355_TYPE_Q4_K, 8>), dim3(nb, ky), dim3(512), 0, 0, a);
+        if (tpw == 2) hipLaunchKernelGGL((mmsk2_kernel<MI355_TYPE_Q4_K, 8, 2>), dim3(nb, ky), dim3(512), 0, 0, a);
+        else          hipLaunchKernelGGL((mmsk2_kernel<MI355_TYPE_Q4_K, 8>), dim3(nb, ky), dim3(512), 0, 0, a);
         hipDeviceSynchronize();
     }
     std::vector<long long> h(nst);
