@@ -350,10 +350,16 @@ mmdq_kernel(const DArgs a) {
     const uint16_t * xcol;
     if (IDS) {
         // column tile blockIdx.x -> (expert, tile inside the expert); the grid is sized for the worst case
+        // (the expert = the number of experts whose tiles end at or before ti: table entries requested together and counted with a
+        // ballot, not walked one dependent load at a time)
         const int ti = blockIdx.x;
-        if (ti >= a.tile_off[a.n_expert]) return;
+        const int total_tiles = a.tile_off[a.n_expert];
         int e = 0;
-        while (a.tile_off[e + 1] <= ti) e++;
+        for (int b0 = 0; b0 < a.n_expert; b0 += 64) {
+            const int end = b0 + lane < a.n_expert ? a.tile_off[b0 + lane + 1] : 0x7fffffff;
+            e += __builtin_popcountll(__ballot(end <= ti));
+        }
+        if (ti >= total_tiles) return;
         const int base = a.off[e] + (ti - a.tile_off[e]) * BN, cnt = a.off[e + 1] - base;
         if (tid < BN) s_pair[tid] = tid < cnt ? a.sorted[base + tid] : -1;
         __syncthreads();

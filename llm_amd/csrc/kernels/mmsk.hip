@@ -176,10 +176,16 @@ template <> struct SK<MI355_TYPE_Q4_0> {
 struct ColMap { int ncol, ky_idx, ky_cnt; int64_t w_off; };
 static __device__ __forceinline__ bool col_map(const IdsArgs & I, int n, int tid, int * s_row, int * s_pair, ColMap & cm) {
     if (I.sorted) {
-        const int ti = blockIdx.y;
-        if (ti >= I.tile_off[I.n_expert]) return false;
+        // the expert of column pass ti = the number of experts whose passes end at or before it: the table entries are requested
+        // together (64 per step) and counted with a ballot, instead of walked one dependent load at a time
+        const int ti = blockIdx.y, ln = tid & 63;
+        const int total = I.tile_off[I.n_expert];
         int e = 0;
-        while (I.tile_off[e + 1] <= ti) e++;
+        for (int b0 = 0; b0 < I.n_expert; b0 += 64) {
+            const int end = b0 + ln < I.n_expert ? I.tile_off[b0 + ln + 1] : 0x7fffffff;
+            e += __builtin_popcountll(__ballot(end <= ti));
+        }
+        if (ti >= total) return false;
         const int base = I.off[e] + (ti - I.tile_off[e]) * 32, left = I.off[e + 1] - base;
         cm.ncol = left < 32 ? left : 32;
         if (tid < 32) {
@@ -525,16 +531,18 @@ mmsk2_kernel(const S2Args a) {
     __syncthreads();
     SK_STAMP(4);
     float * red = (float *)lds;      // [WAVES][16][64]
+    if (lr < cm.ncol) {              // a lane's 16 results are one column's: columns that do not exist are neither written nor added
 #pragma unroll
-    for (int r = 0; r < 16; r++) red[(wave * 16 + r) * 64 + lane] = acc[r];
+        for (int r = 0; r < 16; r++) red[(wave * 16 + r) * 64 + lane] = acc[r];
+    }
     __syncthreads();
     for (int e = tid; e < TPW * 16 * 64; e += WAVES * 64) {
         const int tl = e >> 10, r = (e >> 6) & 15, l = e & 63;
-        float s = 0.0f;
-#pragma unroll
-        for (int w = 0; w < WK; w++) s += red[((tl * WK + w) * 16 + r) * 64 + l];
         const int orow = ((int)blockIdx.x * TPW + tl) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), ocol = l & 31;
         if (orow < a.m && ocol < cm.ncol) {
+            float s = 0.0f;
+#pragma unroll
+            for (int w = 0; w < WK; w++) s += red[((tl * WK + w) * 16 + r) * 64 + l];
             float * o = a.dst + (int64_t)s_pair[ocol] * a.dst_col_stride + orow;
             if (cm.ky_cnt > 1) atomicAdd(o, s); else *o = s;
         }
@@ -686,15 +694,16 @@ mmsk6_kernel(const S2Args a) {
     __syncthreads();
     float * red = (float *)lds;      // [WAVES][16][64]
 #pragma unroll
-    for (int r = 0; r < 16; r++) red[(wave * 16 + r) * 64 + lane] = acc[r];
+    for (int r = 0; r < 16; r++)     // (columns that do not exist are neither written nor added)
+        if ((r & 3) + 8 * (r >> 2) + 4 * lh < cm.ncol) red[(wave * 16 + r) * 64 + lane] = acc[r];
     __syncthreads();
     for (int e = tid; e < TPW * 16 * 64; e += WAVES * 64) {
         const int tl = e >> 10, r = (e >> 6) & 15, l = e & 63;
-        float s = 0.0f;
-#pragma unroll
-        for (int w = 0; w < WK; w++) s += red[((tl * WK + w) * 16 + r) * 64 + l];
         const int orow = ((int)blockIdx.x * TPW + tl) * 32 + (l & 31), ocol = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
         if (orow < a.m && ocol < cm.ncol) {
+            float s = 0.0f;
+#pragma unroll
+            for (int w = 0; w < WK; w++) s += red[((tl * WK + w) * 16 + r) * 64 + l];
             float * o = a.dst + (int64_t)s_pair[ocol] * a.dst_col_stride + orow;
             if (cm.ky_cnt > 1) atomicAdd(o, s); else *o = s;
         }
@@ -702,8 +711,11 @@ mmsk6_kernel(const S2Args a) {
 }
 
 // two row tiles per workgroup where one per workgroup is more than a round and a half of the chip and K is short (few steps per wave)
-static int sk_tpw(int64_t m, int64_t k) {
+// (ids: MUL_MAT_ID -- the grid is that many workgroups per column pass, several passes: MI355_SK_TPW_ID picks 1 / 2 / 4 there)
+static int sk_tpw(int64_t m, int64_t k, bool ids = false) {
     static const int v = [] { const char * e = getenv("MI355_SK_TPW"); return e ? atoi(e) : 0; }();
+    static const int vi = [] { const char * e = getenv("MI355_SK_TPW_ID"); return e ? atoi(e) : 0; }();
+    if (ids && vi) return vi == 4 ? 4 : vi == 2 ? 2 : 1;
     if (v) return v == 2 ? 2 : 1;
     return (m + 31) / 32 >= 384 && k <= 8192 ? 2 : 1;
 }
@@ -914,7 +926,13 @@ extern "C" int mi355_mul_mat_id_skinny(int type, const void * as, int64_t w_row_
         S2Args a = {};
         a.W = (const uint8_t *)as; a.w_row_stride = w_row_stride; a.aq = (const int8_t *)ws; a.ad = (const float *)(ws + b0);
         a.bs = (const int16_t *)(ws + b0 + b1); a.dst = dst; a.dst_col_stride = m; a.m = (int)m; a.n = 32; a.k = (int)k; a.ids = I;
-        if (sk_tpw(m, k) == 2) {
+        const int tpw = sk_tpw(m, k, true);
+        if (tpw == 4) {
+            const unsigned nb4 = (nb + 3) / 4;
+            if (type == MI355_TYPE_Q4_K)      MI355_LAUNCH("mmsk2_id_q4_K", (mmsk2_kernel<MI355_TYPE_Q4_K, 8, 4>), dim3(nb4, max_tiles), dim3(512), 0, s, a);
+            else if (type == MI355_TYPE_Q5_K) MI355_LAUNCH("mmsk2_id_q5_K", (mmsk2_kernel<MI355_TYPE_Q5_K, 8, 4>), dim3(nb4, max_tiles), dim3(512), 0, s, a);
+            else                              MI355_LAUNCH("mmsk6_id_q6_K", (mmsk6_kernel<8, 4>), dim3(nb4, max_tiles), dim3(512), 0, s, a);
+        } else if (tpw == 2) {
             const unsigned nb2 = (nb + 1) / 2;
             if (type == MI355_TYPE_Q4_K)      MI355_LAUNCH("mmsk2_id_q4_K", (mmsk2_kernel<MI355_TYPE_Q4_K, 8, 2>), dim3(nb2, max_tiles), dim3(512), 0, s, a);
             else if (type == MI355_TYPE_Q5_K) MI355_LAUNCH("mmsk2_id_q5_K", (mmsk2_kernel<MI355_TYPE_Q5_K, 8, 2>), dim3(nb2, max_tiles), dim3(512), 0, s, a);
