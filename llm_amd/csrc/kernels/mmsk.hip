@@ -711,13 +711,20 @@ mmsk6_kernel(const S2Args a) {
 }
 
 // two row tiles per workgroup where one per workgroup is more than a round and a half of the chip and K is short (few steps per wave)
-// (ids: MUL_MAT_ID -- the grid is that many workgroups per column pass, several passes: MI355_SK_TPW_ID picks 1 / 2 / 4 there)
-static int sk_tpw(int64_t m, int64_t k, bool ids = false) {
+// MUL_MAT_ID (n_expert > 0): the grid is that many workgroups per column pass and there is about a pass per expert in use, so four
+// tiles per workgroup (two waves each) still fill the chip and the fixed costs are paid once per 128 rows: 8x7B-shaped Q4_K_M pp8 /
+// 16 / 32 / 64 604 / 1089 / 1995 / 3754 t/s with one tile, 638 / 1160 / 2130 / 4108 with two, 659 / 1193 / 2192 / 4183 with four
+// (profiles/r03_skinny_tiles_per_workgroup.txt).  MI355_SK_TPW / MI355_SK_TPW_ID override.
+static int sk_tpw(int64_t m, int64_t k, int64_t n_expert = 0) {
     static const int v = [] { const char * e = getenv("MI355_SK_TPW"); return e ? atoi(e) : 0; }();
     static const int vi = [] { const char * e = getenv("MI355_SK_TPW_ID"); return e ? atoi(e) : 0; }();
-    if (ids && vi) return vi == 4 ? 4 : vi == 2 ? 2 : 1;
+    const int64_t nb = (m + 31) / 32;
+    if (n_expert > 0) {
+        if (vi) return vi == 4 ? 4 : vi == 2 ? 2 : 1;
+        return (nb + 3) / 4 * n_expert >= 256 ? 4 : (nb + 1) / 2 * n_expert >= 256 ? 2 : 1;
+    }
     if (v) return v == 2 ? 2 : 1;
-    return (m + 31) / 32 >= 384 && k <= 8192 ? 2 : 1;
+    return nb >= 384 && k <= 8192 ? 2 : 1;
 }
 
 static int launch6(const S2Args & a, hipStream_t s, const char * tag) {
@@ -926,7 +933,7 @@ extern "C" int mi355_mul_mat_id_skinny(int type, const void * as, int64_t w_row_
         S2Args a = {};
         a.W = (const uint8_t *)as; a.w_row_stride = w_row_stride; a.aq = (const int8_t *)ws; a.ad = (const float *)(ws + b0);
         a.bs = (const int16_t *)(ws + b0 + b1); a.dst = dst; a.dst_col_stride = m; a.m = (int)m; a.n = 32; a.k = (int)k; a.ids = I;
-        const int tpw = sk_tpw(m, k, true);
+        const int tpw = sk_tpw(m, k, n_expert);
         if (tpw == 4) {
             const unsigned nb4 = (nb + 3) / 4;
             if (type == MI355_TYPE_Q4_K)      MI355_LAUNCH("mmsk2_id_q4_K", (mmsk2_kernel<MI355_TYPE_Q4_K, 8, 4>), dim3(nb4, max_tiles), dim3(512), 0, s, a);
