@@ -322,6 +322,15 @@ MI355_API int mi355_mul_mat_skinny_k(int type, const void *W, int64_t w_row_stri
                                      const int16_t *act_bsums, float *dst, int64_t dst_col_stride, int64_t m, int64_t k,
                                      int64_t n, void *stream);
 
+/* Up to four weight matrices of ONE K-quant type and one k against the SAME q8_K activations in one launch: the wq / wk / wv
+ * products of a step of 5..32 tokens (llama-graph.cpp build_attn's three ggml_mul_mat on one input).  Each result is what
+ * mi355_mul_mat_skinny_k writes for that matrix to within the order of the f32 additions over K (here always one workgroup per 32
+ * rows and a fixed order; the single call may cut K over two workgroups and add with atomics).  Replaces three launches of
+ * mul_mat_q / mul_mat_vec_q (mmq.cuh:3095-3175, mmvq.cu:137-224). */
+MI355_API int mi355_mul_mat_skinny_k_group(int type, int n_mats, const void *const *W, const int64_t *w_row_stride, float *const *dst,
+                                           const int64_t *dst_col_stride, const int64_t *m, const int8_t *act_q, const float *act_d,
+                                           const int16_t *act_bsums, int64_t k, int64_t n, void *stream);
+
 /* MUL_MAT_ID for a few to a few hundred (token, slot) pairs -- the regime of SURVEY config 5 (8x7B, T = 8..64): the
  * pairs are bucketed by expert on the device and every expert's matrix is streamed once per 32 of its columns through
  * the skinny int8-MFMA kernels (Q4_K / Q5_K on q8_K activations, the other types on q8_1).  Same arguments as

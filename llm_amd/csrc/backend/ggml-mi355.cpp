@@ -2356,7 +2356,37 @@ static bool mi355_try_fuse_qkv_small(mi355_backend_ctx * ctx, ggml_cgraph * cgra
     if (hd <= 0 || (hd & 1) || f.n_dims > hd || (f.n_dims & 1) || Mq % hd || Mk % hd || (f.mode != 0 && f.mode != 2)) return false;
     if ((f.k_out_type != (int32_t)GGML_TYPE_F16 && f.k_out_type != (int32_t)GGML_TYPE_F32) || (f.v_out_type != (int32_t)GGML_TYPE_F16 && f.v_out_type != (int32_t)GGML_TYPE_F32)) return false;
     if (((uintptr_t)f.v_out & 15) || ((uintptr_t)f.q_out & 3) || ((uintptr_t)f.k_out & 3)) return false;
+    // The K-quant products of wq's type leave as ONE launch over all their row tiles (Q4_K_M: wq + wk, and wv where it is q4_K too):
+    // 128 + 32 + 32 tiles of an 8B layer are three launches that each cut K over two workgroups behind a memset, or one launch of
+    // 192 workgroups with neither.
+    bool grouped[3] = {false, false, false};
+    const int64_t K = x->ne[0];
+    if (N <= 32 && x->ne[2] == 1 && x->ne[3] == 1 && !MI355_ENV_SET("GGML_MI355_NO_SKINNY_GROUP") &&
+        mi355_mul_mat_path(mm[0]->src[0], x, mm[0]) == MM_SKINNY_K) {
+        const void * Wg[3]; int64_t rs[3], dcs[3], mg[3]; float * dg[3];
+        int cnt = 0, who[3];
+        for (int m = 0; m < 3; m++) {
+            const ggml_tensor * w = mm[m]->src[0];
+            if (w->type != mm[0]->src[0]->type || mi355_mul_mat_path(w, x, mm[m]) != MM_SKINNY_K) continue;
+            Wg[cnt] = w->data; rs[cnt] = (int64_t)w->nb[1]; dg[cnt] = (float *)(parts + off[m]); dcs[cnt] = mg[cnt] = w->ne[1];
+            who[cnt++] = m;
+        }
+        if (cnt >= 2) {
+            const mi355_act_layout L = mi355_act_planes(MM_SKINNY_K, K, N);
+            char * ws = (char *)ctx->get_scratch(0, L.total());
+            if (!ctx->act_cached(x, 2)) {
+                MI_CHECK(mi355_quantize_act_q8k((const float *)x->data, (int8_t *)ws, (float *)(ws + L.b0), (int16_t *)(ws + L.b0 + L.b1), K, N, 1, 1,
+                                                x->nb[1], x->nb[2], x->nb[3], ctx->stream));
+                ctx->act_remember(x, 2);
+            }
+            const int rc = mi355_mul_mat_skinny_k_group((int)mm[0]->src[0]->type, cnt, Wg, rs, dg, dcs, mg, (const int8_t *)ws, (const float *)(ws + L.b0),
+                                                        (const int16_t *)(ws + L.b0 + L.b1), K, N, ctx->stream);
+            if (rc == MI355_OK) for (int c = 0; c < cnt; c++) grouped[who[c]] = true;
+            else if (rc != MI355_E_UNSUPPORTED && rc != MI355_E_ALIGN && rc != MI355_E_SHAPE) MI_CHECK(rc);
+        }
+    }
     for (int m = 0; m < 3; m++) {
+        if (grouped[m]) continue;
         ggml_tensor t = *mm[m];              // the product of node m, into its plane instead of the node's own bytes
         t.data = parts + off[m];
         mi355_mul_mat(ctx, &t);
@@ -2365,6 +2395,45 @@ static bool mi355_try_fuse_qkv_small(mi355_backend_ctx * ctx, ggml_cgraph * cgra
     if (kv_tmp) MI_CHECK(mi355_kv_store_q8_0(kv_tmp, N * Mk, q.ck->data, kv_tmp + N * Mk, N * Mv, q.cv->data, nullptr, 0, ctx->stream));
     for (int m = 1; m < 7; m++) done[q.idx[m]] = 1;
     ctx->act_invalidate_if_written(q.rq);
+    return true;
+}
+
+// Consecutive small-batch MUL_MATs of one K-quant type on the same activations (ffn_up + ffn_gate of a step of 5..32 tokens,
+// llama-graph.cpp build_ffn) as one launch over all their row tiles.
+static bool mi355_try_group_small(mi355_backend_ctx * ctx, ggml_cgraph * cgraph, int i, std::vector<char> & done) {
+    ggml_tensor * first = ggml_graph_node(cgraph, i);
+    const ggml_tensor * x = first->src[1];
+    if (!small_mm_ok(first) || x->ne[1] > 32 || x->ne[2] != 1 || x->ne[3] != 1 || MI355_ENV_SET("GGML_MI355_NO_SKINNY_GROUP")) return false;
+    if (mi355_mul_mat_path(first->src[0], x, first) != MM_SKINNY_K) return false;
+    const void * Wg[4]; int64_t rs[4], dcs[4], mg[4]; float * dg[4];
+    int cnt = 0;
+    const int n = ggml_graph_n_nodes(cgraph);
+    for (int j = i; j < n && cnt < 4; j++) {
+        ggml_tensor * t = ggml_graph_node(cgraph, j);
+        if (done[j] || !small_mm_ok(t) || t->src[1] != x || t->src[0]->type != first->src[0]->type ||
+            mi355_mul_mat_path(t->src[0], x, t) != MM_SKINNY_K) break;
+        bool clash = ranges_overlap(t->data, ggml_nbytes(t), x->data, ggml_nbytes(x));
+        for (int c = 0; c < cnt; c++) clash = clash || ranges_overlap(t->data, ggml_nbytes(t), dg[c], (size_t)dcs[c] * x->ne[1] * sizeof(float));
+        if (clash) break;
+        Wg[cnt] = t->src[0]->data; rs[cnt] = (int64_t)t->src[0]->nb[1]; dg[cnt] = (float *)t->data;
+        dcs[cnt] = (int64_t)(t->nb[1] / sizeof(float)); mg[cnt] = t->src[0]->ne[1];
+        cnt++;
+    }
+    if (cnt < 2) return false;
+    const int64_t K = x->ne[0], N = x->ne[1];
+    const mi355_act_layout L = mi355_act_planes(MM_SKINNY_K, K, N);
+    char * ws = (char *)ctx->get_scratch(0, L.total());
+    if (!ctx->act_cached(x, 2)) {
+        MI_CHECK(mi355_quantize_act_q8k((const float *)x->data, (int8_t *)ws, (float *)(ws + L.b0), (int16_t *)(ws + L.b0 + L.b1), K, N, 1, 1,
+                                        x->nb[1], x->nb[2], x->nb[3], ctx->stream));
+        ctx->act_remember(x, 2);
+    }
+    const int rc = mi355_mul_mat_skinny_k_group((int)first->src[0]->type, cnt, Wg, rs, dg, dcs, mg, (const int8_t *)ws, (const float *)(ws + L.b0),
+                                                (const int16_t *)(ws + L.b0 + L.b1), K, N, ctx->stream);
+    if (rc == MI355_E_UNSUPPORTED || rc == MI355_E_ALIGN || rc == MI355_E_SHAPE) return false;
+    MI_CHECK(rc);
+    for (int c = 1; c < cnt; c++) done[i + c] = 1;
+    for (int c = 0; c < cnt; c++) ctx->act_invalidate_if_written(ggml_graph_node(cgraph, i + c));
     return true;
 }
 
@@ -2633,6 +2702,7 @@ static enum ggml_status mi355_issue_graph(mi355_backend_ctx * ctx, ggml_cgraph *
         if (fuse && node->op == GGML_OP_MUL_MAT && mi355_try_fuse_qkv_rope(ctx, cgraph, i, done)) continue;
         if (fuse && node->op == GGML_OP_MUL_MAT && mi355_try_fuse_qkv_gemm(ctx, cgraph, i, done)) continue;
         if (fuse && node->op == GGML_OP_MUL_MAT && mi355_try_fuse_qkv_small(ctx, cgraph, i, done)) continue;
+        if (fuse && node->op == GGML_OP_MUL_MAT && mi355_try_group_small(ctx, cgraph, i, done)) continue;
         if (fuse && node->op == GGML_OP_MUL_MAT && mi355_try_fuse_gemm_add_norm(ctx, cgraph, i, done)) {
             i += 3;
             continue;

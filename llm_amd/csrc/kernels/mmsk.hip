@@ -318,12 +318,24 @@ static int launch(const SArgs & a, hipStream_t s, const char * tag) {
 // blocks.  One conversion per super-block: acc += d_row * d8_col * float(C_0 + (C_1 << B) + ...).
 // The min term sum_j (dmin m_j)_row * (d8 bsum_j)_col is a K = 8 f32 product: 4 x v_mfma_f32_32x32x2_f32 per super-block
 // into one accumulator that lives through the whole K loop.
+// Several weight matrices of one type and one K against the SAME activations in one launch (wq / wk / wv of a small batch: three
+// launches of 128 + 32 + 32 tiles, each cut in two along K with a memset in front, become one of 192 tiles with neither).
+struct SkGroup {
+    int n;
+    int tile_end[4];         // running count of 32-row tiles; entries past n hold the total
+    const uint8_t * W[4]; int64_t w_row_stride[4];
+    float * dst[4]; int64_t dst_col_stride[4];
+    int m[4];
+};
+struct SkMat { const uint8_t * W; int64_t w_row_stride; float * dst; int64_t dst_col_stride; int m, tile; };
+
 struct S2Args {
     const uint8_t * W; int64_t w_row_stride;
     const int8_t * aq; const float * ad; const int16_t * bs;     // [n][k], [n][k/256], [n][k/16]
     float * dst; int64_t dst_col_stride;
     int m, n, k;
     IdsArgs ids;
+    SkGroup grp;             // grp.n > 0: blockIdx.x runs over the 32-row tiles of several matrices (W, dst, m above are unused)
 #ifdef SK_STAMPS
     long long * stamps;      // diagnostic build only (lab/mmsk_stamps.hip): [workgroup][wave][8] s_memtime / s_memrealtime
 #endif
@@ -334,6 +346,22 @@ struct S2Args {
 #else
 #define SK_STAMP(i) do { } while (0)
 #endif
+
+// the matrix a 32-row tile belongs to (t is wave-uniform: scalar selects on kernel arguments)
+static __device__ __forceinline__ SkMat sk_mat(const S2Args & a, int t) {
+    SkMat r = { a.W, a.w_row_stride, a.dst, a.dst_col_stride, a.m, t };
+    if (a.grp.n > 0) {
+        const int gi = (t >= a.grp.tile_end[0]) + (t >= a.grp.tile_end[1]) + (t >= a.grp.tile_end[2]);
+        r.W   = gi == 0 ? a.grp.W[0]   : gi == 1 ? a.grp.W[1]   : gi == 2 ? a.grp.W[2]   : a.grp.W[3];
+        r.dst = gi == 0 ? a.grp.dst[0] : gi == 1 ? a.grp.dst[1] : gi == 2 ? a.grp.dst[2] : a.grp.dst[3];
+        r.w_row_stride   = gi == 0 ? a.grp.w_row_stride[0]   : gi == 1 ? a.grp.w_row_stride[1]   : gi == 2 ? a.grp.w_row_stride[2]   : a.grp.w_row_stride[3];
+        r.dst_col_stride = gi == 0 ? a.grp.dst_col_stride[0] : gi == 1 ? a.grp.dst_col_stride[1] : gi == 2 ? a.grp.dst_col_stride[2] : a.grp.dst_col_stride[3];
+        r.m    = gi == 0 ? a.grp.m[0] : gi == 1 ? a.grp.m[1] : gi == 2 ? a.grp.m[2] : a.grp.m[3];
+        r.tile = t - (gi == 0 ? 0 : gi == 1 ? a.grp.tile_end[0] : gi == 2 ? a.grp.tile_end[1] : a.grp.tile_end[2]);
+        if (t >= a.grp.tile_end[3]) r.m = 0;      // past the last matrix: an empty tile
+    }
+    return r;
+}
 
 typedef unsigned short us2 __attribute__((ext_vector_type(2)));
 typedef float v16f __attribute__((ext_vector_type(16)));
@@ -370,8 +398,9 @@ mmsk2_kernel(const S2Args a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // scalar: everything derived from it stays in SGPRs
     const int lr = lane & 31, lh = lane >> 5;
     const int tile = wave / WK, kw = wave % WK;
-    const int m0 = ((int)blockIdx.x * TPW + tile) * 32;
-    const bool tile_ok = m0 < a.m;              // (an odd number of 32-row tiles: the last workgroup's second tile is empty)
+    const SkMat mt = sk_mat(a, (int)blockIdx.x * TPW + tile);
+    const int m0 = mt.tile * 32;
+    const bool tile_ok = m0 < mt.m;             // (an odd number of 32-row tiles: the last workgroup's second tile is empty)
     uint8_t * Lw = lds + wave * REGION, * La = Lw + WBYTES;
     __shared__ int s_row[32], s_pair[32];
     ColMap cm;
@@ -385,15 +414,15 @@ mmsk2_kernel(const S2Args a) {
     // Staging roles.  Addresses are a wave-uniform base (advanced per super-block in SGPRs) plus a 32-bit lane offset
     // that never changes, so the loop spends no vector instructions on addressing.  Lanes without a chunk (lane 63
     // of 7 x 9, rows past 31) load chunk 0 and write it to the dump slot instead of being masked off.
-    const uint8_t * wbase = a.W + cm.w_off + (int64_t)m0 * a.w_row_stride;
+    const uint8_t * wbase = mt.W + cm.w_off + (int64_t)m0 * mt.w_row_stride;
     const int wr_ = lane / CH, wc_ = lane % CH;
     uint32_t woff[NI], wlds[NI];
 #pragma unroll
     for (int i = 0; i < NI; i++) {
         const int r = i * RPI + wr_;
         const bool v = lane < RPI * CH && r < 32;
-        const int rr = !tile_ok ? 0 : (m0 + r < a.m ? r : a.m - 1 - m0);      // rows past the end repeat the last row (never stored)
-        woff[i] = v ? (uint32_t)rr * (uint32_t)a.w_row_stride + wc_ * 16 : 0u;
+        const int rr = !tile_ok ? 0 : (m0 + r < mt.m ? r : mt.m - 1 - m0);      // rows past the end repeat the last row (never stored)
+        woff[i] = v ? (uint32_t)rr * (uint32_t)mt.w_row_stride + wc_ * 16 : 0u;
         wlds[i] = v ? r * BS + wc_ * 16 : WBYTES + ABYTES;
     }
     // Only the columns that exist are staged, four per load instruction: the activations of a super-step are 8 KB for 32 columns
@@ -538,12 +567,13 @@ mmsk2_kernel(const S2Args a) {
     __syncthreads();
     for (int e = tid; e < TPW * 16 * 64; e += WAVES * 64) {
         const int tl = e >> 10, r = (e >> 6) & 15, l = e & 63;
-        const int orow = ((int)blockIdx.x * TPW + tl) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), ocol = l & 31;
-        if (orow < a.m && ocol < cm.ncol) {
+        const SkMat mo = sk_mat(a, (int)blockIdx.x * TPW + tl);      // (tl is wave-uniform: 1024 elements per tile, 64 per wave)
+        const int orow = mo.tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), ocol = l & 31;
+        if (orow < mo.m && ocol < cm.ncol) {
             float s = 0.0f;
 #pragma unroll
             for (int w = 0; w < WK; w++) s += red[((tl * WK + w) * 16 + r) * 64 + l];
-            float * o = a.dst + (int64_t)s_pair[ocol] * a.dst_col_stride + orow;
+            float * o = mo.dst + (int64_t)s_pair[ocol] * mo.dst_col_stride + orow;
             if (cm.ky_cnt > 1) atomicAdd(o, s); else *o = s;
         }
     }
@@ -580,22 +610,23 @@ mmsk6_kernel(const S2Args a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 31, lh = lane >> 5;
     const int tile = wave / WK, kw = wave % WK;
-    const int m0 = ((int)blockIdx.x * TPW + tile) * 32;
-    const bool tile_ok = m0 < a.m;
+    const SkMat mt = sk_mat(a, (int)blockIdx.x * TPW + tile);
+    const int m0 = mt.tile * 32;
+    const bool tile_ok = m0 < mt.m;
     uint8_t * Lw = lds + wave * REGION, * La = Lw + WBYTES;
     __shared__ int s_row[32], s_pair[32];
     ColMap cm;
     if (!col_map(a.ids, a.n, tid, s_row, s_pair, cm)) return;
 
-    const uint8_t * wbase = a.W + cm.w_off + (int64_t)m0 * a.w_row_stride;
+    const uint8_t * wbase = mt.W + cm.w_off + (int64_t)m0 * mt.w_row_stride;
     const int wr_ = lane / CH, wc_ = lane % CH;
     uint32_t woff[NI], wlds[NI];
 #pragma unroll
     for (int i = 0; i < NI; i++) {
         const int r = i * RPI + wr_;
         const bool v = lane < RPI * CH && r < 32;
-        const int rr = !tile_ok ? 0 : (m0 + r < a.m ? r : a.m - 1 - m0);      // rows past the end repeat the last row (never stored)
-        woff[i] = v ? (uint32_t)rr * (uint32_t)a.w_row_stride + (wc_ < 13 ? wc_ * 16 : 194) : 0u;
+        const int rr = !tile_ok ? 0 : (m0 + r < mt.m ? r : mt.m - 1 - m0);      // rows past the end repeat the last row (never stored)
+        woff[i] = v ? (uint32_t)rr * (uint32_t)mt.w_row_stride + (wc_ < 13 ? wc_ * 16 : 194) : 0u;
         wlds[i] = v ? r * IMG + wc_ * 16 : WBYTES + ABYTES;
     }
     const int na = __builtin_amdgcn_readfirstlane((cm.ncol + 3) >> 2);      // only the columns that exist are staged (see mmsk2_kernel)
@@ -699,18 +730,21 @@ mmsk6_kernel(const S2Args a) {
     __syncthreads();
     for (int e = tid; e < TPW * 16 * 64; e += WAVES * 64) {
         const int tl = e >> 10, r = (e >> 6) & 15, l = e & 63;
-        const int orow = ((int)blockIdx.x * TPW + tl) * 32 + (l & 31), ocol = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
-        if (orow < a.m && ocol < cm.ncol) {
+        const SkMat mo = sk_mat(a, (int)blockIdx.x * TPW + tl);
+        const int orow = mo.tile * 32 + (l & 31), ocol = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+        if (orow < mo.m && ocol < cm.ncol) {
             float s = 0.0f;
 #pragma unroll
             for (int w = 0; w < WK; w++) s += red[((tl * WK + w) * 16 + r) * 64 + l];
-            float * o = a.dst + (int64_t)s_pair[ocol] * a.dst_col_stride + orow;
+            float * o = mo.dst + (int64_t)s_pair[ocol] * mo.dst_col_stride + orow;
             if (cm.ky_cnt > 1) atomicAdd(o, s); else *o = s;
         }
     }
 }
 
-// two row tiles per workgroup where one per workgroup is more than a round and a half of the chip and K is short (few steps per wave)
+// Dense: where one 8-wave workgroup per tile is more than a round and a half of the chip and K is short (a wave would have two steps
+// between a ~2000-cycle setup and a ~2000-cycle reduction), a tile gets TWO waves with four times the steps, in workgroups of four
+// waves and two tiles (two of them share a CU, with independent barriers).  A function of (m, k) alone: see the group launch.
 // MUL_MAT_ID (n_expert > 0): the grid is that many workgroups per column pass and there is about a pass per expert in use, so four
 // tiles per workgroup (two waves each) still fill the chip and the fixed costs are paid once per 128 rows: 8x7B-shaped Q4_K_M pp8 /
 // 16 / 32 / 64 604 / 1089 / 1995 / 3754 t/s with one tile, 638 / 1160 / 2130 / 4108 with two, 659 / 1193 / 2192 / 4183 with four
@@ -727,14 +761,23 @@ static int sk_tpw(int64_t m, int64_t k, int64_t n_expert = 0) {
     return nb >= 384 && k <= 8192 ? 2 : 1;
 }
 
+// Fewer than 256 row tiles: K is cut over two workgroups (atomic adds onto a zeroed dst) only where K is long.  At K = 4096 a wave of
+// an uncut tile has two steps instead of one, which costs less than the memset in front of the launch: 8B Q4_K_M steps of 8 / 16 / 32
+// tokens 2117 / 3931 / 6643 t/s cut from 2048, 2116 / 3962 / 6818 from 8192, 2037 / 3741 / 6441 never cut (ffn_down, K = 14336, wants the cut).
+// MI355_SK_KY_MIN_K overrides.
+static int sk_ky_min_k() {
+    static const int v = [] { const char * e = getenv("MI355_SK_KY_MIN_K"); return e ? atoi(e) : 8193; }();
+    return v;
+}
+
 static int launch6(const S2Args & a, hipStream_t s, const char * tag) {
     const unsigned nb = (unsigned)((a.m + 31) / 32);
     if (sk_tpw(a.m, a.k) == 2) {
-        MI355_LAUNCH(tag, (mmsk6_kernel<8, 2>), dim3((nb + 1) / 2, 1), dim3(512), 0, s, a);
+        MI355_LAUNCH(tag, (mmsk6_kernel<4, 2>), dim3((nb + 1) / 2, 1), dim3(256), 0, s, a);
         MI355_CHECK_LAUNCH();
         return MI355_OK;
     }
-    const unsigned ky = nb < 256 && a.k >= 2048 ? 2 : 1;
+    const unsigned ky = nb < 256 && a.k >= sk_ky_min_k() ? 2 : 1;
     if (ky > 1) {
         hipError_t e = a.dst_col_stride == a.m
             ? hipMemsetAsync(a.dst, 0, (size_t)a.n * a.m * sizeof(float), s)
@@ -750,11 +793,11 @@ template <int TYPE>
 static int launch2(const S2Args & a, hipStream_t s, const char * tag) {
     const unsigned nb = (unsigned)((a.m + 31) / 32);
     if (sk_tpw(a.m, a.k) == 2) {
-        MI355_LAUNCH(tag, (mmsk2_kernel<TYPE, 8, 2>), dim3((nb + 1) / 2, 1), dim3(512), 0, s, a);
+        MI355_LAUNCH(tag, (mmsk2_kernel<TYPE, 4, 2>), dim3((nb + 1) / 2, 1), dim3(256), 0, s, a);
         MI355_CHECK_LAUNCH();
         return MI355_OK;
     }
-    const unsigned ky = nb < 256 && a.k >= 2048 ? 2 : 1;
+    const unsigned ky = nb < 256 && a.k >= sk_ky_min_k() ? 2 : 1;
     if (ky > 1) {
         hipError_t e = a.dst_col_stride == a.m
             ? hipMemsetAsync(a.dst, 0, (size_t)a.n * a.m * sizeof(float), s)
@@ -877,6 +920,54 @@ extern "C" int mi355_mul_mat_skinny_k(int type, const void * W, int64_t w_row_st
     return launch2<MI355_TYPE_Q5_K>(a, s, "mmsk2_q5_K");
 }
 
+extern "C" int mi355_mul_mat_skinny_k_group(int type, int n_mats, const void * const * W, const int64_t * w_row_stride, float * const * dst,
+                                            const int64_t * dst_col_stride, const int64_t * m, const int8_t * act_q, const float * act_d,
+                                            const int16_t * act_bsums, int64_t k, int64_t n, void * stream) {
+    if (!W || !w_row_stride || !dst || !dst_col_stride || !m || !act_q || !act_d || !act_bsums) return MI355_E_NULL;
+    if (type != MI355_TYPE_Q4_K && type != MI355_TYPE_Q5_K && type != MI355_TYPE_Q6_K) return mi355_blck_size(type) ? MI355_E_UNSUPPORTED : MI355_E_TYPE;
+    if (n_mats < 1 || n_mats > 4) return MI355_E_SHAPE;
+    if (n < 0 || k <= 0 || k % 256 != 0 || k > 0x3ffffff) return MI355_E_SHAPE;
+    if (n > 32) return MI355_E_UNSUPPORTED;
+    if (((uintptr_t)act_q & 15) || ((uintptr_t)act_d & 3) || ((uintptr_t)act_bsums & 15)) return MI355_E_ALIGN;
+    S2Args a = {};
+    a.aq = act_q; a.ad = act_d; a.bs = act_bsums; a.n = (int)n; a.k = (int)k;
+    int64_t tiles = 0;
+    for (int i = 0; i < n_mats; i++) {
+        if (!W[i] || !dst[i]) return MI355_E_NULL;
+        if (m[i] <= 0 || m[i] > 0x7fffffff || dst_col_stride[i] < m[i] || w_row_stride[i] < mi355_row_size(type, k)) return MI355_E_SHAPE;
+        if (w_row_stride[i] > 0x3ffffff) return MI355_E_UNSUPPORTED;
+        if ((((uintptr_t)W[i] | (uintptr_t)w_row_stride[i]) & (type == MI355_TYPE_Q6_K ? 1 : 15)) || ((uintptr_t)dst[i] & 3)) return MI355_E_ALIGN;
+        tiles += (m[i] + 31) / 32;
+        a.grp.W[i] = (const uint8_t *)W[i]; a.grp.w_row_stride[i] = w_row_stride[i]; a.grp.dst[i] = dst[i];
+        a.grp.dst_col_stride[i] = dst_col_stride[i]; a.grp.m[i] = (int)m[i]; a.grp.tile_end[i] = (int)tiles;
+    }
+    if (tiles > 0x3fffffff) return MI355_E_SHAPE;
+    for (int i = n_mats; i < 4; i++) a.grp.tile_end[i] = (int)tiles;
+    a.grp.n = n_mats;
+    if (n == 0) return MI355_OK;
+    // K is never cut over two workgroups here: no memset, no atomics
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned nb = (unsigned)tiles;
+    // Every matrix is cut over the waves exactly as its own launch would cut it (sk_tpw and the K cut depend on (m, k) alone), so a
+    // matrix gives the same bits alone and in a group; matrices that disagree, or whose own launch cuts K over two workgroups, are
+    // left to the caller to launch one by one.
+    const int tpw = sk_tpw(m[0], k);
+    for (int i = 0; i < n_mats; i++) {
+        if (sk_tpw(m[i], k) != tpw) return MI355_E_UNSUPPORTED;
+        if ((m[i] + 31) / 32 < 256 && k >= sk_ky_min_k()) return MI355_E_UNSUPPORTED;
+    }
+    if (tpw == 2) {      // four waves, two tiles (a workgroup's tiles may belong to two matrices: the lookup is per wave)
+        const unsigned nb2 = (nb + 1) / 2;
+        if (type == MI355_TYPE_Q6_K)      MI355_LAUNCH("mmsk6_group_q6_K", (mmsk6_kernel<4, 2>), dim3(nb2, 1), dim3(256), 0, s, a);
+        else if (type == MI355_TYPE_Q4_K) MI355_LAUNCH("mmsk2_group_q4_K", (mmsk2_kernel<MI355_TYPE_Q4_K, 4, 2>), dim3(nb2, 1), dim3(256), 0, s, a);
+        else                              MI355_LAUNCH("mmsk2_group_q5_K", (mmsk2_kernel<MI355_TYPE_Q5_K, 4, 2>), dim3(nb2, 1), dim3(256), 0, s, a);
+    }
+    else if (type == MI355_TYPE_Q6_K) MI355_LAUNCH("mmsk6_group_q6_K", (mmsk6_kernel<8>), dim3(nb, 1), dim3(512), 0, s, a);
+    else if (type == MI355_TYPE_Q4_K) MI355_LAUNCH("mmsk2_group_q4_K", (mmsk2_kernel<MI355_TYPE_Q4_K, 8>), dim3(nb, 1), dim3(512), 0, s, a);
+    else                              MI355_LAUNCH("mmsk2_group_q5_K", (mmsk2_kernel<MI355_TYPE_Q5_K, 8>), dim3(nb, 1), dim3(512), 0, s, a);
+    MI355_CHECK_LAUNCH();
+    return MI355_OK;
+}
 
 // ---- MUL_MAT_ID for 2 .. a few hundred (token, slot) pairs: every expert's matrix is streamed ONCE per 32 of its
 // columns (the mat-vec path reads it once per pair; the grouped GEMM fills a 128-column tile with a handful of columns)

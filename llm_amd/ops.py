@@ -404,6 +404,22 @@ def mul_mat_skinny_k(t, w, b, m):
     return dst
 
 
+def mul_mat_skinny_k_group(t, ws, b, ms):
+    """Up to four K-quant matrices of type t against the same [n <= 32, k] activations in one launch -> list of [n, m_i]."""
+    import ctypes as C
+    n, k = b.shape
+    q, d, bs = quantize_act_q8k(b)
+    cnt = len(ws)
+    dsts = [torch.empty((n, m), dtype=torch.float32, device=b.device) for m in ms]
+    Wp = (C.c_void_p * cnt)(*[_u8(w).data_ptr() for w in ws])
+    rs = (C.c_int64 * cnt)(*[B.row_size(t, k)] * cnt)
+    dp = (C.c_void_p * cnt)(*[x.data_ptr() for x in dsts])
+    mm = (C.c_int64 * cnt)(*ms)
+    K.check(K.lib.mi355_mul_mat_skinny_k_group(t, cnt, Wp, rs, dp, mm, mm, q.data_ptr(), d.data_ptr(), bs.data_ptr(), k, n, _stream()),
+            "mi355_mul_mat_skinny_k_group")
+    return dsts
+
+
 def mul_mat_qk(t, w, b, m):
     """K-quant prefill MUL_MAT on q8_K activations (digit-split int8-MFMA tile kernel): b = [n, k] f32 -> [n, m]."""
     _u8(w)

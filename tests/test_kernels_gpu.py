@@ -498,6 +498,41 @@ def test_skinny_k_digit_split_vs_q8k_contract(ops, t, m, k, n):
         assert O.nmse(O.mul_mat(t, w, x, m, k, n, "cpu"), got) <= 1e-10
 
 
+@pytest.mark.parametrize("t", [B.Q4_K, B.Q5_K, B.Q6_K])
+@pytest.mark.parametrize("ms,k,n", [((64, 32), 1024, 8), ((4096, 1024, 1024), 4096, 16), ((130, 1, 33, 95), 512, 32), ((257,), 2048, 5), ((96, 32, 31), 1024, 1),
+                                    ((14336, 14336), 4096, 8), ((12320, 12288), 1024, 7)])      # two tiles per workgroup; an odd tile count
+def test_skinny_k_group_of_matrices_in_one_launch(ops, t, ms, k, n):
+    """wq / wk / wv (or ffn_up / ffn_gate) of a small batch as one launch over all their row tiles: every matrix's result is the single
+    call's BIT FOR BIT (a matrix is cut over the waves as a function of its own (m, k) in both), the q8_K contract (f64) holds for
+    each, and rows past a matrix's end never leak into its neighbour."""
+    rng = np.random.default_rng(sum(ms) + k + n)
+    ws = [B.random_blocks(t, m, k, seed=m + n + i) for i, m in enumerate(ms)]
+    x = rng.standard_normal((n, k)).astype(np.float32)
+    xd = dev(x)
+    outs = ops.mul_mat_skinny_k_group(t, [dev(w) for w in ws], xd, list(ms))
+    q, d, _ = _q8k_planes(x)
+    xa = (q.astype(np.float64).reshape(n, k // 256, 256) * d.astype(np.float64)[:, :, None]).reshape(n, k)
+    for w, m, o in zip(ws, ms, outs):
+        got = o.cpu().numpy()
+        single = ops.mul_mat_skinny_k(t, dev(w), xd, m).cpu().numpy()
+        assert np.array_equal(got.view(np.uint32), single.view(np.uint32))
+        wf = np.stack([O.dequantize_row(t, w[i], k) for i in range(m)]).astype(np.float64)
+        ref = (xa @ wf.T).astype(np.float32)
+        assert np.isfinite(got).all() and O.nmse(ref, got) <= 1e-10, O.nmse(ref, got)
+
+
+def test_skinny_k_group_refuses_what_would_change_a_matrix_s_bits(ops):
+    """Matrices whose own launches cut K differently (14336 rows: two waves per tile; 1024 rows: eight), or over two workgroups
+    (K = 14336 with fewer than 256 row tiles), are not grouped: MI355_E_UNSUPPORTED, nothing launched."""
+    import llm_amd.kernels as K
+    for ms, k in (((14336, 1024), 4096), ((4096, 4096), 14336)):
+        ws = [dev(B.random_blocks(B.Q4_K, m, k, seed=m)) for m in ms]
+        x = dev(np.ones((8, k), dtype=np.float32))
+        with pytest.raises(K.Mi355Error) as e:
+            ops.mul_mat_skinny_k_group(B.Q4_K, ws, x, list(ms))
+        assert e.value.code == -6
+
+
 @pytest.mark.parametrize("t", [B.Q4_K, B.Q5_K])
 @pytest.mark.parametrize("m,k,n", [(64, 256, 128), (1, 256, 1), (130, 512, 200), (4096, 4096, 9), (257, 2048, 131), (96, 1024, 512), (1024, 14336, 65)])
 def test_mmqk_digit_split_tile_kernel_vs_q8k_contract(ops, t, m, k, n):
