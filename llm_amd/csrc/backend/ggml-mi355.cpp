@@ -1175,7 +1175,11 @@ static void mi355_mul_mat_id(mi355_backend_ctx * ctx, ggml_tensor * dst) {
                            ((((uintptr_t)b->data) | b->nb[1] | b->nb[2]) & 15) == 0;
     // (measured on 8x7B Q4_K_M, profiles/r03_moe_skinny_min.txt: 16 pairs 642 t/s here against 605 on the per-pair mat-vec since the
     // skinny kernels stage only the columns that exist -- it was 521 against 548 before --, 8 pairs 371 against 444; above 256 the GEMM)
-    if (n_tokens * n_used >= sk_min && n_tokens * n_used <= sk_max && K % 256 == 0 && n_expert <= 256 && dense_dst && is_weight_type(as->type) &&
+    // Many experts: the skinny launch costs a pass per expert in use whatever its count, the per-pair mat-vec a pass per pair -- it stays
+    // ahead up to about 1.5 pairs per expert (tools/moe_lab.py, q4_K: 64 experts x 2048 x 4096 top-6, 48 pairs 43 us against 66, 96 pairs
+    // 74 against 70; 128 experts top-8, 128 pairs 83 against 113, 256 pairs 156 against 122; 8 experts: 16 pairs 89 against 83)
+    const int64_t sk_from = std::max(sk_min, n_expert * 3 / 2);
+    if (n_tokens * n_used >= sk_from && n_tokens * n_used <= sk_max && K % 256 == 0 && n_expert <= 256 && dense_dst && is_weight_type(as->type) &&
         !MI355_ENV_SET("GGML_MI355_NO_SKINNY")) {
         const int64_t need = mi355_mul_mat_id_skinny_workspace_bytes((int)as->type, K, n_tokens, b_ne1, n_used, n_expert);
         void * ws = ctx->get_scratch(0, (size_t)need);
@@ -1190,7 +1194,7 @@ static void mi355_mul_mat_id(mi355_backend_ctx * ctx, ggml_tensor * dst) {
     // prefill-sized batches: bucket the (token, slot) pairs by expert on the device and run one bf16-MFMA GEMM over all
     // experts, so every touched expert matrix is read once.  Below ~64 pairs the per-pair mat-vec (each pair streams
     // its expert's rows, mostly from the Infinity Cache) is faster than dequantizing whole tiles for a few columns.
-    if (n_tokens * n_used >= 64 && K % 64 == 0 && n_expert <= 256 && dense_dst && !MI355_ENV_SET("GGML_MI355_MMQ_INT8")) {
+    if (n_tokens * n_used >= std::max((int64_t)64, sk_from) && K % 64 == 0 && n_expert <= 256 && dense_dst && !MI355_ENV_SET("GGML_MI355_MMQ_INT8")) {
         const int64_t need = mi355_mul_mat_id_dq_workspace_bytes(K, n_tokens, b_ne1, n_used, n_expert);
         void * ws = ctx->get_scratch(0, (size_t)need);
         ctx->act_cache.valid = false;     // the workspace replaces whatever activations were cached in scratch[0]
