@@ -30,6 +30,8 @@
  *   GGML_MI355_NO_FUSE=1     run every graph node with its own kernel, no activation-quantization cache
  *   GGML_MI355_NO_PINNED=1   do not offer the pinned host buffer type
  *   GGML_MI355_NO_SKINNY=1   MUL_MAT with 4..64 columns: mat-vec / bf16 GEMM kernels instead of the skinny int8-MFMA ones
+ *   GGML_MI355_NO_SKINNY_GROUP=1  steps of 5..32 tokens: one skinny launch per matrix instead of one for wq + wk (+ wv) and one for
+ *                            ffn_up + ffn_gate (mi355_mul_mat_skinny_k_group); the results are the same bits either way
  *   GGML_MI355_NO_GLU_MATVEC=1  decode ffn: grouped gate+up mat-vec and a separate GLU kernel instead of mi355_glu_matvec
  *   GGML_MI355_NO_MOE_DOWN=1    MoE decode: MUL_MAT_ID(down_exps), the weight MUL and the expert / residual ADDs as separate nodes
  *   GGML_MI355_NO_MATVEC_ADD=1  decode: wo / ffn_down mat-vec and the residual ADD as separate nodes
