@@ -439,61 +439,89 @@ qkv_finish_kernel(const QkvFin a) {
 
 // the same for fully rotated heads (n_dims == head_dim, head_dim % 8 == 0; every llama-family model): a lane owns FOUR rotated pairs
 // of one token in 4 heads, so every load is a 16-byte one (q / k planes) and k leaves as 8-byte f16 stores.  Same arithmetic per element.
+typedef _Float16 qf_h4 __attribute__((ext_vector_type(4)));
+
+// v: 4 values at flat index j
+static __device__ __forceinline__ void qkv_finish_v4(const QkvFin & a, int64_t j) {
+    v4f v = *(const v4f *)(a.vp + j);
+    for (int z = 1; z < a.kzv; z++) v = v + *(const v4f *)(a.vp + (int64_t)z * a.n * a.mv + j);
+    if (a.v_f16) { const qf_h4 hv = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w}; *(qf_h4 *)(a.v_out + j * 2) = hv; }
+    else         *(v4f *)(a.v_out + j * 4) = v;
+}
+
+// pairs 4c .. 4c + 3 of token tok in the 4 heads of head group g (q groups first, then k), rotated by (cs, sn)
+static __device__ __forceinline__ void qkv_finish_quad(const QkvFin & a, int tok, int g, int c, const float * cs, const float * sn) {
+    const int hd = a.p.ne0;
+    const int nhq = a.mq / hd, nhk = a.mk / hd, gq = (nhq + 3) / 4;
+    const bool neox = (a.p.mode & 2) != 0;
+    const bool is_k = g >= gq;
+    const int h0 = (is_k ? g - gq : g) * 4, nh = is_k ? nhk : nhq, m = is_k ? a.mk : a.mq, kz = is_k ? a.kzk : a.kzq;
+    const float * part = is_k ? a.kp : a.qp;
+    // NEOX: A = x0 of the 4 pairs, B = their x1 (half a head further); NORMAL: A = (x0, x1) of pairs 0, 1, B = of pairs 2, 3
+    const int ea = neox ? 4 * c : 8 * c, eb = neox ? hd / 2 + 4 * c : 8 * c + 4;
+    const int64_t plane = (int64_t)a.n * m, row = (int64_t)tok * m;
+    v4f A[4], B[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const int h = h0 + u < nh ? h0 + u : nh - 1;
+        const float * pa = part + row + h * hd + ea, * pb = part + row + h * hd + eb;
+        A[u] = *(const v4f *)pa; B[u] = *(const v4f *)pb;
+        for (int z = 1; z < kz; z++) { A[u] = A[u] + *(const v4f *)(pa + z * plane); B[u] = B[u] + *(const v4f *)(pb + z * plane); }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        if (h0 + u >= nh) break;
+        v4f YA, YB;
+        if (neox) {
+            YA = v4f{A[u].x * cs[0] - B[u].x * sn[0], A[u].y * cs[1] - B[u].y * sn[1], A[u].z * cs[2] - B[u].z * sn[2], A[u].w * cs[3] - B[u].w * sn[3]};
+            YB = v4f{A[u].x * sn[0] + B[u].x * cs[0], A[u].y * sn[1] + B[u].y * cs[1], A[u].z * sn[2] + B[u].z * cs[2], A[u].w * sn[3] + B[u].w * cs[3]};
+        } else {
+            YA = v4f{A[u].x * cs[0] - A[u].y * sn[0], A[u].x * sn[0] + A[u].y * cs[0], A[u].z * cs[1] - A[u].w * sn[1], A[u].z * sn[1] + A[u].w * cs[1]};
+            YB = v4f{B[u].x * cs[2] - B[u].y * sn[2], B[u].x * sn[2] + B[u].y * cs[2], B[u].z * cs[3] - B[u].w * sn[3], B[u].z * sn[3] + B[u].w * cs[3]};
+        }
+        const int64_t o = row + (h0 + u) * hd;
+        if (!is_k) { *(v4f *)(a.q_out + o + ea) = YA; *(v4f *)(a.q_out + o + eb) = YB; }
+        else if (a.k_f16) {
+            const qf_h4 ha = {(_Float16)YA.x, (_Float16)YA.y, (_Float16)YA.z, (_Float16)YA.w}, hb = {(_Float16)YB.x, (_Float16)YB.y, (_Float16)YB.z, (_Float16)YB.w};
+            *(qf_h4 *)((__half *)a.k_out + o + ea) = ha; *(qf_h4 *)((__half *)a.k_out + o + eb) = hb;
+        } else { *(v4f *)((float *)a.k_out + o + ea) = YA; *(v4f *)((float *)a.k_out + o + eb) = YB; }
+    }
+}
+
 __global__ void __launch_bounds__(256)
 qkv_finish_vec_kernel(const QkvFin a) {
     const int hd = a.p.ne0, nquad = hd / 8;
     const int nhq = a.mq / hd, nhk = a.mk / hd, gq = (nhq + 3) / 4, gk = (nhk + 3) / 4;
     const int64_t nrope = (int64_t)nquad * a.n * (gq + gk), nv = (int64_t)a.n * (a.mv / 4);
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    const bool neox = (a.p.mode & 2) != 0;
-    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nrope + nv; i += stride) {
-        if (i >= nrope) {                              // v: 4 values
-            const int64_t j = (i - nrope) * 4;
-            v4f v = *(const v4f *)(a.vp + j);
-            for (int z = 1; z < a.kzv; z++) v = v + *(const v4f *)(a.vp + (int64_t)z * a.n * a.mv + j);
-            if (a.v_f16) { const h4 hv = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w}; *(h4 *)(a.v_out + j * 2) = hv; }
-            else         *(v4f *)(a.v_out + j * 4) = v;
-            continue;
-        }
+        if (i >= nrope) { qkv_finish_v4(a, (i - nrope) * 4); continue; }
         const int c = (int)(i % nquad);                // pairs 4c .. 4c + 3
         const int64_t r = i / nquad;
         const int tok = (int)(r % a.n), g = (int)(r / a.n);
-        const bool is_k = g >= gq;
-        const int h0 = (is_k ? g - gq : g) * 4, nh = is_k ? nhk : nhq, m = is_k ? a.mk : a.mq, kz = is_k ? a.kzk : a.kzq;
-        const float * part = is_k ? a.kp : a.qp;
         float cs[4], sn[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) rope_cos_sin(a.p, a.pos[tok], a.ff, 4 * c + u, cs[u], sn[u]);
-        // NEOX: A = x0 of the 4 pairs, B = their x1 (half a head further); NORMAL: A = (x0, x1) of pairs 0, 1, B = of pairs 2, 3
-        const int ea = neox ? 4 * c : 8 * c, eb = neox ? hd / 2 + 4 * c : 8 * c + 4;
-        const int64_t plane = (int64_t)a.n * m, row = (int64_t)tok * m;
-        v4f A[4], B[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int h = h0 + u < nh ? h0 + u : nh - 1;
-            const float * pa = part + row + h * hd + ea, * pb = part + row + h * hd + eb;
-            A[u] = *(const v4f *)pa; B[u] = *(const v4f *)pb;
-            for (int z = 1; z < kz; z++) { A[u] = A[u] + *(const v4f *)(pa + z * plane); B[u] = B[u] + *(const v4f *)(pb + z * plane); }
-        }
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            if (h0 + u >= nh) break;
-            v4f YA, YB;
-            if (neox) {
-                YA = v4f{A[u].x * cs[0] - B[u].x * sn[0], A[u].y * cs[1] - B[u].y * sn[1], A[u].z * cs[2] - B[u].z * sn[2], A[u].w * cs[3] - B[u].w * sn[3]};
-                YB = v4f{A[u].x * sn[0] + B[u].x * cs[0], A[u].y * sn[1] + B[u].y * cs[1], A[u].z * sn[2] + B[u].z * cs[2], A[u].w * sn[3] + B[u].w * cs[3]};
-            } else {
-                YA = v4f{A[u].x * cs[0] - A[u].y * sn[0], A[u].x * sn[0] + A[u].y * cs[0], A[u].z * cs[1] - A[u].w * sn[1], A[u].z * sn[1] + A[u].w * cs[1]};
-                YB = v4f{B[u].x * cs[2] - B[u].y * sn[2], B[u].x * sn[2] + B[u].y * cs[2], B[u].z * cs[3] - B[u].w * sn[3], B[u].z * sn[3] + B[u].w * cs[3]};
-            }
-            const int64_t o = row + (h0 + u) * hd;
-            if (!is_k) { *(v4f *)(a.q_out + o + ea) = YA; *(v4f *)(a.q_out + o + eb) = YB; }
-            else if (a.k_f16) {
-                const h4 ha = {(_Float16)YA.x, (_Float16)YA.y, (_Float16)YA.z, (_Float16)YA.w}, hb = {(_Float16)YB.x, (_Float16)YB.y, (_Float16)YB.z, (_Float16)YB.w};
-                *(h4 *)((__half *)a.k_out + o + ea) = ha; *(h4 *)((__half *)a.k_out + o + eb) = hb;
-            } else { *(v4f *)((float *)a.k_out + o + ea) = YA; *(v4f *)((float *)a.k_out + o + eb) = YB; }
-        }
+        qkv_finish_quad(a, tok, g, c, cs, sn);
+    }
+}
+
+// Few tokens (a step of 5..64): one workgroup per token.  In the kernel above every lane computes the cos / sin of its four pairs -- a
+// chain of four powf + sincosf that ten lanes (one per head group) repeat -- and at 16 tokens the launch is 26 workgroups of little
+// else: 7.2 us.  Here the token's hd / 2 rotations are computed once, by hd / 2 lanes, into LDS.  Same function, same arguments, same
+// arithmetic after it: the same bits.
+__global__ void __launch_bounds__(256)
+qkv_finish_tok_kernel(const QkvFin a) {
+    __shared__ float s_cs[256], s_sn[256];
+    const int hd = a.p.ne0, nquad = hd / 8, tok = blockIdx.x;
+    const int nhq = a.mq / hd, nhk = a.mk / hd, gq = (nhq + 3) / 4, gk = (nhk + 3) / 4;
+    for (int p = threadIdx.x; p < hd / 2; p += 256) rope_cos_sin(a.p, a.pos[tok], a.ff, p, s_cs[p], s_sn[p]);
+    __syncthreads();
+    const int nrope = nquad * (gq + gk), nv = a.mv / 4;
+    for (int i = threadIdx.x; i < nrope + nv; i += 256) {
+        if (i >= nrope) { qkv_finish_v4(a, ((int64_t)tok * nv + (i - nrope)) * 4); continue; }
+        const int c = i % nquad, g = i / nquad;
+        qkv_finish_quad(a, tok, g, c, s_cs + 4 * c, s_sn + 4 * c);
     }
 }
 
@@ -894,7 +922,8 @@ int mi355_qkv_finish(const mi355_qkv_finish_args * f, void * stream) {
     if (f->n_dims == hd && hd % 8 == 0 && (al & 15) == 0) {
         const int64_t gq = (f->m_q / hd + 3) / 4, gk = (f->m_k / hd + 3) / 4;
         const int64_t lanes = hd / 8 * f->n * (gq + gk) + f->n * (f->m_v / 4);
-        MI355_LAUNCH("qkv_finish", qkv_finish_vec_kernel, dim3(grid_for(lanes)), dim3(256), 0, (hipStream_t)stream, a);
+        if (f->n <= 64 && hd <= 512) MI355_LAUNCH("qkv_finish", qkv_finish_tok_kernel, dim3((unsigned)f->n), dim3(256), 0, (hipStream_t)stream, a);
+        else                         MI355_LAUNCH("qkv_finish", qkv_finish_vec_kernel, dim3(grid_for(lanes)), dim3(256), 0, (hipStream_t)stream, a);
         MI355_CHECK_LAUNCH();
         return MI355_OK;
     }

@@ -754,7 +754,7 @@ static int sk_tpw(int64_t m, int64_t k, int64_t n_expert = 0) {
     static const int vi = [] { const char * e = getenv("MI355_SK_TPW_ID"); return e ? atoi(e) : 0; }();
     const int64_t nb = (m + 31) / 32;
     if (n_expert > 0) {
-        if (vi) return vi == 4 ? 4 : vi == 2 ? 2 : 1;
+        if (vi) return vi == 42 ? 42 : vi == 4 ? 4 : vi == 2 ? 2 : 1;
         return (nb + 3) / 4 * n_expert >= 256 ? 4 : (nb + 1) / 2 * n_expert >= 256 ? 2 : 1;
     }
     if (v) return v == 2 ? 2 : 1;
@@ -1025,7 +1025,12 @@ extern "C" int mi355_mul_mat_id_skinny(int type, const void * as, int64_t w_row_
         a.W = (const uint8_t *)as; a.w_row_stride = w_row_stride; a.aq = (const int8_t *)ws; a.ad = (const float *)(ws + b0);
         a.bs = (const int16_t *)(ws + b0 + b1); a.dst = dst; a.dst_col_stride = m; a.m = (int)m; a.n = 32; a.k = (int)k; a.ids = I;
         const int tpw = sk_tpw(m, k, n_expert);
-        if (tpw == 4) {
+        if (tpw == 42) {      // lab: two tiles x two waves in 4-wave workgroups (two per CU)
+            const unsigned nb2 = (nb + 1) / 2;
+            if (type == MI355_TYPE_Q4_K)      MI355_LAUNCH("mmsk2_id_q4_K", (mmsk2_kernel<MI355_TYPE_Q4_K, 4, 2>), dim3(nb2, max_tiles), dim3(256), 0, s, a);
+            else if (type == MI355_TYPE_Q5_K) MI355_LAUNCH("mmsk2_id_q5_K", (mmsk2_kernel<MI355_TYPE_Q5_K, 4, 2>), dim3(nb2, max_tiles), dim3(256), 0, s, a);
+            else                              MI355_LAUNCH("mmsk6_id_q6_K", (mmsk6_kernel<4, 2>), dim3(nb2, max_tiles), dim3(256), 0, s, a);
+        } else if (tpw == 4) {
             const unsigned nb4 = (nb + 3) / 4;
             if (type == MI355_TYPE_Q4_K)      MI355_LAUNCH("mmsk2_id_q4_K", (mmsk2_kernel<MI355_TYPE_Q4_K, 8, 4>), dim3(nb4, max_tiles), dim3(512), 0, s, a);
             else if (type == MI355_TYPE_Q5_K) MI355_LAUNCH("mmsk2_id_q5_K", (mmsk2_kernel<MI355_TYPE_Q5_K, 8, 4>), dim3(nb4, max_tiles), dim3(512), 0, s, a);

@@ -267,6 +267,10 @@ def test_glu_mul_mat_dq_has_the_bits_of_the_three_launches(ops, t, op):
     (4096, 1024, 4096, 2048, 128, 128, 0, False, True, B.Q4_K, B.Q4_K),     # 2048 tokens: q in one K range, k / v split
     (1024, 256, 1024, 160, 64, 32, 0, False, False, B.Q8_0, B.Q8_0),        # small shapes, partial rotation, f32 cache
     (2048, 512, 2048, 300, 128, 128, 2, False, True, B.Q5_K, B.Q5_K),
+    (4096, 1024, 4096, 16, 128, 128, 2, True, True, B.Q4_K, B.Q6_K),        # <= 64 tokens: one workgroup per token, rotations through LDS
+    (4096, 1024, 4096, 33, 128, 128, 0, False, True, B.Q4_K, B.Q4_K),
+    (1024, 256, 1024, 7, 64, 64, 0, True, False, B.Q8_0, B.Q8_0),
+    (2048, 512, 2048, 64, 128, 128, 2, False, False, B.Q5_K, B.Q5_K),
 ])
 def test_qkv_parts_and_finish_have_the_bits_of_the_separate_launches(ops, mq, mkv, k, n, hd, n_dims, mode, ff, kv16, tq, tv):
     """Prefill Q / K / V: mi355_mul_mat_dq_parts x 3 (the GEMMs stopped before their slice sum) + mi355_qkv_finish (slice sum, rope of
