@@ -57,6 +57,8 @@ enum mi355_error {
     MI355_E_WORKSPACE   = -5, /* workspace too small */
     MI355_E_UNSUPPORTED = -6, /* valid ggml op, but a variant this library does not implement */
 };
+/* Every entry point returns 0, one of the negative codes above (nothing was launched), or a POSITIVE hipError_t when a HIP runtime
+ * call (launch, memset, symbol lookup) failed; mi355_error_string() describes all three. */
 
 /* library / device introspection */
 #define MI355_ABI_VERSION 5                             /* bumped on any signature or struct change */
@@ -647,7 +649,12 @@ MI355_API int     mi355_flash_attn_ext_bf16(const mi355_fattn_args *args, void *
  * array inside the library: 64 KiB + 4 MiB per GPU, held until the process ends.  Calls no hipMalloc / hipFree or any
  * allocating routine.  MI355_E_WORKSPACE when mi355_flash_attn_ext_workspace_bytes(args) exceeds the array (e.g.
  * n_q * n_head * (d + 2) * 256 B > 4 MiB: use the workspace form).  All calls on one GPU share the array: calls that
- * overlap on one GPU (two streams) race; order them on one stream. */
+ * overlap on one GPU (two streams) race; order them on one stream.  The device that owns `stream` must be the current device
+ * (the array's copy is chosen by the current device; MI355_E_UNSUPPORTED otherwise).  The array's address on a device is looked
+ * up on the first call there (hipGetSymbolAddress): a caller whose first call would be under stream capture calls
+ * mi355_flash_attn_ext_noalloc_max_bytes() once per device beforehand, which performs the lookup for the current device.
+ * Return codes as everywhere in this library: 0, a negative MI355_E_* for refused arguments, a positive hipError_t when a HIP
+ * call failed (mi355_error_string handles all three). */
 MI355_API int64_t mi355_flash_attn_ext_noalloc_max_bytes(void);
 MI355_API int     mi355_flash_attn_ext_noalloc(const mi355_fattn_args *args, void *stream);
 

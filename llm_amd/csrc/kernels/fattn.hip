@@ -1041,11 +1041,17 @@ constexpr int MAX_DEVICES = 64;
 std::mutex g_scratch_mu;
 void * g_scratch_ptr[MAX_DEVICES] = {};
 
-int scratch_for_current_device(void ** out) {
+// stream: the stream the call will launch on (nullptr: the current device's null stream).  Its device must be the current one -- the
+// array's copy is picked by the current device, and a launch on another GPU's stream would be handed a pointer into the wrong GPU.
+int scratch_for_current_device(void ** out, hipStream_t stream = nullptr) {
     int dev = -1;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return (int)e;
     if (dev < 0 || dev >= MAX_DEVICES) return MI355_E_UNSUPPORTED;
+    if (stream) {
+        hipDevice_t sdev = -1;
+        if (hipStreamGetDevice(stream, &sdev) == hipSuccess && (int)sdev != dev) return MI355_E_UNSUPPORTED;
+    }
     std::lock_guard<std::mutex> lk(g_scratch_mu);
     if (!g_scratch_ptr[dev]) {
         void * ptr = nullptr;
@@ -1059,7 +1065,13 @@ int scratch_for_current_device(void ** out) {
 }
 } // namespace
 
-int64_t mi355_flash_attn_ext_noalloc_max_bytes(void) { return MI355_FATTN_SCRATCH_BYTES; }
+// also resolves the array's address on the current device, so that a caller who will first use the entry point under stream capture
+// can have the symbol lookup happen outside it (a failure here is reported by the entry point itself)
+int64_t mi355_flash_attn_ext_noalloc_max_bytes(void) {
+    void * ws = nullptr;
+    (void)scratch_for_current_device(&ws);
+    return MI355_FATTN_SCRATCH_BYTES;
+}
 
 int mi355_flash_attn_ext_noalloc(const mi355_fattn_args * p, void * stream) {
     if (!p) return MI355_E_NULL;
@@ -1068,7 +1080,7 @@ int mi355_flash_attn_ext_noalloc(const mi355_fattn_args * p, void * stream) {
     const int64_t need = mi355_flash_attn_ext_workspace_bytes(p);
     if (need < 0 || need > MI355_FATTN_SCRATCH_BYTES) return MI355_E_WORKSPACE;
     void * ws = nullptr;
-    const int rc = scratch_for_current_device(&ws);
+    const int rc = scratch_for_current_device(&ws, (hipStream_t)stream);
     if (rc != MI355_OK) return rc;
     // The array keeps the last call's contents.  The partials are written before they are read; the arrival counters
     // must start at zero: every call leaves them at zero again, and they are cleared here as well (a memset node under

@@ -49,3 +49,21 @@ def test_noalloc_rejects_sizes_beyond_the_array():
     with pytest.raises(K.Mi355Error) as e:
         ops.flash_attn_ext(q, k, v, mask, B.F16, 256, scale, noalloc=True)
     assert e.value.code == -5                                          # MI355_E_WORKSPACE
+
+
+def test_noalloc_is_capturable_into_a_graph():
+    """The callers the entry point exists for: under stream capture nothing may allocate or synchronise.  The call is captured
+    (memset node + kernel nodes), replayed twice, and gives the bits of the workspace form.  mi355_flash_attn_ext_noalloc_max_bytes()
+    has resolved the array's address on this device before the capture starts, as the header asks."""
+    wsb = K.lib.mi355_flash_attn_ext_noalloc_max_bytes()
+    q, k, v, mask, scale = _case(32, 8, 128, 1, 2048, B.F16, 5)
+    want = ops.flash_attn_ext(q, k, v, mask, B.F16, 2048, scale, workspace_bytes=wsb)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        got = ops.flash_attn_ext(q, k, v, mask, B.F16, 2048, scale, noalloc=True)
+    for _ in range(2):
+        got.fill_(7.0)
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(got.view(torch.int32), want.view(torch.int32))
