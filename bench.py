@@ -12,8 +12,9 @@ value = algorithmic bytes of the whole step / step time (GB/s, whole job).
   python bench.py --gpus N --steps K --warmup W     (N > 1: launched by torch.distributed.run)
 
 N > 1 is the reference's `-sm row`: every matrix is row-split across the ranks
-(llm_amd/split.py), each rank runs the mat-vec on its slice and the slices are combined with an
-RCCL all-gather; the total work is fixed, so "scaling" is "strong".
+(llm_amd/split.py), each rank runs the mat-vecs on its slices -- a layer's launches replayed as one
+graph -- and a layer's slices are combined with one RCCL all-gather; the total work is fixed, so
+"scaling" is "strong".
 """
 import argparse
 import json
@@ -328,24 +329,33 @@ def main():
             prev[3].append(i)
         else:
             plan.append([need_q, None, 0, [i]])
-    # N > 1: the row slices a launch produces are exchanged with ONE all-gather per launch.  Slices of a matrix are
-    # equal on all ranks whenever M is a multiple of 128 * N (all 8B matrices but output.weight); the launch's
-    # outputs are then views into one send buffer and the gather needs no staging; otherwise the padded path of
-    # llm_amd/split.py is used for that matrix.
-    gathers = []   # per plan entry: (send, recv) or None
-    for p in plan:
-        equal = world > 1 and all(len({hi - lo for lo, hi in row_split(mats[i].m, world)}) == 1 for i in p[3])
-        if equal:
-            sizes = [rows[i][1] - rows[i][0] for i in p[3]]
-            send = torch.empty(sum(sizes), dtype=torch.float32, device="cuda")
-            recv = torch.empty(world * sum(sizes), dtype=torch.float32, device="cuda")
+    # N > 1: the row slices a LAYER produces are exchanged with ONE all-gather (a real row-split decoder needs three exchanges per
+    # layer -- attention output, gated activation, layer output; the launches of this bench do not consume each other's results, so
+    # one per layer is the lower bound the schedule is priced at).  Slices of a matrix are equal on all ranks whenever M is a
+    # multiple of 128 * N (all 8B matrices but output.weight): those outputs are views into the layer's send buffer and the gather
+    # needs no staging; the others take the padded path of llm_amd/split.py, one gather each.  A layer's launches are captured
+    # into one graph per layer; the collectives stay outside the graphs.
+    def layer_of(p):
+        name = mats[p[3][0]].name
+        return name.split(".")[1] if name.startswith("blk.") else name
+    segments = []
+    if world > 1:
+        for j, p in enumerate(plan):
+            if not segments or segments[-1]["key"] != layer_of(p):
+                segments.append({"key": layer_of(p), "plan": [], "eq": [], "uneq": [], "graph": None})
+            segments[-1]["plan"].append(j)
+            for i in p[3]:
+                equal = len({hi - lo for lo, hi in row_split(mats[i].m, world)}) == 1
+                segments[-1]["eq" if equal else "uneq"].append(i)
+        for sg in segments:
+            sizes = [rows[i][1] - rows[i][0] for i in sg["eq"]]
+            sg["send"] = torch.empty(max(1, sum(sizes)), dtype=torch.float32, device="cuda") if sizes else None
+            sg["recv"] = torch.empty(world * sum(sizes), dtype=torch.float32, device="cuda") if sizes else None
             off = 0
-            for i, n_ in zip(p[3], sizes):
-                outs[i] = send[off:off + n_].view(1, n_)
+            for i, n_ in zip(sg["eq"], sizes):
+                outs[i] = sg["send"][off:off + n_].view(1, n_)
                 off += n_
-            gathers.append((send, recv))
-        else:
-            gathers.append(None)
+    for p in plan:
         names = [mats[i].name.split(".")[-1] for i in p[3]]
         if fuse_glu and names == ["ffn_gate", "ffn_up"] and mats[p[3][0]].m % 32 == 0 and mats[p[3][0]].m <= 16384:
             p[1], p[2] = glu_arg(*p[3]), 0
@@ -391,29 +401,38 @@ def main():
             if nb > 0:
                 K.check(K.lib.mi355_prefetch(weights[i].data_ptr(), nb, pf_wgs, pf_stream.cuda_stream), "mi355_prefetch")
 
-    def step():
-        """one decode token's mat-vecs on the current stream"""
+    def launch(j):
+        need_q, arr, n, idx = plan[j]
         stream = torch.cuda.current_stream().cuda_stream
-        for j, ((need_q, arr, n, idx), g) in enumerate(zip(plan, gathers)):
-            if pf_stream is not None:
-                prefetch_next(j)
-            if need_q is not None:
-                quantize(need_q, stream)
-            if n == 0:
-                K.check(K.lib.mi355_glu_matvec(arr, stream), "mi355_glu_matvec")
-            elif n < 0:
-                K.check(K.lib.mi355_qkv_rope_matvec(arr, stream), "mi355_qkv_rope_matvec")
+        if pf_stream is not None:
+            prefetch_next(j)
+        if need_q is not None:
+            quantize(need_q, stream)
+        if n == 0:
+            K.check(K.lib.mi355_glu_matvec(arr, stream), "mi355_glu_matvec")
+        elif n < 0:
+            K.check(K.lib.mi355_qkv_rope_matvec(arr, stream), "mi355_qkv_rope_matvec")
+        else:
+            K.check(K.lib.mi355_mul_mat_vec_q_group(arr, n, stream), "mi355_mul_mat_vec_q_group")
+
+    def step(eager=False):
+        """one decode token's mat-vecs on the current stream (eager: no per-layer graphs -- the timing mode's event pairs are not replayed)"""
+        if world == 1:
+            for j in range(len(plan)):
+                launch(j)
+        for sg in segments:
+            if sg["graph"] is not None and not eager:
+                sg["graph"].replay()
             else:
-                K.check(K.lib.mi355_mul_mat_vec_q_group(arr, n, stream), "mi355_mul_mat_vec_q_group")
-            if world > 1:
-                # rehearsal backends (gloo) gather through host memory; nccl = RCCL gathers device buffers over xGMI
-                if g is not None and backend == "nccl":
-                    dist.all_gather_into_tensor(g[1], g[0])
-                elif g is not None:
-                    dist.all_gather_into_tensor(g[1].cpu(), g[0].cpu())
-                else:
-                    for i in idx:
-                        all_gather_rows(outs[i] if backend == "nccl" else outs[i].cpu(), mats[i].m, rank, world, dist)
+                for j in sg["plan"]:
+                    launch(j)
+            # rehearsal backends (gloo) gather through host memory; nccl = RCCL gathers device buffers over xGMI
+            if sg["send"] is not None and backend == "nccl":
+                dist.all_gather_into_tensor(sg["recv"], sg["send"])
+            elif sg["send"] is not None:
+                dist.all_gather_into_tensor(sg["recv"].cpu(), sg["send"].cpu())
+            for i in sg["uneq"]:
+                all_gather_rows(outs[i] if backend == "nccl" else outs[i].cpu(), mats[i].m, rank, world, dist)
         if pf_stream is not None:      # join the second stream (a captured graph must end on one stream)
             ev = torch.cuda.Event()
             ev.record(pf_stream)
@@ -426,6 +445,17 @@ def main():
 
     use_graph = world == 1 and not args.no_graph
     run = step
+    if world > 1 and not args.no_graph and pf_stream is None:
+        # one graph per layer: its launches replay without the host in between; the all-gathers are issued between the graphs
+        step()
+        torch.cuda.synchronize()
+        for sg in segments:
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr):
+                for j in sg["plan"]:
+                    launch(j)
+            sg["graph"] = gr
+        say(f"{len(segments)} per-layer graphs captured")
     if use_graph:
         side = torch.cuda.Stream()
         with torch.cuda.stream(side):
@@ -461,7 +491,7 @@ def main():
     K.lib.mi355_timing_enable(1)
     nroof = max(1, min(args.steps, 5))
     for _ in range(nroof):
-        step()
+        step(eager=True)
     torch.cuda.synchronize()
     K.lib.mi355_timing_enable(0)
     # dominant kernel by time: the fused gate/up launch (mmvq_glu_kernel<q4_K>) when it is in the plan, else the grouped
@@ -566,8 +596,8 @@ def main():
                                    "step" + (", in the launches the plugin uses for a decode token (rms-norm + q8_1 in the prologue of the fused "
                                              "QKV+rope and gate/up+GLU launches, residual add in the wo / down epilogue)" if fuse_norm else
                                              " + q8_1 activation quantization") + ", random-init GGUF blocks",
-                       "parallelism": "single GPU" if world == 1 else f"row split x{world} + RCCL all-gather",
-                       "launch": "hipGraph replay" if use_graph else "eager",
+                       "parallelism": "single GPU" if world == 1 else f"row split x{world} + one RCCL all-gather per layer",
+                       "launch": "hipGraph replay" if use_graph else ("one hipGraph per layer, collectives between them" if segments and segments[0]["graph"] is not None else "eager"),
                        "launches_per_step": n_launches, "grouped": not args.no_group,
                        "pct_hbm_peak": round(value / (HBM_PEAK_GBPS * world) * 100, 2),
                        "decode_tokens_per_s_matvec_only": round(1e3 / ms_per_step, 1)},
