@@ -46,6 +46,11 @@
  *   GGML_MI355_NO_GRAPHS=1   decode tokens are launched eagerly, not replayed from a captured hipGraph (GGML_MI355_GRAPH_STATS=1
  *                            prints replay / capture / eager counts when the backend is freed, GGML_MI355_GRAPH_DEBUG=1 why a graph
  *                            was captured again)
+ *   GGML_MI355_NO_SPLIT_FUSE=1   -sm row decode: split MUL_MATs one at a time (quantize, copy, launch per device) instead of the fused
+ *                            decode launches on row slices; GGML_MI355_NO_SPLIT_GRAPH=1 keeps those but never captures a split token;
+ *                            GGML_MI355_SPLIT_GRAPH=1 captures split tokens also when the devices are several physical GPUs (default:
+ *                            only when they are one, i.e. virtual devices -- untested otherwise); GGML_MI355_SPLIT_STREAMS=1 issues a
+ *                            same-GPU device's slice on its helper stream instead of the main stream
  *   GGML_MI355_SPLIT_GATHER=rccl   row split: gather the devices' row slices with an RCCL all-gather (ncclCommInitAll, one rank per
  *                            physical GPU; librccl.so is opened only then) instead of peer stores into the main device's dst; falls
  *                            back to peer stores, with a warning, when two devices share a GPU or RCCL cannot be set up

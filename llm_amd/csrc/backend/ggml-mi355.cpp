@@ -593,8 +593,8 @@ struct mi355_backend_ctx {
     //       here, then [0] and [2] trade places      [3] partial tiles of a split-K prefill GEMM (mi355_mul_mat_dq_slice_ws)
     //   [4] a decode token's K and V rows in f32, between the fused Q/K/V launch and their quantization into a q8_0 cache
     //   [5] the sync blocks of a token's persistent decode-layer launches (mi355_decode_layer), cleared by one memset per graph
-    void * scratch[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    size_t scratch_size[6] = {0, 0, 0, 0, 0, 0};
+    void * scratch[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};     // [6]: a row nobody reads (see mi355_try_fuse_glu_matvec)
+    size_t scratch_size[7] = {0, 0, 0, 0, 0, 0, 0};
     int dl_used = 0;                // decode-layer launches issued for the graph in flight (= sync blocks handed out)
     void swap_act_scratch() { std::swap(scratch[0], scratch[2]); std::swap(scratch_size[0], scratch_size[2]); }
 
@@ -670,6 +670,9 @@ struct mi355_backend_ctx {
         std::vector<node_sig> sig;   // the last graph seen
         hipGraphExec_t exec = nullptr;
         std::vector<int> kv_nodes;   // CPY node indices, two per table slot (K, V), in launch order
+        std::vector<size_t> kv_off;  // byte offset of the entry's destination inside that node's row (a row-split slice), else 0
+        void kv_push(int node, size_t off) { kv_nodes.push_back(node); kv_off.push_back(off); }
+        void kv_clear() { kv_nodes.clear(); kv_off.clear(); }
         void ** kv_dev = nullptr;    // device table, MI355_KV_SLOTS * 2 pointers
         void ** kv_host = nullptr;   // pinned staging ring, MI355_KV_RING copies of the table
         int  ring = 0;
@@ -682,7 +685,7 @@ struct mi355_backend_ctx {
         hipEvent_t ring_ev[MI355_KV_RING] = {};    // recorded behind the table copy that reads ring slot i: the slot is reused only after it
         void drop() {
             if (exec) { HIP_CHECK(hipGraphExecDestroy(exec)); exec = nullptr; n_dropped++; }
-            sig.clear(); kv_nodes.clear(); recaptures = 0;
+            sig.clear(); kv_clear(); recaptures = 0;
         }
     } gc;
 
@@ -741,7 +744,7 @@ static void mi355_backend_free(ggml_backend_t backend) {
     mi355_backend_ctx * ctx = (mi355_backend_ctx *)backend->context;
     mi355_set_device(ctx->device);
     HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    for (int i = 0; i < 6; i++) if (ctx->scratch[i]) HIP_CHECK(hipFree(ctx->scratch[i]));
+    for (int i = 0; i < 7; i++) if (ctx->scratch[i]) HIP_CHECK(hipFree(ctx->scratch[i]));
     if (MI355_ENV_SET("GGML_MI355_KERNEL_TIMES")) {      // per-kernel launch counts and device time of the whole process so far
         std::vector<char> rep((size_t)mi355_timing_report(nullptr, 0));
         mi355_timing_report(rep.data(), (int64_t)rep.size());
@@ -1126,6 +1129,11 @@ static void mi355_mul_mat(mi355_backend_ctx * ctx, ggml_tensor * dst) {
         mi355_backend_ctx::peer_t & p = ctx->peer(d);
         mi355_set_device(d);
         HIP_CHECK(hipStreamWaitEvent(p.stream, ctx->ev_ready, 0));
+        if (p.act_size < qb + db && ctx->gc.capturing) {      // no allocation under capture: this capture is given up (nothing captured
+            ctx->gc.capture_failed = true;                    // ever runs), the eager run that follows grows the buffer
+            HIP_CHECK(hipEventRecord(p.done, p.stream));
+            continue;
+        }
         if (p.act_size < qb + db) {
             HIP_CHECK(hipStreamSynchronize(p.stream));
             if (p.act) HIP_CHECK(hipFree(p.act));
@@ -1542,10 +1550,19 @@ static bool is_view_op(const ggml_tensor * t) {
 
 static const ggml_tensor * view_root(const ggml_tensor * t) { return t->view_src ? t->view_src : t; }
 
+// Row-split weights (-sm row) in the fused decode launches: every fused kernel takes a row range, and the 128-row rounding of the
+// split keeps rope pairs, GLU pairs and q8_1 blocks inside a slice -- so each device that owns rows runs the SAME launch on its slice
+// (weights from its own memory, activations and results in the main device's over xGMI) between one event fork and one join
+// (mi355_split_fan_out).  GGML_MI355_NO_SPLIT_FUSE=1: split MUL_MATs run one by one through mi355_mul_mat as before.
+static bool split_fusable(const ggml_tensor * w) {
+    static const bool off = MI355_ENV_SET("GGML_MI355_NO_SPLIT_FUSE");
+    return !off && tensor_is_split(w) && w->extra && w->ne[2] == 1 && w->ne[3] == 1;
+}
+
 static bool matvec_groupable(const ggml_tensor * node) {
     if (node->op != GGML_OP_MUL_MAT) return false;
     const ggml_tensor * a = node->src[0], * b = node->src[1];
-    if (!is_weight_type(a->type) || tensor_is_split(a) || a->op != GGML_OP_NONE || a->view_src) return false;
+    if (!is_weight_type(a->type) || (tensor_is_split(a) && !split_fusable(a)) || a->op != GGML_OP_NONE || a->view_src) return false;
     if (a->ne[2] != 1 || a->ne[3] != 1 || b->ne[2] != 1 || b->ne[3] != 1 || b->ne[1] < 1 || b->ne[1] > 8) return false;
     if (mi355_mul_mat_path(a, b) != MM_VEC) return false;      // e.g. 4..8 columns of a K-quant: the skinny MFMA kernel is faster
     return ggml_is_contiguous(node) && a->ne[1] > 0;
@@ -1561,7 +1578,7 @@ static int mi355_collect_matvec_group(ggml_cgraph * cgraph, int i, const std::ve
     for (int j = i + 1; j < horizon && cnt < MI355_MMVQ_MAX_GROUP; j++) {
         const ggml_tensor * cand = ggml_graph_node(cgraph, j);
         if (done[j] || !matvec_groupable(cand) || cand->src[1] != src1 || cand->src[0]->type != first->src[0]->type ||
-            cand->src[0]->ne[0] != first->src[0]->ne[0]) continue;
+            cand->src[0]->ne[0] != first->src[0]->ne[0] || tensor_is_split(cand->src[0]) != tensor_is_split(first->src[0])) continue;
         const size_t dn = ggml_nbytes(cand);
         bool safe = !ranges_overlap(cand->data, dn, src1->data, ggml_nbytes(src1));
         for (int m = 0; m < cnt && safe; m++) {
@@ -1587,6 +1604,47 @@ static int mi355_collect_matvec_group(ggml_cgraph * cgraph, int i, const std::ve
     }
     return cnt;
 }
+
+// One fused decode op over row-split weights: `has[d]` says which devices own rows, `launch(d, stream)` issues device d's slice.  The
+// helpers start behind everything the main stream has issued so far (one event), the main stream goes on behind all of them (one
+// event each).  Under capture the helper streams join the capture through the first wait and leave it through the last.
+// A slice whose device is the SAME physical GPU as the main device (virtual devices) is issued on the main stream itself: a second
+// stream on one GPU buys no parallel hardware and every fork / join edge costs ~5 us on the GPU and in hipGraphLaunch (2 virtual
+// devices, 8B Q4_K_M tg64: 313 t/s through helper streams, 100 before the split forms; unsplit 510).  GGML_MI355_SPLIT_STREAMS=1
+// keeps the helper streams there too -- the tests run both, so that the fork / join path stays exercised on the one-GPU box.
+template <class F>
+static void mi355_split_fan_out(mi355_backend_ctx * ctx, const bool * has, F launch) {
+    const int ndev = mi355_device_count();
+    static const bool force_streams = MI355_ENV_SET("GGML_MI355_SPLIT_STREAMS");
+    bool helper[MI355_MAX_DEVICES] = {};
+    int n_helpers = 0;
+    for (int d = 0; d < ndev; d++) {
+        helper[d] = d != ctx->device && has[d] && (force_streams || mi355_phys(d) != mi355_phys(ctx->device));
+        n_helpers += helper[d];
+    }
+    if (n_helpers == 0) {
+        for (int d = 0; d < ndev; d++) if (has[d]) launch(d, ctx->stream);
+        return;
+    }
+    if (!ctx->ev_ready) HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_ready, hipEventDisableTiming));
+    HIP_CHECK(hipEventRecord(ctx->ev_ready, ctx->stream));
+    for (int d = 0; d < ndev; d++) {
+        if (!helper[d]) continue;
+        mi355_backend_ctx::peer_t & p = ctx->peer(d);
+        mi355_set_device(d);
+        HIP_CHECK(hipStreamWaitEvent(p.stream, ctx->ev_ready, 0));
+        launch(d, p.stream);
+        HIP_CHECK(hipEventRecord(p.done, p.stream));
+    }
+    mi355_set_device(ctx->device);
+    for (int d = 0; d < ndev; d++) if (has[d] && !helper[d]) launch(d, ctx->stream);      // the main device's slice (and same-GPU ones)
+    for (int d = 0; d < ndev; d++) {
+        if (!helper[d]) continue;
+        HIP_CHECK(hipStreamWaitEvent(ctx->stream, ctx->peers[d].done, 0));
+    }
+}
+
+static const mi355_split_extra * split_extra_of(const ggml_tensor * w) { return (const mi355_split_extra *)w->extra; }
 
 // norm_x / norm_w / norm_eps (one column only): src1 = (norm_x * rsqrt(mean(norm_x^2) + eps)) * norm_w is computed, stored and quantized in the
 // launch's prologue (mi355_mmvq_args.src_f32) instead of being read from a launch of its own
@@ -1619,6 +1677,31 @@ static void mi355_mul_mat_group(mi355_backend_ctx * ctx, ggml_cgraph * cgraph, c
         }
     }
     a[0].residual = residual; a[0].sum = sum;      // mat-vec + ADD (cnt == 1)
+    if (tensor_is_split(first->src[0])) {
+        // every device launches the group over its row slices: the members it owns rows of, results (and the residual sum) at the
+        // slice's place in the main device's tensors
+        bool has[MI355_MAX_DEVICES] = {};
+        const int ndev = mi355_device_count();
+        for (int m = 0; m < cnt; m++) {
+            const mi355_split_extra * ex = split_extra_of(ggml_graph_node(cgraph, members[m])->src[0]);
+            for (int d = 0; d < ndev; d++) if (ex->data[d] && ex->row_high[d] > ex->row_low[d]) has[d] = true;
+        }
+        mi355_split_fan_out(ctx, has, [&](int d, hipStream_t st) {
+            mi355_mmvq_args b[MI355_MMVQ_MAX_GROUP];
+            int nb = 0;
+            for (int m = 0; m < cnt; m++) {
+                const mi355_split_extra * ex = split_extra_of(ggml_graph_node(cgraph, members[m])->src[0]);
+                const int64_t lo = ex->row_low[d], rows = ex->row_high[d] - lo;
+                if (!ex->data[d] || rows <= 0) continue;
+                b[nb] = a[m];
+                b[nb].W = ex->data[d]; b[nb].m = rows; b[nb].dst = a[m].dst + lo;
+                if (a[m].residual) { b[nb].residual = a[m].residual + lo; b[nb].sum = a[m].sum + lo; }
+                nb++;
+            }
+            if (nb) MI_CHECK(mi355_mul_mat_vec_q_group(b, nb, st));
+        });
+        return;
+    }
     MI_CHECK(mi355_mul_mat_vec_q_group(a, cnt, ctx->stream));
 }
 
@@ -1714,7 +1797,10 @@ static bool mi355_try_fuse_glu_matvec(mi355_backend_ctx * ctx, ggml_cgraph * cgr
     else if (ranges_overlap(glu->data, ggml_nbytes(glu), gate->data, ggml_nbytes(gate))) return false;
     if (glu->data == up->data) up_out = nullptr;
     else if (ranges_overlap(glu->data, ggml_nbytes(glu), up->data, ggml_nbytes(up))) return false;
-    if (ranges_overlap(glu->data, ggml_nbytes(glu), src1->data, ggml_nbytes(src1))) return false;
+    // The GLU result on the bytes of src1 (ggml-alloc does that once the two mat-vecs, src1's last readers, are behind it -- seen with
+    // row-split weights): the kernel never reads src1's f32 form (the activations arrive quantized, or are normalised from the norm's
+    // input in every workgroup), so the only conflict is the prologue's store of the norm result, which then goes to a row nobody reads.
+    const bool glu_on_src1 = ranges_overlap(glu->data, ggml_nbytes(glu), src1->data, ggml_nbytes(src1));
 
     const size_t qb = align_up((size_t)mi355_act_q_bytes(K, 1), 256), db = align_up((size_t)mi355_act_ds_bytes(K, 1), 256);
     const size_t oqb = align_up((size_t)mi355_act_q_bytes(M, 1), 256), odb = align_up((size_t)mi355_act_ds_bytes(M, 1), 256);
@@ -1729,13 +1815,18 @@ static bool mi355_try_fuse_glu_matvec(mi355_backend_ctx * ctx, ggml_cgraph * cgr
         const ggml_tensor * x = norm->src[0];
         const ggml_tensor * w = src1->src[0] == norm ? src1->src[1] : src1->src[0];
         // outputs that coincide (a GLU result in place on gate / up) were already reduced to one above
-        const ggml_tensor * outs[4] = {src1, glu, nullptr, nullptr};
+        ggml_tensor norm_dst = *src1;                      // where the prologue stores the norm result
+        if (glu_on_src1) {
+            norm_dst.data = ctx->get_scratch(6, (size_t)K * sizeof(float));
+            if (ctx->scratch_size[6] < (size_t)K * sizeof(float)) return false;
+        }
+        const ggml_tensor * outs[4] = {&norm_dst, glu, nullptr, nullptr};
         size_t ob[4] = {ggml_nbytes(src1), ggml_nbytes(glu), 0, 0};
         int no = 2;
         if (gate_out) { outs[no] = gate; ob[no++] = ggml_nbytes(gate); }
         if (up_out)   { outs[no] = up;   ob[no++] = ggml_nbytes(up); }
         if (!norm_prologue_ok(x, w, K, 8192, outs, ob, no)) return false;
-        a.norm_x = (const float *)x->data; a.norm_w = (const float *)w->data; a.norm_out = (float *)src1->data;
+        a.norm_x = (const float *)x->data; a.norm_w = (const float *)w->data; a.norm_out = (float *)norm_dst.data;
         memcpy(&a.norm_eps, norm->op_params, sizeof(float));
         os = (char *)ctx->get_scratch(0, oqb + odb);      // scratch[0] is not read by this launch: the result goes straight in
     } else {
@@ -1753,9 +1844,33 @@ static bool mi355_try_fuse_glu_matvec(mi355_backend_ctx * ctx, ggml_cgraph * cgr
     if (ws) { a.act_q = (const int8_t *)ws; a.act_ds = (const float *)(ws + qb); }
     a.gate_out = gate_out; a.up_out = up_out; a.dst = (float *)glu->data;
     a.out_q = (int8_t *)os; a.out_ds = (float *)(os + oqb);
-    const int rc = mi355_glu_matvec(&a, ctx->stream);
-    if (rc == MI355_E_UNSUPPORTED || rc == MI355_E_ALIGN) return false;
-    MI_CHECK(rc);
+    if (tensor_is_split(gate->src[0])) {
+        // row-split gate / up: both matrices are cut at the same rows (same shape, same split), a device computes rows [lo, hi) of
+        // gate, up, the GLU result and its q8_1 form (128-row rounding: whole q8_1 blocks)
+        const mi355_split_extra * eg = split_extra_of(gate->src[0]), * eu = split_extra_of(up->src[0]);
+        if (!tensor_is_split(up->src[0])) return false;
+        bool has[MI355_MAX_DEVICES] = {};
+        const int ndev = mi355_device_count();
+        for (int d = 0; d < ndev; d++) {
+            if (eg->row_low[d] != eu->row_low[d] || eg->row_high[d] != eu->row_high[d] || (eg->row_low[d] % 32)) return false;
+            const int64_t rows = eg->row_high[d] - eg->row_low[d];
+            has[d] = rows > 0 && eg->data[d] && eu->data[d];
+            if (has[d] && rows % 32) return false;
+        }
+        mi355_split_fan_out(ctx, has, [&](int d, hipStream_t st) {
+            mi355_glu_matvec_args b = a;
+            const int64_t lo = eg->row_low[d];
+            b.w_gate = eg->data[d]; b.w_up = eu->data[d]; b.m = eg->row_high[d] - lo;
+            if (a.gate_out) b.gate_out = a.gate_out + lo;
+            if (a.up_out)   b.up_out   = a.up_out + lo;
+            b.dst = a.dst + lo; b.out_q = a.out_q + lo; b.out_ds = a.out_ds + lo / 32 * 2;
+            MI_CHECK(mi355_glu_matvec(&b, st));
+        });
+    } else {
+        const int rc = mi355_glu_matvec(&a, ctx->stream);
+        if (rc == MI355_E_UNSUPPORTED || rc == MI355_E_ALIGN) return false;
+        MI_CHECK(rc);
+    }
     if (norm_idx < 0) ctx->swap_act_scratch();            // scratch[0] now holds the q8_1 form of the GLU result
     ctx->act_remember(glu);
     return true;
@@ -2503,12 +2618,54 @@ static bool mi355_try_fuse_qkv_rope(mi355_backend_ctx * ctx, ggml_cgraph * cgrap
         MI_CHECK(mi355_quantize_act((const float *)x->data, (int8_t *)ws, (float *)(ws + qb), K, 1, 1, 1, x->nb[1], x->nb[2], x->nb[3], ctx->stream));
         ctx->act_remember(x);
     }
+    if (tensor_is_split(wq)) {
+        // row-split wq / wk / wv: a device rotates and stores the heads whose rows it owns (the split's 128-row rounding keeps a head's
+        // rows together for head_dim <= 128); K and V land at the slice's place in the cache row -- under capture through a table
+        // slot of the device's own, whose entries carry the slice's byte offset
+        const mi355_split_extra * eq = split_extra_of(wq), * ek = split_extra_of(wk), * ev = split_extra_of(wv);
+        if (kv_q8 || !tensor_is_split(wk) || !tensor_is_split(wv)) return false;
+        bool has[MI355_MAX_DEVICES] = {};
+        const int ndev = mi355_device_count();
+        int n_has = 0;
+        for (int d = 0; d < ndev; d++) {
+            const int64_t rq_ = eq->row_high[d] - eq->row_low[d], rk_ = ek->row_high[d] - ek->row_low[d], rv_ = ev->row_high[d] - ev->row_low[d];
+            if (rq_ <= 0 && rk_ <= 0 && rv_ <= 0) continue;
+            // the kernel wants rows of all three; whole heads; 16-byte aligned slice starts in the f16 cache rows
+            if (rq_ <= 0 || rk_ <= 0 || rv_ <= 0 || rq_ % hd || rk_ % hd || eq->row_low[d] % hd || ek->row_low[d] % hd || rv_ % 8 || ev->row_low[d] % 8) return false;
+            has[d] = true; n_has++;
+        }
+        if (ctx->gc.capturing && ctx->gc.n_slots + n_has > MI355_KV_SLOTS) { ctx->gc.capture_failed = true; kv_table = nullptr; }
+        const size_t ksz = ggml_type_size(ck->type), vsz = ggml_type_size(cv->type);
+        int slot_of[MI355_MAX_DEVICES] = {};
+        if (kv_table) {
+            for (int d = 0; d < ndev; d++) {
+                if (!has[d]) continue;
+                slot_of[d] = ctx->gc.n_slots++;
+                ctx->gc.kv_push(idx[5], (size_t)ek->row_low[d] * ksz);
+                ctx->gc.kv_push(idx[6], (size_t)ev->row_low[d] * vsz);
+            }
+        }
+        mi355_split_fan_out(ctx, has, [&](int d, hipStream_t st) {
+            mi355_qkv_rope_args b = a;
+            b.wq = eq->data[d]; b.wk = ek->data[d]; b.wv = ev->data[d];
+            b.m_q = eq->row_high[d] - eq->row_low[d]; b.m_k = ek->row_high[d] - ek->row_low[d]; b.m_v = ev->row_high[d] - ev->row_low[d];
+            b.q_out = a.q_out + eq->row_low[d];
+            b.k_out = (char *)ck->data + (size_t)ek->row_low[d] * ksz;
+            b.v_out = (char *)cv->data + (size_t)ev->row_low[d] * vsz;
+            b.kv_table = kv_table; b.kv_slot = slot_of[d];
+            MI_CHECK(mi355_qkv_rope_matvec(&b, st));
+        });
+        for (int m = 1; m < 7; m++) done[idx[m]] = 1;
+        ctx->act_invalidate_if_written(rq);
+        if (norm_idx >= 0) ctx->act_invalidate_if_written(x);
+        return true;
+    }
     const int rc = mi355_qkv_rope_matvec(&a, ctx->stream);
     if (rc == MI355_E_UNSUPPORTED || rc == MI355_E_SHAPE || rc == MI355_E_ALIGN) return false;
     MI_CHECK(rc);
     if (kv_q8) MI_CHECK(mi355_kv_store_q8_0(kv_tmp, Mk, ck->data, kv_tmp + Mk, Mv, cv->data, kv_table, kv_slot, ctx->stream));
     for (int m = 1; m < 7; m++) done[idx[m]] = 1;
-    if (kv_table) { ctx->gc.kv_nodes.push_back(idx[5]); ctx->gc.kv_nodes.push_back(idx[6]); ctx->gc.n_slots++; }
+    if (kv_table) { ctx->gc.kv_push(idx[5], 0); ctx->gc.kv_push(idx[6], 0); ctx->gc.n_slots++; }
     ctx->act_invalidate_if_written(rq);
     if (norm_idx >= 0) ctx->act_invalidate_if_written(x);
     return true;
@@ -2536,7 +2693,7 @@ static bool mi355_try_fuse_decode_layer(mi355_backend_ctx * ctx, ggml_cgraph * c
     ggml_tensor * nd[9];
     for (int j = 0; j < 9; j++) { nd[j] = ggml_graph_node(cgraph, i + j); if (done[i + j]) return false; }
     ggml_tensor * mm0 = nd[0], * add0 = nd[1], * norm1 = nd[2], * mul1 = nd[3], * glu = nd[6], * mm2 = nd[7], * add2 = nd[8];
-    if (!matvec_groupable(mm0) || mm0->src[1]->ne[1] != 1 || mm0->src[0]->ne[1] < 2048) return false;
+    if (!matvec_groupable(mm0) || tensor_is_split(mm0->src[0]) || mm0->src[1]->ne[1] != 1 || mm0->src[0]->ne[1] < 2048) return false;
     auto add_of = [](const ggml_tensor * add, const ggml_tensor * mm) -> const ggml_tensor * {     // the residual operand (mi355_try_fuse_matvec_add's checks)
         if (add->op != GGML_OP_ADD || add->type != GGML_TYPE_F32) return nullptr;
         const ggml_tensor * r = add->src[0] == mm ? add->src[1] : (add->src[1] == mm ? add->src[0] : nullptr);
@@ -2663,7 +2820,7 @@ static bool mi355_try_fuse_decode_layer(mi355_backend_ctx * ctx, ggml_cgraph * c
     if (tail) {
         done[i + 9] = 1; done[i + 10] = 1;
         for (int m = 0; m < 7; m++) done[qn.idx[m]] = 1;
-        if (kv_table) { ctx->gc.kv_nodes.push_back(qn.idx[5]); ctx->gc.kv_nodes.push_back(qn.idx[6]); ctx->gc.n_slots++; }
+        if (kv_table) { ctx->gc.kv_push(qn.idx[5], 0); ctx->gc.kv_push(qn.idx[6], 0); ctx->gc.n_slots++; }
     }
     ctx->act_cache.valid = false;        // nothing of what scratch[0] held describes a tensor the following nodes read
     return true;
@@ -2781,6 +2938,16 @@ static bool node_computes(const ggml_tensor * t) {
 // A graph is a candidate when it is a single-token step on this device alone: every MUL_MAT / MUL_MAT_ID has one
 // activation column (prefill graphs change shape from call to call and amortise their launches anyway) and no tensor
 // lives in a row-split buffer (helper streams and cross-device events are not captured; ggml-cuda.cu:2593-2598 likewise).
+static bool mi355_split_graphs_ok() {
+    static const bool ok = [] {
+        if (MI355_ENV_SET("GGML_MI355_NO_SPLIT_GRAPH") || MI355_ENV_SET("GGML_MI355_NO_SPLIT_FUSE") || mi355_split_gather_rccl()) return false;
+        if (MI355_ENV_SET("GGML_MI355_SPLIT_GRAPH")) return true;
+        for (int d = 1; d < mi355_device_count(); d++) if (mi355_phys(d) != mi355_phys(0)) return false;
+        return true;
+    }();
+    return ok;
+}
+
 static bool mi355_graph_capturable(ggml_cgraph * cgraph) {
     const int n = ggml_graph_n_nodes(cgraph);
     if (n < 8) return false;
@@ -2795,7 +2962,11 @@ static bool mi355_graph_capturable(ggml_cgraph * cgraph) {
             if (cols > max_cols) return false;
             if (t->op == GGML_OP_MUL_MAT && ggml_is_quantized(t->src[0]->type)) any = true;
         }
-        for (int k = 0; k < GGML_MAX_SRC; k++) if (t->src[k] && tensor_is_split(t->src[k])) return false;
+        // Row-split weights: the token's launches fork onto helper streams and join again (mi355_split_fan_out), which a capture
+        // records like any other dependency.  Captured when every ggml device is the same physical GPU (virtual devices: measured
+        // and tested) or on request (GGML_MI355_SPLIT_GRAPH=1): a graph whose kernel nodes sit on several physical GPUs could not
+        // be tried on the one-GPU development box.  The reference never captures split graphs (ggml-cuda.cu:2593-2598).
+        for (int k = 0; k < GGML_MAX_SRC; k++) if (t->src[k] && tensor_is_split(t->src[k]) && !mi355_split_graphs_ok()) return false;
     }
     return any;
 }
@@ -2853,7 +3024,7 @@ static void mi355_graph_refresh_kv_table(mi355_backend_ctx * ctx, ggml_cgraph * 
     if (ev) HIP_CHECK(hipEventSynchronize(ev));
     else    HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     gc.ring = (gc.ring + 1) % MI355_KV_RING;
-    for (size_t j = 0; j < gc.kv_nodes.size(); j++) h[j] = ggml_graph_node(cgraph, gc.kv_nodes[j])->data;
+    for (size_t j = 0; j < gc.kv_nodes.size(); j++) h[j] = (char *)ggml_graph_node(cgraph, gc.kv_nodes[j])->data + gc.kv_off[j];
     HIP_CHECK(hipMemcpyAsync(gc.kv_dev, h, gc.kv_nodes.size() * sizeof(void *), hipMemcpyHostToDevice, ctx->stream));
     HIP_CHECK(hipEventRecord(ev, ctx->stream));
 }
@@ -2898,7 +3069,7 @@ static enum ggml_status mi355_backend_graph_compute(ggml_backend_t backend, ggml
         // first sighting of this graph: run it eagerly (this also sizes the scratch buffers); a second identical one is captured
         if (gc.exec) { HIP_CHECK(hipGraphExecDestroy(gc.exec)); gc.exec = nullptr; }
         mi355_graph_signature(cgraph, gc.sig);
-        gc.kv_nodes.clear();
+        gc.kv_clear();
         if (++gc.recaptures > 8) {                 // a graph that never settles (ggml-cuda.cu:2674-2690 gives up the same way)
             gc.disabled = true;
             MI_LOG_INFO("%s: decode graph keeps changing, hipGraph replay disabled for this backend\n", __func__);
@@ -2913,7 +3084,7 @@ static enum ggml_status mi355_backend_graph_compute(ggml_backend_t backend, ggml
         HIP_CHECK(hipMalloc((void **)&gc.kv_dev, MI355_KV_SLOTS * 2 * sizeof(void *)));
         HIP_CHECK(hipHostMalloc((void **)&gc.kv_host, (size_t)MI355_KV_RING * MI355_KV_SLOTS * 2 * sizeof(void *), hipHostMallocDefault));
     }
-    gc.kv_nodes.clear(); gc.n_slots = 0; gc.capture_failed = false;
+    gc.kv_clear(); gc.n_slots = 0; gc.capture_failed = false;
     HIP_CHECK(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
     gc.capturing = true;
     const enum ggml_status st = mi355_issue_graph(ctx, cgraph);
@@ -2922,7 +3093,7 @@ static enum ggml_status mi355_backend_graph_compute(ggml_backend_t backend, ggml
     HIP_CHECK(hipStreamEndCapture(ctx->stream, &graph));
     if (st != GGML_STATUS_SUCCESS || gc.capture_failed || !graph) {
         if (graph) HIP_CHECK(hipGraphDestroy(graph));
-        gc.kv_nodes.clear();
+        gc.kv_clear();
         if (st != GGML_STATUS_SUCCESS) return st;
         if (++gc.recaptures > 8) gc.disabled = true;
         gc.n_eager++;

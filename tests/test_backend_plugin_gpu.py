@@ -360,3 +360,33 @@ def test_llama_row_split_logits_equal_single_device(tmp_path):
             assert "MI355_0_Split" in r.stderr + r.stdout, (r.stderr + r.stdout)[-3000:]
         outs.append(np.fromfile(path, dtype=np.uint32))
     assert np.array_equal(outs[0], outs[1])
+
+
+def test_row_split_decode_fused_forms_and_graph_replay_are_bit_exact(tmp_path):
+    """`-sm row` decode over two virtual devices with the fused launches running on row slices (Q/K/V + rope + KV store, wo / ffn_down
+    + residual, gate / up + GLU; mi355_split_fan_out) and the token replayed from a captured graph whose K / V table entries carry the
+    slice offsets: 70 decode steps of the `mid` model (2048 wide, 4 KV heads of 128: every slice is whole heads) give the unsplit run's
+    logits to the bit -- with the same-GPU slices on the main stream (default), through helper streams and events
+    (GGML_MI355_SPLIT_STREAMS=1: the fork / join path a multi-GPU node takes), and with the split forms off (one MUL_MAT at a time,
+    eager) -- and the split graphs did replay."""
+    import numpy as np
+    tool = os.path.join(ROOT, "tools", "run_llama_bench.sh")
+    variants = {"unsplit": None, "split": {}, "split_streams": {"GGML_MI355_SPLIT_STREAMS": "1"}, "split_unfused": {"GGML_MI355_NO_SPLIT_FUSE": "1"}}
+    outs = {}
+    for name, extra in variants.items():
+        path = str(tmp_path / f"logits_{name}.bin")
+        env = dict(os.environ, GGML_MI355_GRAPH_STATS="1")
+        args = [tool, "mid", "Q4_K_M", "--dump-logits", path, "--decode-steps", "70"]
+        if extra is not None:
+            env.update(extra, GGML_MI355_VIRTUAL_DEVICES="2")
+            args += ["-sm", "row", "-ts", "1,1"]
+        r = subprocess.run(args, capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stderr[-3000:]
+        outs[name] = np.fromfile(path, dtype=np.uint32)
+        replays = sum(int(x) for x in re.findall(r"decode graphs: (\d+) replays", r.stderr))
+        if name in ("split", "split_streams"):
+            assert replays >= 60, r.stderr[-2000:]
+        if name == "split_unfused":
+            assert replays == 0, r.stderr[-2000:]
+    for name in ("split", "split_streams", "split_unfused"):
+        assert outs[name].size == outs["unsplit"].size and np.array_equal(outs[name], outs["unsplit"]), name
