@@ -176,7 +176,7 @@ def test_llama_logits_match_ggml_cpu(ftype, ctk, tmp_path):
     assert d <= 2.0 * e_cpu + 2e-4, (d, e_cpu)        # two roundings of the same exact values
 
 
-@pytest.mark.parametrize("model", ["tiny", "tinymoe"])
+@pytest.mark.parametrize("model", ["tiny", "tinymoe", "mid", "wideffn"])      # mid: 2048 wide, 4 KV heads of 128, ffn 5120; wideffn: Llama-8B's 14336
 def test_fusions_are_bit_exact(tmp_path, model, kv="f16", extra_env=None):
     """The backend's graph-level fusions (RMS_NORM*weight, fused q8_1 quantization, activation cache, Q/K/V + rope + store,
     and for the 8-expert model the one-launch MoE router) keep the f32 op order of the unfused graph: logits with and
