@@ -157,11 +157,16 @@ def other_configs(budget_s):
     exe, mk = os.path.join(ref, "llama-bench"), os.path.join(ref, "make-random-gguf")
     if not all(os.path.exists(x) for x in (exe, mk, plugin)):
         return {"error": "oracle/_ref/llama-bench, make-random-gguf or the plugin is not built"}
-    legs = [("config3_8b_q8_0_q8kv", "8b", "Q8_0", ["-p", "2048", "-n", "0", "-ctk", "q8_0", "-ctv", "q8_0"]),
-            ("config5_8x7b_q4km", "8x7b", "Q4_K_M", ["-p", "8,16,32,64", "-n", "64"]),
-            ("config4_70b_q4km_1gpu", "70b", "Q4_K_M", ["-p", "512", "-n", "64"])]
+    # (name, model, ftype, llama-bench arguments, extra environment, keep the GGUF for the next leg)
+    legs = [("config3_8b_q8_0_q8kv", "8b", "Q8_0", ["-p", "2048", "-n", "0", "-ctk", "q8_0", "-ctv", "q8_0"], {}, False),
+            ("config5_8x7b_q4km", "8x7b", "Q4_K_M", ["-p", "8,16,32,64", "-n", "64"], {}, False),
+            ("config4_70b_q4km_1gpu", "70b", "Q4_K_M", ["-p", "512", "-n", "64"], {}, True),
+            # the row-split code path of config 4 (-sm row: fused launches on row slices, the token replayed as a graph) rehearsed on
+            # this one GPU as two ggml devices: what the split costs, not what it gains -- the 2 / 4 / 8-GPU rows need a node
+            ("config4_70b_q4km_row_split_2_virtual_devices", "70b", "Q4_K_M", ["-p", "0", "-n", "64", "-sm", "row", "-ts", "1/1"],
+             {"GGML_MI355_VIRTUAL_DEVICES": "2"}, False)]
     out, t_all = {}, time.perf_counter()
-    for name, model, ftype, extra in legs:
+    for name, model, ftype, extra, leg_env, keep in legs:
         left = budget_s - (time.perf_counter() - t_all)
         if left < 45:
             out[name] = {"skipped": "time budget of the default run used up"}
@@ -172,7 +177,7 @@ def other_configs(budget_s):
             if not os.path.exists(gguf):
                 subprocess.run([mk, gguf, model, ftype], check=True, capture_output=True, timeout=left)
             r = subprocess.run([exe, "-m", gguf, "-ngl", "99", "-fa", "1", "-r", "2", "-o", "json"] + extra, capture_output=True, text=True,
-                               timeout=max(30, left - (time.perf_counter() - t0)), env=dict(os.environ, GGML_BACKEND_PATH=plugin))
+                               timeout=max(30, left - (time.perf_counter() - t0)), env=dict(os.environ, GGML_BACKEND_PATH=plugin, **leg_env))
             rows = json.loads(r.stdout)
             res = {}
             for x in rows:
@@ -183,10 +188,14 @@ def other_configs(budget_s):
         except Exception as e:  # noqa: BLE001
             out[name] = {"error": f"{type(e).__name__}: {e}"[:200]}
         finally:
-            try:
-                os.remove(gguf)
-            except OSError:
-                pass
+            if not keep:
+                try:
+                    os.remove(gguf)
+                except OSError:
+                    pass
+    for leftover in {f"/tmp/random-{m}-{t}.gguf" for _, m, t, _, _, _ in legs}:
+        if os.path.exists(leftover):
+            os.remove(leftover)
     out["harness"] = "the reference's llama-bench (unmodified) + reference libllama + plugin, 2 reps, random-init GGUFs (tools/make_random_gguf.cpp), flash attention"
     return out
 
