@@ -345,6 +345,14 @@ MI355_API int mi355_mul_mat_id_skinny(int type, const void *as, int64_t w_row_st
                                       int64_t k, int64_t n_expert, int64_t n_used, int64_t n_tokens, int64_t b_ne1, void *workspace,
                                       int64_t workspace_bytes, void *stream);
 
+/* Two expert tensors of one K-quant type, shape and strides on the same b and ids -- ffn_up_exps and ffn_gate_exps of a MoE layer
+ * (build_moe_ffn, llama-graph.cpp:650-795) -- in ONE launch: one activation quantization, one bucketing, one grid over the row tiles of
+ * both.  dst0 / dst1 receive exactly what two mi355_mul_mat_id_skinny calls write.  Workspace as for one call.  Q4_K / Q5_K / Q6_K. */
+MI355_API int mi355_mul_mat_id_skinny_pair(int type, const void *as0, const void *as1, int64_t w_row_stride, int64_t w_expert_stride,
+                                           const float *b, int64_t b_nb1, int64_t b_nb2, const int32_t *ids, int64_t ids_stride,
+                                           float *dst0, float *dst1, int64_t m, int64_t k, int64_t n_expert, int64_t n_used,
+                                           int64_t n_tokens, int64_t b_ne1, void *workspace, int64_t workspace_bytes, void *stream);
+
 /* Prefill MUL_MAT of a K-quant (Q4_K, Q5_K; others MI355_E_UNSUPPORTED) on q8_K activations, any n: the tile-kernel
  * form of mi355_mul_mat_skinny_k (64 rows x 128 columns per workgroup, digit planes prepared once per weight while the
  * tile is staged, one f32 fold per 256 weights).  Replaces mul_mat_q (mmq.cuh:2606-2841) for these types.

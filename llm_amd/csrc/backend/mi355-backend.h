@@ -269,6 +269,7 @@ int  mi355_mul_mat_path(const ggml_tensor * src0, const ggml_tensor * src1, cons
 mi355_act_layout mi355_act_planes(int path, int64_t K, int64_t rows);
 void mi355_mul_mat(mi355_backend_ctx * ctx, ggml_tensor * dst);
 void mi355_mul_mat_id(mi355_backend_ctx * ctx, ggml_tensor * dst);
+bool mi355_mul_mat_id_pair(mi355_backend_ctx * ctx, ggml_tensor * d0, ggml_tensor * d1);      // up_exps + gate_exps of a small batch in one launch
 bool mi355_flash_attn_supported(const ggml_tensor * op);
 bool mi355_compute_forward(mi355_backend_ctx * ctx, ggml_tensor * node, const ggml_tensor * next = nullptr);
 bool mi355_try_fuse_rms_norm_mul(mi355_backend_ctx * ctx, ggml_cgraph * cgraph, int i, ggml_tensor * add = nullptr, const ggml_tensor * gemm = nullptr);

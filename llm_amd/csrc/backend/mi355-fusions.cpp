@@ -1349,6 +1349,10 @@ enum ggml_status mi355_issue_graph(mi355_backend_ctx * ctx, ggml_cgraph * cgraph
             continue;
         }
         if (fuse && node->op == GGML_OP_MUL_MAT_ID && mi355_try_fuse_moe_down(ctx, cgraph, i, done)) continue;
+        if (fuse && node->op == GGML_OP_MUL_MAT_ID && i + 1 < n && !done[i + 1] && mi355_mul_mat_id_pair(ctx, node, ggml_graph_node(cgraph, i + 1))) {
+            done[i + 1] = 1;
+            continue;
+        }
         // fusion: decode mat-vecs that share their activation run as one grouped launch
         if (fuse && matvec_groupable(node)) {
             int members[MI355_MMVQ_MAX_GROUP];

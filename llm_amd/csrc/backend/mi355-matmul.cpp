@@ -328,6 +328,45 @@ void mi355_mul_mat(mi355_backend_ctx * ctx, ggml_tensor * dst) {
 // oracle ggml_compute_forward_mul_mat_id, ggml-cpu.c:1470-1648).  Expert routing stays on the
 // device: the kernel reads ids itself, so there is no stream sync + host-side sort per call
 // (the reference does both, ggml-cuda/mmq.cu:157-158,188-189).
+// the skinny regime of MUL_MAT_ID (see mi355_mul_mat_id): pairs from max(12, 1.5 * n_expert) to 256, K-quants and q4_0 / q8_0
+static bool moe_skinny_regime(const ggml_tensor * dst) {
+    const ggml_tensor * as = dst->src[0], * b = dst->src[1], * ids = dst->src[2];
+    const int64_t K = as->ne[0], M = as->ne[1], n_expert = as->ne[2], n_tokens = b->ne[2], n_used = ids->ne[0];
+    static const int64_t sk_max = getenv("GGML_MI355_MOE_SKINNY_MAX") ? atoll(getenv("GGML_MI355_MOE_SKINNY_MAX")) : 256;
+    static const int64_t sk_min = getenv("GGML_MI355_MOE_SKINNY_MIN") ? atoll(getenv("GGML_MI355_MOE_SKINNY_MIN")) : 12;
+    const bool dense_dst = dst->nb[1] == (size_t)M * sizeof(float) && dst->nb[2] == (size_t)M * n_used * sizeof(float) &&
+                           ((((uintptr_t)b->data) | b->nb[1] | b->nb[2]) & 15) == 0;
+    return n_tokens * n_used >= std::max(sk_min, n_expert * 3 / 2) && n_tokens * n_used <= sk_max && K % 256 == 0 && n_expert <= 256 && dense_dst &&
+           is_weight_type(as->type) && !MI355_ENV_SET("GGML_MI355_NO_SKINNY");
+}
+
+// MUL_MAT_ID(ffn_up_exps) and MUL_MAT_ID(ffn_gate_exps) of a MoE layer (two consecutive nodes on the same b and ids, build_moe_ffn) in
+// the skinny regime: ONE launch -- one activation quantization, one bucketing, one grid over both tensors' row tiles
+// (mi355_mul_mat_id_skinny_pair; each result has the bits of its own launch).  GGML_MI355_NO_MOE_PAIR=1 launches them one by one.
+bool mi355_mul_mat_id_pair(mi355_backend_ctx * ctx, ggml_tensor * d0, ggml_tensor * d1) {
+    if (d0->op != GGML_OP_MUL_MAT_ID || d1->op != GGML_OP_MUL_MAT_ID || MI355_ENV_SET("GGML_MI355_NO_MOE_PAIR")) return false;
+    const ggml_tensor * a0 = d0->src[0], * a1 = d1->src[0], * b = d0->src[1], * ids = d0->src[2];
+    if (d1->src[1] != b || d1->src[2] != ids || a0->type != a1->type || !ggml_are_same_shape(a0, a1) || a0->nb[1] != a1->nb[1] || a0->nb[2] != a1->nb[2]) return false;
+    if (a0->type != GGML_TYPE_Q4_K && a0->type != GGML_TYPE_Q5_K && a0->type != GGML_TYPE_Q6_K) return false;
+    if (tensor_is_split(a0) || tensor_is_split(a1) || a0->ne[3] != 1 || d0->type != GGML_TYPE_F32 || d1->type != GGML_TYPE_F32) return false;
+    if (!moe_skinny_regime(d0) || !moe_skinny_regime(d1)) return false;
+    const size_t nb = ggml_nbytes(d0);
+    auto overlap = [](const void * p, size_t pn, const void * q, size_t qn) { return (const char *)p < (const char *)q + qn && (const char *)q < (const char *)p + pn; };
+    if (overlap(d0->data, nb, d1->data, ggml_nbytes(d1)) || overlap(d0->data, nb, b->data, ggml_nbytes(b)) || overlap(d1->data, ggml_nbytes(d1), b->data, ggml_nbytes(b)) ||
+        overlap(d0->data, nb, ids->data, ggml_nbytes(ids)) || overlap(d1->data, ggml_nbytes(d1), ids->data, ggml_nbytes(ids))) return false;
+    const int64_t K = a0->ne[0], M = a0->ne[1], n_expert = a0->ne[2], b_ne1 = b->ne[1], n_tokens = b->ne[2], n_used = ids->ne[0];
+    const int64_t need = mi355_mul_mat_id_skinny_workspace_bytes((int)a0->type, K, n_tokens, b_ne1, n_used, n_expert);
+    void * ws = ctx->get_scratch(0, (size_t)need);
+    if (ctx->scratch_size[0] < (size_t)need) return false;
+    ctx->act_cache.valid = false;
+    const int rc = mi355_mul_mat_id_skinny_pair((int)a0->type, a0->data, a1->data, (int64_t)a0->nb[1], (int64_t)a0->nb[2], (const float *)b->data,
+                                                (int64_t)b->nb[1], (int64_t)b->nb[2], (const int32_t *)ids->data, (int64_t)(ids->nb[1] / sizeof(int32_t)),
+                                                (float *)d0->data, (float *)d1->data, M, K, n_expert, n_used, n_tokens, b_ne1, ws, need, ctx->stream);
+    if (rc == MI355_E_UNSUPPORTED || rc == MI355_E_ALIGN) return false;
+    MI_CHECK(rc);
+    return true;
+}
+
 void mi355_mul_mat_id(mi355_backend_ctx * ctx, ggml_tensor * dst) {
     const ggml_tensor * as  = dst->src[0];
     const ggml_tensor * b   = dst->src[1];

@@ -984,10 +984,37 @@ extern "C" int64_t mi355_mul_mat_id_skinny_workspace_bytes(int type, int64_t k, 
     return ids_ws_layout(type, k, n_tokens * b_ne1, &b0, &b1, &b2) + (n_tokens * n_used + 2 * (n_expert + 1)) * 4 + 256;
 }
 
+static int mul_mat_id_skinny_impl(int type, const void * as, const void * as2, int64_t w_row_stride, int64_t w_expert_stride, const float * b,
+                                  int64_t b_nb1, int64_t b_nb2, const int32_t * ids, int64_t ids_stride, float * dst, float * dst2, int64_t m,
+                                  int64_t k, int64_t n_expert, int64_t n_used, int64_t n_tokens, int64_t b_ne1, void * workspace,
+                                  int64_t workspace_bytes, void * stream);
+
 extern "C" int mi355_mul_mat_id_skinny(int type, const void * as, int64_t w_row_stride, int64_t w_expert_stride, const float * b,
                                        int64_t b_nb1, int64_t b_nb2, const int32_t * ids, int64_t ids_stride, float * dst, int64_t m,
                                        int64_t k, int64_t n_expert, int64_t n_used, int64_t n_tokens, int64_t b_ne1, void * workspace,
                                        int64_t workspace_bytes, void * stream) {
+    return mul_mat_id_skinny_impl(type, as, nullptr, w_row_stride, w_expert_stride, b, b_nb1, b_nb2, ids, ids_stride, dst, nullptr, m, k, n_expert, n_used,
+                                  n_tokens, b_ne1, workspace, workspace_bytes, stream);
+}
+
+extern "C" int mi355_mul_mat_id_skinny_pair(int type, const void * as0, const void * as1, int64_t w_row_stride, int64_t w_expert_stride,
+                                            const float * b, int64_t b_nb1, int64_t b_nb2, const int32_t * ids, int64_t ids_stride, float * dst0,
+                                            float * dst1, int64_t m, int64_t k, int64_t n_expert, int64_t n_used, int64_t n_tokens, int64_t b_ne1,
+                                            void * workspace, int64_t workspace_bytes, void * stream) {
+    if (!as1 || !dst1) return MI355_E_NULL;
+    if (type != MI355_TYPE_Q4_K && type != MI355_TYPE_Q5_K && type != MI355_TYPE_Q6_K) return mi355_blck_size(type) ? MI355_E_UNSUPPORTED : MI355_E_TYPE;
+    return mul_mat_id_skinny_impl(type, as0, as1, w_row_stride, w_expert_stride, b, b_nb1, b_nb2, ids, ids_stride, dst0, dst1, m, k, n_expert, n_used,
+                                  n_tokens, b_ne1, workspace, workspace_bytes, stream);
+}
+
+// as2 / dst2 (K-quants only): a second expert tensor of the same type, shape and strides on the same b and ids -- ffn_up_exps and
+// ffn_gate_exps of a MoE layer -- computed by the same launch (blockIdx.x runs over the row tiles of both, S2Args.grp): one activation
+// quantization, one bucketing and one grid instead of two of each.  Each result has the bits of its own call (the cut of a tile over
+// the waves is the same function of (m, k, n_expert) in both).
+static int mul_mat_id_skinny_impl(int type, const void * as, const void * as2, int64_t w_row_stride, int64_t w_expert_stride, const float * b,
+                                  int64_t b_nb1, int64_t b_nb2, const int32_t * ids, int64_t ids_stride, float * dst, float * dst2, int64_t m,
+                                  int64_t k, int64_t n_expert, int64_t n_used, int64_t n_tokens, int64_t b_ne1, void * workspace,
+                                  int64_t workspace_bytes, void * stream) {
     if (!as || !b || !ids || !dst || !workspace) return MI355_E_NULL;
     const int64_t bs = mi355_blck_size(type);
     if (bs == 0 || type == MI355_TYPE_F32 || type == MI355_TYPE_F16 || type == MI355_TYPE_Q8_1) return MI355_E_TYPE;
@@ -997,7 +1024,8 @@ extern "C" int mi355_mul_mat_id_skinny(int type, const void * as, int64_t w_row_
     if (workspace_bytes < mi355_mul_mat_id_skinny_workspace_bytes(type, k, n_tokens, b_ne1, n_used, n_expert)) return MI355_E_WORKSPACE;
     if (((uintptr_t)workspace & 15) || ((uintptr_t)dst & 3) || ((uintptr_t)ids & 3)) return MI355_E_ALIGN;
     const bool kq = type == MI355_TYPE_Q4_K || type == MI355_TYPE_Q5_K || type == MI355_TYPE_Q6_K;      // q8_K activations
-    if (((uintptr_t)as | (uintptr_t)w_row_stride | (uintptr_t)w_expert_stride) & (kq && type != MI355_TYPE_Q6_K ? 15 : 1)) return MI355_E_ALIGN;
+    if (((uintptr_t)as | (uintptr_t)as2 | (uintptr_t)w_row_stride | (uintptr_t)w_expert_stride) & (kq && type != MI355_TYPE_Q6_K ? 15 : 1)) return MI355_E_ALIGN;
+    if ((uintptr_t)dst2 & 3) return MI355_E_ALIGN;
     if (w_row_stride < mi355_row_size(type, k)) return MI355_E_SHAPE;
     if (m == 0 || n_tokens == 0) return MI355_OK;
     hipStream_t s = (hipStream_t)stream;
@@ -1017,13 +1045,21 @@ extern "C" int mi355_mul_mat_id_skinny(int type, const void * as, int64_t w_row_
     IdsArgs I;
     I.sorted = sorted; I.off = off; I.tile_off = tile_off; I.n_expert = (int)n_expert; I.n_used = (int)n_used; I.act_ne1 = (int)b_ne1;
     I.w_expert_stride = w_expert_stride;
-    const unsigned nb = (unsigned)((m + 31) / 32);
+    const unsigned nb1 = (unsigned)((m + 31) / 32);
     const unsigned max_tiles = (unsigned)((n_tokens * n_used + 31) / 32 + n_expert);   // sum over experts of ceil(cnt_e / 32) never exceeds this
     if (max_tiles > 65535) return MI355_E_UNSUPPORTED;
     if (kq) {
         S2Args a = {};
         a.W = (const uint8_t *)as; a.w_row_stride = w_row_stride; a.aq = (const int8_t *)ws; a.ad = (const float *)(ws + b0);
         a.bs = (const int16_t *)(ws + b0 + b1); a.dst = dst; a.dst_col_stride = m; a.m = (int)m; a.n = 32; a.k = (int)k; a.ids = I;
+        unsigned nb = nb1;
+        if (as2) {
+            a.grp.n = 2;
+            a.grp.W[0] = (const uint8_t *)as; a.grp.W[1] = (const uint8_t *)as2; a.grp.dst[0] = dst; a.grp.dst[1] = dst2;
+            for (int i = 0; i < 2; i++) { a.grp.w_row_stride[i] = w_row_stride; a.grp.dst_col_stride[i] = m; a.grp.m[i] = (int)m; a.grp.tile_end[i] = (int)nb1 * (i + 1); }
+            a.grp.tile_end[2] = a.grp.tile_end[3] = 2 * (int)nb1;
+            nb = 2 * nb1;
+        }
         const int tpw = sk_tpw(m, k, n_expert);
         if (tpw == 42) {      // lab: two tiles x two waves in 4-wave workgroups (two per CU)
             const unsigned nb2 = (nb + 1) / 2;
@@ -1045,6 +1081,8 @@ extern "C" int mi355_mul_mat_id_skinny(int type, const void * as, int64_t w_row_
         else if (type == MI355_TYPE_Q5_K) MI355_LAUNCH("mmsk2_id_q5_K", (mmsk2_kernel<MI355_TYPE_Q5_K, 8>), dim3(nb, max_tiles), dim3(512), 0, s, a);
         else                              MI355_LAUNCH("mmsk6_id_q6_K", (mmsk6_kernel<8>), dim3(nb, max_tiles), dim3(512), 0, s, a);
     } else {
+        if (as2) return MI355_E_UNSUPPORTED;
+        const unsigned nb = nb1;
         SArgs a = {};
         a.W = (const uint8_t *)as; a.w_row_stride = w_row_stride; a.aq = (const int8_t *)ws; a.ads = (const float *)(ws + b0);
         a.dst = dst; a.dst_col_stride = m; a.m = (int)m; a.n = 32; a.k = (int)k; a.ids = I;

@@ -368,6 +368,22 @@ def mul_mat_id_skinny(t, as_, b, ids, m, n_expert):
     return dst
 
 
+def mul_mat_id_skinny_pair(t, as0, as1, b, ids, m, n_expert):
+    """two expert tensors (ffn_up_exps, ffn_gate_exps) on the same b and ids in one skinny launch -> two [n_tokens, n_used, m]."""
+    _u8(as0); _u8(as1)
+    n_tok, b_ne1, k = b.shape
+    n_used = ids.shape[1]
+    rs = B.row_size(t, k)
+    need = K.lib.mi355_mul_mat_id_skinny_workspace_bytes(t, k, n_tok, b_ne1, n_used, n_expert)
+    ws = torch.empty(need, dtype=torch.uint8, device=b.device)
+    d0 = torch.full((n_tok, n_used, m), float("nan"), dtype=torch.float32, device=b.device)
+    d1 = torch.full((n_tok, n_used, m), float("nan"), dtype=torch.float32, device=b.device)
+    K.check(K.lib.mi355_mul_mat_id_skinny_pair(t, as0.data_ptr(), as1.data_ptr(), rs, rs * m, b.data_ptr(), k * 4, b_ne1 * k * 4, ids.data_ptr(),
+                                               n_used, d0.data_ptr(), d1.data_ptr(), m, k, n_expert, n_used, n_tok, b_ne1, ws.data_ptr(), need,
+                                               _stream()), "mi355_mul_mat_id_skinny_pair")
+    return d0, d1
+
+
 def mul_mat_skinny(t, w, b, m):
     """MUL_MAT for small batches through the int8-MFMA skinny kernel, in passes of 32 columns: b = [n, k] f32 -> [n, m]."""
     _u8(w)

@@ -1153,6 +1153,26 @@ def test_mul_mat_id_skinny(ops, t, m, k, n_exp, n_used, n_tok, b1):
     assert O.nmse(vec, got) <= 5e-4
 
 
+@pytest.mark.parametrize("t", [B.Q4_K, B.Q5_K, B.Q6_K])
+@pytest.mark.parametrize("m,k,n_exp,n_used,n_tok", [(96, 256, 4, 2, 6), (130, 512, 8, 2, 8), (2080, 1024, 8, 2, 40), (14336, 4096, 8, 2, 16)])
+def test_mul_mat_id_skinny_pair_has_the_bits_of_two_calls(ops, t, m, k, n_exp, n_used, n_tok):
+    """ffn_up_exps and ffn_gate_exps of a MoE layer in one skinny launch (one quantization, one bucketing, one grid over the row tiles
+    of both): each result is its own call's, bit for bit -- odd tile counts, an out-of-range id and the full Mixtral shape included."""
+    from test_decode_layer_gpu import gpu_blocks
+    rng = np.random.default_rng(m + k + n_tok)
+    w0, w1 = gpu_blocks(t, n_exp * m, k, seed=70 + t), gpu_blocks(t, n_exp * m, k, seed=71 + t)
+    b = dev(rng.standard_normal((n_tok, 1, k)).astype(np.float32))
+    ids = np.stack([rng.permutation(n_exp)[:n_used] for _ in range(n_tok)]).astype(np.int32)
+    ids[n_tok // 2, 1] = n_exp + 1                                      # pair skipped: both results keep their NaN there
+    idd = dev(ids)
+    d0, d1 = ops.mul_mat_id_skinny_pair(t, w0, w1, b, idd, m, n_exp)
+    s0 = ops.mul_mat_id_skinny(t, w0, b, idd, m, n_exp)
+    s1 = ops.mul_mat_id_skinny(t, w1, b, idd, m, n_exp)
+    assert torch.equal(d0.view(torch.int32), s0.view(torch.int32)) and torch.equal(d1.view(torch.int32), s1.view(torch.int32))
+    ok = torch.from_numpy((ids >= 0) & (ids < n_exp)).cuda()
+    assert torch.isfinite(d0[ok]).all() and torch.isfinite(d1[ok]).all() and torch.isnan(d0[~ok]).all() and torch.isnan(d1[~ok]).all()
+
+
 @pytest.mark.parametrize("t", [B.Q4_K, B.Q6_K])
 @pytest.mark.parametrize("m,k", [(14336, 4096), (4096, 14336)])
 @pytest.mark.parametrize("n_tok", [8, 32, 64])
