@@ -390,3 +390,20 @@ def test_row_split_decode_fused_forms_and_graph_replay_are_bit_exact(tmp_path):
             assert replays == 0, r.stderr[-2000:]
     for name in ("split", "split_streams", "split_unfused"):
         assert outs[name].size == outs["unsplit"].size and np.array_equal(outs[name], outs["unsplit"]), name
+
+
+@pytest.mark.parametrize("ndev,ts", [(3, "2,1,1"), (8, "1,1,1,1,1,1,1,1"), (4, "0,1,1,2"), (2, "3,1")])
+def test_row_split_decode_uneven_layouts_are_bit_exact(tmp_path, ndev, ts):
+    """The split decode forms over uneven tensor splits, a device that owns nothing, and eight devices (where a device owns rows of wq
+    but none of wk: the fused Q/K/V form steps aside for that layer and the token is not captured): 40 decode steps of the `mid`
+    model give the unsplit logits to the bit."""
+    import numpy as np
+    tool = os.path.join(ROOT, "tools", "run_llama_bench.sh")
+    ref_path, path = str(tmp_path / "ref.bin"), str(tmp_path / "split.bin")
+    r = subprocess.run([tool, "mid", "Q4_K_M", "--dump-logits", ref_path, "--decode-steps", "40"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    env = dict(os.environ, GGML_MI355_VIRTUAL_DEVICES=str(ndev))
+    r = subprocess.run([tool, "mid", "Q4_K_M", "--dump-logits", path, "--decode-steps", "40", "-sm", "row", "-ts", ts], capture_output=True, text=True,
+                       timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert np.array_equal(np.fromfile(ref_path, dtype=np.uint32), np.fromfile(path, dtype=np.uint32))
