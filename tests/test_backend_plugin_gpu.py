@@ -17,7 +17,7 @@ PLUGIN = os.path.join(ROOT, "llm_amd", "lib", "libggml-mi355.so")
 OPS = ["MUL_MAT", "MUL_MAT_ID", "FLASH_ATTN_EXT", "ADD", "MUL", "SUB", "DIV", "RMS_NORM", "ROPE", "REGLU", "GEGLU", "SWIGLU", "CPY", "CONT", "DUP",
        "GET_ROWS", "SET_ROWS", "SCALE", "SOFT_MAX", "ARGSORT", "SUM_ROWS"]
 # lower bounds on the number of cases that must actually RUN on the device (not "not supported")
-MIN_RUN = {"MUL_MAT": 600, "SET_ROWS": 50, "MUL_MAT_ID": 100, "FLASH_ATTN_EXT": 1000, "ROPE": 50, "SOFT_MAX": 100}
+MIN_RUN = {"MUL_MAT": 640, "SET_ROWS": 50, "MUL_MAT_ID": 160, "FLASH_ATTN_EXT": 1390, "ROPE": 50, "SOFT_MAX": 100}
 
 
 def _run(op):
