@@ -316,7 +316,9 @@ MI355_API int mi355_mul_mat_skinny(int type, const void *W, int64_t w_row_stride
 MI355_API int mi355_quantize_act_q8k(const float *x, int8_t *q, float *d, int16_t *bsums, int64_t k, int64_t ne1, int64_t ne2,
                                      int64_t ne3, int64_t nb1, int64_t nb2, int64_t nb3, void *stream);
 
-/* Skinny MUL_MAT of a K-quant (Q4_K, Q5_K; others MI355_E_UNSUPPORTED) on q8_K activations, n <= 32 columns: the
+/* Skinny MUL_MAT of a K-quant (Q4_K, Q5_K, Q6_K; others MI355_E_UNSUPPORTED) on q8_K activations, n <= 64 columns (33..64: the two
+ * column halves of a 32-row tile are two tiles of one workgroup, so the weights still cross HBM once and the launch's fixed costs
+ * are paid once; same integers, the f32 additions over K in a different order than two calls of 32 columns): the
  * arithmetic of ggml_vec_dot_q4_K_q8_K / q5_K_q8_K (ggml-cpu/quants.c; the ggml-cpu contract of MUL_MAT,
  * ggml-cpu.c:1196-1388) with the integer sub-block scales folded into the int8 MFMA operands, so there is one
  * f32 rescale per 256 weights instead of one per 32.  dst[c*dst_col_stride + r]. */
@@ -325,7 +327,7 @@ MI355_API int mi355_mul_mat_skinny_k(int type, const void *W, int64_t w_row_stri
                                      int64_t n, void *stream);
 
 /* Up to four weight matrices of ONE K-quant type and one k against the SAME q8_K activations in one launch: the wq / wk / wv
- * products of a step of 5..32 tokens (llama-graph.cpp build_attn's three ggml_mul_mat on one input).  Each result is what
+ * products of a step of 5..64 tokens (llama-graph.cpp build_attn's three ggml_mul_mat on one input).  Each result is what
  * mi355_mul_mat_skinny_k writes for that matrix to within the order of the f32 additions over K (here always one workgroup per 32
  * rows and a fixed order; the single call may cut K over two workgroups and add with atomics).  Replaces three launches of
  * mul_mat_q / mul_mat_vec_q (mmq.cuh:3095-3175, mmvq.cu:137-224). */

@@ -902,11 +902,19 @@ static bool small_mm_ok(const ggml_tensor * t) {
     return path == MM_SKINNY_K || path == MM_SKINNY;
 }
 
+// wk / wv beside a wq that takes a skinny kernel: any quantized product will do (each lands in its plane through mi355_mul_mat, whatever
+// kernel that picks) -- an 8-expert Q4_K_M model has q8_0 wk / wv, which at 33..64 columns take the GEMM while wq stays skinny
+static bool small_qkv_sibling_ok(const ggml_tensor * t) {
+    const ggml_tensor * w = t->src[0], * x = t->src[1];
+    return t->op == GGML_OP_MUL_MAT && t->type == GGML_TYPE_F32 && x->type == GGML_TYPE_F32 && w->ne[2] == 1 && w->ne[3] == 1 && !tensor_is_split(w) &&
+           is_weight_type(w->type) && ggml_is_contiguous(t);
+}
+
 static bool mi355_try_fuse_qkv_small(mi355_backend_ctx * ctx, ggml_cgraph * cgraph, int i, std::vector<char> & done) {
     ggml_tensor * mq0 = ggml_graph_node(cgraph, i);
     if (mq0->src[1]->ne[1] <= 1 || !small_mm_ok(mq0) || MI355_ENV_SET("GGML_MI355_NO_QKV_SMALL")) return false;
     qkv_nodes q;
-    if (!qkv_match(cgraph, i, done, small_mm_ok, q)) return false;
+    if (!qkv_match(cgraph, i, done, small_qkv_sibling_ok, q)) return false;
     const ggml_tensor * x = q.mq->src[1];
     ggml_tensor * mm[3] = {q.mq, q.mk, q.mv};
     const int64_t N = x->ne[1], hd = q.rq->ne[0];
@@ -950,7 +958,7 @@ static bool mi355_try_fuse_qkv_small(mi355_backend_ctx * ctx, ggml_cgraph * cgra
     // 192 workgroups with neither.
     bool grouped[3] = {false, false, false};
     const int64_t K = x->ne[0];
-    if (N <= 32 && x->ne[2] == 1 && x->ne[3] == 1 && !MI355_ENV_SET("GGML_MI355_NO_SKINNY_GROUP") &&
+    if (N <= 64 && x->ne[2] == 1 && x->ne[3] == 1 && !MI355_ENV_SET("GGML_MI355_NO_SKINNY_GROUP") &&
         mi355_mul_mat_path(mm[0]->src[0], x, mm[0]) == MM_SKINNY_K) {
         const void * Wg[3]; int64_t rs[3], dcs[3], mg[3]; float * dg[3];
         int cnt = 0, who[3];
@@ -992,7 +1000,7 @@ static bool mi355_try_fuse_qkv_small(mi355_backend_ctx * ctx, ggml_cgraph * cgra
 static bool mi355_try_group_small(mi355_backend_ctx * ctx, ggml_cgraph * cgraph, int i, std::vector<char> & done) {
     ggml_tensor * first = ggml_graph_node(cgraph, i);
     const ggml_tensor * x = first->src[1];
-    if (!small_mm_ok(first) || x->ne[1] > 32 || x->ne[2] != 1 || x->ne[3] != 1 || MI355_ENV_SET("GGML_MI355_NO_SKINNY_GROUP")) return false;
+    if (!small_mm_ok(first) || x->ne[1] > 64 || x->ne[2] != 1 || x->ne[3] != 1 || MI355_ENV_SET("GGML_MI355_NO_SKINNY_GROUP")) return false;
     if (mi355_mul_mat_path(first->src[0], x, first) != MM_SKINNY_K) return false;
     const void * Wg[4]; int64_t rs[4], dcs[4], mg[4]; float * dg[4];
     int cnt = 0;

@@ -62,8 +62,15 @@ int mi355_mul_mat_path(const ggml_tensor * src0, const ggml_tensor * src1, const
         // One pass of 32 columns.  A second pass streams the weights again, and since the GEMM splits K its time is flat up to 128
         // columns (4096 x 14336 q4_K: 41 us at 33..128 columns against 37 / 56 / 74 for 2 / 3 / 4 skinny passes; 4096 x 4096: 18 against
         // 24 for 2), and the GEMM path brings the fused Q/K/V finish with it: 8B pp64 6889 -> 7545 t/s, pp128 12.3k -> 13.8k.
-        static const int64_t skinny_max = [] { const char * e = getenv("GGML_MI355_SKINNY_MAX"); return e ? atoll(e) : 32; }();
-        if (kq  && N >= (src0->type == GGML_TYPE_Q6_K ? 5 : 4) && N <= skinny_max) return MM_SKINNY_K;
+        // Round 3: 33..64 columns are ONE skinny launch too (two column tiles per workgroup: the weights cross HBM once, the fixed costs of
+        // a launch are paid once): 8B pp33 / 40 / 48 / 64 4445 / 5394 / 6403 / 8389 t/s on the GEMM, 5216 / 6198 / 7285 / 9148 here.
+        static const int64_t skinny_max = [] { const char * e = getenv("GGML_MI355_SKINNY_MAX"); return e ? atoll(e) : 64; }();
+        // ... for the large matrices (ffn, 70B's wq / wo): on the 4096 x 4096 class the two tie as kernels and the GEMM brings the fused
+        // Q/K/V finish and add + norm launches with it (8x7B, whose dense matrices are all of that class: pp64 4294 on the GEMM, 4069 here).
+        // src0->ne[1] is the whole matrix's row count, so a row-split matrix still takes the unsplit one's path.
+        static const int64_t wide_min = [] { const char * e = getenv("GGML_MI355_SKINNY_WIDE_MIN"); return e ? atoll(e) : (int64_t)32 << 20; }();
+        const int64_t n_max = src0->ne[1] * K >= wide_min ? skinny_max : std::min<int64_t>(skinny_max, 32);
+        if (kq  && N >= (src0->type == GGML_TYPE_Q6_K ? 5 : 4) && N <= n_max) return MM_SKINNY_K;
         if (!kq && N > 8  && N <= (K >= 8192 ? 64 : 32))  return MM_SKINNY;
     }
     if (N > 8 && int8_mmq && K % 128 == 0) return MM_Q_INT8;
@@ -110,8 +117,9 @@ static void mi355_mul_mat_launch(const ggml_tensor * dst, const char * W, int64_
                 } else if (path == MM_Q_INT8) {
                     MI_CHECK(mi355_mul_mat_q((int)src0->type, Wc, (int64_t)src0->nb[1], aq + arow * K, ads + arow * (K / 32) * 2, d, dcol, M, K, N, stream));
                 } else {
-                    for (int64_t c0 = 0; c0 < N; c0 += 32) {
-                        const int64_t r = arow + c0, nc = N - c0 < 32 ? N - c0 : 32;
+                    const int64_t pass = path == MM_SKINNY_K ? 64 : 32;      // the K-quant kernels take 33..64 columns as two column tiles per workgroup
+                    for (int64_t c0 = 0; c0 < N; c0 += pass) {
+                        const int64_t r = arow + c0, nc = N - c0 < pass ? N - c0 : pass;
                         if (path == MM_SKINNY_K) {
                             const int16_t * bs = (const int16_t *)(act + L.b0 + L.b1);
                             MI_CHECK(mi355_mul_mat_skinny_k((int)src0->type, Wc, (int64_t)src0->nb[1], aq + r * K, ads + r * (K / 256), bs + r * (K / 16),

@@ -327,7 +327,7 @@ struct SkGroup {
     float * dst[4]; int64_t dst_col_stride[4];
     int m[4];
 };
-struct SkMat { const uint8_t * W; int64_t w_row_stride; float * dst; int64_t dst_col_stride; int m, tile; };
+struct SkMat { const uint8_t * W; int64_t w_row_stride; float * dst; int64_t dst_col_stride; int m, tile, col0; };
 
 struct S2Args {
     const uint8_t * W; int64_t w_row_stride;
@@ -336,6 +336,7 @@ struct S2Args {
     int m, n, k;
     IdsArgs ids;
     SkGroup grp;             // grp.n > 0: blockIdx.x runs over the 32-row tiles of several matrices (W, dst, m above are unused)
+    int ct;                  // column tiles of 32 per row tile (plain MUL_MAT, 33..64 columns: 2; else 1): tile index t -> (t / ct, column half t % ct)
 #ifdef SK_STAMPS
     long long * stamps;      // diagnostic build only (lab/mmsk_stamps.hip): [workgroup][wave][8] s_memtime / s_memrealtime
 #endif
@@ -349,7 +350,9 @@ struct S2Args {
 
 // the matrix a 32-row tile belongs to (t is wave-uniform: scalar selects on kernel arguments)
 static __device__ __forceinline__ SkMat sk_mat(const S2Args & a, int t) {
-    SkMat r = { a.W, a.w_row_stride, a.dst, a.dst_col_stride, a.m, t };
+    int col0 = 0;
+    if (a.ct > 1) { col0 = (t % a.ct) * 32; t /= a.ct; }      // consecutive tiles of a workgroup: the column halves of one row tile
+    SkMat r = { a.W, a.w_row_stride, a.dst, a.dst_col_stride, a.m, t, col0 };
     if (a.grp.n > 0) {
         const int gi = (t >= a.grp.tile_end[0]) + (t >= a.grp.tile_end[1]) + (t >= a.grp.tile_end[2]);
         r.W   = gi == 0 ? a.grp.W[0]   : gi == 1 ? a.grp.W[1]   : gi == 2 ? a.grp.W[2]   : a.grp.W[3];
@@ -405,6 +408,10 @@ mmsk2_kernel(const S2Args a) {
     __shared__ int s_row[32], s_pair[32];
     ColMap cm;
     if (!col_map(a.ids, a.n, tid, s_row, s_pair, cm)) return;
+    // this wave's columns: a pass of an expert's pairs (IDS), or columns col0 .. col0 + 31 of the batch
+    const bool ids_mode = a.ids.sorted != nullptr;
+    const int ncol = ids_mode ? cm.ncol : (a.n - mt.col0 < 32 ? (a.n - mt.col0 > 0 ? a.n - mt.col0 : 0) : 32);
+    auto srow = [&](int j) { return ids_mode ? s_row[j] : (mt.col0 + j < a.n ? mt.col0 + j : a.n - 1); };
 #ifdef SK_STAMPS
     long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (lane == 0) st_[7] = __builtin_amdgcn_s_memrealtime();
@@ -428,14 +435,14 @@ mmsk2_kernel(const S2Args a) {
     // Only the columns that exist are staged, four per load instruction: the activations of a super-step are 8 KB for 32 columns
     // against 4.6 KB of weights, and both go through the CU's load path -- at 8 columns they are 2 KB.  Lanes of the MFMA's other
     // columns read column 0 from LDS (finite values, results never stored).
-    const int na = __builtin_amdgcn_readfirstlane((cm.ncol + 3) >> 2);
+    const int na = __builtin_amdgcn_readfirstlane((ncol + 3) >> 2);
     const int lrc = lr < 4 * na ? lr : 0;
     uint32_t aoff[8];
 #pragma unroll
     for (int i = 0; i < 8; i++) {
-        aoff[i] = (uint32_t)s_row[i * 4 + (lane >> 4)] * (uint32_t)a.k + (lane & 15) * 16;
+        aoff[i] = (uint32_t)srow(i * 4 + (lane >> 4)) * (uint32_t)a.k + (lane & 15) * 16;
     }
-    const int col = s_row[lr];
+    const int col = srow(lr);
     const uint32_t doff = (uint32_t)col * (uint32_t)(a.k / 256) * 4;
     const uint32_t soff = (uint32_t)col * (uint32_t)(a.k / 8) + lh * 16;      // bsums of blocks 4 lh .. 4 lh + 3 (two int16 each)
 
@@ -560,7 +567,7 @@ mmsk2_kernel(const S2Args a) {
     __syncthreads();
     SK_STAMP(4);
     float * red = (float *)lds;      // [WAVES][16][64]
-    if (lr < cm.ncol) {              // a lane's 16 results are one column's: columns that do not exist are neither written nor added
+    if (lr < ncol) {                 // a lane's 16 results are one column's: columns that do not exist are neither written nor added
 #pragma unroll
         for (int r = 0; r < 16; r++) red[(wave * 16 + r) * 64 + lane] = acc[r];
     }
@@ -569,11 +576,12 @@ mmsk2_kernel(const S2Args a) {
         const int tl = e >> 10, r = (e >> 6) & 15, l = e & 63;
         const SkMat mo = sk_mat(a, (int)blockIdx.x * TPW + tl);      // (tl is wave-uniform: 1024 elements per tile, 64 per wave)
         const int orow = mo.tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), ocol = l & 31;
-        if (orow < mo.m && ocol < cm.ncol) {
+        const int ncol_o = ids_mode ? cm.ncol : (a.n - mo.col0 < 32 ? a.n - mo.col0 : 32);
+        if (orow < mo.m && ocol < ncol_o) {
             float s = 0.0f;
 #pragma unroll
             for (int w = 0; w < WK; w++) s += red[((tl * WK + w) * 16 + r) * 64 + l];
-            float * o = mo.dst + (int64_t)s_pair[ocol] * mo.dst_col_stride + orow;
+            float * o = mo.dst + (int64_t)(ids_mode ? s_pair[ocol] : mo.col0 + ocol) * mo.dst_col_stride + orow;
             if (cm.ky_cnt > 1) atomicAdd(o, s); else *o = s;
         }
     }
@@ -617,6 +625,10 @@ mmsk6_kernel(const S2Args a) {
     __shared__ int s_row[32], s_pair[32];
     ColMap cm;
     if (!col_map(a.ids, a.n, tid, s_row, s_pair, cm)) return;
+    // this wave's columns: a pass of an expert's pairs (IDS), or columns col0 .. col0 + 31 of the batch
+    const bool ids_mode = a.ids.sorted != nullptr;
+    const int ncol = ids_mode ? cm.ncol : (a.n - mt.col0 < 32 ? (a.n - mt.col0 > 0 ? a.n - mt.col0 : 0) : 32);
+    auto srow = [&](int j) { return ids_mode ? s_row[j] : (mt.col0 + j < a.n ? mt.col0 + j : a.n - 1); };
 
     const uint8_t * wbase = mt.W + cm.w_off + (int64_t)m0 * mt.w_row_stride;
     const int wr_ = lane / CH, wc_ = lane % CH;
@@ -629,12 +641,12 @@ mmsk6_kernel(const S2Args a) {
         woff[i] = v ? (uint32_t)rr * (uint32_t)mt.w_row_stride + (wc_ < 13 ? wc_ * 16 : 194) : 0u;
         wlds[i] = v ? r * IMG + wc_ * 16 : WBYTES + ABYTES;
     }
-    const int na = __builtin_amdgcn_readfirstlane((cm.ncol + 3) >> 2);      // only the columns that exist are staged (see mmsk2_kernel)
+    const int na = __builtin_amdgcn_readfirstlane((ncol + 3) >> 2);      // only the columns that exist are staged (see mmsk2_kernel)
     const int lrc = lr < 4 * na ? lr : 0;
     uint32_t aoff[8];
 #pragma unroll
-    for (int i = 0; i < 8; i++) aoff[i] = (uint32_t)s_row[i * 4 + (lane >> 4)] * (uint32_t)a.k + (lane & 15) * 16;
-    const uint32_t doff = (uint32_t)s_row[lr] * (uint32_t)(a.k / 256) * 4;
+    for (int i = 0; i < 8; i++) aoff[i] = (uint32_t)srow(i * 4 + (lane >> 4)) * (uint32_t)a.k + (lane & 15) * 16;
+    const uint32_t doff = (uint32_t)srow(lr) * (uint32_t)(a.k / 256) * 4;
 
     const int nsb = a.k / 256, per = (nsb + cm.ky_cnt - 1) / cm.ky_cnt;
     const int sb0 = cm.ky_idx * per, sb1 = sb0 + per < nsb ? sb0 + per : nsb;
@@ -726,17 +738,18 @@ mmsk6_kernel(const S2Args a) {
     float * red = (float *)lds;      // [WAVES][16][64]
 #pragma unroll
     for (int r = 0; r < 16; r++)     // (columns that do not exist are neither written nor added)
-        if ((r & 3) + 8 * (r >> 2) + 4 * lh < cm.ncol) red[(wave * 16 + r) * 64 + lane] = acc[r];
+        if ((r & 3) + 8 * (r >> 2) + 4 * lh < ncol) red[(wave * 16 + r) * 64 + lane] = acc[r];
     __syncthreads();
     for (int e = tid; e < TPW * 16 * 64; e += WAVES * 64) {
         const int tl = e >> 10, r = (e >> 6) & 15, l = e & 63;
         const SkMat mo = sk_mat(a, (int)blockIdx.x * TPW + tl);
         const int orow = mo.tile * 32 + (l & 31), ocol = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
-        if (orow < mo.m && ocol < cm.ncol) {
+        const int ncol_o = ids_mode ? cm.ncol : (a.n - mo.col0 < 32 ? a.n - mo.col0 : 32);
+        if (orow < mo.m && ocol < ncol_o) {
             float s = 0.0f;
 #pragma unroll
             for (int w = 0; w < WK; w++) s += red[((tl * WK + w) * 16 + r) * 64 + l];
-            float * o = mo.dst + (int64_t)s_pair[ocol] * mo.dst_col_stride + orow;
+            float * o = mo.dst + (int64_t)(ids_mode ? s_pair[ocol] : mo.col0 + ocol) * mo.dst_col_stride + orow;
             if (cm.ky_cnt > 1) atomicAdd(o, s); else *o = s;
         }
     }
@@ -770,8 +783,16 @@ static int sk_ky_min_k() {
     return v;
 }
 
+// 33..64 columns (a.ct == 2): the two column halves of a row tile are two "tiles" of one workgroup -- the weights cross HBM once and
+// the launch's fixed costs are paid once, where two passes of 32 pay both twice; a tile's K is cut over half as many waves.
 static int launch6(const S2Args & a, hipStream_t s, const char * tag) {
     const unsigned nb = (unsigned)((a.m + 31) / 32);
+    if (a.ct == 2) {
+        if (sk_tpw(a.m, a.k) == 2) MI355_LAUNCH(tag, (mmsk6_kernel<8, 4>), dim3((nb + 1) / 2, 1), dim3(512), 0, s, a);
+        else                       MI355_LAUNCH(tag, (mmsk6_kernel<8, 2>), dim3(nb, 1), dim3(512), 0, s, a);
+        MI355_CHECK_LAUNCH();
+        return MI355_OK;
+    }
     if (sk_tpw(a.m, a.k) == 2) {
         MI355_LAUNCH(tag, (mmsk6_kernel<4, 2>), dim3((nb + 1) / 2, 1), dim3(256), 0, s, a);
         MI355_CHECK_LAUNCH();
@@ -792,6 +813,12 @@ static int launch6(const S2Args & a, hipStream_t s, const char * tag) {
 template <int TYPE>
 static int launch2(const S2Args & a, hipStream_t s, const char * tag) {
     const unsigned nb = (unsigned)((a.m + 31) / 32);
+    if (a.ct == 2) {
+        if (sk_tpw(a.m, a.k) == 2) MI355_LAUNCH(tag, (mmsk2_kernel<TYPE, 8, 4>), dim3((nb + 1) / 2, 1), dim3(512), 0, s, a);
+        else                       MI355_LAUNCH(tag, (mmsk2_kernel<TYPE, 8, 2>), dim3(nb, 1), dim3(512), 0, s, a);
+        MI355_CHECK_LAUNCH();
+        return MI355_OK;
+    }
     if (sk_tpw(a.m, a.k) == 2) {
         MI355_LAUNCH(tag, (mmsk2_kernel<TYPE, 4, 2>), dim3((nb + 1) / 2, 1), dim3(256), 0, s, a);
         MI355_CHECK_LAUNCH();
@@ -905,15 +932,15 @@ extern "C" int mi355_mul_mat_skinny_k(int type, const void * W, int64_t w_row_st
     if (!W || !act_q || !act_d || !act_bsums || !dst) return MI355_E_NULL;
     if (type != MI355_TYPE_Q4_K && type != MI355_TYPE_Q5_K && type != MI355_TYPE_Q6_K) return mi355_blck_size(type) ? MI355_E_UNSUPPORTED : MI355_E_TYPE;
     if (m < 0 || n < 0 || k <= 0 || k % 256 != 0 || m > 0x7fffffff || k > 0x7fffffff || dst_col_stride < m) return MI355_E_SHAPE;
-    if (n > 32) return MI355_E_UNSUPPORTED;
-    if (w_row_stride > 0x3ffffff || k > 0x3ffffff) return MI355_E_UNSUPPORTED;      // 32-bit lane offsets: 32 rows / 32 columns
+    if (n > 64) return MI355_E_UNSUPPORTED;
+    if (w_row_stride > 0x3ffffff || k > 0x1ffffff) return MI355_E_UNSUPPORTED;      // 32-bit lane offsets: 32 rows / 64 columns
     if (((uintptr_t)act_q & 15) || ((uintptr_t)act_d & 3) || ((uintptr_t)act_bsums & 15) || ((uintptr_t)dst & 3)) return MI355_E_ALIGN;
     if (((uintptr_t)W | (uintptr_t)w_row_stride) & (type == MI355_TYPE_Q6_K ? 1 : 15)) return MI355_E_ALIGN;
     if (w_row_stride < mi355_row_size(type, k)) return MI355_E_SHAPE;
     if (m == 0 || n == 0) return MI355_OK;
     S2Args a = {};
     a.W = (const uint8_t *)W; a.w_row_stride = w_row_stride; a.aq = act_q; a.ad = act_d; a.bs = act_bsums;
-    a.dst = dst; a.dst_col_stride = dst_col_stride; a.m = (int)m; a.n = (int)n; a.k = (int)k;
+    a.dst = dst; a.dst_col_stride = dst_col_stride; a.m = (int)m; a.n = (int)n; a.k = (int)k; a.ct = n > 32 ? 2 : 1;
     hipStream_t s = (hipStream_t)stream;
     if (type == MI355_TYPE_Q6_K) return launch6(a, s, "mmsk6_q6_K");
     if (type == MI355_TYPE_Q4_K) return launch2<MI355_TYPE_Q4_K>(a, s, "mmsk2_q4_K");
@@ -926,11 +953,11 @@ extern "C" int mi355_mul_mat_skinny_k_group(int type, int n_mats, const void * c
     if (!W || !w_row_stride || !dst || !dst_col_stride || !m || !act_q || !act_d || !act_bsums) return MI355_E_NULL;
     if (type != MI355_TYPE_Q4_K && type != MI355_TYPE_Q5_K && type != MI355_TYPE_Q6_K) return mi355_blck_size(type) ? MI355_E_UNSUPPORTED : MI355_E_TYPE;
     if (n_mats < 1 || n_mats > 4) return MI355_E_SHAPE;
-    if (n < 0 || k <= 0 || k % 256 != 0 || k > 0x3ffffff) return MI355_E_SHAPE;
-    if (n > 32) return MI355_E_UNSUPPORTED;
+    if (n < 0 || k <= 0 || k % 256 != 0 || k > 0x1ffffff) return MI355_E_SHAPE;
+    if (n > 64) return MI355_E_UNSUPPORTED;
     if (((uintptr_t)act_q & 15) || ((uintptr_t)act_d & 3) || ((uintptr_t)act_bsums & 15)) return MI355_E_ALIGN;
     S2Args a = {};
-    a.aq = act_q; a.ad = act_d; a.bs = act_bsums; a.n = (int)n; a.k = (int)k;
+    a.aq = act_q; a.ad = act_d; a.bs = act_bsums; a.n = (int)n; a.k = (int)k; a.ct = n > 32 ? 2 : 1;
     int64_t tiles = 0;
     for (int i = 0; i < n_mats; i++) {
         if (!W[i] || !dst[i]) return MI355_E_NULL;
@@ -956,7 +983,19 @@ extern "C" int mi355_mul_mat_skinny_k_group(int type, int n_mats, const void * c
         if (sk_tpw(m[i], k) != tpw) return MI355_E_UNSUPPORTED;
         if ((m[i] + 31) / 32 < 256 && k >= sk_ky_min_k()) return MI355_E_UNSUPPORTED;
     }
-    if (tpw == 2) {      // four waves, two tiles (a workgroup's tiles may belong to two matrices: the lookup is per wave)
+    if (a.ct == 2) {     // 33..64 columns: column halves as tiles (see launch2)
+        if (tpw == 2) {
+            const unsigned g = (nb + 1) / 2;
+            if (type == MI355_TYPE_Q6_K)      MI355_LAUNCH("mmsk6_group_q6_K", (mmsk6_kernel<8, 4>), dim3(g, 1), dim3(512), 0, s, a);
+            else if (type == MI355_TYPE_Q4_K) MI355_LAUNCH("mmsk2_group_q4_K", (mmsk2_kernel<MI355_TYPE_Q4_K, 8, 4>), dim3(g, 1), dim3(512), 0, s, a);
+            else                              MI355_LAUNCH("mmsk2_group_q5_K", (mmsk2_kernel<MI355_TYPE_Q5_K, 8, 4>), dim3(g, 1), dim3(512), 0, s, a);
+        } else {
+            if (type == MI355_TYPE_Q6_K)      MI355_LAUNCH("mmsk6_group_q6_K", (mmsk6_kernel<8, 2>), dim3(nb, 1), dim3(512), 0, s, a);
+            else if (type == MI355_TYPE_Q4_K) MI355_LAUNCH("mmsk2_group_q4_K", (mmsk2_kernel<MI355_TYPE_Q4_K, 8, 2>), dim3(nb, 1), dim3(512), 0, s, a);
+            else                              MI355_LAUNCH("mmsk2_group_q5_K", (mmsk2_kernel<MI355_TYPE_Q5_K, 8, 2>), dim3(nb, 1), dim3(512), 0, s, a);
+        }
+    }
+    else if (tpw == 2) {      // four waves, two tiles (a workgroup's tiles may belong to two matrices: the lookup is per wave)
         const unsigned nb2 = (nb + 1) / 2;
         if (type == MI355_TYPE_Q6_K)      MI355_LAUNCH("mmsk6_group_q6_K", (mmsk6_kernel<4, 2>), dim3(nb2, 1), dim3(256), 0, s, a);
         else if (type == MI355_TYPE_Q4_K) MI355_LAUNCH("mmsk2_group_q4_K", (mmsk2_kernel<MI355_TYPE_Q4_K, 4, 2>), dim3(nb2, 1), dim3(256), 0, s, a);

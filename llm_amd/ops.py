@@ -408,20 +408,21 @@ def quantize_act_q8k(x):
     return q, d, bs
 
 
-def mul_mat_skinny_k(t, w, b, m):
-    """K-quant MUL_MAT on q8_K activations through the digit-split int8-MFMA kernel, passes of 32 columns."""
+def mul_mat_skinny_k(t, w, b, m, pass_cols=32):
+    """K-quant MUL_MAT on q8_K activations through the digit-split int8-MFMA kernel, passes of 32 (or 64: two column tiles per
+    workgroup) columns."""
     _u8(w)
     n, k = b.shape
     q, d, bs = quantize_act_q8k(b)
     dst = torch.empty((n, m), dtype=torch.float32, device=b.device)
-    for c0 in range(0, n, 32):
+    for c0 in range(0, n, pass_cols):
         K.check(K.lib.mi355_mul_mat_skinny_k(t, w.data_ptr(), B.row_size(t, k), q[c0:].data_ptr(), d[c0:].data_ptr(), bs[c0:].data_ptr(),
-                                             dst[c0:].data_ptr(), m, m, k, min(32, n - c0), _stream()), "mi355_mul_mat_skinny_k")
+                                             dst[c0:].data_ptr(), m, m, k, min(pass_cols, n - c0), _stream()), "mi355_mul_mat_skinny_k")
     return dst
 
 
 def mul_mat_skinny_k_group(t, ws, b, ms):
-    """Up to four K-quant matrices of type t against the same [n <= 32, k] activations in one launch -> list of [n, m_i]."""
+    """Up to four K-quant matrices of type t against the same [n <= 64, k] activations in one launch -> list of [n, m_i]."""
     import ctypes as C
     n, k = b.shape
     q, d, bs = quantize_act_q8k(b)

@@ -503,8 +503,28 @@ def test_skinny_k_digit_split_vs_q8k_contract(ops, t, m, k, n):
 
 
 @pytest.mark.parametrize("t", [B.Q4_K, B.Q5_K, B.Q6_K])
+@pytest.mark.parametrize("m,k,n", [(32, 256, 33), (130, 512, 64), (4096, 4096, 40), (257, 2048, 63), (14336, 4096, 48), (2816, 14336, 37), (96, 1024, 150)])
+def test_skinny_k_two_column_tiles_per_workgroup(ops, t, m, k, n):
+    """33..64 columns in one launch: the two column halves of a row tile are two tiles of one workgroup (the weights cross HBM once).
+    The integers are still those of ggml_vec_dot_q*_K_q8_K: NMSE <= 1e-10 against dequantize(W) . dequantize(q8_K(x)) in f64, and
+    <= 1e-12 against the same product done in passes of 32 (only the order of the f32 additions over K differs)."""
+    rng = np.random.default_rng(m + k + n)
+    w = B.random_blocks(t, m, k, seed=m + n)
+    x = rng.standard_normal((n, k)).astype(np.float32)
+    got = ops.mul_mat_skinny_k(t, dev(w), dev(x), m, pass_cols=64).cpu().numpy()
+    by32 = ops.mul_mat_skinny_k(t, dev(w), dev(x), m).cpu().numpy()
+    wf = np.stack([O.dequantize_row(t, w[i], k) for i in range(m)]).astype(np.float64)
+    q, d, _ = _q8k_planes(x)
+    xa = q.astype(np.float64).reshape(n, k // 256, 256) * d.astype(np.float64)[:, :, None]
+    ref = (xa.reshape(n, k) @ wf.T).astype(np.float32)
+    assert np.isfinite(got).all() and O.nmse(ref, got) <= 1e-10, O.nmse(ref, got)
+    assert O.nmse(by32, got) <= 1e-12
+
+
+@pytest.mark.parametrize("t", [B.Q4_K, B.Q5_K, B.Q6_K])
 @pytest.mark.parametrize("ms,k,n", [((64, 32), 1024, 8), ((4096, 1024, 1024), 4096, 16), ((130, 1, 33, 95), 512, 32), ((257,), 2048, 5), ((96, 32, 31), 1024, 1),
-                                    ((14336, 14336), 4096, 8), ((12320, 12288), 1024, 7)])      # two tiles per workgroup; an odd tile count
+                                    ((14336, 14336), 4096, 8), ((12320, 12288), 1024, 7),      # two tiles per workgroup; an odd tile count
+                                    ((4096, 1024, 1024), 4096, 40), ((14336, 14336), 4096, 64), ((130, 1, 33), 512, 33)])     # 33..64 columns
 def test_skinny_k_group_of_matrices_in_one_launch(ops, t, ms, k, n):
     """wq / wk / wv (or ffn_up / ffn_gate) of a small batch as one launch over all their row tiles: every matrix's result is the single
     call's BIT FOR BIT (a matrix is cut over the waves as a function of its own (m, k) in both), the q8_K contract (f64) holds for
@@ -518,7 +538,7 @@ def test_skinny_k_group_of_matrices_in_one_launch(ops, t, ms, k, n):
     xa = (q.astype(np.float64).reshape(n, k // 256, 256) * d.astype(np.float64)[:, :, None]).reshape(n, k)
     for w, m, o in zip(ws, ms, outs):
         got = o.cpu().numpy()
-        single = ops.mul_mat_skinny_k(t, dev(w), xd, m).cpu().numpy()
+        single = ops.mul_mat_skinny_k(t, dev(w), xd, m, pass_cols=64).cpu().numpy()
         assert np.array_equal(got.view(np.uint32), single.view(np.uint32))
         wf = np.stack([O.dequantize_row(t, w[i], k) for i in range(m)]).astype(np.float64)
         ref = (xa @ wf.T).astype(np.float32)
