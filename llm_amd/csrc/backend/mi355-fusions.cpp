@@ -899,7 +899,9 @@ static bool small_mm_ok(const ggml_tensor * t) {
     if (!(t->op == GGML_OP_MUL_MAT && t->type == GGML_TYPE_F32 && x->type == GGML_TYPE_F32 && w->ne[2] == 1 && w->ne[3] == 1 && !tensor_is_split(w) &&
           is_weight_type(w->type) && ggml_is_contiguous(t))) return false;
     const int path = mi355_mul_mat_path(w, x);
-    return path == MM_SKINNY_K || path == MM_SKINNY;
+    // (2..8 columns on the column-group mat-vec: a step of two or three tokens -- a short speculative draft -- has the same 7-node Q/K/V
+    // pattern and the same launches to save)
+    return path == MM_SKINNY_K || path == MM_SKINNY || (path == MM_VEC && x->ne[1] > 1 && x->ne[1] <= 8);
 }
 
 // wk / wv beside a wq that takes a skinny kernel: any quantized product will do (each lands in its plane through mi355_mul_mat, whatever
@@ -980,6 +982,31 @@ static bool mi355_try_fuse_qkv_small(mi355_backend_ctx * ctx, ggml_cgraph * cgra
                                                         (const int16_t *)(ws + L.b0 + L.b1), K, N, ctx->stream);
             if (rc == MI355_OK) for (int c = 0; c < cnt; c++) grouped[who[c]] = true;
             else if (rc != MI355_E_UNSUPPORTED && rc != MI355_E_ALIGN && rc != MI355_E_SHAPE) MI_CHECK(rc);
+        }
+    }
+    if (N <= 8 && x->ne[2] == 1 && x->ne[3] == 1 && mi355_mul_mat_path(mm[0]->src[0], x, mm[0]) == MM_VEC) {
+        // 2..8 columns: the mat-vecs of wq's type as one grouped launch (mi355_mul_mat_vec_q_group), results into the planes
+        mi355_mmvq_args a[3];
+        memset(a, 0, sizeof(a));
+        int cnt = 0, who[3];
+        const size_t qb = align_up((size_t)mi355_act_q_bytes(K, N), 256), db = align_up((size_t)mi355_act_ds_bytes(K, N), 256);
+        char * ws = (char *)ctx->get_scratch(0, qb + db);
+        for (int m = 0; m < 3; m++) {
+            const ggml_tensor * w = mm[m]->src[0];
+            if (w->type != mm[0]->src[0]->type || mi355_mul_mat_path(w, x, mm[m]) != MM_VEC) continue;
+            a[cnt].type = (int32_t)w->type; a[cnt].W = w->data; a[cnt].w_row_stride = (int64_t)w->nb[1];
+            a[cnt].act_q = (const int8_t *)ws; a[cnt].act_ds = (const float *)(ws + qb); a[cnt].act_ch_stride = N;
+            a[cnt].dst = (float *)(parts + off[m]); a[cnt].dst_col_stride = w->ne[1];
+            a[cnt].m = w->ne[1]; a[cnt].k = K; a[cnt].ncols = (int32_t)N; a[cnt].nchannels = 1; a[cnt].ch_ratio = 1;
+            who[cnt++] = m;
+        }
+        if (cnt >= 2) {
+            if (!ctx->act_cached(x)) {
+                MI_CHECK(mi355_quantize_act((const float *)x->data, (int8_t *)ws, (float *)(ws + qb), K, N, 1, 1, x->nb[1], x->nb[2], x->nb[3], ctx->stream));
+                ctx->act_remember(x);
+            }
+            MI_CHECK(mi355_mul_mat_vec_q_group(a, cnt, ctx->stream));
+            for (int c = 0; c < cnt; c++) grouped[who[c]] = true;
         }
     }
     for (int m = 0; m < 3; m++) {
