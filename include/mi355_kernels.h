@@ -309,6 +309,10 @@ MI355_API int mi355_decode_layer(const mi355_decode_layer_args *args, void *sync
  * columns or use the other kernels).  dst[c*dst_col_stride + r]. */
 MI355_API int mi355_mul_mat_skinny(int type, const void *W, int64_t w_row_stride, const int8_t *act_q, const float *act_ds,
                                    float *dst, int64_t dst_col_stride, int64_t m, int64_t k, int64_t n, void *stream);
+/* same for m rows of a matrix of m_total rows (row split): whether K is cut over two workgroups follows the whole matrix, so a slice
+ * gives the bits of the unsplit call (ggml-cuda.cu:1431-1749 runs its kernels on row slices likewise). */
+MI355_API int mi355_mul_mat_skinny_slice(int type, const void *W, int64_t w_row_stride, const int8_t *act_q, const float *act_ds,
+                                         float *dst, int64_t dst_col_stride, int64_t m, int64_t m_total, int64_t k, int64_t n, void *stream);
 
 /* q8_K activations, the per-256 quantization ggml-cpu pairs with the K-quants (quantize_row_q8_K_ref,
  * ggml-quants.c:2471-2508; bit-exact), as three planes: q int8 [rows][k], d f32 [rows][k/256], bsums int16 [rows][k/16].
@@ -325,6 +329,11 @@ MI355_API int mi355_quantize_act_q8k(const float *x, int8_t *q, float *d, int16_
 MI355_API int mi355_mul_mat_skinny_k(int type, const void *W, int64_t w_row_stride, const int8_t *act_q, const float *act_d,
                                      const int16_t *act_bsums, float *dst, int64_t dst_col_stride, int64_t m, int64_t k,
                                      int64_t n, void *stream);
+/* same for m rows of a matrix of m_total rows (row split, ggml-cuda.cu:1431-1749): the launch geometry that fixes the order of the f32
+ * additions over K follows the whole matrix, so a slice's results are the bits the unsplit call gives those rows. */
+MI355_API int mi355_mul_mat_skinny_k_slice(int type, const void *W, int64_t w_row_stride, const int8_t *act_q, const float *act_d,
+                                           const int16_t *act_bsums, float *dst, int64_t dst_col_stride, int64_t m, int64_t m_total,
+                                           int64_t k, int64_t n, void *stream);
 
 /* Up to four weight matrices of ONE K-quant type and one k against the SAME q8_K activations in one launch: the wq / wk / wv
  * products of a step of 5..64 tokens (llama-graph.cpp build_attn's three ggml_mul_mat on one input).  Each result is what

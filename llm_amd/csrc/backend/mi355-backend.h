@@ -113,8 +113,11 @@ struct mi355_backend_ctx {
     //       here, then [0] and [2] trade places      [3] partial tiles of a split-K prefill GEMM (mi355_mul_mat_dq_slice_ws)
     //   [4] a decode token's K and V rows in f32, between the fused Q/K/V launch and their quantization into a q8_0 cache
     //   [5] the sync blocks of a token's persistent decode-layer launches (mi355_decode_layer), cleared by one memset per graph
-    void * scratch[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};     // [6]: a row nobody reads (see mi355_try_fuse_glu_matvec)
-    size_t scratch_size[7] = {0, 0, 0, 0, 0, 0, 0};
+    // [0] activations of the current MUL_MAT, [1] attention workspace, [2] the other activation buffer (swap_act_scratch), [3] split-K workspace
+    // of the prefill GEMM / its Q-K-V planes, [4] f32 K / V rows on their way into a q8_0 cache, [5] decode-layer sync blocks, [6] a row nobody
+    // reads (mi355_try_fuse_glu_matvec), [7] the Q / K / V planes of a small batch (whose members may run a GEMM that uses [3])
+    void * scratch[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t scratch_size[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int dl_used = 0;                // decode-layer launches issued for the graph in flight (= sync blocks handed out)
     void swap_act_scratch() { std::swap(scratch[0], scratch[2]); std::swap(scratch_size[0], scratch_size[2]); }
 

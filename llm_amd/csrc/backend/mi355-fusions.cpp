@@ -930,8 +930,8 @@ static bool mi355_try_fuse_qkv_small(mi355_backend_ctx * ctx, ggml_cgraph * cgra
         if (ranges_overlap(outs[a]->data, ggml_nbytes(outs[a]), q.rq->src[1]->data, ggml_nbytes(q.rq->src[1]))) return false;
         if (ranges_overlap(outs[a]->data, ggml_nbytes(outs[a]), x->data, ggml_nbytes(x))) return false;
     }
-    char * parts = (char *)ctx->get_scratch(3, total);
-    if (ctx->scratch_size[3] < total) return false;
+    char * parts = (char *)ctx->get_scratch(7, total);      // not [3]: a member that takes the GEMM brings its split-K workspace from there
+    if (ctx->scratch_size[7] < total) return false;
     float * kv_tmp = nullptr;
     if (q.kv_q8) {
         const size_t need = (size_t)N * (Mk + Mv) * sizeof(float);

@@ -122,11 +122,11 @@ static void mi355_mul_mat_launch(const ggml_tensor * dst, const char * W, int64_
                         const int64_t r = arow + c0, nc = N - c0 < pass ? N - c0 : pass;
                         if (path == MM_SKINNY_K) {
                             const int16_t * bs = (const int16_t *)(act + L.b0 + L.b1);
-                            MI_CHECK(mi355_mul_mat_skinny_k((int)src0->type, Wc, (int64_t)src0->nb[1], aq + r * K, ads + r * (K / 256), bs + r * (K / 16),
-                                                            d + c0 * dcol, dcol, M, K, nc, stream));
+                            MI_CHECK(mi355_mul_mat_skinny_k_slice((int)src0->type, Wc, (int64_t)src0->nb[1], aq + r * K, ads + r * (K / 256), bs + r * (K / 16),
+                                                                  d + c0 * dcol, dcol, M, src0->ne[1], K, nc, stream));
                         } else {
-                            MI_CHECK(mi355_mul_mat_skinny((int)src0->type, Wc, (int64_t)src0->nb[1], aq + r * K, ads + r * (K / 32) * 2,
-                                                          d + c0 * dcol, dcol, M, K, nc, stream));
+                            MI_CHECK(mi355_mul_mat_skinny_slice((int)src0->type, Wc, (int64_t)src0->nb[1], aq + r * K, ads + r * (K / 32) * 2,
+                                                                d + c0 * dcol, dcol, M, src0->ne[1], K, nc, stream));
                         }
                     }
                 }

@@ -37,6 +37,7 @@ struct SArgs {
     float * dst; int64_t dst_col_stride;
     int m, n, k;
     IdsArgs ids;      // MUL_MAT_ID mode when ids.sorted != nullptr: blockIdx.y = pass of 32 gathered columns of one expert
+    int m_cut;        // rows of the whole matrix when the launch covers a row slice (0: m): decides whether K is cut over two workgroups
 };
 
 // per-wave LDS scale table: [8 blocks of the super-step][2 sub-groups (q6_K)][32 rows]
@@ -291,7 +292,7 @@ mmsk_kernel(const SArgs a) {
 template <int TYPE>
 static int launch(const SArgs & a, hipStream_t s, const char * tag) {
     const unsigned nb = (unsigned)((a.m + 31) / 32);
-    const unsigned ky = nb < 256 && a.k >= 2048 ? 2 : 1;      // few row tiles: split K over two workgroups
+    const unsigned ky = ((a.m_cut ? a.m_cut : a.m) + 31) / 32 < 256 && a.k >= 2048 ? 2 : 1;      // few row tiles (of the WHOLE matrix): split K over two workgroups
     if (ky > 1) {
         hipError_t e = a.dst_col_stride == a.m
             ? hipMemsetAsync(a.dst, 0, (size_t)a.n * a.m * sizeof(float), s)
@@ -336,6 +337,7 @@ struct S2Args {
     int m, n, k;
     IdsArgs ids;
     SkGroup grp;             // grp.n > 0: blockIdx.x runs over the 32-row tiles of several matrices (W, dst, m above are unused)
+    int m_cut;               // rows of the WHOLE matrix when this launch covers a row slice of it (0: a.m): what sk_tpw is asked with
     int ct;                  // column tiles of 32 per row tile (plain MUL_MAT, 33..64 columns: 2; else 1): tile index t -> (t / ct, column half t % ct)
 #ifdef SK_STAMPS
     long long * stamps;      // diagnostic build only (lab/mmsk_stamps.hip): [workgroup][wave][8] s_memtime / s_memrealtime
@@ -787,18 +789,19 @@ static int sk_ky_min_k() {
 // the launch's fixed costs are paid once, where two passes of 32 pay both twice; a tile's K is cut over half as many waves.
 static int launch6(const S2Args & a, hipStream_t s, const char * tag) {
     const unsigned nb = (unsigned)((a.m + 31) / 32);
+    const int64_t m_cut = a.m_cut ? a.m_cut : a.m;
     if (a.ct == 2) {
-        if (sk_tpw(a.m, a.k) == 2) MI355_LAUNCH(tag, (mmsk6_kernel<8, 4>), dim3((nb + 1) / 2, 1), dim3(512), 0, s, a);
+        if (sk_tpw(m_cut, a.k) == 2) MI355_LAUNCH(tag, (mmsk6_kernel<8, 4>), dim3((nb + 1) / 2, 1), dim3(512), 0, s, a);
         else                       MI355_LAUNCH(tag, (mmsk6_kernel<8, 2>), dim3(nb, 1), dim3(512), 0, s, a);
         MI355_CHECK_LAUNCH();
         return MI355_OK;
     }
-    if (sk_tpw(a.m, a.k) == 2) {
+    if (sk_tpw(m_cut, a.k) == 2) {
         MI355_LAUNCH(tag, (mmsk6_kernel<4, 2>), dim3((nb + 1) / 2, 1), dim3(256), 0, s, a);
         MI355_CHECK_LAUNCH();
         return MI355_OK;
     }
-    const unsigned ky = nb < 256 && a.k >= sk_ky_min_k() ? 2 : 1;
+    const unsigned ky = (m_cut + 31) / 32 < 256 && a.k >= sk_ky_min_k() ? 2 : 1;
     if (ky > 1) {
         hipError_t e = a.dst_col_stride == a.m
             ? hipMemsetAsync(a.dst, 0, (size_t)a.n * a.m * sizeof(float), s)
@@ -813,18 +816,19 @@ static int launch6(const S2Args & a, hipStream_t s, const char * tag) {
 template <int TYPE>
 static int launch2(const S2Args & a, hipStream_t s, const char * tag) {
     const unsigned nb = (unsigned)((a.m + 31) / 32);
+    const int64_t m_cut = a.m_cut ? a.m_cut : a.m;
     if (a.ct == 2) {
-        if (sk_tpw(a.m, a.k) == 2) MI355_LAUNCH(tag, (mmsk2_kernel<TYPE, 8, 4>), dim3((nb + 1) / 2, 1), dim3(512), 0, s, a);
+        if (sk_tpw(m_cut, a.k) == 2) MI355_LAUNCH(tag, (mmsk2_kernel<TYPE, 8, 4>), dim3((nb + 1) / 2, 1), dim3(512), 0, s, a);
         else                       MI355_LAUNCH(tag, (mmsk2_kernel<TYPE, 8, 2>), dim3(nb, 1), dim3(512), 0, s, a);
         MI355_CHECK_LAUNCH();
         return MI355_OK;
     }
-    if (sk_tpw(a.m, a.k) == 2) {
+    if (sk_tpw(m_cut, a.k) == 2) {
         MI355_LAUNCH(tag, (mmsk2_kernel<TYPE, 4, 2>), dim3((nb + 1) / 2, 1), dim3(256), 0, s, a);
         MI355_CHECK_LAUNCH();
         return MI355_OK;
     }
-    const unsigned ky = nb < 256 && a.k >= sk_ky_min_k() ? 2 : 1;
+    const unsigned ky = (m_cut + 31) / 32 < 256 && a.k >= sk_ky_min_k() ? 2 : 1;
     if (ky > 1) {
         hipError_t e = a.dst_col_stride == a.m
             ? hipMemsetAsync(a.dst, 0, (size_t)a.n * a.m * sizeof(float), s)
@@ -886,7 +890,13 @@ quant_q8k_kernel(const char * x, int8_t * q, float * dd, int16_t * bs, int k, in
 
 extern "C" int mi355_mul_mat_skinny(int type, const void * W, int64_t w_row_stride, const int8_t * act_q, const float * act_ds,
                                     float * dst, int64_t dst_col_stride, int64_t m, int64_t k, int64_t n, void * stream) {
+    return mi355_mul_mat_skinny_slice(type, W, w_row_stride, act_q, act_ds, dst, dst_col_stride, m, m, k, n, stream);
+}
+
+extern "C" int mi355_mul_mat_skinny_slice(int type, const void * W, int64_t w_row_stride, const int8_t * act_q, const float * act_ds,
+                                          float * dst, int64_t dst_col_stride, int64_t m, int64_t m_total, int64_t k, int64_t n, void * stream) {
     if (!W || !act_q || !act_ds || !dst) return MI355_E_NULL;
+    if (m_total < m || m_total > 0x7fffffff) return MI355_E_SHAPE;
     const int64_t bs = mi355_blck_size(type);
     if (bs == 0 || type == MI355_TYPE_F32 || type == MI355_TYPE_F16 || type == MI355_TYPE_Q8_1) return MI355_E_TYPE;
     if (m < 0 || n < 0 || k <= 0 || k % bs != 0 || m > 0x7fffffff || k > 0x7fffffff || dst_col_stride < m) return MI355_E_SHAPE;
@@ -898,7 +908,7 @@ extern "C" int mi355_mul_mat_skinny(int type, const void * W, int64_t w_row_stri
     if (m == 0 || n == 0) return MI355_OK;
     SArgs a = {};
     a.W = (const uint8_t *)W; a.w_row_stride = w_row_stride; a.aq = act_q; a.ads = act_ds;
-    a.dst = dst; a.dst_col_stride = dst_col_stride; a.m = (int)m; a.n = (int)n; a.k = (int)k;
+    a.dst = dst; a.dst_col_stride = dst_col_stride; a.m = (int)m; a.n = (int)n; a.k = (int)k; a.m_cut = (int)m_total;
     hipStream_t s = (hipStream_t)stream;
     switch (type) {
         case MI355_TYPE_Q4_0: return launch<MI355_TYPE_Q4_0>(a, s, "mmsk_q4_0");
@@ -929,7 +939,16 @@ extern "C" int mi355_quantize_act_q8k(const float * x, int8_t * q, float * d, in
 extern "C" int mi355_mul_mat_skinny_k(int type, const void * W, int64_t w_row_stride, const int8_t * act_q, const float * act_d,
                                       const int16_t * act_bsums, float * dst, int64_t dst_col_stride, int64_t m, int64_t k, int64_t n,
                                       void * stream) {
+    return mi355_mul_mat_skinny_k_slice(type, W, w_row_stride, act_q, act_d, act_bsums, dst, dst_col_stride, m, m, k, n, stream);
+}
+
+// m rows of a matrix of m_total rows (a row-split slice): how a tile's K is cut over waves and workgroups follows the WHOLE matrix, so
+// the slice's results are the bits the unsplit launch gives those rows
+extern "C" int mi355_mul_mat_skinny_k_slice(int type, const void * W, int64_t w_row_stride, const int8_t * act_q, const float * act_d,
+                                            const int16_t * act_bsums, float * dst, int64_t dst_col_stride, int64_t m, int64_t m_total, int64_t k,
+                                            int64_t n, void * stream) {
     if (!W || !act_q || !act_d || !act_bsums || !dst) return MI355_E_NULL;
+    if (m_total < m || m_total > 0x7fffffff) return MI355_E_SHAPE;
     if (type != MI355_TYPE_Q4_K && type != MI355_TYPE_Q5_K && type != MI355_TYPE_Q6_K) return mi355_blck_size(type) ? MI355_E_UNSUPPORTED : MI355_E_TYPE;
     if (m < 0 || n < 0 || k <= 0 || k % 256 != 0 || m > 0x7fffffff || k > 0x7fffffff || dst_col_stride < m) return MI355_E_SHAPE;
     if (n > 64) return MI355_E_UNSUPPORTED;
@@ -940,7 +959,7 @@ extern "C" int mi355_mul_mat_skinny_k(int type, const void * W, int64_t w_row_st
     if (m == 0 || n == 0) return MI355_OK;
     S2Args a = {};
     a.W = (const uint8_t *)W; a.w_row_stride = w_row_stride; a.aq = act_q; a.ad = act_d; a.bs = act_bsums;
-    a.dst = dst; a.dst_col_stride = dst_col_stride; a.m = (int)m; a.n = (int)n; a.k = (int)k; a.ct = n > 32 ? 2 : 1;
+    a.dst = dst; a.dst_col_stride = dst_col_stride; a.m = (int)m; a.n = (int)n; a.k = (int)k; a.ct = n > 32 ? 2 : 1; a.m_cut = (int)m_total;
     hipStream_t s = (hipStream_t)stream;
     if (type == MI355_TYPE_Q6_K) return launch6(a, s, "mmsk6_q6_K");
     if (type == MI355_TYPE_Q4_K) return launch2<MI355_TYPE_Q4_K>(a, s, "mmsk2_q4_K");

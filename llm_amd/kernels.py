@@ -25,7 +25,7 @@ EXPORTS = [
     "mi355_timing_enable", "mi355_timing_reset", "mi355_timing_read", "mi355_timing_report",
     "mi355_binary_f32", "mi355_rms_norm_f32", "mi355_rms_norm_mul_f32", "mi355_rms_norm_mul_quant_f32", "mi355_glu_quant_f32", "mi355_rms_norm_mul_bf16_f32", "mi355_glu_bf16_f32", "mi355_prefetch", "mi355_parts_add_rms_norm_mul_bf16_f32", "mi355_rms_norm_mul_q8k_f32", "mi355_glu_q8k_f32", "mi355_add_rms_norm_mul_f32", "mi355_mul_mat_vec_q_group", "mi355_qkv_rope_matvec", "mi355_glu_matvec", "mi355_moe_down_matvec", "mi355_rope_f32", "mi355_glu_f32", "mi355_cpy", "mi355_get_rows", "mi355_set_rows", "mi355_mul_mat_f",
     "mi355_scale_f32", "mi355_soft_max_f32", "mi355_flash_attn_ext_workspace_bytes", "mi355_flash_attn_ext", "mi355_flash_attn_ext_quant", "mi355_flash_attn_ext_bf16", "mi355_flash_attn_ext_noalloc_max_bytes", "mi355_flash_attn_ext_noalloc",
-    "mi355_dequantize_row", "mi355_mul_mat_vec_q", "mi355_mul_mat_q", "mi355_mul_mat_skinny", "mi355_quantize_act_q8k", "mi355_mul_mat_skinny_k", "mi355_mul_mat_skinny_k_group", "mi355_mul_mat_qk", "mi355_mul_mat_id_skinny_workspace_bytes", "mi355_mul_mat_id_skinny", "mi355_mul_mat_id_skinny_pair", "mi355_argsort_f32", "mi355_moe_router_f32", "mi355_sum_rows_f32", "mi355_mul_mat_f32", "mi355_mul_mat_dq", "mi355_mul_mat_dq_slice", "mi355_kv_store_q8_0", "mi355_mul_mat_dq_slice_ws", "mi355_glu_mul_mat_dq", "mi355_mul_mat_dq_parts_bytes", "mi355_mul_mat_dq_parts", "mi355_mul_mat_dq_parts_pair", "mi355_qkv_finish", "mi355_mul_mat_dq_workspace_bytes", "mi355_act_bf16", "mi355_mul_mat_id_dq_workspace_bytes", "mi355_mul_mat_id_dq", "mi355_mul_mat_workspace_bytes", "mi355_mul_mat",
+    "mi355_dequantize_row", "mi355_mul_mat_vec_q", "mi355_mul_mat_q", "mi355_mul_mat_skinny", "mi355_mul_mat_skinny_slice", "mi355_quantize_act_q8k", "mi355_mul_mat_skinny_k", "mi355_mul_mat_skinny_k_slice", "mi355_mul_mat_skinny_k_group", "mi355_mul_mat_qk", "mi355_mul_mat_id_skinny_workspace_bytes", "mi355_mul_mat_id_skinny", "mi355_mul_mat_id_skinny_pair", "mi355_argsort_f32", "mi355_moe_router_f32", "mi355_sum_rows_f32", "mi355_mul_mat_f32", "mi355_mul_mat_dq", "mi355_mul_mat_dq_slice", "mi355_kv_store_q8_0", "mi355_mul_mat_dq_slice_ws", "mi355_glu_mul_mat_dq", "mi355_mul_mat_dq_parts_bytes", "mi355_mul_mat_dq_parts", "mi355_mul_mat_dq_parts_pair", "mi355_qkv_finish", "mi355_mul_mat_dq_workspace_bytes", "mi355_act_bf16", "mi355_mul_mat_id_dq_workspace_bytes", "mi355_mul_mat_id_dq", "mi355_mul_mat_workspace_bytes", "mi355_mul_mat",
     "mi355_decode_layer_sync_bytes", "mi355_decode_layer", "mi355_stream_read",
 ]
 
@@ -213,6 +213,7 @@ lib.mi355_mul_mat_vec_q_group.argtypes = [C.POINTER(MmvqArgs), C.c_int, _vp]
 lib.mi355_mul_mat_skinny.argtypes = [C.c_int, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp]
 lib.mi355_quantize_act_q8k.argtypes = [_vp, _vp, _vp, _vp] + [_i64] * 7 + [_vp]
 lib.mi355_mul_mat_skinny_k.argtypes = [C.c_int, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp]
+lib.mi355_mul_mat_skinny_k_slice.argtypes = [C.c_int, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp]
 lib.mi355_mul_mat_skinny_k_group.argtypes = [C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp]
 lib.mi355_mul_mat_qk.argtypes = [C.c_int, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp]
 lib.mi355_mul_mat_q.argtypes = [C.c_int, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp]

@@ -176,7 +176,9 @@ def test_llama_logits_match_ggml_cpu(ftype, ctk, tmp_path):
     assert d <= 2.0 * e_cpu + 2e-4, (d, e_cpu)        # two roundings of the same exact values
 
 
-@pytest.mark.parametrize("model", ["tiny", "tinymoe", "mid", "wideffn"])      # mid: 2048 wide, 4 KV heads of 128, ffn 5120; wideffn: Llama-8B's 14336
+# mid: 2048 wide, 4 KV heads of 128, ffn 5120; wideffn: Llama-8B's 14336; 70b2: two layers of Llama-3-70B's shapes (K = 8192: norm in
+# the grouped gate / up launch, 28672 rows: no one-launch GLU form, q5_K wv)
+@pytest.mark.parametrize("model", ["tiny", "tinymoe", "mid", "wideffn", "70b2"])
 def test_fusions_are_bit_exact(tmp_path, model, kv="f16", extra_env=None):
     """The backend's graph-level fusions (RMS_NORM*weight, fused q8_1 quantization, activation cache, Q/K/V + rope + store,
     and for the 8-expert model the one-launch MoE router) keep the f32 op order of the unfused graph: logits with and
@@ -390,6 +392,23 @@ def test_row_split_decode_fused_forms_and_graph_replay_are_bit_exact(tmp_path):
             assert replays == 0, r.stderr[-2000:]
     for name in ("split", "split_streams", "split_unfused"):
         assert outs[name].size == outs["unsplit"].size and np.array_equal(outs[name], outs["unsplit"]), name
+
+
+@pytest.mark.parametrize("ndev,ts", [(2, "1,1"), (8, "1,1,1,1,1,1,1,1")])
+def test_row_split_decode_70b_shapes_bit_exact(tmp_path, ndev, ts):
+    """Llama-3-70B's shapes (two layers of them) row-split over 2 and 8 virtual devices -- 8 KV heads over 8 devices is one head per
+    device, the finest cut the fused Q/K/V form takes -- against the unsplit logits: equal to the bit, and the split tokens replayed."""
+    import numpy as np
+    tool = os.path.join(ROOT, "tools", "run_llama_bench.sh")
+    ref_path, path = str(tmp_path / "ref.bin"), str(tmp_path / "split.bin")
+    r = subprocess.run([tool, "70b2", "Q4_K_M", "--dump-logits", ref_path, "--decode-steps", "24"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    env = dict(os.environ, GGML_MI355_VIRTUAL_DEVICES=str(ndev), GGML_MI355_GRAPH_STATS="1")
+    r = subprocess.run([tool, "70b2", "Q4_K_M", "--dump-logits", path, "--decode-steps", "24", "-sm", "row", "-ts", ts], capture_output=True, text=True,
+                       timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert np.array_equal(np.fromfile(ref_path, dtype=np.uint32), np.fromfile(path, dtype=np.uint32))
+    assert sum(int(x) for x in re.findall(r"decode graphs: (\d+) replays", r.stderr)) >= 20, r.stderr[-2000:]
 
 
 @pytest.mark.parametrize("ndev,ts", [(3, "2,1,1"), (8, "1,1,1,1,1,1,1,1"), (4, "0,1,1,2"), (2, "3,1")])

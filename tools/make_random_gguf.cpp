@@ -93,6 +93,7 @@ int main(int argc, char ** argv) {
     Dims d;
     if (model == "8b")        d = {4096, 32, 32, 8, 14336, 128256, false};
     else if (model == "70b")  d = {8192, 80, 64, 8, 28672, 128256, true};
+    else if (model == "70b2") d = {8192, 2, 64, 8, 28672, 32000, true};       // two layers of Llama-3-70B's shapes (K = 8192, 28672-row ffn, GQA 8, the 70B type rules): the matchers' other size class
     else if (model == "tiny") d = {1024, 4, 8, 2, 2816, 32000, false};
     else if (model == "mid")  d = {2048, 3, 16, 4, 5120, 32000, false};      // the smallest shapes the persistent decode-layer launch takes (multiples of 1024, >= 2048)
     else if (model == "wideffn") d = {1024, 2, 8, 2, 14336, 32000, false};   // Llama-8B's feed-forward width on a small trunk: a 512-token batch reaches the fused gate / up / GLU GEMM

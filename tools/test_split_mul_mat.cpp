@@ -167,6 +167,13 @@ int main() {
             ran += run_case(reg, split_buft, last, ramp, t, 1536, 512, 7, 2);     // broadcast over ne2
             want += 7;
         }
+        // the skinny kernels choose their launch geometry (waves per tile, K over two workgroups) by the row count: it must be the WHOLE
+        // matrix's, or a slice's f32 sums over K are added in another order than the unsplit matrix's
+        ran += run_case(reg, split_buft, 0, all, GGML_TYPE_Q4_K, 28672, 4096, 16, 1);   // >= 384 tiles whole, < 384 per slice (two waves per tile)
+        ran += run_case(reg, split_buft, 0, all, GGML_TYPE_Q6_K, 28672, 4096, 48, 1);   // ... with two column tiles per workgroup
+        ran += run_case(reg, split_buft, last, all, GGML_TYPE_Q4_K, 16384, 8448, 16, 1); // >= 256 tiles whole (K uncut), < 256 per slice
+        ran += run_case(reg, split_buft, 0, all, GGML_TYPE_Q8_0, 16384, 2048, 16, 1);   // the same for the q8_1 kernel
+        want += 4;
         ran += run_case(reg, split_buft, 0, all, GGML_TYPE_Q4_K, 8192, 8192, 1, 1);    // 70B wq at full size
         ran += run_case(reg, split_buft, 0, all, GGML_TYPE_Q6_K, 1024, 8192, 1, 1);    // 70B wv (use_more_bits layers)
         ran += run_case(reg, split_buft, 0, all, GGML_TYPE_Q4_K, 8192, 8192, 512, 1);  // ... prefill
