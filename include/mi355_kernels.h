@@ -626,7 +626,9 @@ MI355_API int mi355_soft_max_f32(const mi355_tensor *x, const mi355_tensor *mask
 
 /* ---------------------------------------------------------------------------------------------
  * FLASH_ATTN_EXT (ggml.h:2012-2033): dst = softmax(scale * Q K^T [softcap] + slope * mask) V with
- * f16, bf16, q8_0 or q4_0 K/V (K and V of the same type), head size d in {64, 128, 256} (dk == dv).
+ * f16, bf16, q8_0 or q4_0 K/V (K and V of the same type), head size d any multiple of 8 up to 256 (V's may be smaller, see dv; whole 32-blocks
+ * for q8_0 / q4_0 rows, else MI355_E_SHAPE) -- the reference's kernels cover 40, 64, 72, 80, 96, 112, 128 and 256 of these.  The
+ * kernels are built for 64 / 96 / 128 / 256 features per row; another size runs on the next one up with zeros past the row.
  * Replaces ggml_cuda_flash_attn_ext (ggml/src/ggml-cuda/fattn.cu:271-346); oracle
  * ggml_compute_forward_flash_attn_ext_f16 (ggml/src/ggml-cpu/ops.cpp:7975-8192).
  *   q    f32 [d, n_q, n_head, ne3]      byte strides q_nb1..3 (rows contiguous, 16-byte aligned)
@@ -646,18 +648,19 @@ typedef struct mi355_fattn_args {
     float       *dst;  int64_t d_nb1, d_nb2, d_nb3;
     int64_t d, n_q, n_kv, n_head, n_head_kv, ne3;
     float scale, max_bias, logit_softcap;
+    int64_t dv;          /* V's (and dst's) head size where it differs from K's (DeepSeek: d 192, dv 128); 0 = d.  dv <= d. */
 } mi355_fattn_args;
 
 MI355_API int64_t mi355_flash_attn_ext_workspace_bytes(const mi355_fattn_args *args);
 MI355_API int     mi355_flash_attn_ext(const mi355_fattn_args *args, void *workspace, int64_t workspace_bytes, void *stream);
 /* same, and additionally the q8_1 form of dst in the internal activation layout (row = token, k = n_head * d), so
- * the attention-output MUL_MAT needs no quantization launch.  Decode-sized batches only (n_q < 32), else
- * MI355_E_UNSUPPORTED.  act_q / act_ds as in mi355_quantize_act. */
+ * the attention-output MUL_MAT needs no quantization launch.  Decode-sized batches only (n_q < 32) and d % 32 == 0 (a 32-block
+ * of the row lies inside one head), else MI355_E_UNSUPPORTED.  act_q / act_ds as in mi355_quantize_act. */
 MI355_API int     mi355_flash_attn_ext_quant(const mi355_fattn_args *args, void *workspace, int64_t workspace_bytes,
                                              int8_t *act_q, float *act_ds, void *stream);
 /* same for prefill-sized batches: additionally the bf16 form of dst (rows [ne3][n_q][n_head * d], the rounding of mi355_act_bf16),
- * so the attention-output GEMM needs no conversion launch.  Only where the matrix-core kernel runs (n_q >= 32, d 64 / 128, K and V
- * of one type, no ALiBi / softcap), else MI355_E_UNSUPPORTED. */
+ * so the attention-output GEMM needs no conversion launch.  Only where the matrix-core kernel runs (n_q >= 32, K and V
+ * of one type), else MI355_E_UNSUPPORTED. */
 MI355_API int     mi355_flash_attn_ext_bf16(const mi355_fattn_args *args, void *workspace, int64_t workspace_bytes,
                                             uint16_t *act_bf16, void *stream);
 

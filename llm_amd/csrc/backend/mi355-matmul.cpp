@@ -470,7 +470,7 @@ static void fattn_args_from(const ggml_tensor * dst, mi355_fattn_args * a) {
     a->v = v->data; a->type_v = (int32_t)v->type; a->v_nb1 = v->nb[1]; a->v_nb2 = v->nb[2]; a->v_nb3 = v->nb[3];
     if (mask) { a->mask = mask->data; a->m_nb1 = mask->nb[1]; a->m_nb2 = mask->nb[2]; a->m_nb3 = mask->nb[3]; a->m_ne2 = mask->ne[2]; a->m_ne3 = mask->ne[3]; }
     a->dst = (float *)dst->data; a->d_nb1 = dst->nb[1]; a->d_nb2 = dst->nb[2]; a->d_nb3 = dst->nb[3];
-    a->d = q->ne[0]; a->n_q = q->ne[1]; a->n_head = q->ne[2]; a->ne3 = q->ne[3]; a->n_kv = k->ne[1]; a->n_head_kv = k->ne[2];
+    a->d = q->ne[0]; a->dv = v->ne[0]; a->n_q = q->ne[1]; a->n_head = q->ne[2]; a->ne3 = q->ne[3]; a->n_kv = k->ne[1]; a->n_head_kv = k->ne[2];
     memcpy(&a->scale, (const float *)dst->op_params + 0, 4);
     memcpy(&a->max_bias, (const float *)dst->op_params + 1, 4);
     memcpy(&a->logit_softcap, (const float *)dst->op_params + 2, 4);
@@ -481,7 +481,10 @@ bool mi355_flash_attn_supported(const ggml_tensor * op) {
     if (q->type != GGML_TYPE_F32 || op->type != GGML_TYPE_F32) return false;
     if (k->type != v->type || (k->type != GGML_TYPE_F16 && k->type != GGML_TYPE_BF16 && k->type != GGML_TYPE_Q8_0 && k->type != GGML_TYPE_Q4_0)) return false;
     const int64_t d = q->ne[0];
-    if ((d != 64 && d != 128 && d != 256) || k->ne[0] != d || v->ne[0] != d) return false;
+    // head sizes: multiples of 8 up to 256, V's at most K's (DeepSeek's 192 / 128; not the 576 / 512 of its MLA form); quantized K/V rows are
+    // whole 32-blocks by construction
+    const int64_t dv = v->ne[0];
+    if (d < 8 || d > 256 || d % 8 != 0 || k->ne[0] != d || dv < 8 || dv > d || dv % 8 != 0) return false;
     if (k->ne[3] != q->ne[3] || v->ne[3] != q->ne[3] || k->ne[2] != v->ne[2] || q->ne[2] % k->ne[2] != 0) return false;
     if (q->nb[0] != sizeof(float) || k->nb[0] != ggml_type_size(k->type) || v->nb[0] != ggml_type_size(v->type)) return false;
     if ((q->nb[1] | q->nb[2] | q->nb[3]) & 15) return false;
@@ -505,7 +508,7 @@ static void mi355_flash_attn(mi355_backend_ctx * ctx, ggml_tensor * dst) {
     }
     // decode: the result (all heads of a token = one activation row) feeds the attention-output MUL_MAT; emit its
     // q8_1 form from the same kernel
-    const int64_t K = a.d * a.n_head, rows = a.n_q * a.ne3;
+    const int64_t K = a.dv * a.n_head, rows = a.n_q * a.ne3;
     if (rows <= 8 && ggml_is_contiguous(dst) && !MI355_ENV_SET("GGML_MI355_NO_FUSE")) {
         const size_t qb = align_up((size_t)mi355_act_q_bytes(K, rows), 256), db = align_up((size_t)mi355_act_ds_bytes(K, rows), 256);
         char * act = (char *)ctx->get_scratch(0, qb + db);

@@ -26,6 +26,9 @@ struct FArgs {
     const char * mask; int64_t m_nb1, m_nb2, m_nb3, m_ne2, m_ne3;
     char * dst; int64_t d_nb1, d_nb2, d_nb3;
     int n_q, n_kv, n_head, n_head_kv, ne3;
+    int dv;  // V's head size (<= the kernels' D like d; DeepSeek's 192 / 128)
+    int d;   // head size.  The kernels' D is the next size they are built for (vec: 64 / 128 / 256, matrix cores: a multiple of 32);
+             // lanes and tile columns past d hold zeros and store nothing
     float scale, max_bias, logit_softcap, m0, m1;
     uint32_t n_head_log2;
     int nsplit;
@@ -173,7 +176,7 @@ static __device__ __forceinline__ void fattn_store(const FArgs & a, int h, int i
         int sum = q;
 #pragma unroll
         for (int s = 1; s < 32; s <<= 1) sum += __shfl_xor(sum, s, 64);
-        const int64_t row = (int64_t)i3 * a.n_q + iq, kk = (int64_t)a.n_head * D, e = (int64_t)h * D + d;
+        const int64_t row = (int64_t)i3 * a.n_q + iq, kk = (int64_t)a.n_head * a.dv, e = (int64_t)h * a.dv + d;
         a.act_q[row * kk + e] = (int8_t)q;
         if ((d & 31) == 0) { v2f ds; ds.x = __half2float(__float2half_rn(dd)); ds.y = (float)sum; *(v2f *)(a.act_ds + (row * (kk / 32) + e / 32) * 2) = ds; }
     }
@@ -199,6 +202,8 @@ fattn_vec_kernel(const FArgs a) {
 #endif
     FA_STAMP(0);
     const int j = tid % LPR, g = tid / LPR;
+    const bool live = j * 8 < a.d;                // (head sizes 40 / 72 / 80 / 96 / 112: the lanes past the row work on zeros)
+    const int jl = live ? j : 0, jv = j * 8 < a.dv ? j : 0;
     const int ratio = a.n_head / a.n_head_kv;
     const int hgroups = (ratio + R - 1) / R;      // workgroups per kv head
     const int hk = blockIdx.x / hgroups;          // kv head
@@ -232,8 +237,8 @@ fattn_vec_kernel(const FArgs a) {
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const int iu = at + u * G < kv1 ? at + u * G : (at < kv1 ? at : kv1 - 1);     // past the end: re-read a valid row, ignored below
-            kd[u].load(kbase + (int64_t)iu * a.k_nb1, j);
-            vd[u].load(vbase + (int64_t)iu * a.v_nb1, j);
+            kd[u].load(kbase + (int64_t)iu * a.k_nb1, jl);
+            vd[u].load(vbase + (int64_t)iu * a.v_nb1, jv);
 #pragma unroll
             for (int r = 0; r < R; r++) md[r][u] = mrow[r] ? ((const __half *)mrow[r])[iu] : __half(0.0f);
         }
@@ -248,8 +253,9 @@ fattn_vec_kernel(const FArgs a) {
 #pragma unroll
     for (int r = 0; r < R; r++) {
         const int h = h0 + r < hk * ratio + ratio ? h0 + r : hk * ratio + ratio - 1; // clamp (ratio % R != 0)
-        const float * qp = (const float *)(a.q + iq * a.q_nb1 + h * a.q_nb2 + i3 * a.q_nb3) + j * 8;
-        const v4f q0 = *(const v4f *)qp, q1 = *(const v4f *)(qp + 4);
+        const float * qp = (const float *)(a.q + iq * a.q_nb1 + h * a.q_nb2 + i3 * a.q_nb3) + jl * 8;
+        v4f q0 = *(const v4f *)qp, q1 = *(const v4f *)(qp + 4);
+        if (!live) { q0 = v4f{0.0f, 0.0f, 0.0f, 0.0f}; q1 = q0; }     // a zero query: whatever K row bytes the lane re-read add nothing
         qf[r].set(q0, q1);
         slope[r] = alibi_slope(a, (uint32_t)h);
     }
@@ -353,7 +359,7 @@ fattn_vec_kernel(const FArgs a) {
     for (int idx = tid; idx < R * D; idx += FA_THREADS) {
         const int r = idx / D, d = idx % D;
         const int h = h0 + r;
-        if (h >= hk * ratio + ratio) continue;
+        if (h >= hk * ratio + ratio || d >= a.dv) continue;
         const float * base = sm + (size_t)r * G * (D + 2) + d;
         const float * wr = wsm + r * G;
         float O = 0.0f;
@@ -399,7 +405,7 @@ fattn_vec_kernel(const FArgs a) {
     for (int idx = tid; idx < R * D; idx += FA_THREADS) {
         const int r = idx / D, d = idx % D;
         const int h = h0 + r;
-        if (h >= hk * ratio + ratio) continue;
+        if (h >= hk * ratio + ratio || d >= a.dv) continue;
         const float * p = a.part + (((size_t)i3 * a.n_q + iq) * a.n_head + h) * a.nsplit * (D + 2);
         // eight slices at a time with all their loads issued before the first use: the partials sit in L2 / HBM and
         // a load-use-load chain over the slices would cost one memory round trip per slice
@@ -431,7 +437,7 @@ fattn_vec_kernel(const FArgs a) {
 
 // ------------------------------------------------------------------------------------------------
 // Prefill: tile kernel on the f16 matrix cores (v_mfma_f32_32x32x16_f16); f16 K/V, or q8_0 / q4_0 K/V dequantized
-// to f16 while a block is staged; no ALiBi / softcap.
+// to f16 while a block is staged; ALiBi slopes and the logit softcap as the vec kernel has them.
 //   workgroup = 256 threads = 4 waves; a wave owns 32 query rows of one head and the 4 waves take up to 4 heads of one KV
 //   head (or further 32-query blocks), so the KV blocks of 64 rows the workgroup walks are staged in LDS once for all of
 //   them; K and V both row-major (coalesced 16-byte loads, 16-byte LDS stores).
@@ -502,12 +508,12 @@ template <> struct MmaChunk<MI355_TYPE_Q4_0> {
 // blocks = 512 -- a unit is shared by TWO waves that take alternate 64-row KV blocks (a workgroup stages 128 rows per step for 2 units x
 // 2 halves) and merge their (m, l, O) through LDS at the end: twice the workgroups, half the chain of KV steps per wave.
 template <int D, int TKV, bool SPLIT = false>
-__global__ void __launch_bounds__(MMA_THREADS, SPLIT ? 1 : 2)
+__global__ void __launch_bounds__(MMA_THREADS, SPLIT || D > 128 ? 1 : 2)
 fattn_mma_kernel(const FArgs a) {
     constexpr int BKV = SPLIT ? 2 * MMA_BKV : MMA_BKV;      // KV rows staged per step
     constexpr int UNITS = SPLIT ? MMA_WAVES / 2 : MMA_WAVES;
     constexpr int KP = D * 2 + 16;          // K tile row pitch (bytes)
-    constexpr int VP = D * 2 + 64;          // V tile row pitch (bytes): 4 consecutive rows land on 4 disjoint groups of 16 banks, so
+    constexpr int VP = D * 2 + ((D / 32) % 2 == 1 ? 0 : 64);   // V tile row pitch (bytes), 16 or 48 dwords mod 64: 4 consecutive rows land on 4 disjoint groups of 16 banks, so
                                             // the transposed reads below (4 rows x 64 B per 32-lane half) are conflict-free
     constexpr int DT = D / 32, KS = D / 16;
     __shared__ __attribute__((aligned(16))) uint8_t Ks[BKV * KP];
@@ -582,8 +588,8 @@ fattn_mma_kernel(const FArgs a) {
             const int c = tid + MMA_THREADS * i;
             const int row = c / (D / 8), cc = c % (D / 8);
             const int kv = kv0 + row < a.n_kv ? kv0 + row : a.n_kv - 1;
-            kreg[i].load(kbase + (int64_t)kv * a.k_nb1, cc);
-            vreg[i].load(vbase + (int64_t)kv * a.v_nb1, cc);
+            if (cc * 8 < a.d)  kreg[i].load(kbase + (int64_t)kv * a.k_nb1, cc);
+            if (cc * 8 < a.dv) vreg[i].load(vbase + (int64_t)kv * a.v_nb1, cc);
         }
     };
     auto commit = [&]() {
@@ -591,8 +597,9 @@ fattn_mma_kernel(const FArgs a) {
         for (int i = 0; i < CH; i++) {
             const int c = tid + MMA_THREADS * i;
             const int row = c / (D / 8), cc = c % (D / 8);
-            *(v4i *)(Ks + row * KP + cc * 16) = kreg[i].f16();
-            *(v4i *)(Vs + row * VP + cc * 16) = vreg[i].f16();
+            // tile columns past the head size: zeros
+            *(v4i *)(Ks + row * KP + cc * 16) = cc * 8 < a.d  ? kreg[i].f16() : v4i{0, 0, 0, 0};
+            *(v4i *)(Vs + row * VP + cc * 16) = cc * 8 < a.dv ? vreg[i].f16() : v4i{0, 0, 0, 0};
         }
     };
     // A block that is masked out for every query of the workgroup (the upper triangle of causal prefill: almost half of all
@@ -610,13 +617,17 @@ fattn_mma_kernel(const FArgs a) {
     // (the scores live in the log2 domain: Q carries scale * log2(e), the mask is multiplied by log2(e) when it is added, and
     // the exponentials are bare v_exp_f32)
     constexpr float LOG2E = 1.4426950408889634f;
-    const float qs = a.scale * LOG2E;
+    // logit softcap (Gemma-2): Q carries scale / softcap instead, and the scores go through softcap * tanh before the mask is added
+    const bool capped = a.logit_softcap != 0.0f;
+    const float qs = capped ? a.scale / a.logit_softcap : a.scale * LOG2E;
+    const float mslope = alibi_slope(a, (uint32_t)h) * LOG2E;       // ALiBi: the mask is the position bias, scaled per head (1 without max_bias)
     half8 qf[KS];
     {
         const float * qp = (const float *)(a.q + (int64_t)qc * a.q_nb1 + (int64_t)h * a.q_nb2 + (int64_t)i3 * a.q_nb3);
 #pragma unroll
         for (int ks = 0; ks < KS; ks++) {
-            const v4f x0 = *(const v4f *)(qp + 16 * ks + 8 * lh), x1 = *(const v4f *)(qp + 16 * ks + 8 * lh + 4);
+            v4f x0 = {0.0f, 0.0f, 0.0f, 0.0f}, x1 = x0;
+            if (16 * ks + 8 * lh < a.d) { x0 = *(const v4f *)(qp + 16 * ks + 8 * lh); x1 = *(const v4f *)(qp + 16 * ks + 8 * lh + 4); }
             qf[ks][0] = (_Float16)(x0.x * qs); qf[ks][1] = (_Float16)(x0.y * qs);
             qf[ks][2] = (_Float16)(x0.z * qs); qf[ks][3] = (_Float16)(x0.w * qs);
             qf[ks][4] = (_Float16)(x1.x * qs); qf[ks][5] = (_Float16)(x1.y * qs);
@@ -661,11 +672,21 @@ fattn_mma_kernel(const FArgs a) {
             }
         }
         // ---- online softmax for query column lr
+        if (capped) {      // softcap * tanh(x), tanh(x) = 1 - 2 / (1 + e^2x) on v_exp_f32 / v_rcp_f32 (x -> +-inf: e = inf / 0, exact limits)
+            const float cap2 = a.logit_softcap * LOG2E;
+#pragma unroll
+            for (int t = 0; t < 2; t++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const float e = __builtin_amdgcn_exp2f(sacc[t][r] * (2.0f * LOG2E));
+                    sacc[t][r] = cap2 - 2.0f * cap2 * __builtin_amdgcn_rcpf(1.0f + e);
+                }
+        }
         float mx = -INFINITY;
 #pragma unroll
         for (int t = 0; t < 2; t++)
 #pragma unroll
-            for (int r = 0; r < 16; r++) { sacc[t][r] = __builtin_fmaf(mv[t][r], LOG2E, sacc[t][r]); mx = fmaxf(mx, sacc[t][r]); }
+            for (int r = 0; r < 16; r++) { sacc[t][r] = __builtin_fmaf(mv[t][r], mslope, sacc[t][r]); mx = fmaxf(mx, sacc[t][r]); }
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float mn = fmaxf(m, mx);
         const float msafe = mn == -INFINITY ? 0.0f : mn;          // fully masked so far: every p below is exp(-inf) = 0
@@ -759,12 +780,13 @@ fattn_mma_kernel(const FArgs a) {
         for (int i = 0; i < DT; i++)
 #pragma unroll
             for (int g = 0; g < 4; g++) {
+                if (32 * i + 8 * g + 4 * lh >= a.dv) continue;
                 v4f v = {o[i][4 * g] * inv, o[i][4 * g + 1] * inv, o[i][4 * g + 2] * inv, o[i][4 * g + 3] * inv};
                 *(v4f *)(op + 32 * i + 8 * g + 4 * lh) = v;
                 if (a.act_bf) {     // the rounding of mi355_act_bf16, for the attention-output GEMM that reads this row next
                     typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
                     const bf4 b = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
-                    *(bf4 *)(a.act_bf + (((int64_t)i3 * a.n_q + q) * a.n_head + h) * D + 32 * i + 8 * g + 4 * lh) = b;
+                    *(bf4 *)(a.act_bf + (((int64_t)i3 * a.n_q + q) * a.n_head + h) * a.dv + 32 * i + 8 * g + 4 * lh) = b;
                 }
             }
     }
@@ -777,7 +799,7 @@ fattn_mma_merge_kernel(const FArgs a, int64_t rows) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t row = i / (D / 4);
     const int d4 = (int)(i % (D / 4));
-    if (row >= rows) return;
+    if (row >= rows || 4 * d4 >= a.dv) return;
     const float * pp = a.part + row * a.kvs * (D + 4);
     float M = -INFINITY;
     for (int s = 0; s < a.kvs; s++) M = fmaxf(M, pp[s * (D + 4) + D]);
@@ -798,7 +820,7 @@ fattn_mma_merge_kernel(const FArgs a, int64_t rows) {
     if (a.act_bf) {
         typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
         const bf4 b = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
-        *(bf4 *)(a.act_bf + row * D + 4 * d4) = b;
+        *(bf4 *)(a.act_bf + row * a.dv + 4 * d4) = b;
     }
 }
 
@@ -822,7 +844,7 @@ static int launch_mma(const FArgs & a, int tkv, hipStream_t s) {
     // fewer (head, 32-query) units than SIMDs, and more than one KV step each: two waves per unit (MI355_FA_MMA_SPLIT=0: never)
     static const int split_on = [] { const char * e = getenv("MI355_FA_MMA_SPLIT"); return e ? atoi(e) : 1; }();
     const int64_t units = (int64_t)((a.n_q + 31) / 32) * a.n_head * a.ne3;
-    if (split_on && units < 1024 && a.n_kv > MMA_BKV) {
+    if (split_on > (D > 128 ? 1 : 0) && units < 1024 && a.n_kv > MMA_BKV) {     // (D = 256: the two-wave form's 128-row staging registers spill; MI355_FA_MMA_SPLIT=2 to try it)
         const int hpw = ratio % 2 == 0 ? 2 : 1, qpw = (MMA_WAVES / 2) / hpw, bq = 32 * qpw;
         const dim3 grid((unsigned)((a.n_q + bq - 1) / bq), (unsigned)(a.n_head / hpw), (unsigned)a.ne3);
         if (tkv == MI355_TYPE_F16)       MI355_LAUNCH("fattn_mma", (fattn_mma_kernel<D, MI355_TYPE_F16, true>), grid, dim3(MMA_THREADS), 0, s, a);
@@ -908,6 +930,17 @@ static int dispatch_types(const FArgs & a, int tk, int tv, hipStream_t s) {
     return MI355_E_TYPE;
 }
 
+// Head sizes: any multiple of 8 up to 256 (the reference's kernels cover 40, 64, 72, 80, 96, 112, 128, 256 of these: fattn.cu:271-346,
+// test-backend-ops.cpp:4866-4906).  The vec kernel is built for 64 / 128 / 256 features per row and the matrix-core kernel for 64 / 96 / 128 /
+// 256; another size runs on the next one up, with zeros past the row.
+static int fa_vec_d(int64_t d) { return d <= 64 ? 64 : d <= 128 ? 128 : 256; }
+static int fa_mma_d(int64_t d) { return d <= 64 ? 64 : d <= 96 ? 96 : d <= 128 ? 128 : 256; }
+// lab switch: head sizes above this take the vec kernel for prefill too (MI355_FA_MMA_MAX_D=128: the behaviour before the 256 tile kernel)
+static int fa_mma_max_d() {
+    static const int v = [] { const char * e = getenv("MI355_FA_MMA_MAX_D"); return e ? atoi(e) : 256; }();
+    return v;
+}
+
 } // namespace
 
 extern "C" {
@@ -919,7 +952,8 @@ int64_t mi355_flash_attn_ext_workspace_bytes(const mi355_fattn_args * p) {
     if (!p) return -1;
     // header + partials for the largest split the launcher may choose: 64 slices for the vec kernel, 8 shares for the matrix-core one
     const int64_t slices = p->n_q >= 32 ? 8 : 64;
-    return WS_HEADER + (int64_t)p->ne3 * p->n_q * p->n_head * slices * (p->d + (p->n_q >= 32 ? 4 : 2)) * (int64_t)sizeof(float);
+    if (p->d < 8 || p->d > 256 || p->dv < 0 || p->dv > p->d) return -1;
+    return WS_HEADER + (int64_t)p->ne3 * p->n_q * p->n_head * slices * (fa_vec_d(p->d) + (p->n_q >= 32 ? 4 : 2)) * (int64_t)sizeof(float);
 }
 
 int mi355_flash_attn_ext(const mi355_fattn_args * p, void * workspace, int64_t workspace_bytes, void * stream) {
@@ -941,7 +975,11 @@ int mi355_flash_attn_ext_bf16(const mi355_fattn_args * p, void * workspace, int6
 
 static int fattn_run(const mi355_fattn_args * p, void * workspace, int64_t workspace_bytes, int8_t * act_q, float * act_ds, uint16_t * act_bf, void * stream) {
     if (!p || !p->q || !p->k || !p->v || !p->dst) return MI355_E_NULL;
-    if (p->d != 64 && p->d != 128 && p->d != 256) return MI355_E_UNSUPPORTED;
+    const int64_t dv_ = p->dv ? p->dv : p->d;                      // V's head size: 0 = the same as K's
+    if (p->d < 8 || p->d > 256 || p->d % 8 != 0 || dv_ < 8 || dv_ > p->d || dv_ % 8 != 0) return MI355_E_UNSUPPORTED;
+    if ((p->type_k == MI355_TYPE_Q8_0 || p->type_k == MI355_TYPE_Q4_0) && p->d % 32 != 0) return MI355_E_SHAPE;
+    if ((p->type_v == MI355_TYPE_Q8_0 || p->type_v == MI355_TYPE_Q4_0) && dv_ % 32 != 0) return MI355_E_SHAPE;
+    if (act_q && dv_ % 32 != 0) return MI355_E_UNSUPPORTED;      // the q8_1 form's 32-blocks would straddle heads
     if (p->n_head_kv < 1 || p->n_head % p->n_head_kv != 0 || p->n_q < 0 || p->n_kv < 0 || p->ne3 < 1) return MI355_E_SHAPE;
     if (p->n_q > 65535 || p->ne3 * 64 > 65535) return MI355_E_SHAPE;
     if (p->mask && (p->m_ne2 < 1 || p->m_ne3 < 1)) return MI355_E_SHAPE;
@@ -953,6 +991,8 @@ static int fattn_run(const mi355_fattn_args * p, void * workspace, int64_t works
     if (p->n_q == 0 || p->n_head == 0) return MI355_OK;
 
     FArgs a;
+    a.d = (int)p->d; a.dv = (int)dv_;
+    const int64_t dv = fa_vec_d(p->d), dm = fa_mma_d(p->d);
     a.act_q = act_q; a.act_ds = act_ds; a.act_bf = nullptr; a.counters = nullptr; a.kvs = 1;
     a.q = (const char *)p->q; a.q_nb1 = p->q_nb1; a.q_nb2 = p->q_nb2; a.q_nb3 = p->q_nb3;
     a.k = (const char *)p->k; a.k_nb1 = p->k_nb1; a.k_nb2 = p->k_nb2; a.k_nb3 = p->k_nb3;
@@ -965,10 +1005,10 @@ static int fattn_run(const mi355_fattn_args * p, void * workspace, int64_t works
     a.m0 = powf(2.0f, -(p->max_bias) / a.n_head_log2);
     a.m1 = powf(2.0f, -(p->max_bias / 2.0f) / a.n_head_log2);
 
-    // prefill-sized batches of f16 KV without ALiBi / softcap: matrix-core tile kernel
+    // prefill-sized batches of f16 / q8_0 / q4_0 KV: matrix-core tile kernel
     if (p->type_k == p->type_v && (p->type_k == MI355_TYPE_F16 || p->type_k == MI355_TYPE_Q8_0 || p->type_k == MI355_TYPE_Q4_0) &&
-        (p->d == 128 || p->d == 64) && p->n_q >= 32 &&
-        !(p->max_bias > 0.0f) && p->logit_softcap == 0.0f && p->n_head <= 65535 && p->ne3 <= 65535 &&
+        p->n_q >= 32 && dm <= fa_mma_max_d() &&
+        p->n_head <= 65535 && p->ne3 <= 65535 &&
         ((p->d_nb1 | p->d_nb2 | p->d_nb3 | (int64_t)(uintptr_t)p->dst) & 15) == 0 && (!p->mask || (p->m_nb1 & 1) == 0)) {
         if (act_q) return MI355_E_UNSUPPORTED;   // the fused q8_1 output exists for decode-sized batches only
         a.nsplit = 1; a.part = nullptr; a.act_bf = act_bf; a.kvs = 1;
@@ -977,13 +1017,18 @@ static int fattn_run(const mi355_fattn_args * p, void * workspace, int64_t works
         static const int kvs_env = [] { const char * e = getenv("MI355_FA_KVS"); return e ? atoi(e) : 4; }();
         static const int kvs_min = [] { const char * e = getenv("MI355_FA_KVS_MIN"); return e ? atoi(e) : 1024; }();
         const int64_t units = (int64_t)((p->n_q + 31) / 32) * p->n_head * p->ne3;
-        const int64_t part_bytes = (int64_t)p->ne3 * p->n_q * p->n_head * kvs_env * (p->d + 4) * (int64_t)sizeof(float);
+        const int64_t part_bytes = (int64_t)p->ne3 * p->n_q * p->n_head * kvs_env * (dm + 4) * (int64_t)sizeof(float);
         if (kvs_env > 1 && kvs_env <= 8 && units < 1024 && p->n_kv >= kvs_min && workspace && ((uintptr_t)workspace & 15) == 0 &&
             workspace_bytes >= WS_HEADER + part_bytes && p->ne3 * kvs_env <= 65535) {
             a.kvs = kvs_env;
             a.part = (float *)((char *)workspace + WS_HEADER);
         }
-        return p->d == 128 ? launch_mma<128>(a, p->type_k, (hipStream_t)stream) : launch_mma<64>(a, p->type_k, (hipStream_t)stream);
+        switch (dm) {
+            case 64:  return launch_mma<64>(a, p->type_k, (hipStream_t)stream);
+            case 96:  return launch_mma<96>(a, p->type_k, (hipStream_t)stream);
+            case 128: return launch_mma<128>(a, p->type_k, (hipStream_t)stream);
+        }
+        return launch_mma<256>(a, p->type_k, (hipStream_t)stream);
     }
     if (act_bf) return MI355_E_UNSUPPORTED;      // the bf16 copy exists for the matrix-core kernel only
     // KV split.  The KV loop is a chain of memory round trips (one per G = 512/(d/8) rows), so for decode-sized
@@ -991,11 +1036,11 @@ static int fattn_run(const mi355_fattn_args * p, void * workspace, int64_t works
     // then in flight at once -- up to 64 slices, bounded by the workspace; the partials are merged by
     int nsplit = 1;
     const int64_t base_wgs = (int64_t)p->n_head_kv * p->n_q * p->ne3;
-    const int64_t G = FA_THREADS / (p->d / 8);
+    const int64_t G = FA_THREADS / (dv / 8);
     const int64_t ratio = p->n_head / p->n_head_kv;
-    const int64_t rr = fa_heads_per_wg(ratio, p->d, p->n_kv);      // R chosen by dispatch_r
+    const int64_t rr = fa_heads_per_wg(ratio, dv, p->n_kv);      // R chosen by dispatch_r
     const int64_t n_counters = (int64_t)p->ne3 * p->n_q * p->n_head_kv * ((ratio + rr - 1) / rr);
-    const bool short_ctx = p->d <= 128 && p->type_k == p->type_v && p->n_kv <= fa_short_rows();
+    const bool short_ctx = dv <= 128 && p->type_k == p->type_v && p->n_kv <= fa_short_rows();
     if (!short_ctx && workspace && workspace_bytes > WS_HEADER && ((uintptr_t)workspace & 15) == 0 && n_counters * 4 <= WS_HEADER &&
         base_wgs < 512 && p->n_kv >= 4 * G) {
         // Every slice costs a partial store, a device-scope arrival and a share of the merge, so more slices only pay
@@ -1011,7 +1056,7 @@ static int fattn_run(const mi355_fattn_args * p, void * workspace, int64_t works
         if (want > 8) want = chain4 > 8 ? chain4 : 8;
         if (want > fill) want = fill > 8 ? fill : 8;
         if (want > 64) want = 64;
-        const int64_t per = (int64_t)p->ne3 * p->n_q * p->n_head * (p->d + 2) * (int64_t)sizeof(float);
+        const int64_t per = (int64_t)p->ne3 * p->n_q * p->n_head * (dv + 2) * (int64_t)sizeof(float);
         if (per > 0 && want * per > workspace_bytes - WS_HEADER) want = (workspace_bytes - WS_HEADER) / per;
         if (want > 1) nsplit = (int)want;
     }
@@ -1019,7 +1064,7 @@ static int fattn_run(const mi355_fattn_args * p, void * workspace, int64_t works
     a.counters = (int *)workspace;
     a.part = (float *)((char *)workspace + WS_HEADER);
     hipStream_t s = (hipStream_t)stream;
-    switch (p->d) {
+    switch (dv) {
         case 64:  return dispatch_types<64>(a, p->type_k, p->type_v, s);
         case 128: return dispatch_types<128>(a, p->type_k, p->type_v, s);
         case 256: return dispatch_types<256>(a, p->type_k, p->type_v, s);

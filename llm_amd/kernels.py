@@ -104,6 +104,7 @@ class FattnArgs(C.Structure):
         ("dst", _vp), ("d_nb1", _i64), ("d_nb2", _i64), ("d_nb3", _i64),
         ("d", _i64), ("n_q", _i64), ("n_kv", _i64), ("n_head", _i64), ("n_head_kv", _i64), ("ne3", _i64),
         ("scale", C.c_float), ("max_bias", C.c_float), ("logit_softcap", C.c_float),
+        ("dv", _i64),
     ]
 
 

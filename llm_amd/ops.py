@@ -149,23 +149,27 @@ def mul_mat_id(t, as_, b, ids, m, n_expert):
 
 
 def flash_attn_ext(q, k, v, mask, type_kv, n_kv, scale, max_bias=0.0, logit_softcap=0.0, use_workspace=True, quant=False,
-                   workspace_bytes=None, noalloc=False, bf16=False):
+                   workspace_bytes=None, noalloc=False, bf16=False, dv=None):
     """ggml_flash_attn_ext, batch 1.  q: [n_head, n_q, d] f32; k, v: [n_head_kv, n_kv, row_bytes] uint8 rows of
-    type_kv (F16 / BF16 / Q8_0 / Q4_0); mask: [n_q_pad, n_kv] f16 bits (int16) or None -> [n_q, n_head, d] f32."""
+    type_kv (F16 / BF16 / Q8_0 / Q4_0); mask: [n_q_pad, n_kv] f16 bits (int16) or None -> [n_q, n_head, dv] f32 (dv: V's head size
+    where it differs from d, e.g. 192 / 128)."""
     assert q.is_cuda and q.dtype == torch.float32 and q.is_contiguous() and k.is_contiguous() and v.is_contiguous()
     n_head, n_q, d = q.shape
     n_head_kv = k.shape[0]
+    d_k, d = d, (dv if dv else d)          # below, d is the head size of V and dst
     dst = torch.empty((n_q, n_head, d), dtype=torch.float32, device=q.device)
     a = K.FattnArgs()
-    a.q, a.q_nb1, a.q_nb2, a.q_nb3 = q.data_ptr(), d * 4, n_q * d * 4, n_head * n_q * d * 4
+    a.q, a.q_nb1, a.q_nb2, a.q_nb3 = q.data_ptr(), d_k * 4, n_q * d_k * 4, n_head * n_q * d_k * 4
     rb = k.shape[2] * k.element_size()
     a.k, a.type_k, a.k_nb1, a.k_nb2, a.k_nb3 = k.data_ptr(), type_kv, rb, rb * k.shape[1], rb * k.shape[1] * n_head_kv
+    rb = v.shape[2] * v.element_size()
     a.v, a.type_v, a.v_nb1, a.v_nb2, a.v_nb3 = v.data_ptr(), type_kv, rb, rb * v.shape[1], rb * v.shape[1] * n_head_kv
     if mask is not None:
         assert mask.is_contiguous() and mask.element_size() == 2
         a.mask, a.m_nb1, a.m_nb2, a.m_nb3, a.m_ne2, a.m_ne3 = mask.data_ptr(), mask.shape[1] * 2, mask.numel() * 2, mask.numel() * 2, 1, 1
     a.dst, a.d_nb1, a.d_nb2, a.d_nb3 = dst.data_ptr(), d * 4, n_head * d * 4, n_q * n_head * d * 4
-    a.d, a.n_q, a.n_kv, a.n_head, a.n_head_kv, a.ne3 = d, n_q, n_kv, n_head, n_head_kv, 1
+    a.d, a.n_q, a.n_kv, a.n_head, a.n_head_kv, a.ne3 = d_k, n_q, n_kv, n_head, n_head_kv, 1
+    a.dv = d if dv else 0
     a.scale, a.max_bias, a.logit_softcap = scale, max_bias, logit_softcap
     ws, wsb = None, 0
     if noalloc:      # the entry point that allocates nothing: the split-KV scratch is a fixed array inside the library

@@ -17,7 +17,7 @@ PLUGIN = os.path.join(ROOT, "llm_amd", "lib", "libggml-mi355.so")
 OPS = ["MUL_MAT", "MUL_MAT_ID", "FLASH_ATTN_EXT", "ADD", "MUL", "SUB", "DIV", "RMS_NORM", "ROPE", "REGLU", "GEGLU", "SWIGLU", "CPY", "CONT", "DUP",
        "GET_ROWS", "SET_ROWS", "SCALE", "SOFT_MAX", "ARGSORT", "SUM_ROWS"]
 # lower bounds on the number of cases that must actually RUN on the device (not "not supported")
-MIN_RUN = {"MUL_MAT": 640, "SET_ROWS": 50, "MUL_MAT_ID": 160, "FLASH_ATTN_EXT": 1390, "ROPE": 50, "SOFT_MAX": 100}
+MIN_RUN = {"MUL_MAT": 640, "SET_ROWS": 50, "MUL_MAT_ID": 160, "FLASH_ATTN_EXT": 1900, "ROPE": 50, "SOFT_MAX": 100}
 
 
 def _run(op):
@@ -176,9 +176,25 @@ def test_llama_logits_match_ggml_cpu(ftype, ctk, tmp_path):
     assert d <= 2.0 * e_cpu + 2e-4, (d, e_cpu)        # two roundings of the same exact values
 
 
+@pytest.mark.parametrize("model,ctk", [("hd80", "f16"), ("hd96", "f16"), ("hd96", "q8_0"), ("hd256", "f16"), ("hd256", "q8_0")])
+def test_other_head_sizes_match_ggml_cpu(model, ctk, tmp_path):
+    """Llama graphs with head sizes 80, 96 and 256 (FLASH_ATTN_EXT on the kernels built for 128 / 96 / 256 features per row, the fused Q/K/V +
+    rope + KV-store forms per head size, f16 and q8_0 KV cache where a row is whole 32-blocks): no CPU compute split, and the logits are
+    as close to the exact twin's as ggml-cpu's are (the yardstick of test_llama_logits_match_ggml_cpu)."""
+    tool = os.path.join(ROOT, "tools", "run_llama_bench.sh")
+    r = subprocess.run([tool, model, "Q4_K_M", "-ctk", ctk, "-ctv", ctk, "-p", "64", "-n", "8", "-r", "1"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "graph splits = 2" in r.stderr + r.stdout, (r.stderr + r.stdout)[-3000:]
+    e_cpu, e_gpu, d = _logits_vs_exact_twin(tmp_path, model, "Q4_K_M", ctk)
+    assert e_cpu < 5e-2, e_cpu
+    assert e_gpu <= 1.25 * e_cpu + 2e-4, (e_gpu, e_cpu)
+    assert d <= 2.0 * e_cpu + 2e-4, (d, e_cpu)
+
+
 # mid: 2048 wide, 4 KV heads of 128, ffn 5120; wideffn: Llama-8B's 14336; 70b2: two layers of Llama-3-70B's shapes (K = 8192: norm in
 # the grouped gate / up launch, 28672 rows: no one-launch GLU form, q5_K wv)
-@pytest.mark.parametrize("model", ["tiny", "tinymoe", "mid", "wideffn", "70b2"])
+# hd80 / hd96 / hd256: head sizes 80 (no GQA), 96 (GQA 4) and 256 (GQA 2) -- rope, the K/V store and FLASH_ATTN_EXT per head size
+@pytest.mark.parametrize("model", ["tiny", "tinymoe", "mid", "wideffn", "70b2", "hd80", "hd96", "hd256"])
 def test_fusions_are_bit_exact(tmp_path, model, kv="f16", extra_env=None):
     """The backend's graph-level fusions (RMS_NORM*weight, fused q8_1 quantization, activation cache, Q/K/V + rope + store,
     and for the 8-expert model the one-launch MoE router) keep the f32 op order of the unfused graph: logits with and

@@ -1010,7 +1010,17 @@ def test_flash_attn_golden(ops, tag):
                                                       # a long causal prompt whose upper-triangle blocks are never staged
                                                       (128, 4, 2, 70, 130, True), (128, 6, 2, 50, 90, True), (128, 8, 2, 700, 700, True),
                                                       # a 512-token ubatch late in a long prompt: KV blocks dealt to two workgroups per unit group + merge
-                                                      (128, 32, 8, 512, 2048, True), (64, 8, 2, 100, 1100, True), (128, 6, 2, 33, 1029, False)])
+                                                      (128, 32, 8, 512, 2048, True), (64, 8, 2, 100, 1100, True), (128, 6, 2, 33, 1029, False),
+                                                      # head sizes between the ones the kernels are built for (the reference's list, fattn.cu:271-346, and
+                                                      # test-backend-ops' hs values 40 / 72 / 80 / 96 / 112; 192 and 24 for the rule itself): decode and
+                                                      # prefill shapes, with and without the KV split, ragged query blocks, the short-context form
+                                                      (80, 8, 8, 1, 300, False), (80, 8, 2, 70, 130, True), (80, 32, 32, 1, 5000, False), (80, 8, 8, 512, 1536, True),
+                                                      (96, 8, 2, 96, 200, True), (96, 32, 32, 1, 5000, False), (96, 6, 2, 3, 700, True), (96, 32, 32, 512, 2048, True),
+                                                      (112, 4, 2, 33, 64, True), (112, 8, 2, 2, 9000, False), (40, 4, 4, 3, 100, False), (40, 4, 2, 64, 64, True),
+                                                      (40, 8, 8, 1, 4000, False), (72, 6, 2, 50, 90, True), (72, 6, 2, 1, 1000, False), (72, 8, 8, 130, 1333, True),
+                                                      (192, 4, 2, 40, 100, True), (192, 4, 2, 1, 600, False), (24, 4, 4, 2, 77, False), (24, 4, 4, 40, 77, True),
+                                                      # head size 256 on the matrix cores (Gemma): GQA 2 and 1, the KV shares + merge, ragged ends
+                                                      (256, 4, 2, 96, 200, True), (256, 16, 8, 512, 512, True), (256, 8, 8, 70, 1100, True), (256, 16, 8, 512, 1536, True)])
 def test_flash_attn_f16_vs_f64_oracle(ops, d, nh, nhkv, nq, nkv, causal):
     """prefill shapes take the matrix-core tile kernel (n_q >= 32), decode shapes the split-KV vec kernel; both
     against the oracle's double-precision evaluation of the op on the same f16 K/V."""
@@ -1033,7 +1043,9 @@ def test_flash_attn_f16_vs_f64_oracle(ops, d, nh, nhkv, nq, nkv, causal):
 
 @pytest.mark.parametrize("tkv", [B.Q8_0, B.Q4_0])
 @pytest.mark.parametrize("d,nh,nhkv,nq,nkv", [(128, 8, 2, 96, 200), (64, 4, 4, 33, 130), (128, 8, 2, 3, 300), (128, 32, 8, 1, 17000),
-                                              (128, 8, 2, 512, 2048)])      # SURVEY config 3: a 512-token ubatch at n_kv 2048 (GQA 4)
+                                              (128, 8, 2, 512, 2048),       # SURVEY config 3: a 512-token ubatch at n_kv 2048 (GQA 4)
+                                              (96, 8, 2, 96, 200), (96, 8, 2, 1, 3000), (96, 8, 8, 3, 100), (256, 4, 2, 40, 300), (256, 4, 2, 2, 3000),
+                                              (32, 4, 4, 40, 100), (32, 4, 4, 1, 100), (160, 4, 2, 33, 130)])
 def test_flash_attn_quantized_kv_vs_f64_oracle(ops, tkv, d, nh, nhkv, nq, nkv):
     """q8_0 / q4_0 KV cache: the tile kernel dequantizes K/V blocks to f16 while staging (n_q >= 32), the vec
     kernel in registers (decode); both vs the oracle's f64 evaluation on the same quantized rows."""
@@ -1052,7 +1064,8 @@ def test_flash_attn_quantized_kv_vs_f64_oracle(ops, tkv, d, nh, nhkv, nq, nkv):
     assert np.isfinite(got).all() and O.nmse(ref, got) <= 5e-5, O.nmse(ref, got)
 
 
-@pytest.mark.parametrize("d,nh,nhkv,nq,nkv", [(128, 8, 2, 1, 300), (64, 4, 4, 33, 130), (128, 8, 2, 3, 5000), (256, 4, 2, 2, 100), (128, 32, 8, 70, 200)])
+@pytest.mark.parametrize("d,nh,nhkv,nq,nkv", [(128, 8, 2, 1, 300), (64, 4, 4, 33, 130), (128, 8, 2, 3, 5000), (256, 4, 2, 2, 100), (128, 32, 8, 70, 200),
+                                              (80, 8, 2, 1, 300), (96, 4, 4, 33, 130), (112, 8, 2, 3, 5000), (40, 4, 2, 70, 200)])
 def test_flash_attn_bf16_kv_vs_f64_oracle(ops, d, nh, nhkv, nq, nkv):
     """bf16 KV cache (test-backend-ops.cpp:4866-4906 type_KV list; the vec kernel for any n_q): K / V values that both bf16 and f16
     hold exactly, so the oracle's f64 evaluation on the f16 rows is the reference; the query is rounded to bf16 as the CPU path
@@ -1077,11 +1090,12 @@ def test_flash_attn_bf16_kv_vs_f64_oracle(ops, d, nh, nhkv, nq, nkv):
         assert np.isfinite(got).all() and O.nmse(ref, got) <= 5e-5, O.nmse(ref, got)
 
 
+@pytest.mark.parametrize("d", [128, 96])
 @pytest.mark.parametrize("nq,nkv,use_ws", [(1, 300, True), (1, 300, False), (4, 4096, True), (8, 96, True)])
-def test_flash_attn_fused_q8_1_output(ops, nq, nkv, use_ws):
+def test_flash_attn_fused_q8_1_output(ops, nq, nkv, use_ws, d):
     """mi355_flash_attn_ext_quant: dst equals the plain call bit for bit and the fused q8_1 form equals
     mi355_quantize_act(dst); run twice on one workspace (the arrival counters re-arm themselves)."""
-    d, nh, nhkv = 128, 8, 2
+    nh, nhkv = 8, 2
     rng = np.random.default_rng(nq + nkv)
     q = dev(rng.standard_normal((nh, nq, d)).astype(np.float32))
     k = dev(rng.standard_normal((nhkv, nkv, d)).astype(np.float16).view(np.uint8).reshape(nhkv, nkv, -1))
@@ -1094,8 +1108,76 @@ def test_flash_attn_fused_q8_1_output(ops, nq, nkv, use_ws):
     assert torch.equal(aq, aq2) and torch.equal(ads.view(torch.int32), ads2.view(torch.int32))
 
 
+@pytest.mark.parametrize("tkv", [B.F16, B.Q8_0])
+@pytest.mark.parametrize("dk,dv,nh,nhkv,nq,nkv", [(192, 128, 8, 2, 1, 700), (192, 128, 4, 4, 3, 100), (192, 128, 8, 2, 70, 130), (192, 128, 16, 16, 512, 1536),
+                                                  (128, 64, 8, 2, 40, 100), (96, 32, 4, 2, 2, 5000)])
+def test_flash_attn_v_head_size_smaller_than_k(ops, tkv, dk, dv, nh, nhkv, nq, nkv):
+    """K and V rows of different sizes (DeepSeek-V2's 192 / 128; test-backend-ops.cpp hsk / hsv): decode and prefill kernels vs the
+    oracle's f64 evaluation on the same rows."""
+    rng = np.random.default_rng(dk + dv + nq + nkv)
+    q = rng.standard_normal((nh, nq, dk)).astype(np.float32)
+    if tkv == B.F16:
+        k = rng.standard_normal((nhkv, nkv, dk)).astype(np.float16).view(np.uint8).reshape(nhkv, nkv, -1)
+        v = rng.standard_normal((nhkv, nkv, dv)).astype(np.float16).view(np.uint8).reshape(nhkv, nkv, -1)
+        scale = 1.0 / np.sqrt(dk)
+    else:
+        k = B.random_blocks(tkv, nhkv * nkv, dk, seed=11).reshape(nhkv, nkv, -1)
+        v = B.random_blocks(tkv, nhkv * nkv, dv, seed=12).reshape(nhkv, nkv, -1)
+        scale = 20.0
+    mask = np.zeros(((nq + 63) // 64 * 64, nkv), np.float16)
+    for i in range(nq):
+        mask[i, i + nkv - nq + 1:] = -np.inf
+    ref = O.flash_attn_ext(q, k, v, mask.view(np.uint16), tkv, tkv, dk, dv, nq, nkv, nh, nhkv, scale, exact=True)
+    for use_ws in (True, False):
+        got = ops.flash_attn_ext(dev(q), dev(k), dev(v), dev(mask.view(np.int16)), tkv, nkv, scale, dv=dv, use_workspace=use_ws).cpu().numpy()
+        assert got.shape == ref.shape and np.isfinite(got).all() and O.nmse(ref, got) <= 5e-5, O.nmse(ref, got)
+
+
+@pytest.mark.parametrize("max_bias,softcap", [(8.0, 0.0), (0.0, 10.0), (4.0, 30.0)])
+@pytest.mark.parametrize("d,nh,nhkv,nq,nkv", [(128, 8, 2, 96, 200), (256, 8, 4, 70, 300), (64, 12, 12, 33, 64), (128, 32, 8, 512, 1536)])
+def test_flash_attn_prefill_alibi_and_softcap(ops, d, nh, nhkv, nq, nkv, max_bias, softcap):
+    """ALiBi slopes (max_bias; the mask carries the position bias, ggml.c:4733-4786 / ops.cpp:8041-8047) and the logit softcap (Gemma-2,
+    ops.cpp:8094-8098) on the matrix-core kernel -- prefill-sized batches -- and, with the same inputs cut to 3 queries, on the vec kernel."""
+    rng = np.random.default_rng(d + nq + nkv)
+    k = rng.standard_normal((nhkv, nkv, d)).astype(np.float16).view(np.uint8).reshape(nhkv, nkv, -1)
+    v = rng.standard_normal((nhkv, nkv, d)).astype(np.float16).view(np.uint8).reshape(nhkv, nkv, -1)
+    scale = 1.0 / np.sqrt(d)
+    for n in (nq, 3):
+        q = (3.0 * rng.standard_normal((nh, n, d))).astype(np.float32)      # scores that reach the cap
+        mask = np.zeros(((n + 63) // 64 * 64, nkv), np.float16)
+        for i in range(n):
+            mask[i, :] = -0.25 * np.abs(np.arange(nkv) - (i + nkv - n))      # a position bias
+            mask[i, i + nkv - n + 1:] = -np.inf
+        ref = O.flash_attn_ext(q, k, v, mask.view(np.uint16), O.F16, O.F16, d, d, n, nkv, nh, nhkv, scale, max_bias, softcap, exact=True)
+        got = ops.flash_attn_ext(dev(q), dev(k), dev(v), dev(mask.view(np.int16)), B.F16, nkv, scale, max_bias, softcap).cpu().numpy()
+        assert np.isfinite(got).all() and O.nmse(ref, got) <= 5e-5, (n, O.nmse(ref, got))
+
+
+def test_flash_attn_head_size_rules(ops):
+    """What the op refuses, by return code: head sizes that are not a multiple of 8 or above 256 (MI355_E_UNSUPPORTED: the plugin's supports_op
+    says no to the same), quantized K/V rows that are not whole 32-blocks (MI355_E_SHAPE), and the fused q8_1 output for a head size whose
+    32-blocks would straddle heads (MI355_E_UNSUPPORTED: the caller quantizes the row itself)."""
+    import llm_amd.kernels as K
+    def run(d, tkv=B.F16, rb=None, **kw):
+        q = torch.zeros(4, 1, d, device="cuda")
+        kv = torch.zeros(4, 64, rb if rb else d * 2, dtype=torch.uint8, device="cuda")
+        return ops.flash_attn_ext(q, kv, kv, None, tkv, 64, 1.0, **kw)
+    for d in (36, 260, 4, 512):
+        with pytest.raises(K.Mi355Error) as e:
+            run(d)
+        assert e.value.code == -6      # MI355_E_UNSUPPORTED
+    with pytest.raises(K.Mi355Error) as e:
+        run(80, B.Q8_0, rb=85)
+    assert e.value.code == -2          # MI355_E_SHAPE
+    with pytest.raises(K.Mi355Error) as e:
+        run(80, quant=True)
+    assert e.value.code == -6
+    assert torch.isfinite(run(80)).all() and torch.isfinite(run(8)).all()
+
+
 @pytest.mark.parametrize("tkv,d,nh,nhkv,nq,nkv", [(B.F16, 128, 32, 8, 512, 512), (B.F16, 128, 6, 2, 50, 90), (B.Q8_0, 64, 4, 4, 130, 333), (B.F16, 128, 8, 2, 8, 300),
-                                                  (B.F16, 128, 32, 8, 512, 1536)])
+                                                  (B.F16, 128, 32, 8, 512, 1536), (B.F16, 80, 8, 2, 100, 300), (B.Q8_0, 96, 4, 4, 130, 333), (B.F16, 256, 8, 4, 512, 1536),
+                                                  (B.F16, 72, 6, 2, 33, 64)])
 def test_flash_attn_fused_bf16_output(ops, tkv, d, nh, nhkv, nq, nkv):
     """mi355_flash_attn_ext_bf16 (prefill): dst equals the plain call bit for bit and the bf16 rows equal mi355_act_bf16(dst); ragged
     query blocks; a decode-sized batch (vec kernel) is refused, not served by something else."""

@@ -80,7 +80,7 @@ static void fill_blocks(ggml_tensor * t) {
 }
 
 int main(int argc, char ** argv) {
-    if (argc < 3) { fprintf(stderr, "usage: %s out.gguf 8b|70b|8x7b|tiny|tinymoe [Q4_K_M|Q8_0|Q4_0|Q4_1|Q5_0|Q5_1|Q2_K|Q3_K|IQ4_NL|IQ4_XS|F16] [vocab.gguf]\n", argv[0]); return 2; }
+    if (argc < 3) { fprintf(stderr, "usage: %s out.gguf 8b|70b|70b2|8x7b|tiny|tinymoe|mid|wideffn|hd80|hd96|hd256 [Q4_K_M|Q8_0|Q4_0|Q4_1|Q5_0|Q5_1|Q2_K|Q3_K|IQ4_NL|IQ4_XS|F16] [vocab.gguf]\n", argv[0]); return 2; }
     const std::string out = argv[1], model = argv[2];
     std::string ftype = argc > 3 ? argv[3] : "Q4_K_M";
     // "<ftype>+F32": the same random blocks, stored dequantized as F32 -- the model's exact twin, against which both ggml-cpu's and
@@ -97,6 +97,10 @@ int main(int argc, char ** argv) {
     else if (model == "tiny") d = {1024, 4, 8, 2, 2816, 32000, false};
     else if (model == "mid")  d = {2048, 3, 16, 4, 5120, 32000, false};      // the smallest shapes the persistent decode-layer launch takes (multiples of 1024, >= 2048)
     else if (model == "wideffn") d = {1024, 2, 8, 2, 14336, 32000, false};   // Llama-8B's feed-forward width on a small trunk: a 512-token batch reaches the fused gate / up / GLU GEMM
+    // head sizes other than 128: Phi-3-mini's 96 (3072 wide, GQA 4 here), StableLM / Phi-2's 80 (2560 wide, no GQA), Gemma's 256 (2048 wide, GQA 2)
+    else if (model == "hd96")  d = {3072, 2, 32, 8, 8192, 8000, false};
+    else if (model == "hd80")  d = {2560, 2, 32, 32, 6912, 8000, false};
+    else if (model == "hd256") d = {2048, 2, 8, 4, 5632, 8000, false};
     else if (model == "8x7b")    { d = {4096, 32, 32, 8, 14336, 32000, false}; d.n_expert = 8; d.n_expert_used = 2; }
     else if (model == "tinymoe") { d = {1024, 4, 8, 2, 2816, 32000, false};    d.n_expert = 8; d.n_expert_used = 2; }
     else { fprintf(stderr, "unknown model %s\n", model.c_str()); return 2; }
