@@ -61,7 +61,7 @@ enum mi355_error {
  * call (launch, memset, symbol lookup) failed; mi355_error_string() describes all three. */
 
 /* library / device introspection */
-#define MI355_ABI_VERSION 5                             /* bumped on any signature or struct change */
+#define MI355_ABI_VERSION 6                             /* bumped on any signature or struct change */
 MI355_API int         mi355_abi_version(void);          /* == MI355_ABI_VERSION of the header the library was built from;
                                                          * the plugin and the Python binding refuse a library that differs */
 MI355_API int64_t     mi355_args_sizeof(int which);     /* sizeof of 0 mi355_mmvq_args, 1 qkv_rope, 2 glu_matvec, 3 moe_down,
@@ -588,6 +588,22 @@ MI355_API int mi355_kv_store_q8_0(const float *k_src, int64_t n_k, void *k_dst, 
 
 /* dst = x * scale + bias (f32, contiguous).  ggml_cuda_op_scale (ggml-cuda/scale.cu). */
 MI355_API int mi355_scale_f32(const mi355_tensor *x, const mi355_tensor *dst, float scale, float bias, void *stream);
+
+/* Element-wise maps, f32 -> f32 of the same shape, any byte strides: the UNARY ops in ggml's order (ggml.h:536-553; arithmetic of
+ * ggml-cpu/unary-ops.cpp:3-65, vec.h:547-640), SQR / SQRT / SIN / COS / LOG, and CLAMP to [p0, p1] (p0, p1 ignored otherwise).
+ * ggml_cuda_op_unary & co. (ggml-cuda/unary.cu), ggml_cuda_op_clamp (ggml-cuda/clamp.cu).  Outside the Llama / Mixtral graphs of
+ * what Gemma (TANH for the final softcap), Phi / StableLM / Falcon (GELU, NORM) graphs add to them. */
+enum mi355_map_op {
+    MI355_MAP_ABS = 0, MI355_MAP_SGN, MI355_MAP_NEG, MI355_MAP_STEP, MI355_MAP_TANH, MI355_MAP_ELU, MI355_MAP_RELU, MI355_MAP_SIGMOID,
+    MI355_MAP_GELU, MI355_MAP_GELU_QUICK, MI355_MAP_SILU, MI355_MAP_HARDSWISH, MI355_MAP_HARDSIGMOID, MI355_MAP_EXP, MI355_MAP_GELU_ERF,
+    MI355_MAP_SQR, MI355_MAP_SQRT, MI355_MAP_SIN, MI355_MAP_COS, MI355_MAP_LOG, MI355_MAP_CLAMP
+};
+MI355_API int mi355_map_f32(int op, const mi355_tensor *x, const mi355_tensor *dst, float p0, float p1, void *stream);
+
+/* NORM: dst = (x - mean(x)) / sqrt(var(x) + eps) per row (LayerNorm without the affine part; oracle ggml_compute_forward_norm_f32,
+ * ggml-cpu/ops.cpp:3905-3960; ggml_cuda_op_norm, ggml-cuda/norm.cu); l2 != 0: L2_NORM, dst = x / max(|x|_2, eps) (ops.cpp:4314-4358).
+ * Rows contiguous. */
+MI355_API int mi355_norm_f32(const mi355_tensor *x, const mi355_tensor *dst, float eps, int l2, void *stream);
 
 /* dst (i32, same shape) = indices that sort each row of x (f32, rows of at most 1024 values), ascending or descending;
  * ties by index.  ggml_cuda_op_argsort (ggml-cuda/argsort.cu); oracle ggml_compute_forward_argsort_f32 (ggml-cpu/ops.cpp).

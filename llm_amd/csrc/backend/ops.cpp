@@ -79,6 +79,12 @@ bool mi355_ops_supported(const ggml_tensor * op) {
                    ((b->nb[0] | b->nb[1] | b->nb[2]) & 7) == 0;
         case GGML_OP_SCALE:
             return is_f32(a) && is_f32(op) && ggml_is_contiguous(a) && ggml_is_contiguous(op);
+        case GGML_OP_UNARY:
+            return is_f32(a) && is_f32(op) && (int)ggml_get_unary_op(op) <= (int)GGML_UNARY_OP_GELU_ERF;
+        case GGML_OP_SQR: case GGML_OP_SQRT: case GGML_OP_SIN: case GGML_OP_COS: case GGML_OP_LOG: case GGML_OP_CLAMP:
+            return is_f32(a) && is_f32(op);
+        case GGML_OP_NORM: case GGML_OP_L2_NORM:
+            return is_f32(a) && is_f32(op) && a->nb[0] == sizeof(float) && op->nb[0] == sizeof(float);
         case GGML_OP_SOFT_MAX:
             return is_f32(a) && is_f32(op) && a->nb[0] == sizeof(float) && ggml_is_contiguous(op) &&
                    (!b || ((b->type == GGML_TYPE_F16 || b->type == GGML_TYPE_F32) && b->nb[0] == ggml_type_size(b->type)));
@@ -147,6 +153,31 @@ bool mi355_ops_forward(ggml_tensor * node, hipStream_t stream) {
         case GGML_OP_SET_ROWS: {
             mi355_tensor ta = T(a), tb = T(b);
             MI_CHECK(mi355_set_rows(&ta, &tb, &td, stream));
+            return true;
+        }
+        case GGML_OP_UNARY: case GGML_OP_SQR: case GGML_OP_SQRT: case GGML_OP_SIN: case GGML_OP_COS: case GGML_OP_LOG: case GGML_OP_CLAMP: {
+            // the UNARY ops map one to one (mi355_map_op follows ggml_unary_op's order, checked below); CLAMP's bounds are op_params[0..1]
+            static_assert((int)GGML_UNARY_OP_ABS == (int)MI355_MAP_ABS && (int)GGML_UNARY_OP_TANH == (int)MI355_MAP_TANH &&
+                          (int)GGML_UNARY_OP_SILU == (int)MI355_MAP_SILU && (int)GGML_UNARY_OP_GELU_ERF == (int)MI355_MAP_GELU_ERF, "unary op order");
+            int mop; float p0 = 0.0f, p1 = 0.0f;
+            switch (node->op) {
+                case GGML_OP_UNARY: mop = (int)ggml_get_unary_op(node); break;
+                case GGML_OP_SQR:   mop = MI355_MAP_SQR;  break;
+                case GGML_OP_SQRT:  mop = MI355_MAP_SQRT; break;
+                case GGML_OP_SIN:   mop = MI355_MAP_SIN;  break;
+                case GGML_OP_COS:   mop = MI355_MAP_COS;  break;
+                case GGML_OP_LOG:   mop = MI355_MAP_LOG;  break;
+                default:            mop = MI355_MAP_CLAMP; memcpy(&p0, (const float *)node->op_params + 0, 4); memcpy(&p1, (const float *)node->op_params + 1, 4); break;
+            }
+            mi355_tensor ta = T(a);
+            MI_CHECK(mi355_map_f32(mop, &ta, &td, p0, p1, stream));
+            return true;
+        }
+        case GGML_OP_NORM: case GGML_OP_L2_NORM: {
+            float eps;
+            memcpy(&eps, node->op_params, sizeof(float));
+            mi355_tensor ta = T(a);
+            MI_CHECK(mi355_norm_f32(&ta, &td, eps, node->op == GGML_OP_L2_NORM, stream));
             return true;
         }
         case GGML_OP_SCALE: {

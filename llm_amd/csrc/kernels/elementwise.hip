@@ -718,6 +718,76 @@ scale_kernel(const float * x, float * d, float scale, float bias, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) d[i] = x[i] * scale + bias;
 }
 
+// ---------------------------------------------------------------- element-wise maps (UNARY ops, SQR / SQRT / SIN / COS / LOG, CLAMP)
+// the arithmetic of ggml-cpu/unary-ops.cpp:3-65 and vec.h:547-640 (f32 in, f32 out, any strides)
+static __device__ __forceinline__ float map_elem(int op, float x, float p0, float p1) {
+    switch (op) {
+        case MI355_MAP_ABS:         return fabsf(x);
+        case MI355_MAP_SGN:         return x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : 0.0f);
+        case MI355_MAP_NEG:         return -x;
+        case MI355_MAP_STEP:        return x > 0.0f ? 1.0f : 0.0f;
+        case MI355_MAP_TANH:        return tanhf(x);
+        case MI355_MAP_ELU:         return x > 0.0f ? x : expm1f(x);
+        case MI355_MAP_RELU:        return x > 0.0f ? x : 0.0f;
+        case MI355_MAP_SIGMOID:     return 1.0f / (1.0f + expf(-x));
+        case MI355_MAP_GELU:        return 0.5f * x * (1.0f + tanhf(0.79788456080286535587989211986876f * x * (1.0f + 0.044715f * x * x)));
+        case MI355_MAP_GELU_QUICK:  return x * (1.0f / (1.0f + expf(-1.702f * x)));
+        case MI355_MAP_SILU:        return x / (1.0f + expf(-x));
+        case MI355_MAP_HARDSWISH:   return x * fminf(1.0f, fmaxf(0.0f, (x + 3.0f) / 6.0f));
+        case MI355_MAP_HARDSIGMOID: return fminf(1.0f, fmaxf(0.0f, (x + 3.0f) / 6.0f));
+        case MI355_MAP_EXP:         return expf(x);
+        case MI355_MAP_GELU_ERF:    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440084436210484f));
+        case MI355_MAP_SQR:         return x * x;
+        case MI355_MAP_SQRT:        return sqrtf(x);
+        case MI355_MAP_SIN:         return sinf(x);
+        case MI355_MAP_COS:         return cosf(x);
+        case MI355_MAP_LOG:         return logf(x);
+        default:                    return x < p0 ? p0 : (x > p1 ? p1 : x);      // MI355_MAP_CLAMP
+    }
+}
+__global__ void __launch_bounds__(256)
+map_kernel(int op, const T4 x, const T4 d, float p0, float p1, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int64_t i0 = i % d.ne[0], r = i / d.ne[0];
+        const int64_t i1 = r % d.ne[1], r2 = r / d.ne[1];
+        const int64_t i2 = r2 % d.ne[2], i3 = r2 / d.ne[2];
+        const float v = *(const float *)(x.data + i0 * x.nb[0] + i1 * x.nb[1] + i2 * x.nb[2] + i3 * x.nb[3]);
+        *(float *)(d.data + i0 * d.nb[0] + i1 * d.nb[1] + i2 * d.nb[2] + i3 * d.nb[3]) = map_elem(op, v, p0, p1);
+    }
+}
+
+// ---------------------------------------------------------------- NORM (LayerNorm without the affine part) and L2_NORM: one wave per row
+// NORM: mean, then the variance of (x - mean), as ggml_compute_forward_norm_f32 (ops.cpp:3905-3960) does in two passes;
+// L2_NORM: x / max(sqrt(sum x^2), eps) (ops.cpp:4314-4358)
+template <bool L2>
+__global__ void __launch_bounds__(256)
+norm_kernel(const T4 x, const T4 d, float eps, int64_t rows) {
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const int64_t i1 = row % x.ne[1], i2 = (row / x.ne[1]) % x.ne[2], i3 = row / (x.ne[1] * x.ne[2]);
+    const float * xr = (const float *)(x.data + i1 * x.nb[1] + i2 * x.nb[2] + i3 * x.nb[3]);
+    float * dr = (float *)(d.data + i1 * d.nb[1] + i2 * d.nb[2] + i3 * d.nb[3]);
+    const int64_t n = x.ne[0];
+    float mean = 0.0f, scale;
+    if (L2) {
+        float s = 0.0f;
+        for (int64_t i = lane; i < n; i += 64) s += xr[i] * xr[i];
+        s = wave_sum(s);
+        scale = 1.0f / fmaxf(sqrtf(s), eps);
+    } else {
+        float s = 0.0f;
+        for (int64_t i = lane; i < n; i += 64) s += xr[i];
+        mean = wave_sum(s) / (float)n;
+        float s2 = 0.0f;
+        for (int64_t i = lane; i < n; i += 64) { const float v = xr[i] - mean; s2 += v * v; }
+        s2 = wave_sum(s2);
+        scale = 1.0f / sqrtf(s2 / (float)n + eps);
+    }
+    for (int64_t i = lane; i < n; i += 64) dr[i] = (xr[i] - mean) * scale;
+}
+
 // ---------------------------------------------------------------- soft_max (one block per row)
 template <bool MASK_F16>
 __global__ void __launch_bounds__(256)
@@ -1116,6 +1186,33 @@ int mi355_scale_f32(const mi355_tensor * x, const mi355_tensor * dst, float scal
     const int64_t n = nelem(x);
     if (n == 0) return MI355_OK;
     MI355_LAUNCH("scale", scale_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const float *)x->data, (float *)dst->data, scale, bias, n);
+    MI355_CHECK_LAUNCH();
+    return MI355_OK;
+}
+
+int mi355_map_f32(int op, const mi355_tensor * x, const mi355_tensor * dst, float p0, float p1, void * stream) {
+    CHECK_T(x); CHECK_T(dst);
+    if (op < 0 || op > MI355_MAP_CLAMP) return MI355_E_UNSUPPORTED;
+    if (x->type != MI355_TYPE_F32 || dst->type != MI355_TYPE_F32) return MI355_E_TYPE;
+    if (!same_shape(x, dst)) return MI355_E_SHAPE;
+    if (((uintptr_t)x->data | (uintptr_t)dst->data | (uintptr_t)(x->nb[0] | x->nb[1] | x->nb[2] | x->nb[3] | dst->nb[0] | dst->nb[1] | dst->nb[2] | dst->nb[3])) & 3) return MI355_E_ALIGN;
+    const int64_t n = nelem(x);
+    if (n == 0) return MI355_OK;
+    MI355_LAUNCH("map", map_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, op, t4(x), t4(dst), p0, p1, n);
+    MI355_CHECK_LAUNCH();
+    return MI355_OK;
+}
+
+int mi355_norm_f32(const mi355_tensor * x, const mi355_tensor * dst, float eps, int l2, void * stream) {
+    CHECK_T(x); CHECK_T(dst);
+    if (x->type != MI355_TYPE_F32 || dst->type != MI355_TYPE_F32) return MI355_E_TYPE;
+    if (!same_shape(x, dst) || x->nb[0] != 4 || dst->nb[0] != 4 || !(eps >= 0.0f)) return MI355_E_SHAPE;
+    if (((uintptr_t)x->data | (uintptr_t)dst->data | (uintptr_t)(x->nb[1] | x->nb[2] | x->nb[3] | dst->nb[1] | dst->nb[2] | dst->nb[3])) & 3) return MI355_E_ALIGN;
+    const int64_t rows = nrows(x);
+    if (rows == 0 || x->ne[0] == 0) return MI355_OK;
+    if ((rows + 3) / 4 > 0x7fffffff) return MI355_E_SHAPE;
+    if (l2) MI355_LAUNCH("l2_norm", norm_kernel<true>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, t4(x), t4(dst), eps, rows);
+    else    MI355_LAUNCH("norm", norm_kernel<false>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, t4(x), t4(dst), eps, rows);
     MI355_CHECK_LAUNCH();
     return MI355_OK;
 }

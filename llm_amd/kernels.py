@@ -17,7 +17,7 @@ lib = C.CDLL(LIB_PATH)
 
 _vp, _i64, _i32 = C.c_void_p, C.c_int64, C.c_int32
 
-ABI_VERSION = 5          # MI355_ABI_VERSION of include/mi355_kernels.h this binding mirrors
+ABI_VERSION = 6          # MI355_ABI_VERSION of include/mi355_kernels.h this binding mirrors
 
 EXPORTS = [
     "mi355_abi_version", "mi355_args_sizeof", "mi355_error_string", "mi355_blck_size", "mi355_type_size", "mi355_row_size",
@@ -26,7 +26,7 @@ EXPORTS = [
     "mi355_binary_f32", "mi355_rms_norm_f32", "mi355_rms_norm_mul_f32", "mi355_rms_norm_mul_quant_f32", "mi355_glu_quant_f32", "mi355_rms_norm_mul_bf16_f32", "mi355_glu_bf16_f32", "mi355_prefetch", "mi355_parts_add_rms_norm_mul_bf16_f32", "mi355_rms_norm_mul_q8k_f32", "mi355_glu_q8k_f32", "mi355_add_rms_norm_mul_f32", "mi355_mul_mat_vec_q_group", "mi355_qkv_rope_matvec", "mi355_glu_matvec", "mi355_moe_down_matvec", "mi355_rope_f32", "mi355_glu_f32", "mi355_cpy", "mi355_get_rows", "mi355_set_rows", "mi355_mul_mat_f",
     "mi355_scale_f32", "mi355_soft_max_f32", "mi355_flash_attn_ext_workspace_bytes", "mi355_flash_attn_ext", "mi355_flash_attn_ext_quant", "mi355_flash_attn_ext_bf16", "mi355_flash_attn_ext_noalloc_max_bytes", "mi355_flash_attn_ext_noalloc",
     "mi355_dequantize_row", "mi355_mul_mat_vec_q", "mi355_mul_mat_q", "mi355_mul_mat_skinny", "mi355_mul_mat_skinny_slice", "mi355_quantize_act_q8k", "mi355_mul_mat_skinny_k", "mi355_mul_mat_skinny_k_slice", "mi355_mul_mat_skinny_k_group", "mi355_mul_mat_qk", "mi355_mul_mat_id_skinny_workspace_bytes", "mi355_mul_mat_id_skinny", "mi355_mul_mat_id_skinny_pair", "mi355_argsort_f32", "mi355_moe_router_f32", "mi355_sum_rows_f32", "mi355_mul_mat_f32", "mi355_mul_mat_dq", "mi355_mul_mat_dq_slice", "mi355_kv_store_q8_0", "mi355_mul_mat_dq_slice_ws", "mi355_glu_mul_mat_dq", "mi355_mul_mat_dq_parts_bytes", "mi355_mul_mat_dq_parts", "mi355_mul_mat_dq_parts_pair", "mi355_qkv_finish", "mi355_mul_mat_dq_workspace_bytes", "mi355_act_bf16", "mi355_mul_mat_id_dq_workspace_bytes", "mi355_mul_mat_id_dq", "mi355_mul_mat_workspace_bytes", "mi355_mul_mat",
-    "mi355_decode_layer_sync_bytes", "mi355_decode_layer", "mi355_stream_read",
+    "mi355_decode_layer_sync_bytes", "mi355_decode_layer", "mi355_stream_read", "mi355_map_f32", "mi355_norm_f32",
 ]
 
 
@@ -192,6 +192,8 @@ lib.mi355_rms_norm_mul_f32.argtypes = [_T, _vp, _T, C.c_float, _vp]
 lib.mi355_rms_norm_mul_quant_f32.argtypes = [_T, _vp, _T, C.c_float, _vp, _vp, _vp]
 lib.mi355_add_rms_norm_mul_f32.argtypes = [_T, _T, _T, _vp, _T, C.c_float, _vp, _vp, _vp]
 lib.mi355_scale_f32.argtypes = [_T, _T, C.c_float, C.c_float, _vp]
+lib.mi355_map_f32.argtypes = [C.c_int, _T, _T, C.c_float, C.c_float, _vp]
+lib.mi355_norm_f32.argtypes = [_T, _T, C.c_float, C.c_int, _vp]
 lib.mi355_binary_f32.argtypes = [C.c_int, _T, _T, _T, _vp]
 lib.mi355_glu_f32.argtypes = [C.c_int, _T, _T, _T, C.c_int, _vp]
 lib.mi355_glu_quant_f32.argtypes = [C.c_int, _T, _T, _T, C.c_int, _vp, _vp, _vp]

@@ -23,7 +23,7 @@ def test_kernel_library_exports_every_declared_symbol():
 def test_python_binding_lists_the_same_symbols():
     import llm_amd.kernels as K
     assert sorted(K.EXPORTS) == sorted(_declared("mi355_kernels.h"))
-    assert K.lib.mi355_abi_version() == K.ABI_VERSION == 5
+    assert K.lib.mi355_abi_version() == K.ABI_VERSION == 6
 
 
 def test_sizes_match_block_formats():

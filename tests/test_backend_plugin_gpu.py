@@ -15,7 +15,10 @@ TBO = os.path.join(ROOT, "oracle", "_ref", "test-backend-ops")
 PLUGIN = os.path.join(ROOT, "llm_amd", "lib", "libggml-mi355.so")
 
 OPS = ["MUL_MAT", "MUL_MAT_ID", "FLASH_ATTN_EXT", "ADD", "MUL", "SUB", "DIV", "RMS_NORM", "ROPE", "REGLU", "GEGLU", "SWIGLU", "CPY", "CONT", "DUP",
-       "GET_ROWS", "SET_ROWS", "SCALE", "SOFT_MAX", "ARGSORT", "SUM_ROWS"]
+       "GET_ROWS", "SET_ROWS", "SCALE", "SOFT_MAX", "ARGSORT", "SUM_ROWS",
+       # what other model families' graphs add to a Llama / Mixtral graph (Gemma: TANH; Phi / StableLM / Falcon: GELU, NORM; ...)
+       "ABS", "SGN", "NEG", "STEP", "TANH", "ELU", "RELU", "SIGMOID", "GELU", "GELU_QUICK", "SILU", "HARDSWISH", "HARDSIGMOID", "EXP", "GELU_ERF",
+       "SQR", "SQRT", "SIN", "COS", "LOG", "CLAMP", "NORM", "L2_NORM"]
 # lower bounds on the number of cases that must actually RUN on the device (not "not supported")
 MIN_RUN = {"MUL_MAT": 640, "SET_ROWS": 50, "MUL_MAT_ID": 160, "FLASH_ATTN_EXT": 1900, "ROPE": 50, "SOFT_MAX": 100}
 
