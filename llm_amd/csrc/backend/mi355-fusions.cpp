@@ -646,7 +646,7 @@ static bool mi355_try_fuse_moe_router(mi355_backend_ctx * ctx, ggml_cgraph * cgr
     const ggml_tensor * g = mm->src[0], * x = mm->src[1];
     if (g->type != GGML_TYPE_F32 || x->type != GGML_TYPE_F32 || tensor_is_split(g)) return false;
     const int64_t K = g->ne[0], E = g->ne[1], T = x->ne[1];
-    if (g->ne[2] != 1 || g->ne[3] != 1 || x->ne[2] != 1 || x->ne[3] != 1 || E < 1 || E > 256 || T < 1 || T > 16) return false;
+    if (g->ne[2] != 1 || g->ne[3] != 1 || x->ne[2] != 1 || x->ne[3] != 1 || E < 1 || E > 256 || T < 1 || T > 64) return false;
     if (g->nb[0] != sizeof(float) || x->nb[0] != sizeof(float) || !ggml_is_contiguous(mm)) return false;
     // The chain's nodes in graph order; llama.cpp's graph puts the three expert MUL_MAT_IDs between the top-k and the
     // weight gathering, so other nodes may sit in between -- they are remembered and checked below.
@@ -694,25 +694,48 @@ static bool mi355_try_fuse_moe_router(mi355_backend_ctx * ctx, ggml_cgraph * cgr
         // ... and none may overwrite the probabilities or the order before the (now earlier) gathering would have read them
         if (ranges_overlap(t->data, ggml_nbytes(t), sm->data, ggml_nbytes(sm)) || ranges_overlap(t->data, ggml_nbytes(t), as->data, ggml_nbytes(as))) return false;
     }
-    // outputs: pairwise disjoint, or exactly the same rows (in-place reuse by ggml-alloc); inputs untouched
+    // Several tokens = several workgroups in flight.  The logits are dead once the probabilities exist, the probabilities once the
+    // weights are gathered, the weight sums once the division is done -- so ggml-alloc hands the bytes of the first two to the third,
+    // and one token's sum would land in another token's probabilities while those are still being read.  A tensor of the chain that
+    // nobody outside the chain reads goes to scratch instead, and its node's bytes are left alone.
     const ggml_tensor * outs[6] = {mm, sm, as, gr, sr, dv};
+    bool aside[6] = {false, false, false, false, false, false};
+    if (T > 1) {
+        auto inside_only = [&](const ggml_tensor * t, std::initializer_list<const ggml_tensor *> readers) {
+            if (t->flags & GGML_TENSOR_FLAG_OUTPUT) return false;
+            for (int j = 0; j < n; j++) {
+                const ggml_tensor * r = ggml_graph_node(cgraph, j);
+                bool known = false;
+                for (const ggml_tensor * k : readers) known |= r == k;
+                if (known) continue;
+                for (int k = 0; k < GGML_MAX_SRC; k++) if (r->src[k] && view_root(r->src[k]) == t) return false;
+            }
+            return true;
+        };
+        aside[0] = inside_only(mm, {sm});
+        aside[1] = inside_only(sm, {as, gr});
+        aside[4] = inside_only(sr, {dv});
+    }
+    // outputs: pairwise disjoint, or exactly the same rows (in-place reuse by ggml-alloc); inputs untouched
     const size_t rowb[6] = {(size_t)E * 4, (size_t)E * 4, (size_t)E * 4, (size_t)U * 4, 4, (size_t)U * 4};
     for (int p = 0; p < 6; p++) {
+        if (aside[p]) continue;
         if (ranges_overlap(outs[p]->data, ggml_nbytes(outs[p]), x->data, ggml_nbytes(x)) ||
             ranges_overlap(outs[p]->data, ggml_nbytes(outs[p]), g->data, ggml_nbytes(g))) return false;
         for (int q = p + 1; q < 6; q++) {
-            if (!ranges_overlap(outs[p]->data, ggml_nbytes(outs[p]), outs[q]->data, ggml_nbytes(outs[q]))) continue;
+            if (aside[q] || !ranges_overlap(outs[p]->data, ggml_nbytes(outs[p]), outs[q]->data, ggml_nbytes(outs[q]))) continue;
             if (T > 1 && (outs[p]->data != outs[q]->data || rowb[p] != rowb[q])) return false;
             // one token = one workgroup: logits, probs and order are written in phases separated by barriers, so a later
             // tensor may reuse an earlier one's memory freely; the last three are written together by one wave
             if (T == 1 && p >= 3 && !(p == 3 && q == 5 && outs[p]->data == outs[q]->data)) return false;
         }
     }
+    float * side = aside[0] || aside[1] || aside[4] ? (float *)ctx->get_scratch(6, (size_t)(2 * E + 1) * T * sizeof(float)) : nullptr;
     MI_CHECK(mi355_moe_router_f32((const float *)x->data, (int64_t)x->nb[1], (const float *)g->data, (int64_t)g->nb[1], K, E, U, T,
-                                  (float *)mm->data, (float *)sm->data, (int32_t *)as->data, (float *)gr->data, (float *)sr->data,
-                                  (float *)dv->data, ctx->stream));
+                                  aside[0] ? side : (float *)mm->data, aside[1] ? side + E * T : (float *)sm->data, (int32_t *)as->data, (float *)gr->data,
+                                  aside[4] ? side + 2 * E * T : (float *)sr->data, (float *)dv->data, ctx->stream));
     for (int m = 0; m < 5; m++) done[idx[m]] = 1;
-    for (const ggml_tensor * o : outs) ctx->act_invalidate_if_written(o);
+    for (int p = 0; p < 6; p++) if (!aside[p]) ctx->act_invalidate_if_written(outs[p]);
     return true;
 }
 

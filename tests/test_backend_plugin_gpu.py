@@ -78,6 +78,22 @@ def test_mixtral_style_graph_runs_entirely_on_the_device(tmp_path):
     assert e_cpu < 0.5 and e_gpu <= 1.25 * e_cpu + 1e-3, (e_cpu, e_gpu, d)
 
 
+def test_moe_router_is_one_launch_for_small_batches_too():
+    """Steps of 2..64 tokens: the router chain (MUL_MAT SOFT_MAX ARGSORT GET_ROWS SUM_ROWS DIV) is mi355_moe_router_f32's one launch per
+    layer, as for one token.  ggml-alloc lays the weight sums over the dead logits / probabilities, which with several workgroups in
+    flight would be a race: the chain's tensors that nobody outside it reads go to scratch (bit-exactness of the fused graph for 2-, 3- and
+    12-token batches: test_fusions_are_bit_exact[tinymoe])."""
+    tool = os.path.join(ROOT, "tools", "run_llama_bench.sh")
+    env = dict(os.environ, GGML_MI355_KERNEL_TIMES="1")
+    r = subprocess.run([tool, "tinymoe", "Q4_K_M", "-p", "12", "-n", "0", "-r", "2"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    count = lambda name: sum(int(m.group(1)) for m in re.finditer(r"\[mi355\] kernel %s (\d+) " % name, r.stderr))
+    # 4 layers x (1 warm-up + 2 timed) steps.  The last layer of each step routes one token (the only output row) and stays unfused:
+    # ggml-alloc puts its gathered weights on the bytes of the layer's dead input there, which the experts still read when the fused
+    # launch would write them
+    assert count("moe_router") == 9 and count("argsort") == 3 and count("soft_max") == 3, r.stderr[-2000:]
+
+
 def _env_for(ngl):
     """reference runs (-ngl 0) are ggml-cpu alone: with the plugin loaded the scheduler would offload their large batches to it"""
     env = dict(os.environ)
