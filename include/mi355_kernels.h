@@ -363,6 +363,21 @@ MI355_API int mi355_mul_mat_id_skinny_pair(int type, const void *as0, const void
                                            const float *b, int64_t b_nb1, int64_t b_nb2, const int32_t *ids, int64_t ids_stride,
                                            float *dst0, float *dst1, int64_t m, int64_t k, int64_t n_expert, int64_t n_used,
                                            int64_t n_tokens, int64_t b_ne1, void *workspace, int64_t workspace_bytes, void *stream);
+/* The same launches with the two preparatory steps open to the caller (ggml-cuda's MUL_MAT_ID re-sorts the ids on the host and
+ * re-quantizes b in every call, ggml-cuda.cu:2065-2206, mmq.cu:141-223): as1 / dst1 may be NULL (one tensor, as mi355_mul_mat_id_skinny) or given (as
+ * _pair).  `tables` (mi355_mul_mat_id_tables_bytes, 4-byte aligned; NULL: inside the workspace): where the routing tables of these ids
+ * are built -- and kept, so that the next MUL_MAT_ID on the same ids (ffn_down after ffn_up / ffn_gate) can pass
+ * MI355_IDS_TABLES_READY and skip the bucketing launch.  MI355_IDS_ACT_READY: the workspace already starts with b's activation
+ * planes in the layout of mi355_quantize_act_q8k (K-quants: q at 0, d at up256(rows k), bsums after up256(rows k / 256 * 4)) or
+ * mi355_quantize_act (other types) -- written by the launch that produced b (mi355_rms_norm_mul_q8k_f32, mi355_glu_q8k_f32). */
+#define MI355_IDS_ACT_READY    1
+#define MI355_IDS_TABLES_READY 2
+MI355_API int64_t mi355_mul_mat_id_tables_bytes(int64_t n_tokens, int64_t n_used, int64_t n_expert);
+MI355_API int mi355_mul_mat_id_skinny_ex(int type, const void *as0, const void *as1, int64_t w_row_stride, int64_t w_expert_stride,
+                                         const float *b, int64_t b_nb1, int64_t b_nb2, const int32_t *ids, int64_t ids_stride, float *dst0,
+                                         float *dst1, int64_t m, int64_t k, int64_t n_expert, int64_t n_used, int64_t n_tokens, int64_t b_ne1,
+                                         void *workspace, int64_t workspace_bytes, int32_t *tables, int flags, void *stream);
+
 
 /* Prefill MUL_MAT of a K-quant (Q4_K, Q5_K; others MI355_E_UNSUPPORTED) on q8_K activations, any n: the tile-kernel
  * form of mi355_mul_mat_skinny_k (64 rows x 128 columns per workgroup, digit planes prepared once per weight while the

@@ -518,7 +518,7 @@ static void mi355_backend_free(ggml_backend_t backend) {
     mi355_backend_ctx * ctx = (mi355_backend_ctx *)backend->context;
     mi355_set_device(ctx->device);
     HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    for (int i = 0; i < 8; i++) if (ctx->scratch[i]) HIP_CHECK(hipFree(ctx->scratch[i]));
+    for (int i = 0; i < 9; i++) if (ctx->scratch[i]) HIP_CHECK(hipFree(ctx->scratch[i]));
     if (MI355_ENV_SET("GGML_MI355_KERNEL_TIMES")) {      // per-kernel launch counts and device time of the whole process so far
         std::vector<char> rep((size_t)mi355_timing_report(nullptr, 0));
         mi355_timing_report(rep.data(), (int64_t)rep.size());

@@ -115,9 +115,10 @@ struct mi355_backend_ctx {
     //   [5] the sync blocks of a token's persistent decode-layer launches (mi355_decode_layer), cleared by one memset per graph
     // [0] activations of the current MUL_MAT, [1] attention workspace, [2] the other activation buffer (swap_act_scratch), [3] split-K workspace
     // of the prefill GEMM / its Q-K-V planes, [4] f32 K / V rows on their way into a q8_0 cache, [5] decode-layer sync blocks, [6] a row nobody
-    // reads (mi355_try_fuse_glu_matvec), [7] the Q / K / V planes of a small batch (whose members may run a GEMM that uses [3])
-    void * scratch[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    size_t scratch_size[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    // reads (mi355_try_fuse_glu_matvec), [7] the Q / K / V planes of a small batch (whose members may run a GEMM that uses [3]),
+    // [8] the routing tables of a MoE layer's ids (built by the up / gate launch, reused by the down launch)
+    void * scratch[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t scratch_size[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     int dl_used = 0;                // decode-layer launches issued for the graph in flight (= sync blocks handed out)
     void swap_act_scratch() { std::swap(scratch[0], scratch[2]); std::swap(scratch_size[0], scratch_size[2]); }
 
@@ -131,6 +132,28 @@ struct mi355_backend_ctx {
         int64_t ne[4] = {0, 0, 0, 0};
         size_t nb[4] = {0, 0, 0, 0};
     } act_cache;
+    // the ids tensor whose routing tables (moe_bucket) currently sit in scratch[8]: the MUL_MAT_IDs of one MoE layer share their ids.
+    // Dropped as soon as any node writes into the ids, with every new graph, and when scratch[8] moves.
+    struct {
+        bool valid = false;
+        const void * data = nullptr;
+        size_t span = 0;
+        int64_t n_tokens = 0, n_used = 0, n_expert = 0, stride = 0;
+    } moe_tables;
+    bool moe_tables_cached(const ggml_tensor * ids, int64_t n_expert) const {
+        return moe_tables.valid && moe_tables.data == ids->data && moe_tables.n_tokens == ids->ne[1] && moe_tables.n_used == ids->ne[0] &&
+               moe_tables.n_expert == n_expert && moe_tables.stride == (int64_t)ids->nb[1];
+    }
+    void moe_tables_remember(const ggml_tensor * ids, int64_t n_expert) {
+        moe_tables.valid = true; moe_tables.data = ids->data; moe_tables.span = ggml_nbytes(ids);
+        moe_tables.n_tokens = ids->ne[1]; moe_tables.n_used = ids->ne[0]; moe_tables.n_expert = n_expert; moe_tables.stride = (int64_t)ids->nb[1];
+    }
+    // the activation planes of `rows` rows of K values starting at `data`, whatever shape the reader's view of them has
+    bool act_cached_rows(const void * data, int64_t K, int64_t rows, int fmt) const {
+        if (!act_cache.valid || act_cache.data != data || act_cache.fmt != fmt || act_cache.ne[0] != K || act_cache.nb[0] != sizeof(float)) return false;
+        if (act_cache.ne[1] * act_cache.ne[2] * act_cache.ne[3] != rows || act_cache.span != (size_t)(rows * K) * sizeof(float)) return false;
+        return true;        // span == rows * K * 4: the cached tensor was contiguous
+    }
 
     // row split: this stream is the "main" one of a split MUL_MAT; every other device that owns rows gets a
     // helper stream, a copy of the quantized activations and an event the main stream waits on
@@ -226,6 +249,7 @@ struct mi355_backend_ctx {
             gc.drop();
         }
         if (which == 0) act_cache.valid = false;
+        if (which == 8) moe_tables.valid = false;
         scratch_size[which] = (need + (8u << 20)) & ~((size_t)(1u << 20) - 1);
         HIP_CHECK(hipMalloc(&scratch[which], scratch_size[which]));
         // the flash-attention workspace starts with arrival counters that must be zero before the first use
@@ -249,6 +273,11 @@ struct mi355_backend_ctx {
         for (int i = 0; i < 4; i++) { act_cache.ne[i] = t->ne[i]; act_cache.nb[i] = t->nb[i]; }
     }
     void act_invalidate_if_written(const ggml_tensor * node) {
+        if (moe_tables.valid) {
+            const char * w0 = (const char *)node->data, * w1 = w0 + ggml_nbytes(node);
+            const char * c0 = (const char *)moe_tables.data, * c1 = c0 + moe_tables.span;
+            if (w0 < c1 && c0 < w1) moe_tables.valid = false;
+        }
         if (!act_cache.valid) return;
         const char * w0 = (const char *)node->data, * w1 = w0 + ggml_nbytes(node);
         const char * c0 = (const char *)act_cache.data, * c1 = c0 + act_cache.span;

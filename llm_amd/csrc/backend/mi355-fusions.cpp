@@ -1357,6 +1357,7 @@ static bool mi355_try_fuse_decode_layer(mi355_backend_ctx * ctx, ggml_cgraph * c
 // issue the launches of a graph on ctx->stream (eagerly, or into the stream capture in progress)
 enum ggml_status mi355_issue_graph(mi355_backend_ctx * ctx, ggml_cgraph * cgraph) {
     ctx->act_cache.valid = false; // tensors may have been rewritten through set_tensor / copies between calls
+    ctx->moe_tables.valid = false;
     ctx->dl_used = 0;
     const int n = ggml_graph_n_nodes(cgraph);
     const bool fuse = !MI355_ENV_SET("GGML_MI355_NO_FUSE");

@@ -351,6 +351,37 @@ static bool moe_skinny_regime(const ggml_tensor * dst) {
 // MUL_MAT_ID(ffn_up_exps) and MUL_MAT_ID(ffn_gate_exps) of a MoE layer (two consecutive nodes on the same b and ids, build_moe_ffn) in
 // the skinny regime: ONE launch -- one activation quantization, one bucketing, one grid over both tensors' row tiles
 // (mi355_mul_mat_id_skinny_pair; each result has the bits of its own launch).  GGML_MI355_NO_MOE_PAIR=1 launches them one by one.
+// What a skinny MUL_MAT_ID launch finds prepared: its activation planes in scratch[0] -- written by the launch that produced b (the norm
+// or the GLU, see mi355_try_fuse_rms_norm_mul / mi355_glu_with_quant) or by an earlier MUL_MAT_ID on the same b -- and the routing tables of
+// its ids in scratch[8] (the layer's up / gate launch built them; ffn_down routes by the same ids).  Returns the flags for
+// mi355_mul_mat_id_skinny_ex; *tables: where the tables are or go (NULL: inside the workspace).  Call after get_scratch(0, need).
+static int moe_skinny_prepared(mi355_backend_ctx * ctx, const ggml_tensor * b, const ggml_tensor * ids, enum ggml_type type, int64_t n_expert, int32_t ** tables) {
+    *tables = nullptr;
+    if (MI355_ENV_SET("GGML_MI355_NO_MOE_READY") || MI355_ENV_SET("GGML_MI355_NO_FUSE")) { ctx->act_cache.valid = false; ctx->moe_tables.valid = false; return 0; }
+    int flags = 0;
+    const bool kq = type == GGML_TYPE_Q4_K || type == GGML_TYPE_Q5_K || type == GGML_TYPE_Q6_K;
+    const int64_t K = b->ne[0], rows = b->ne[1] * b->ne[2];
+    const bool dense_b = b->nb[0] == sizeof(float) && b->nb[1] == (size_t)K * sizeof(float) && b->nb[2] == (size_t)K * b->ne[1] * sizeof(float);
+    if (dense_b && ctx->act_cached_rows(b->data, K, rows, kq ? 2 : 0)) flags |= MI355_IDS_ACT_READY;
+    const int64_t tb = mi355_mul_mat_id_tables_bytes(ids->ne[1], ids->ne[0], n_expert);
+    if (tb > 0) {
+        const bool cached = ctx->moe_tables_cached(ids, n_expert);       // (asked before get_scratch, which forgets them if the block moves)
+        int32_t * t = (int32_t *)ctx->get_scratch(8, (size_t)tb);
+        if (ctx->scratch_size[8] >= (size_t)tb) {
+            *tables = t;
+            if (cached && ctx->moe_tables.valid) flags |= MI355_IDS_TABLES_READY;
+        }
+    }
+    return flags;
+}
+// ... and what it leaves behind: b's planes at the start of scratch[0], the tables in scratch[8]
+static void moe_skinny_remember(mi355_backend_ctx * ctx, const ggml_tensor * b, const ggml_tensor * ids, enum ggml_type type, int64_t n_expert, const int32_t * tables) {
+    const bool kq = type == GGML_TYPE_Q4_K || type == GGML_TYPE_Q5_K || type == GGML_TYPE_Q6_K;
+    if (ggml_is_contiguous(b) && !MI355_ENV_SET("GGML_MI355_NO_MOE_READY") && !MI355_ENV_SET("GGML_MI355_NO_FUSE")) ctx->act_remember(b, kq ? 2 : 0);
+    else ctx->act_cache.valid = false;
+    if (tables) ctx->moe_tables_remember(ids, n_expert); else ctx->moe_tables.valid = false;
+}
+
 bool mi355_mul_mat_id_pair(mi355_backend_ctx * ctx, ggml_tensor * d0, ggml_tensor * d1) {
     if (d0->op != GGML_OP_MUL_MAT_ID || d1->op != GGML_OP_MUL_MAT_ID || MI355_ENV_SET("GGML_MI355_NO_MOE_PAIR")) return false;
     const ggml_tensor * a0 = d0->src[0], * a1 = d1->src[0], * b = d0->src[1], * ids = d0->src[2];
@@ -366,12 +397,15 @@ bool mi355_mul_mat_id_pair(mi355_backend_ctx * ctx, ggml_tensor * d0, ggml_tenso
     const int64_t need = mi355_mul_mat_id_skinny_workspace_bytes((int)a0->type, K, n_tokens, b_ne1, n_used, n_expert);
     void * ws = ctx->get_scratch(0, (size_t)need);
     if (ctx->scratch_size[0] < (size_t)need) return false;
-    ctx->act_cache.valid = false;
-    const int rc = mi355_mul_mat_id_skinny_pair((int)a0->type, a0->data, a1->data, (int64_t)a0->nb[1], (int64_t)a0->nb[2], (const float *)b->data,
-                                                (int64_t)b->nb[1], (int64_t)b->nb[2], (const int32_t *)ids->data, (int64_t)(ids->nb[1] / sizeof(int32_t)),
-                                                (float *)d0->data, (float *)d1->data, M, K, n_expert, n_used, n_tokens, b_ne1, ws, need, ctx->stream);
-    if (rc == MI355_E_UNSUPPORTED || rc == MI355_E_ALIGN) return false;
+    int32_t * tables = nullptr;
+    const int flags = moe_skinny_prepared(ctx, b, ids, a0->type, n_expert, &tables);
+    const int rc = mi355_mul_mat_id_skinny_ex((int)a0->type, a0->data, a1->data, (int64_t)a0->nb[1], (int64_t)a0->nb[2], (const float *)b->data,
+                                              (int64_t)b->nb[1], (int64_t)b->nb[2], (const int32_t *)ids->data, (int64_t)(ids->nb[1] / sizeof(int32_t)),
+                                              (float *)d0->data, (float *)d1->data, M, K, n_expert, n_used, n_tokens, b_ne1, ws, need, tables, flags,
+                                              ctx->stream);
+    if (rc == MI355_E_UNSUPPORTED || rc == MI355_E_ALIGN) { ctx->act_cache.valid = false; ctx->moe_tables.valid = false; return false; }
     MI_CHECK(rc);
+    moe_skinny_remember(ctx, b, ids, a0->type, n_expert, tables);
     return true;
 }
 
@@ -399,12 +433,14 @@ void mi355_mul_mat_id(mi355_backend_ctx * ctx, ggml_tensor * dst) {
         !MI355_ENV_SET("GGML_MI355_NO_SKINNY")) {
         const int64_t need = mi355_mul_mat_id_skinny_workspace_bytes((int)as->type, K, n_tokens, b_ne1, n_used, n_expert);
         void * ws = ctx->get_scratch(0, (size_t)need);
-        ctx->act_cache.valid = false;
-        const int rc = mi355_mul_mat_id_skinny((int)as->type, as->data, (int64_t)as->nb[1], (int64_t)as->nb[2], (const float *)b->data,
-                                               (int64_t)b->nb[1], (int64_t)b->nb[2], (const int32_t *)ids->data,
-                                               (int64_t)(ids->nb[1] / sizeof(int32_t)), (float *)dst->data, M, K, n_expert, n_used,
-                                               n_tokens, b_ne1, ws, need, ctx->stream);
-        if (rc == MI355_OK) return;
+        int32_t * tables = nullptr;
+        const int flags = moe_skinny_prepared(ctx, b, ids, as->type, n_expert, &tables);
+        const int rc = mi355_mul_mat_id_skinny_ex((int)as->type, as->data, nullptr, (int64_t)as->nb[1], (int64_t)as->nb[2], (const float *)b->data,
+                                                  (int64_t)b->nb[1], (int64_t)b->nb[2], (const int32_t *)ids->data,
+                                                  (int64_t)(ids->nb[1] / sizeof(int32_t)), (float *)dst->data, nullptr, M, K, n_expert, n_used,
+                                                  n_tokens, b_ne1, ws, need, tables, flags, ctx->stream);
+        if (rc == MI355_OK) { moe_skinny_remember(ctx, b, ids, as->type, n_expert, tables); return; }
+        ctx->act_cache.valid = false; ctx->moe_tables.valid = false;
         if (rc != MI355_E_UNSUPPORTED) MI_CHECK(rc);
     }
     // prefill-sized batches: bucket the (token, slot) pairs by expert on the device and run one bf16-MFMA GEMM over all
@@ -615,7 +651,16 @@ bool mi355_try_fuse_rms_norm_mul(mi355_backend_ctx * ctx, ggml_cgraph * cgraph, 
         int fmt = -1;
         for (int j = i + 2; j < nn && j < i + 16 && fmt < 0; j++) {
             const ggml_tensor * t = ggml_graph_node(cgraph, j);
-            if (t->op == GGML_OP_MUL_MAT && t->src[1] == mul && !tensor_is_split(t->src[0])) fmt = mm_path_fmt(mi355_mul_mat_path(t->src[0], mul, t));
+            if (t->op == GGML_OP_MUL_MAT && t->src[1] == mul && !tensor_is_split(t->src[0])) {
+                const int path = mi355_mul_mat_path(t->src[0], mul, t);
+                if (path == MM_FLOAT) continue;          // a float-weight product (the MoE router) reads the f32 rows themselves
+                fmt = mm_path_fmt(path);
+            }
+            // the experts of a MoE layer in the skinny regime read the q8_K planes too (the tensor they name is a reshaped view of the result)
+            if (t->op == GGML_OP_MUL_MAT_ID && t->src[1]->data == mul->data && (t->src[1] == mul || t->src[1]->view_src == mul) && moe_skinny_regime(t) &&
+                t->src[1]->ne[0] == K && t->src[1]->ne[1] * t->src[1]->ne[2] == rows && ggml_is_contiguous(t->src[1]) &&
+                (t->src[0]->type == GGML_TYPE_Q4_K || t->src[0]->type == GGML_TYPE_Q5_K || t->src[0]->type == GGML_TYPE_Q6_K) &&
+                !MI355_ENV_SET("GGML_MI355_NO_MOE_READY")) fmt = 2;
         }
         if (fmt == 2) {
             const mi355_act_layout L = mi355_act_planes(MM_SKINNY_K, K, rows);
@@ -726,6 +771,20 @@ static bool mi355_glu_with_quant(mi355_backend_ctx * ctx, ggml_tensor * node, co
         mi355_mul_mat_path(next->src[0], node) == MM_SKINNY_K && !MI355_ENV_SET("GGML_MI355_NO_NORM_Q8K")) {
         const mi355_act_layout L = mi355_act_planes(MM_SKINNY_K, K, rows);
         char * ws = (char *)ctx->get_scratch(0, L.total());
+        const int rc = mi355_glu_q8k_f32((int)ggml_get_glu_op(node), &ta, b ? &tb : nullptr, &td, ((const int32_t *)node->op_params)[1],
+                                         (int8_t *)ws, (float *)(ws + L.b0), (int16_t *)(ws + L.b0 + L.b1), ctx->stream);
+        if (rc == MI355_OK) { ctx->act_remember(node, 2); return true; }
+        if (rc != MI355_E_UNSUPPORTED) MI_CHECK(rc);
+    }
+    // ... and the same for the experts' ffn_down of a MoE layer in the skinny regime (its MUL_MAT_ID would quantize the rows itself)
+    if (next && next->op == GGML_OP_MUL_MAT_ID && next->src[1] == node && rows > 1 && K % 256 == 0 && moe_skinny_regime(next) &&
+        (next->src[0]->type == GGML_TYPE_Q4_K || next->src[0]->type == GGML_TYPE_Q5_K || next->src[0]->type == GGML_TYPE_Q6_K) &&
+        !MI355_ENV_SET("GGML_MI355_NO_NORM_Q8K") && !MI355_ENV_SET("GGML_MI355_NO_MOE_READY")) {
+        const mi355_act_layout L = mi355_act_planes(MM_SKINNY_K, K, rows);
+        // sized for the MUL_MAT_ID's whole workspace already, so that its own request does not move the block
+        const ggml_tensor * ids = next->src[2];
+        const int64_t need = mi355_mul_mat_id_skinny_workspace_bytes((int)next->src[0]->type, K, node->ne[2], node->ne[1], ids->ne[0], next->src[0]->ne[2]);
+        char * ws = (char *)ctx->get_scratch(0, std::max(L.total(), (size_t)(need > 0 ? need : 0)));
         const int rc = mi355_glu_q8k_f32((int)ggml_get_glu_op(node), &ta, b ? &tb : nullptr, &td, ((const int32_t *)node->op_params)[1],
                                          (int8_t *)ws, (float *)(ws + L.b0), (int16_t *)(ws + L.b0 + L.b1), ctx->stream);
         if (rc == MI355_OK) { ctx->act_remember(node, 2); return true; }

@@ -1045,7 +1045,28 @@ extern "C" int64_t mi355_mul_mat_id_skinny_workspace_bytes(int type, int64_t k, 
 static int mul_mat_id_skinny_impl(int type, const void * as, const void * as2, int64_t w_row_stride, int64_t w_expert_stride, const float * b,
                                   int64_t b_nb1, int64_t b_nb2, const int32_t * ids, int64_t ids_stride, float * dst, float * dst2, int64_t m,
                                   int64_t k, int64_t n_expert, int64_t n_used, int64_t n_tokens, int64_t b_ne1, void * workspace,
-                                  int64_t workspace_bytes, void * stream);
+                                  int64_t workspace_bytes, void * stream, int32_t * tables = nullptr, int flags = 0);
+
+extern "C" int64_t mi355_mul_mat_id_tables_bytes(int64_t n_tokens, int64_t n_used, int64_t n_expert) {
+    if (n_tokens < 0 || n_used < 1 || n_expert < 1) return -1;
+    return ((n_tokens * n_used + 2 * (n_expert + 1)) * 4 + 255) / 256 * 256;
+}
+
+// as2 / dst2 may be NULL (one tensor).  tables: the routing tables' place when they should outlive the call (else inside the workspace);
+// flags: MI355_IDS_ACT_READY the workspace already starts with b's activation planes, MI355_IDS_TABLES_READY `tables` already holds the
+// tables of these ids
+extern "C" int mi355_mul_mat_id_skinny_ex(int type, const void * as0, const void * as1, int64_t w_row_stride, int64_t w_expert_stride,
+                                          const float * b, int64_t b_nb1, int64_t b_nb2, const int32_t * ids, int64_t ids_stride, float * dst0,
+                                          float * dst1, int64_t m, int64_t k, int64_t n_expert, int64_t n_used, int64_t n_tokens, int64_t b_ne1,
+                                          void * workspace, int64_t workspace_bytes, int32_t * tables, int flags, void * stream) {
+    if ((as1 == nullptr) != (dst1 == nullptr)) return MI355_E_NULL;
+    if (flags & ~3) return MI355_E_UNSUPPORTED;
+    if ((flags & MI355_IDS_TABLES_READY) && !tables) return MI355_E_NULL;
+    if ((uintptr_t)tables & 3) return MI355_E_ALIGN;
+    if (as1 && type != MI355_TYPE_Q4_K && type != MI355_TYPE_Q5_K && type != MI355_TYPE_Q6_K) return mi355_blck_size(type) ? MI355_E_UNSUPPORTED : MI355_E_TYPE;
+    return mul_mat_id_skinny_impl(type, as0, as1, w_row_stride, w_expert_stride, b, b_nb1, b_nb2, ids, ids_stride, dst0, dst1, m, k, n_expert, n_used,
+                                  n_tokens, b_ne1, workspace, workspace_bytes, stream, tables, flags);
+}
 
 extern "C" int mi355_mul_mat_id_skinny(int type, const void * as, int64_t w_row_stride, int64_t w_expert_stride, const float * b,
                                        int64_t b_nb1, int64_t b_nb2, const int32_t * ids, int64_t ids_stride, float * dst, int64_t m,
@@ -1072,7 +1093,7 @@ extern "C" int mi355_mul_mat_id_skinny_pair(int type, const void * as0, const vo
 static int mul_mat_id_skinny_impl(int type, const void * as, const void * as2, int64_t w_row_stride, int64_t w_expert_stride, const float * b,
                                   int64_t b_nb1, int64_t b_nb2, const int32_t * ids, int64_t ids_stride, float * dst, float * dst2, int64_t m,
                                   int64_t k, int64_t n_expert, int64_t n_used, int64_t n_tokens, int64_t b_ne1, void * workspace,
-                                  int64_t workspace_bytes, void * stream) {
+                                  int64_t workspace_bytes, void * stream, int32_t * tables, int flags) {
     if (!as || !b || !ids || !dst || !workspace) return MI355_E_NULL;
     const int64_t bs = mi355_blck_size(type);
     if (bs == 0 || type == MI355_TYPE_F32 || type == MI355_TYPE_F16 || type == MI355_TYPE_Q8_1) return MI355_E_TYPE;
@@ -1091,15 +1112,19 @@ static int mul_mat_id_skinny_impl(int type, const void * as, const void * as2, i
     int64_t b0, b1, b2;
     const int64_t act_bytes = ids_ws_layout(type, k, rows, &b0, &b1, &b2);
     char * ws = (char *)workspace;
-    int * sorted = (int *)(ws + act_bytes);
+    int * sorted = tables ? tables : (int *)(ws + act_bytes);
     int * off = sorted + n_tokens * n_used, * tile_off = off + n_expert + 1;
     // activations of all tokens, then the routing tables
-    int rc = kq ? mi355_quantize_act_q8k(b, (int8_t *)ws, (float *)(ws + b0), (int16_t *)(ws + b0 + b1), k, b_ne1, n_tokens, 1, b_nb1, b_nb2, 0, stream)
-                : mi355_quantize_act(b, (int8_t *)ws, (float *)(ws + b0), k, b_ne1, n_tokens, 1, b_nb1, b_nb2, 0, stream);
-    if (rc != MI355_OK) return rc;
-    MI355_LAUNCH("moe_bucket", moe_bucket_kernel, dim3(1), dim3(1024), 0, s, ids, ids_stride, (int)n_tokens, (int)n_used, (int)n_expert, 32,
-                 sorted, off, tile_off);
-    MI355_CHECK_LAUNCH();
+    if (!(flags & MI355_IDS_ACT_READY)) {
+        const int rc = kq ? mi355_quantize_act_q8k(b, (int8_t *)ws, (float *)(ws + b0), (int16_t *)(ws + b0 + b1), k, b_ne1, n_tokens, 1, b_nb1, b_nb2, 0, stream)
+                          : mi355_quantize_act(b, (int8_t *)ws, (float *)(ws + b0), k, b_ne1, n_tokens, 1, b_nb1, b_nb2, 0, stream);
+        if (rc != MI355_OK) return rc;
+    }
+    if (!(flags & MI355_IDS_TABLES_READY)) {
+        MI355_LAUNCH("moe_bucket", moe_bucket_kernel, dim3(1), dim3(1024), 0, s, ids, ids_stride, (int)n_tokens, (int)n_used, (int)n_expert, 32,
+                     sorted, off, tile_off);
+        MI355_CHECK_LAUNCH();
+    }
     IdsArgs I;
     I.sorted = sorted; I.off = off; I.tile_off = tile_off; I.n_expert = (int)n_expert; I.n_used = (int)n_used; I.act_ne1 = (int)b_ne1;
     I.w_expert_stride = w_expert_stride;

@@ -388,6 +388,21 @@ def mul_mat_id_skinny_pair(t, as0, as1, b, ids, m, n_expert):
     return d0, d1
 
 
+def mul_mat_id_skinny_ex(t, as0, as1, b, ids, m, n_expert, ws, tables, flags):
+    """mi355_mul_mat_id_skinny_ex on a caller-kept workspace and routing-table buffer (flags: 1 = the workspace already holds b's
+    activation planes, 2 = `tables` already holds the tables of these ids); as1 None: one tensor -> dst0 (, dst1)."""
+    n_tok, b_ne1, k = b.shape
+    n_used = ids.shape[1]
+    rs = B.row_size(t, k)
+    d0 = torch.full((n_tok, n_used, m), float("nan"), dtype=torch.float32, device=b.device)
+    d1 = torch.full((n_tok, n_used, m), float("nan"), dtype=torch.float32, device=b.device) if as1 is not None else None
+    K.check(K.lib.mi355_mul_mat_id_skinny_ex(t, as0.data_ptr(), as1.data_ptr() if as1 is not None else None, rs, rs * m, b.data_ptr(), k * 4,
+                                             b_ne1 * k * 4, ids.data_ptr(), n_used, d0.data_ptr(), d1.data_ptr() if d1 is not None else None, m, k,
+                                             n_expert, n_used, n_tok, b_ne1, ws.data_ptr(), ws.numel(), tables.data_ptr() if tables is not None else None,
+                                             flags, _stream()), "mi355_mul_mat_id_skinny_ex")
+    return (d0, d1) if as1 is not None else d0
+
+
 def mul_mat_skinny(t, w, b, m):
     """MUL_MAT for small batches through the int8-MFMA skinny kernel, in passes of 32 columns: b = [n, k] f32 -> [n, m]."""
     _u8(w)

@@ -1255,6 +1255,51 @@ def test_mul_mat_id_skinny(ops, t, m, k, n_exp, n_used, n_tok, b1):
     assert O.nmse(vec, got) <= 5e-4
 
 
+@pytest.mark.parametrize("t", [B.Q4_K, B.Q6_K, B.Q8_0])
+def test_mul_mat_id_skinny_with_planes_and_tables_from_the_caller(ops, t):
+    """mi355_mul_mat_id_skinny_ex: the up / gate pair builds the routing tables in a buffer of the caller's, the down product on the same
+    ids reuses them (MI355_IDS_TABLES_READY) and finds its activation planes already in the workspace (MI355_IDS_ACT_READY; written here by
+    mi355_quantize_act_q8k / mi355_quantize_act, in the plugin by the GLU launch): every result has the bits of the plain call."""
+    import llm_amd.kernels as K
+    m, k, n_exp, n_used, n_tok = 256, 512, 8, 2, 13
+    rng = np.random.default_rng(5)
+    w0, w1 = (dev(B.random_blocks(t, n_exp * m, k, seed=s)) for s in (1, 2))
+    wd = dev(B.random_blocks(t, n_exp * k, m, seed=3))           # "down": k rows of m values per expert
+    x = dev(rng.standard_normal((n_tok, 1, k)).astype(np.float32))
+    h = dev(rng.standard_normal((n_tok, n_used, m)).astype(np.float32))
+    ids = dev(np.stack([rng.permutation(n_exp)[:n_used] for _ in range(n_tok)]).astype(np.int32))
+    tb = K.lib.mi355_mul_mat_id_tables_bytes(n_tok, n_used, n_exp)
+    tables = torch.zeros(tb, dtype=torch.uint8, device="cuda")
+    need_up = K.lib.mi355_mul_mat_id_skinny_workspace_bytes(t, k, n_tok, 1, n_used, n_exp)
+    need_dn = K.lib.mi355_mul_mat_id_skinny_workspace_bytes(t, m, n_tok, n_used, n_used, n_exp)
+    ws = torch.zeros(max(need_up, need_dn), dtype=torch.uint8, device="cuda")
+    if t == B.Q8_0:      # no pair form outside the K-quants
+        up = ops.mul_mat_id_skinny_ex(t, w0, None, x, ids, m, n_exp, ws, tables, 0)
+        assert torch.equal(up.view(torch.int32), ops.mul_mat_id_skinny(t, w0, x, ids, m, n_exp).view(torch.int32))
+    else:
+        up, gate = ops.mul_mat_id_skinny_ex(t, w0, w1, x, ids, m, n_exp, ws, tables, 0)
+        want = ops.mul_mat_id_skinny_pair(t, w0, w1, x, ids, m, n_exp)
+        assert torch.equal(up.view(torch.int32), want[0].view(torch.int32)) and torch.equal(gate.view(torch.int32), want[1].view(torch.int32))
+    # the down product: planes of h written into the workspace by the caller, tables from the call above
+    rows = n_tok * n_used
+    up256 = lambda v: (v + 255) // 256 * 256
+    if t == B.Q8_0:
+        aq, ads = ops.quantize_act(h.view(rows, m))
+        ws[:rows * m] = aq.view(torch.uint8).view(-1)
+        ws[up256(rows * m):up256(rows * m) + ads.numel() * 4] = ads.view(-1).view(torch.uint8)
+    else:
+        q, d, bs = ops.quantize_act_q8k(h.view(rows, m))
+        b0, b1 = up256(rows * m), up256(rows * (m // 256) * 4)
+        ws[:rows * m] = q.view(torch.uint8).view(-1)
+        ws[b0:b0 + d.numel() * 4] = d.view(-1).view(torch.uint8)
+        ws[b0 + b1:b0 + b1 + bs.numel() * 2] = bs.view(-1).view(torch.uint8)
+    ids.add_(0)         # (the ids are untouched; the tables would be stale otherwise)
+    down = ops.mul_mat_id_skinny_ex(t, wd, None, h, ids, k, n_exp, ws, tables, 3)
+    assert torch.equal(down.view(torch.int32), ops.mul_mat_id_skinny(t, wd, h, ids, k, n_exp).view(torch.int32))
+    with pytest.raises(K.Mi355Error):
+        ops.mul_mat_id_skinny_ex(t, wd, None, h, ids, k, n_exp, ws, None, 2)      # ready tables need a place
+
+
 @pytest.mark.parametrize("t", [B.Q4_K, B.Q5_K, B.Q6_K])
 @pytest.mark.parametrize("m,k,n_exp,n_used,n_tok", [(96, 256, 4, 2, 6), (130, 512, 8, 2, 8), (2080, 1024, 8, 2, 40), (14336, 4096, 8, 2, 16)])
 def test_mul_mat_id_skinny_pair_has_the_bits_of_two_calls(ops, t, m, k, n_exp, n_used, n_tok):
