@@ -1364,3 +1364,46 @@ def test_errors_are_reported_not_launched(ops):
     with pytest.raises(K.Mi355Error) as e:      # ncols > 8 is not a mat-vec
         ops.mul_mat_vec_q(B.Q4_K, w[:144 * 4], 4, 256, aq, ads, 9)
     assert e.value.code == -2
+
+
+def test_map_and_norm_vs_numpy(ops):
+    """mi355_map_f32 (the UNARY ops, SQR .. LOG, CLAMP) and mi355_norm_f32 (NORM, L2_NORM) against float64 numpy on a strided view
+    (every op also runs under the reference's test-backend-ops in tests/test_backend_plugin_gpu.py); refusals by return code."""
+    import math
+    import llm_amd.kernels as K
+    s = torch.cuda.current_stream().cuda_stream
+    def T(t):                                 # a strided view, ggml-style
+        r = K.Tensor()
+        r.data, r.type = t.data_ptr(), 0
+        sh, st = list(t.shape)[::-1], list(t.stride())[::-1]
+        for i in range(4):
+            r.ne[i] = sh[i] if i < len(sh) else 1
+            r.nb[i] = st[i] * 4 if i < len(sh) else r.nb[i - 1] * r.ne[i - 1]
+        return r
+    rng = np.random.default_rng(3)
+    base = dev(rng.uniform(-4, 4, (3, 5, 40)).astype(np.float32))
+    x = base[:, :, 3:36]                      # rows of 33 values, 160-byte pitch
+    xn = x.cpu().numpy().astype(np.float64)
+    erf = np.vectorize(math.erf)
+    sig = lambda v: 1.0 / (1.0 + np.exp(-v))
+    hs = lambda v: np.minimum(1.0, np.maximum(0.0, (v + 3.0) / 6.0))
+    want = {0: np.abs(xn), 1: np.sign(xn), 2: -xn, 3: (xn > 0) * 1.0, 4: np.tanh(xn), 5: np.where(xn > 0, xn, np.expm1(xn)), 6: np.maximum(xn, 0), 7: sig(xn),
+            8: 0.5 * xn * (1 + np.tanh(0.7978845608028654 * xn * (1 + 0.044715 * xn * xn))), 9: xn * sig(1.702 * xn), 10: xn * sig(xn), 11: xn * hs(xn),
+            12: hs(xn), 13: np.exp(xn), 14: 0.5 * xn * (1 + erf(xn * 0.7071067811865476)), 15: xn * xn, 17: np.sin(xn), 18: np.cos(xn), 20: np.clip(xn, -1.5, 2.25)}
+    for op, w in want.items():
+        y = torch.full_like(base, float("nan"))[:, :, 3:36]
+        K.check(K.lib.mi355_map_f32(op, T(x), T(y), -1.5, 2.25, s), "map")
+        assert np.allclose(y.cpu().numpy(), w, rtol=2e-6, atol=2e-6), op
+    xp = x.abs() + 0.1
+    for op, w in ((16, np.sqrt), (19, np.log)):
+        y = torch.empty_like(base)[:, :, 3:36]
+        K.check(K.lib.mi355_map_f32(op, T(xp), T(y), 0.0, 0.0, s), "map")
+        assert np.allclose(y.cpu().numpy(), w(xp.cpu().numpy().astype(np.float64)), rtol=2e-6, atol=2e-6), op
+    for l2 in (0, 1):
+        y = torch.empty_like(base)[:, :, 3:36]
+        K.check(K.lib.mi355_norm_f32(T(x), T(y), 1e-5, l2, s), "norm")
+        w = xn / np.maximum(np.sqrt((xn ** 2).sum(-1, keepdims=True)), 1e-5) if l2 else (xn - xn.mean(-1, keepdims=True)) / np.sqrt(xn.var(-1, keepdims=True) + 1e-5)
+        assert np.allclose(y.cpu().numpy(), w, rtol=1e-5, atol=1e-6), l2
+    y = torch.empty_like(base)[:, :, 3:36]
+    assert K.lib.mi355_map_f32(21, T(x), T(y), 0.0, 0.0, s) == -6          # no such op
+    assert K.lib.mi355_norm_f32(T(x), T(base), 1e-5, 0, s) == -2            # shapes differ

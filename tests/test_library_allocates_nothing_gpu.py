@@ -45,6 +45,30 @@ def _battery(scale):
         vv = (torch.randn((2, n_kv, 128), device="cuda", generator=g) * 0.5).to(torch.float16).view(torch.uint8).contiguous()
         mask = torch.zeros(((n_q + 63) // 64 * 64, n_kv), dtype=torch.float16, device="cuda").view(torch.int16)
         outs.append(ops.flash_attn_ext(q, kk, vv, mask, B.F16, n_kv, 0.088))
+    # ... other head sizes (the kernels built for the next size up; 256 on the matrix cores; V smaller than K; softcap)
+    for d, dv, n_q, n_kv, cap in ((96, None, 1, 3000 * scale, 0.0), (80, None, 40, 300 * scale, 0.0), (256, None, 64, 400 * scale, 30.0), (192, 128, 2, 2000 * scale, 0.0)):
+        q = torch.randn((8, n_q, d), device="cuda", generator=g)
+        kk = (torch.randn((2, n_kv, d), device="cuda", generator=g) * 0.5).to(torch.float16).view(torch.uint8).contiguous()
+        vv = (torch.randn((2, n_kv, dv or d), device="cuda", generator=g) * 0.5).to(torch.float16).view(torch.uint8).contiguous()
+        mask = torch.zeros(((n_q + 63) // 64 * 64, n_kv), dtype=torch.float16, device="cuda").view(torch.int16)
+        outs.append(ops.flash_attn_ext(q, kk, vv, mask, B.F16, n_kv, 0.088, 0.0, cap, dv=dv))
+    # MUL_MAT_ID with the caller's tables / ready planes, and the element-wise ops added at the end of round 3
+    b = torch.randn((12, 1, k), device="cuda", generator=g)
+    ids = torch.stack([torch.randperm(n_exp, device="cuda", generator=g)[:n_used] for _ in range(12)]).to(torch.int32)
+    import llm_amd.kernels as K
+    ws = torch.zeros(K.lib.mi355_mul_mat_id_skinny_workspace_bytes(B.Q4_K, k, 12, 1, n_used, n_exp), dtype=torch.uint8, device="cuda")
+    tables = torch.zeros(K.lib.mi355_mul_mat_id_tables_bytes(12, n_used, n_exp), dtype=torch.uint8, device="cuda")
+    outs += list(ops.mul_mat_id_skinny_ex(B.Q4_K, we, we, b, ids, 256 * scale, n_exp, ws, tables, 0))
+    outs.append(ops.mul_mat_id_skinny_ex(B.Q4_K, we, None, b, ids, 256 * scale, n_exp, ws, tables, 3))
+    x = torch.rand((7 * scale, 333), device="cuda", generator=g) + 0.5
+    for op in (4, 8, 10, 19):                      # TANH, GELU, SILU, LOG
+        y = torch.empty_like(x)
+        K.check(K.lib.mi355_map_f32(op, K.Tensor.of(x), K.Tensor.of(y), 0.0, 0.0, torch.cuda.current_stream().cuda_stream), "map")
+        outs.append(y)
+    for l2 in (0, 1):
+        y = torch.empty_like(x)
+        K.check(K.lib.mi355_norm_f32(K.Tensor.of(x), K.Tensor.of(y), 1e-5, l2, torch.cuda.current_stream().cuda_stream), "norm")
+        outs.append(y)
     torch.cuda.synchronize()
     assert all(torch.isfinite(o).all() for o in outs)
 
