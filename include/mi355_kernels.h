@@ -649,6 +649,15 @@ MI355_API int mi355_mul_mat_f(const mi355_tensor *a, const mi355_tensor *b, cons
 MI355_API int mi355_moe_router_f32(const float *x, int64_t x_row_stride, const float *gate_inp, int64_t gate_row_stride, int64_t k,
                                    int64_t n_expert, int64_t n_used, int64_t n_tokens, float *logits, float *probs, int32_t *order,
                                    float *w, float *wsum, float *wn, void *stream);
+/* The same with the layer's ffn norm in front, in the same launch: xn = RMS_NORM(x) * norm_w (dense rows [n_tokens][k], the bits of
+ * mi355_rms_norm_mul_f32) and, if asked for, its q8_1 form (act_q / act_ds as mi355_quantize_act writes them: what the experts'
+ * mat-vecs read), then the router on xn.  [RMS_NORM, MUL, MUL_MAT, SOFT_MAX, ARGSORT, GET_ROWS, SUM_ROWS, DIV] of a MoE decode step
+ * in one launch.  k <= 4096 and k % 32 == 0, else MI355_E_UNSUPPORTED. */
+MI355_API int mi355_moe_router_norm_f32(const float *x, int64_t x_row_stride, const float *norm_w, float eps, float *xn, int8_t *act_q,
+                                        float *act_ds, const float *gate_inp, int64_t gate_row_stride, int64_t k, int64_t n_expert,
+                                        int64_t n_used, int64_t n_tokens, float *logits, float *probs, int32_t *order, float *w,
+                                        float *wsum, float *wn, void *stream);
+
 
 /* row softmax with optional f16/f32 mask and ALiBi slope: dst = softmax(x*scale + slope*mask).
  * ggml_cuda_op_soft_max (ggml-cuda/softmax.cu); oracle ggml_compute_forward_soft_max_f32 (ggml-cpu/ops.cpp). */

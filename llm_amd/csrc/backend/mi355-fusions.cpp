@@ -640,7 +640,10 @@ static bool mi355_try_fuse_moe_down(mi355_backend_ctx * ctx, ggml_cgraph * cgrap
 // SUM_ROWS DIV (build_moe_ffn, src/llama-graph.cpp:660-720) -> mi355_moe_router_f32.  Every tensor of the chain is written,
 // with bit-identical values, so no use analysis is needed; the outputs only have to be laid out so that one
 // workgroup's (= one token's) stores cannot land in another token's rows of a different tensor.
-static bool mi355_try_fuse_moe_router(mi355_backend_ctx * ctx, ggml_cgraph * cgraph, int i, std::vector<char> & done) {
+// norm_idx >= 0: the RMS_NORM at that node and its MUL (norm_idx + 1, the router MUL_MAT's src1, one token) run in the same launch
+// (mi355_moe_router_norm_f32: the normalised row and its q8_1 form are written as the norm launch would have) -- the caller has
+// checked decode_norm_pattern
+static bool mi355_try_fuse_moe_router(mi355_backend_ctx * ctx, ggml_cgraph * cgraph, int i, std::vector<char> & done, int norm_idx = -1) {
     const int n = ggml_graph_n_nodes(cgraph);
     ggml_tensor * mm = ggml_graph_node(cgraph, i);
     const ggml_tensor * g = mm->src[0], * x = mm->src[1];
@@ -731,6 +734,34 @@ static bool mi355_try_fuse_moe_router(mi355_backend_ctx * ctx, ggml_cgraph * cgr
         }
     }
     float * side = aside[0] || aside[1] || aside[4] ? (float *)ctx->get_scratch(6, (size_t)(2 * E + 1) * T * sizeof(float)) : nullptr;
+    if (norm_idx >= 0) {
+        const ggml_tensor * norm = ggml_graph_node(cgraph, norm_idx), * mul = ggml_graph_node(cgraph, norm_idx + 1);
+        const ggml_tensor * xr = norm->src[0], * nw = mul->src[0] == norm ? mul->src[1] : mul->src[0];
+        if (x != mul || T != 1 || K > 4096 || K % 32 != 0 || MI355_ENV_SET("GGML_MI355_NO_NORM_ROUTER")) return false;
+        // the row is read by this one workgroup only, but it must not be any of the launch's outputs, nor the weight
+        const ggml_tensor * nouts[7] = {mul, mm, sm, as, gr, sr, dv};
+        size_t nob[7];
+        for (int p = 0; p < 7; p++) nob[p] = ggml_nbytes(nouts[p]);
+        if (((uintptr_t)xr->data | (uintptr_t)nw->data | (uintptr_t)mul->data) & 15) return false;
+        for (int p = 0; p < 7; p++) {
+            if (ranges_overlap(nouts[p]->data, nob[p], xr->data, (size_t)K * 4) || ranges_overlap(nouts[p]->data, nob[p], nw->data, (size_t)K * 4)) return false;
+            if (p > 0 && ranges_overlap(nouts[p]->data, nob[p], mul->data, nob[0])) return false;
+        }
+        float eps;
+        memcpy(&eps, norm->op_params, sizeof(float));
+        const size_t qb = align_up((size_t)mi355_act_q_bytes(K, 1), 256), db = align_up((size_t)mi355_act_ds_bytes(K, 1), 256);
+        char * ws = (char *)ctx->get_scratch(0, qb + db);
+        const int rc = mi355_moe_router_norm_f32((const float *)xr->data, (int64_t)xr->nb[1], (const float *)nw->data, eps, (float *)mul->data, (int8_t *)ws,
+                                                 (float *)(ws + qb), (const float *)g->data, (int64_t)g->nb[1], K, E, U, T, (float *)mm->data, (float *)sm->data,
+                                                 (int32_t *)as->data, (float *)gr->data, (float *)sr->data, (float *)dv->data, ctx->stream);
+        if (rc == MI355_E_UNSUPPORTED || rc == MI355_E_ALIGN) return false;
+        MI_CHECK(rc);
+        for (int m = 0; m < 5; m++) done[idx[m]] = 1;
+        for (int p = 0; p < 6; p++) ctx->act_invalidate_if_written(outs[p]);
+        ctx->act_invalidate_if_written(mul);
+        ctx->act_remember(mul);
+        return true;
+    }
     MI_CHECK(mi355_moe_router_f32((const float *)x->data, (int64_t)x->nb[1], (const float *)g->data, (int64_t)g->nb[1], K, E, U, T,
                                   aside[0] ? side : (float *)mm->data, aside[1] ? side + E * T : (float *)sm->data, (int32_t *)as->data, (float *)gr->data,
                                   aside[4] ? side + 2 * E * T : (float *)sr->data, (float *)dv->data, ctx->stream));
@@ -1436,6 +1467,16 @@ enum ggml_status mi355_issue_graph(mi355_backend_ctx * ctx, ggml_cgraph * cgraph
         if (fuse && node->op == GGML_OP_RMS_NORM && mi355_try_fuse_norm_glu_matvec(ctx, cgraph, i, done)) {
             i += 4;
             continue;
+        }
+        // the ffn norm of a MoE decode step: into the router's launch (the experts find the q8_1 form it leaves)
+        if (fuse && node->op == GGML_OP_RMS_NORM && i + 2 < n && decode_norm_pattern(cgraph, i, done)) {
+            int j = i + 2;      // (the reshaped view of the norm that the experts will read sits in between)
+            while (j < n && !done[j] && is_view_op(ggml_graph_node(cgraph, j))) j++;
+            if (j < n && !done[j] && ggml_graph_node(cgraph, j)->op == GGML_OP_MUL_MAT && ggml_graph_node(cgraph, j)->src[0]->type == GGML_TYPE_F32 &&
+                ggml_graph_node(cgraph, j)->src[1] == ggml_graph_node(cgraph, i + 1) && mi355_try_fuse_moe_router(ctx, cgraph, j, done, i)) {
+                done[i + 1] = 1; done[j] = 1;      // the norm's MUL and the router's MUL_MAT; the five nodes after it are marked done already
+                continue;
+            }
         }
         if (fuse && node->op == GGML_OP_RMS_NORM && i + 2 < n && !MI355_ENV_SET("GGML_MI355_NO_NORM_QKV") && decode_norm_pattern(cgraph, i, done) &&
             ggml_graph_node(cgraph, i + 2)->op == GGML_OP_MUL_MAT && ggml_graph_node(cgraph, i + 2)->src[1] == ggml_graph_node(cgraph, i + 1) &&

@@ -1330,13 +1330,50 @@ mul_mat_f32_kernel(const T4 a, const T4 b, const T4 d) {
 // i.e. the node chain MUL_MAT SOFT_MAX ARGSORT GET_ROWS SUM_ROWS DIV of build_moe_ffn (llama-graph.cpp:660-720), six
 // launches of ~4 us otherwise.  Every intermediate tensor of the chain is written, and each value is computed with
 // the same operation order as the separate kernels above, so the results are bit-identical to the unfused graph.
+// NORM: x is the layer's un-normalised feed-forward input; the workgroup first forms the row RMS_NORM(x) * norm_w exactly as
+// rms_norm_kernel<true, false, 256> does (one 16-value chunk per thread, k <= 4096: the same per-thread sums, the same block
+// reduction, (x * scale) * w), stores it (xn) with its q8_1 form (aq / ads, what the experts' mat-vecs read) and routes on it out of
+// LDS -- the ffn norm launch of a MoE decode step disappears into the router's.
+template <bool NORM>
 __global__ void __launch_bounds__(256)
 moe_router_kernel(const char * x, int64_t x_stride, const char * gate, int64_t gate_stride, int k, int n_expert, int n_used,
-                  float * logits, float * probs, int32_t * order, float * w, float * wsum, float * wn) {
+                  float * logits, float * probs, int32_t * order, float * w, float * wsum, float * wn,
+                  const float * __restrict__ norm_w, float eps, float * __restrict__ xn, int8_t * __restrict__ aq, float * __restrict__ ads) {
     __shared__ float sh[4], p_s[256];
     __shared__ int ord_s[256];
+    __shared__ __attribute__((aligned(16))) float xs[NORM ? 4096 : 4];
     const int tid = threadIdx.x, tok = blockIdx.x;
     const float * br = (const float *)(x + (int64_t)tok * x_stride);
+    if (NORM) {
+        const int nc = k >> 4, c = tid;
+        v4f v[4], wv[4];
+        float s = 0.0f;
+        if (c < nc) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                v[q] = ((const v4f *)br)[4 * c + q];
+                wv[q] = ((const v4f *)norm_w)[4 * c + q];
+                s += v[q].x * v[q].x + v[q].y * v[q].y + v[q].z * v[q].z + v[q].w * v[q].w;
+            }
+        }
+        s = block_sum_n<4>(s, sh);
+        const float scale = 1.0f / sqrtf(s / (float)k + eps);
+        if (c < nc) {
+            float o[16];
+            float * dr = xn + (int64_t)tok * k;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                v4f t = v[q] * scale;
+                t = t * wv[q];
+                ((v4f *)dr)[4 * c + q] = t;
+                ((v4f *)xs)[4 * c + q] = t;
+                o[4 * q] = t.x; o[4 * q + 1] = t.y; o[4 * q + 2] = t.z; o[4 * q + 3] = t.w;
+            }
+            if (aq) quant16_soa(o, aq + (int64_t)tok * k + 16 * c, ads + ((int64_t)tok * (k / QK) + (c >> 1)) * 2, (c & 1) == 0);
+        }
+        __syncthreads();
+        br = xs;
+    }
     // logits: as mul_mat_f32_kernel (256 threads per output, same per-thread and cross-wave summation order), eight
     // experts at a time so that their loads are in flight together (one expert after the other took 20 us)
     __shared__ float part8[8][4];
@@ -1483,8 +1520,27 @@ extern "C" int mi355_moe_router_f32(const float * x, int64_t x_row_stride, const
     if (k <= 0 || k > 0x7fffffff || n_expert < 1 || n_expert > 256 || n_used < 1 || n_used > n_expert || n_tokens < 0 || n_tokens > 0x7fffffff) return MI355_E_SHAPE;
     if ((x_row_stride | gate_row_stride) & 3) return MI355_E_ALIGN;
     if (n_tokens == 0) return MI355_OK;
-    MI355_LAUNCH("moe_router", moe_router_kernel, dim3((unsigned)n_tokens), dim3(256), 0, (hipStream_t)stream, (const char *)x, x_row_stride,
-                 (const char *)gate_inp, gate_row_stride, (int)k, (int)n_expert, (int)n_used, logits, probs, order, w, wsum, wn);
+    MI355_LAUNCH("moe_router", moe_router_kernel<false>, dim3((unsigned)n_tokens), dim3(256), 0, (hipStream_t)stream, (const char *)x, x_row_stride,
+                 (const char *)gate_inp, gate_row_stride, (int)k, (int)n_expert, (int)n_used, logits, probs, order, w, wsum, wn,
+                 (const float *)nullptr, 0.0f, (float *)nullptr, (int8_t *)nullptr, (float *)nullptr);
+    MI355_CHECK_LAUNCH();
+    return MI355_OK;
+}
+
+extern "C" int mi355_moe_router_norm_f32(const float * x, int64_t x_row_stride, const float * norm_w, float eps, float * xn, int8_t * act_q,
+                                         float * act_ds, const float * gate_inp, int64_t gate_row_stride, int64_t k, int64_t n_expert,
+                                         int64_t n_used, int64_t n_tokens, float * logits, float * probs, int32_t * order, float * w,
+                                         float * wsum, float * wn, void * stream) {
+    if (!x || !norm_w || !xn || !gate_inp || !logits || !probs || !order || !w || !wsum || !wn) return MI355_E_NULL;
+    if ((act_q == nullptr) != (act_ds == nullptr)) return MI355_E_NULL;
+    if (k <= 0 || n_expert < 1 || n_expert > 256 || n_used < 1 || n_used > n_expert || n_tokens < 0 || n_tokens > 0x7fffffff) return MI355_E_SHAPE;
+    if (k > 4096 || k % 32 != 0) return MI355_E_UNSUPPORTED;        // one 16-value chunk per thread, whole q8_1 blocks per lane pair
+    if (((uintptr_t)x | (uintptr_t)x_row_stride | (uintptr_t)norm_w | (uintptr_t)xn | (uintptr_t)act_q) & 15) return MI355_E_ALIGN;
+    if (((uintptr_t)act_ds & 7) || (gate_row_stride & 3)) return MI355_E_ALIGN;
+    if (n_tokens == 0) return MI355_OK;
+    MI355_LAUNCH("moe_router_norm", moe_router_kernel<true>, dim3((unsigned)n_tokens), dim3(256), 0, (hipStream_t)stream, (const char *)x, x_row_stride,
+                 (const char *)gate_inp, gate_row_stride, (int)k, (int)n_expert, (int)n_used, logits, probs, order, w, wsum, wn,
+                 norm_w, eps, xn, act_q, act_ds);
     MI355_CHECK_LAUNCH();
     return MI355_OK;
 }

@@ -92,6 +92,11 @@ def test_moe_router_is_one_launch_for_small_batches_too():
     # ggml-alloc puts its gathered weights on the bytes of the layer's dead input there, which the experts still read when the fused
     # launch would write them
     assert count("moe_router") == 9 and count("argsort") == 3 and count("soft_max") == 3, r.stderr[-2000:]
+    # decode: the ffn norm runs in the router's launch too (mi355_moe_router_norm_f32) -- in the layers whose router is fused (not the last)
+    r = subprocess.run([tool, "tinymoe", "Q4_K_M", "-p", "0", "-n", "4", "-r", "1"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    steps = count("moe_router_norm") // 3
+    assert steps >= 4 and count("moe_router_norm") == 3 * steps and count("moe_router") == 0 and count("rms_norm_mul") == steps, r.stderr[-2000:]
 
 
 def _env_for(ngl):

@@ -1407,3 +1407,48 @@ def test_map_and_norm_vs_numpy(ops):
     y = torch.empty_like(base)[:, :, 3:36]
     assert K.lib.mi355_map_f32(21, T(x), T(y), 0.0, 0.0, s) == -6          # no such op
     assert K.lib.mi355_norm_f32(T(x), T(base), 1e-5, 0, s) == -2            # shapes differ
+
+
+@pytest.mark.parametrize("k,n_exp,n_used,n_tok", [(4096, 8, 2, 1), (1024, 8, 2, 3), (2048, 64, 6, 2), (4096, 8, 2, 16)])
+def test_moe_router_and_its_norm_form(ops, k, n_exp, n_used, n_tok):
+    """mi355_moe_router_f32 against numpy (probabilities, the order of the top n_used, normalised weights), and
+    mi355_moe_router_norm_f32 -- the ffn norm in front, in the same launch -- against mi355_rms_norm_mul_quant_f32 followed by the
+    router: the normalised row, its q8_1 planes and every router tensor bit for bit."""
+    import llm_amd.kernels as K
+    s = torch.cuda.current_stream().cuda_stream
+    rng = np.random.default_rng(k + n_exp + n_tok)
+    x = dev(rng.standard_normal((n_tok, k)).astype(np.float32) * 3)
+    nw = dev(rng.uniform(0.5, 1.5, k).astype(np.float32))
+    gate = dev(rng.standard_normal((n_exp, k)).astype(np.float32) * 0.05)
+    def outs():
+        f = lambda *sh: torch.full(sh, float("nan"), device="cuda")
+        return [f(n_tok, n_exp), f(n_tok, n_exp), torch.full((n_tok, n_exp), -1, dtype=torch.int32, device="cuda"), f(n_tok, n_used), f(n_tok), f(n_tok, n_used)]
+    xn = torch.empty_like(x)
+    aq = torch.empty((n_tok, k), dtype=torch.int8, device="cuda"); ads = torch.empty((n_tok, k // 32, 2), device="cuda")
+    if n_tok <= 8:
+        K.check(K.lib.mi355_rms_norm_mul_quant_f32(K.Tensor.of(x), nw.data_ptr(), K.Tensor.of(xn), 1e-5, aq.data_ptr(), ads.data_ptr(), s), "norm")
+    else:
+        K.check(K.lib.mi355_rms_norm_mul_f32(K.Tensor.of(x), nw.data_ptr(), K.Tensor.of(xn), 1e-5, s), "norm")
+        aq, ads = ops.quantize_act(xn)
+    a = outs()
+    K.check(K.lib.mi355_moe_router_f32(xn.data_ptr(), k * 4, gate.data_ptr(), k * 4, k, n_exp, n_used, n_tok, *[t.data_ptr() for t in a], s), "router")
+    # vs numpy
+    xd = xn.cpu().numpy().astype(np.float64)
+    lg = xd @ gate.cpu().numpy().astype(np.float64).T
+    pr = np.exp(lg - lg.max(1, keepdims=True)); pr /= pr.sum(1, keepdims=True)
+    assert np.allclose(a[1].cpu().numpy(), pr, rtol=1e-4, atol=1e-6)
+    top = np.argsort(-pr, axis=1, kind="stable")[:, :n_used]
+    assert np.array_equal(a[2].cpu().numpy()[:, :n_used], top)
+    wsel = np.take_along_axis(pr, top, 1)
+    assert np.allclose(a[5].cpu().numpy(), wsel / wsel.sum(1, keepdims=True), rtol=1e-4)
+    # the norm form
+    b = outs()
+    xn2 = torch.full_like(x, float("nan")); aq2 = torch.zeros_like(aq); ads2 = torch.zeros_like(ads)
+    K.check(K.lib.mi355_moe_router_norm_f32(x.data_ptr(), k * 4, nw.data_ptr(), 1e-5, xn2.data_ptr(), aq2.data_ptr(), ads2.data_ptr(), gate.data_ptr(), k * 4,
+                                            k, n_exp, n_used, n_tok, *[t.data_ptr() for t in b], s), "router_norm")
+    assert torch.equal(xn.view(torch.int32), xn2.view(torch.int32)) and torch.equal(aq, aq2) and torch.equal(ads.view(torch.int32), ads2.view(torch.int32))
+    for u, v in zip(a, b):
+        assert torch.equal(u.view(torch.int32), v.view(torch.int32))
+    assert K.lib.mi355_moe_router_norm_f32(x.data_ptr(), 8192 * 4, nw.data_ptr(), 1e-5, xn2.data_ptr(), None, None, gate.data_ptr(), 8192 * 4,
+                                           8192, n_exp, n_used, 1, *[t.data_ptr() for t in b], s) == -6
+
