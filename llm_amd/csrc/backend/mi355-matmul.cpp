@@ -759,24 +759,8 @@ static bool mi355_glu_with_quant(mi355_backend_ctx * ctx, ggml_tensor * node, co
                                          for (int d = 0; d < 4; d++) { r.ne[d] = t->ne[d]; r.nb[d] = (int64_t)t->nb[d]; } return r; };
     mi355_tensor ta = T(a), tb, td = T(node);
     if (b) tb = T(b);
-    if (rows > MI355_BF16_ROWS_ABOVE && b && K % 4 == 0 && !MI355_ENV_SET("GGML_MI355_MMQ_INT8")) {   // prefill: bf16 rows for the ffn_down GEMM
-        uint16_t * abf = (uint16_t *)ctx->get_scratch(0, align_up((size_t)rows * K * 2, 256));
-        const int rc = mi355_glu_bf16_f32((int)ggml_get_glu_op(node), &ta, &tb, &td, ((const int32_t *)node->op_params)[1], abf, ctx->stream);
-        if (rc == MI355_E_UNSUPPORTED) return false;
-        MI_CHECK(rc);
-        ctx->act_remember(node, 1);
-        return true;
-    }
-    if (next && next->op == GGML_OP_MUL_MAT && next->src[1] == node && !tensor_is_split(next->src[0]) && rows > 1 && K % 256 == 0 &&
-        mi355_mul_mat_path(next->src[0], node) == MM_SKINNY_K && !MI355_ENV_SET("GGML_MI355_NO_NORM_Q8K")) {
-        const mi355_act_layout L = mi355_act_planes(MM_SKINNY_K, K, rows);
-        char * ws = (char *)ctx->get_scratch(0, L.total());
-        const int rc = mi355_glu_q8k_f32((int)ggml_get_glu_op(node), &ta, b ? &tb : nullptr, &td, ((const int32_t *)node->op_params)[1],
-                                         (int8_t *)ws, (float *)(ws + L.b0), (int16_t *)(ws + L.b0 + L.b1), ctx->stream);
-        if (rc == MI355_OK) { ctx->act_remember(node, 2); return true; }
-        if (rc != MI355_E_UNSUPPORTED) MI_CHECK(rc);
-    }
-    // ... and the same for the experts' ffn_down of a MoE layer in the skinny regime (its MUL_MAT_ID would quantize the rows itself)
+    // the experts' ffn_down of a MoE layer in the skinny regime (up to 256 (token, slot) rows) reads q8_K planes: written here, its
+    // MUL_MAT_ID would quantize the rows itself otherwise (asked first: such a step has more than 32 rows from 17 tokens on)
     if (next && next->op == GGML_OP_MUL_MAT_ID && next->src[1] == node && rows > 1 && K % 256 == 0 && moe_skinny_regime(next) &&
         (next->src[0]->type == GGML_TYPE_Q4_K || next->src[0]->type == GGML_TYPE_Q5_K || next->src[0]->type == GGML_TYPE_Q6_K) &&
         !MI355_ENV_SET("GGML_MI355_NO_NORM_Q8K") && !MI355_ENV_SET("GGML_MI355_NO_MOE_READY")) {
@@ -789,6 +773,24 @@ static bool mi355_glu_with_quant(mi355_backend_ctx * ctx, ggml_tensor * node, co
                                          (int8_t *)ws, (float *)(ws + L.b0), (int16_t *)(ws + L.b0 + L.b1), ctx->stream);
         if (rc == MI355_OK) { ctx->act_remember(node, 2); return true; }
         if (rc != MI355_E_UNSUPPORTED) MI_CHECK(rc);
+    }
+    // ... and a ffn_down that takes the K-quant skinny kernels (up to 64 rows: asked before the bf16 form, which starts at 33)
+    if (next && next->op == GGML_OP_MUL_MAT && next->src[1] == node && !tensor_is_split(next->src[0]) && rows > 1 && K % 256 == 0 &&
+        mi355_mul_mat_path(next->src[0], node) == MM_SKINNY_K && !MI355_ENV_SET("GGML_MI355_NO_NORM_Q8K")) {
+        const mi355_act_layout L = mi355_act_planes(MM_SKINNY_K, K, rows);
+        char * ws = (char *)ctx->get_scratch(0, L.total());
+        const int rc = mi355_glu_q8k_f32((int)ggml_get_glu_op(node), &ta, b ? &tb : nullptr, &td, ((const int32_t *)node->op_params)[1],
+                                         (int8_t *)ws, (float *)(ws + L.b0), (int16_t *)(ws + L.b0 + L.b1), ctx->stream);
+        if (rc == MI355_OK) { ctx->act_remember(node, 2); return true; }
+        if (rc != MI355_E_UNSUPPORTED) MI_CHECK(rc);
+    }
+    if (rows > MI355_BF16_ROWS_ABOVE && b && K % 4 == 0 && !MI355_ENV_SET("GGML_MI355_MMQ_INT8")) {   // prefill: bf16 rows for the ffn_down GEMM
+        uint16_t * abf = (uint16_t *)ctx->get_scratch(0, align_up((size_t)rows * K * 2, 256));
+        const int rc = mi355_glu_bf16_f32((int)ggml_get_glu_op(node), &ta, &tb, &td, ((const int32_t *)node->op_params)[1], abf, ctx->stream);
+        if (rc == MI355_E_UNSUPPORTED) return false;
+        MI_CHECK(rc);
+        ctx->act_remember(node, 1);
+        return true;
     }
     if (rows > 8 || K % 32 != 0) return false;
     const size_t qb = align_up((size_t)mi355_act_q_bytes(K, rows), 256), db = align_up((size_t)mi355_act_ds_bytes(K, rows), 256);
