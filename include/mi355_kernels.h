@@ -582,17 +582,18 @@ MI355_API int mi355_prefetch(const void *p, int64_t bytes, int workgroups, void 
 MI355_API int mi355_stream_read(const void *p, int64_t bytes, int workgroups, void *stream);
 
 /* copy / convert with arbitrary strides and equal element counts (ggml_cpy, ggml_cont, ggml_dup):
- * f32 -> f32 | f16 | q8_0, f16 -> f16 | f32.  The q8_0 destination follows quantize_row_q8_0_ref
- * (ggml-quants.c:188-211).  ggml_cuda_cpy (ggml-cuda/cpy.cu); oracle ggml_compute_forward_dup (ggml-cpu/ops.cpp). */
+ * f32 -> f32 | f16 | bf16 | q8_0 | q4_0 (every KV-cache type FLASH_ATTN_EXT reads), f16 -> f16 | f32.  The q8_0 / q4_0 destinations
+ * follow quantize_row_q8_0_ref / quantize_row_q4_0_ref (ggml-quants.c:188-211, 25-60), bf16 ggml_compute_fp32_to_bf16
+ * (ggml-impl.h:453-466), bit for bit.  ggml_cuda_cpy (ggml-cuda/cpy.cu); oracle ggml_compute_forward_dup (ggml-cpu/ops.cpp). */
 MI355_API int mi355_cpy(const mi355_tensor *src, const mi355_tensor *dst, void *stream);
 
 /* dst[:, i, b2, b3] = dequant(src[:, ids[i, b2, b3], b2, b3]); src f32 | f16 | q4_0 | q8_0 | q4_K | q5_K | q6_K, ids i32.
  * ggml_cuda_op_get_rows (ggml-cuda/getrows.cu); oracle ggml_compute_forward_get_rows (ggml-cpu/ops.cpp). */
 MI355_API int mi355_get_rows(const mi355_tensor *src, const mi355_tensor *ids, const mi355_tensor *dst, void *stream);
 
-/* dst[:, ids[i, b2 % ids.ne1, b3 % ids.ne2], b2, b3] = convert(src[:, i, b2, b3]); src f32, ids i64, dst f32 | f16 | q8_0 (the
+/* dst[:, ids[i, b2 % ids.ne1, b3 % ids.ne2], b2, b3] = convert(src[:, i, b2, b3]); src f32, ids i64, dst f32 | f16 | bf16 | q8_0 | q4_0 (the
  * KV-cache store of llama.cpp with LLAMA_SET_ROWS, src/llama-kv-cache-unified.cpp:817-892).  Rows with an index outside
- * [0, dst.ne1) are skipped.  Oracle ggml_compute_forward_set_rows_f32 (ggml-cpu/ops.cpp:5179-5227); ggml-cuda/set-rows.cu. */
+ * [0, dst.ne1) are skipped.  Oracle ggml_compute_forward_set_rows_f32 (ggml-cpu/ops.cpp:5179-5227). */
 MI355_API int mi355_set_rows(const mi355_tensor *src, const mi355_tensor *ids, const mi355_tensor *dst, void *stream);
 /* K and V rows of one decode token, f32 -> q8_0 rows of the KV cache, in one launch (the two CPY f32 -> q8_0 nodes that follow rope / the V
  * projection, ggml-cuda/cpy.cu ggml_cpy_f32_q8_0_cuda; arithmetic: quantize_row_q8_0_ref, ggml-quants.c:188-211, bit-exact).  n_k, n_v:

@@ -28,7 +28,7 @@ static mi355_tensor T(const ggml_tensor * t) {
 static bool is_f32(const ggml_tensor * t) { return t && t->type == GGML_TYPE_F32; }
 
 static bool cpy_types_ok(enum ggml_type s, enum ggml_type d) {
-    if (s == GGML_TYPE_F32) return d == GGML_TYPE_F32 || d == GGML_TYPE_F16 || d == GGML_TYPE_Q8_0;
+    if (s == GGML_TYPE_F32) return d == GGML_TYPE_F32 || d == GGML_TYPE_F16 || d == GGML_TYPE_BF16 || d == GGML_TYPE_Q8_0 || d == GGML_TYPE_Q4_0;   // the KV cache types FLASH_ATTN_EXT reads
     if (s == GGML_TYPE_F16) return d == GGML_TYPE_F16 || d == GGML_TYPE_F32;
     return false;
 }
@@ -65,17 +65,18 @@ bool mi355_ops_supported(const ggml_tensor * op) {
         }
         case GGML_OP_CPY:
             if (!cpy_types_ok(a->type, b->type)) return false;
-            if (b->type == GGML_TYPE_Q8_0) return a->ne[0] % 32 == 0 && a->nb[0] == sizeof(float) && b->nb[0] == ggml_type_size(b->type);
+            if (b->type == GGML_TYPE_Q8_0 || b->type == GGML_TYPE_Q4_0) return a->ne[0] % 32 == 0 && a->nb[0] == sizeof(float) && b->nb[0] == ggml_type_size(b->type);
             return true;
         case GGML_OP_CONT:
         case GGML_OP_DUP:
-            return cpy_types_ok(a->type, op->type) && op->type != GGML_TYPE_Q8_0;
+            return cpy_types_ok(a->type, op->type) && op->type != GGML_TYPE_Q8_0 && op->type != GGML_TYPE_Q4_0;
         case GGML_OP_GET_ROWS:
             return get_rows_type_ok(a->type) && b->type == GGML_TYPE_I32 && is_f32(op) && a->nb[0] == ggml_type_size(a->type);
         case GGML_OP_SET_ROWS:
             // the KV-cache store with LLAMA_SET_ROWS (src/llama-kv-cache-unified.cpp:817-892): f32 rows scattered by an i64 index
             return is_f32(a) && b && b->type == GGML_TYPE_I64 && a->nb[0] == sizeof(float) && op->nb[0] == ggml_type_size(op->type) &&
-                   (op->type == GGML_TYPE_F32 || op->type == GGML_TYPE_F16 || (op->type == GGML_TYPE_Q8_0 && a->ne[0] % 32 == 0)) &&
+                   (op->type == GGML_TYPE_F32 || op->type == GGML_TYPE_F16 || op->type == GGML_TYPE_BF16 ||
+                    ((op->type == GGML_TYPE_Q8_0 || op->type == GGML_TYPE_Q4_0) && a->ne[0] % 32 == 0)) &&
                    ((b->nb[0] | b->nb[1] | b->nb[2]) & 7) == 0;
         case GGML_OP_SCALE:
             return is_f32(a) && is_f32(op) && ggml_is_contiguous(a) && ggml_is_contiguous(op);

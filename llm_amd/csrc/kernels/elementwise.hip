@@ -601,6 +601,15 @@ template <> __device__ __forceinline__ float  cvt<float, float>(float v) { retur
 template <> __device__ __forceinline__ __half cvt<float, __half>(float v) { return __float2half_rn(v); }
 template <> __device__ __forceinline__ __half cvt<__half, __half>(__half v) { return v; }
 template <> __device__ __forceinline__ float  cvt<__half, float>(__half v) { return __half2float(v); }
+// bf16 as the reference rounds it (ggml_compute_fp32_to_bf16, ggml-impl.h:453-466): nearest even on the bits, NaNs made quiet
+struct bf16_bits { uint16_t bits; };
+template <> __device__ __forceinline__ bf16_bits cvt<float, bf16_bits>(float v) {
+    const uint32_t i = __float_as_uint(v);
+    bf16_bits h;
+    if ((i & 0x7fffffffu) > 0x7f800000u) h.bits = (uint16_t)((i >> 16) | 64);
+    else                                 h.bits = (uint16_t)((i + (0x7fffu + ((i >> 16) & 1u))) >> 16);
+    return h;
+}
 
 static __device__ __forceinline__ int64_t off4(const T4 & t, int64_t i, int64_t blk, int64_t step0 = 0) {
     // linear index in units of blk elements along ne[0] -> byte offset; step0 = bytes per unit along ne[0]
@@ -635,6 +644,30 @@ static __device__ __forceinline__ void quant_block_q8_0(const float * xs, uint8_
     }
 }
 
+// 32 f32 -> one q4_0 block (quantize_row_q4_0_ref, ggml-quants.c:25-60): d = (the value of largest magnitude) / -8, q = min(15, trunc(x / d
+// + 8.5)), value j in the low nibble of byte j, value j + 16 in its high nibble
+static __device__ __forceinline__ void quant_block_q4_0(const float * xs, uint8_t * blk) {
+    float v[32], amax = 0.0f, mx = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 32; j++) { v[j] = xs[j]; if (amax < fabsf(v[j])) { amax = fabsf(v[j]); mx = v[j]; } }
+    const float dd = __fmul_rn(mx, -0.125f);      // max / -8, exact; an all-zero block stores d = -0 as the reference does (0x8000)
+    const float id = dd != 0.0f ? __fdiv_rn(1.0f, dd) : 0.0f;
+    *(uint16_t *)blk = mx == 0.0f ? (uint16_t)0x8000 : __half_as_ushort(__float2half_rn(dd));   // (+0 / -8 = -0: spelt out, the product's sign did not survive the compiler)
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        const float x0 = __fmul_rn(v[j], id), x1 = __fmul_rn(v[16 + j], id);
+        // (int8_t)(x + 8.5f): the sum lies in [0.5, 16.5] for finite input; NaN / inf input converts to 0 here (undefined in C)
+        const float s0 = __fadd_rn(x0, 8.5f), s1 = __fadd_rn(x1, 8.5f);
+        const int q0 = fabsf(s0) < 2147483648.0f ? (int)(int8_t)(int)s0 : 0, q1 = fabsf(s1) < 2147483648.0f ? (int)(int8_t)(int)s1 : 0;
+        const uint8_t u0 = (uint8_t)q0 < 15 ? (uint8_t)q0 : 15, u1 = (uint8_t)q1 < 15 ? (uint8_t)q1 : 15;
+        blk[2 + j] = (uint8_t)(u0 | (u1 << 4));
+    }
+}
+template <int TYPE> static __device__ __forceinline__ void quant_block(const float * xs, uint8_t * blk) {
+    if (TYPE == MI355_TYPE_Q8_0) quant_block_q8_0(xs, blk); else quant_block_q4_0(xs, blk);
+}
+template <int TYPE> struct QBlk { static constexpr int bytes = TYPE == MI355_TYPE_Q8_0 ? 34 : 18; };
+
 // K and V rows of one decode token, f32 -> q8_0 cache rows, in one launch; the destinations come from the arguments or, under graph
 // replay, from the device table the fused Q/K/V launch uses (slot pair 2 s, 2 s + 1)
 __global__ void __launch_bounds__(64)
@@ -646,15 +679,16 @@ kv_store_q8_0_kernel(const float * k_src, int nbk, uint8_t * k_dst, const float 
     else          quant_block_q8_0(v_src + 32 * (ib - nbk), v_dst + 34 * (ib - nbk));
 }
 
-// f32 -> q8_0: one lane per 32-value block
+// f32 -> q8_0 / q4_0: one lane per 32-value block
+template <int TYPE>
 __global__ void __launch_bounds__(256)
-cpy_f32_q8_0_kernel(const T4 s, const T4 d, int64_t nblocks) {
+cpy_f32_q_kernel(const T4 s, const T4 d, int64_t nblocks) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t ib = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; ib < nblocks; ib += stride) {
         // the 32 source values are consecutive along the source's ne[0] (ne[0] % 32 == 0, nb[0] == 4)
         const float * xs = (const float *)(s.data + off4(s, ib, 32, 32 * sizeof(float)));
         uint8_t * blk = (uint8_t *)(d.data + off4(d, ib, 32));
-        quant_block_q8_0(xs, blk);
+        quant_block<TYPE>(xs, blk);
     }
 }
 
@@ -679,9 +713,10 @@ set_rows_kernel(const T4 s, const T4 ids, const T4 d, int64_t n) {
     }
 }
 
-// q8_0 destination rows: one lane per 32-value block (quantize_row_q8_0_ref, ggml-quants.c:188-211)
+// q8_0 / q4_0 destination rows: one lane per 32-value block (quantize_row_q8_0_ref / quantize_row_q4_0_ref)
+template <int TYPE>
 __global__ void __launch_bounds__(256)
-set_rows_q8_0_kernel(const T4 s, const T4 ids, const T4 d, int64_t nblocks) {
+set_rows_q_kernel(const T4 s, const T4 ids, const T4 d, int64_t nblocks) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const int64_t nb0 = s.ne[0] / 32;
     for (int64_t ib = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; ib < nblocks; ib += stride) {
@@ -691,8 +726,8 @@ set_rows_q8_0_kernel(const T4 s, const T4 ids, const T4 d, int64_t nblocks) {
         const int64_t o = set_rows_dst(ids, d, i1, i2, i3);
         if (o < 0) continue;
         const float * xs = (const float *)(s.data + b0 * 128 + i1 * s.nb[1] + i2 * s.nb[2] + i3 * s.nb[3]);
-        uint8_t * blk = (uint8_t *)(d.data + o + b0 * 34);
-        quant_block_q8_0(xs, blk);
+        uint8_t * blk = (uint8_t *)(d.data + o + b0 * QBlk<TYPE>::bytes);
+        quant_block<TYPE>(xs, blk);
     }
 }
 
@@ -1085,10 +1120,13 @@ int mi355_cpy(const mi355_tensor * src, const mi355_tensor * dst, void * stream)
     hipStream_t s = (hipStream_t)stream;
     const dim3 block(256);
     const int st = src->type, dt = dst->type;
-    if (st == MI355_TYPE_F32 && dt == MI355_TYPE_Q8_0) {
-        if (src->ne[0] % 32 || dst->ne[0] % 32 || src->nb[0] != 4 || dst->nb[0] != 34) return MI355_E_SHAPE;
+    if (st == MI355_TYPE_F32 && (dt == MI355_TYPE_Q8_0 || dt == MI355_TYPE_Q4_0)) {
+        if (src->ne[0] % 32 || dst->ne[0] % 32 || src->nb[0] != 4 || dst->nb[0] != (dt == MI355_TYPE_Q8_0 ? 34 : 18)) return MI355_E_SHAPE;
         const int64_t nblk = n / 32;
-        MI355_LAUNCH("cpy", cpy_f32_q8_0_kernel, dim3(grid_for(nblk)), block, 0, s, t4(src), t4(dst), nblk);
+        if (dt == MI355_TYPE_Q8_0) MI355_LAUNCH("cpy", cpy_f32_q_kernel<MI355_TYPE_Q8_0>, dim3(grid_for(nblk)), block, 0, s, t4(src), t4(dst), nblk);
+        else                       MI355_LAUNCH("cpy", cpy_f32_q_kernel<MI355_TYPE_Q4_0>, dim3(grid_for(nblk)), block, 0, s, t4(src), t4(dst), nblk);
+    } else if (st == MI355_TYPE_F32 && dt == MI355_TYPE_BF16) {
+        MI355_LAUNCH("cpy", (cpy_kernel<float, bf16_bits>), dim3(grid_for(n)), block, 0, s, t4(src), t4(dst), n);
     } else if (st == MI355_TYPE_F32 && dt == MI355_TYPE_F32) {
         MI355_LAUNCH("cpy", (cpy_kernel<float, float>), dim3(grid_for(n)), block, 0, s, t4(src), t4(dst), n);
     } else if (st == MI355_TYPE_F32 && dt == MI355_TYPE_F16) {
@@ -1137,10 +1175,16 @@ int mi355_set_rows(const mi355_tensor * src, const mi355_tensor * ids, const mi3
         case MI355_TYPE_F16:
             if (((uintptr_t)dst->data | dst->nb[1] | dst->nb[2] | dst->nb[3]) & 1) return MI355_E_ALIGN;
             MI355_LAUNCH("set_rows", (set_rows_kernel<__half>), dim3(grid_for(n)), block, 0, s, t4(src), t4(ids), t4(dst), n); break;
+        case MI355_TYPE_BF16:
+            if (((uintptr_t)dst->data | dst->nb[1] | dst->nb[2] | dst->nb[3]) & 1) return MI355_E_ALIGN;
+            MI355_LAUNCH("set_rows", (set_rows_kernel<bf16_bits>), dim3(grid_for(n)), block, 0, s, t4(src), t4(ids), t4(dst), n); break;
         case MI355_TYPE_Q8_0:
+        case MI355_TYPE_Q4_0:
             if (src->ne[0] % 32) return MI355_E_SHAPE;
             if (((uintptr_t)dst->data | dst->nb[1] | dst->nb[2] | dst->nb[3]) & 1) return MI355_E_ALIGN;
-            MI355_LAUNCH("set_rows", set_rows_q8_0_kernel, dim3(grid_for(n / 32)), block, 0, s, t4(src), t4(ids), t4(dst), n / 32); break;
+            if (dst->type == MI355_TYPE_Q8_0) MI355_LAUNCH("set_rows", set_rows_q_kernel<MI355_TYPE_Q8_0>, dim3(grid_for(n / 32)), block, 0, s, t4(src), t4(ids), t4(dst), n / 32);
+            else                              MI355_LAUNCH("set_rows", set_rows_q_kernel<MI355_TYPE_Q4_0>, dim3(grid_for(n / 32)), block, 0, s, t4(src), t4(ids), t4(dst), n / 32);
+            break;
         default: return MI355_E_TYPE;
     }
     MI355_CHECK_LAUNCH();

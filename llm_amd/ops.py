@@ -509,8 +509,8 @@ def set_rows(src, ids, dst, type_dst):
     or uint8 rows of q8_0 blocks); writes into dst and returns it."""
     ts, ti = _desc(src, B.F32), _desc(ids, B.I64)
     td = _desc(dst, type_dst)
-    if type_dst == B.Q8_0:            # uint8 rows of 34-byte blocks: extents in elements, nb[0] the block size
-        td.ne[0] = dst.shape[-1] // 34 * 32
-        td.nb[0] = 34
+    if type_dst in (B.Q8_0, B.Q4_0):  # uint8 rows of 34- / 18-byte blocks: extents in elements, nb[0] the block size
+        td.ne[0] = dst.shape[-1] // B.TYPE_SIZE[type_dst] * 32
+        td.nb[0] = B.TYPE_SIZE[type_dst]
     K.check(K.lib.mi355_set_rows(ts, ti, td, _stream()), "mi355_set_rows")
     return dst

@@ -152,6 +152,36 @@ static void gen_quant(const std::string & dir) {
 }
 
 // ---- 2. block dequantizers ---------------------------------------------------------------------
+// the KV-cache store formats beyond q8_0: q4_0 blocks (quantize_row_q4_0_ref) and bf16 rows (ggml_fp32_to_bf16_row_ref) of the inputs
+// of quantize.gold, in a file of their own so that the first fixture keeps its bytes
+static void gen_quant2(const std::string & dir) {
+    Gold g;
+    struct In { const char * name; std::vector<float> x; };
+    std::vector<In> ins;
+    ins.push_back({"cos0", cosdata(4096, 0.0f)});
+    ins.push_back({"u1234", uniform(2048, 1234)});
+    ins.push_back({"wide", uniform(1024, 99, -300.0f, 300.0f)});
+    {   // edge blocks: zeros, single +-max, a maximum attained with both signs, ties at k+0.5, denormals, huge, tiny, signed zeros
+        std::vector<float> x(256 * 8, 0.0f);
+        x[256 + 5] = 1.0f;
+        x[512 + 7] = -3.5f;
+        for (int j = 0; j < 256; j++) x[768 + j] = (j % 32 == 3) ? 8.0f : (j % 32 == 9) ? -8.0f : 0.5f * (j % 16) - 3.75f;
+        for (int j = 0; j < 256; j++) x[1024 + j] = 1e-41f * (j - 128);
+        for (int j = 0; j < 256; j++) x[1280 + j] = 3.0e4f * (j % 5 - 2) * 127.0f;
+        for (int j = 0; j < 256; j++) x[1536 + j] = 6e-8f * ((j * 37) % 11 - 5);
+        for (int j = 0; j < 256; j++) x[1792 + j] = (j & 1) ? -0.0f : 0.0f;
+        ins.push_back({"edge", x});
+    }
+    for (auto & in : ins) {
+        g.f32(std::string("x.") + in.name, in.x);
+        g.u8(std::string("q4_0.") + in.name, quant_ref(GGML_TYPE_Q4_0, in.x));
+        std::vector<uint16_t> b(in.x.size());
+        ggml_fp32_to_bf16_row_ref(in.x.data(), (ggml_bf16_t *)b.data(), (int64_t)in.x.size());
+        g.u16(std::string("bf16.") + in.name, b);
+    }
+    g.write(dir + "/quantize2.gold");
+}
+
 static void gen_dequant(const std::string & dir) {
     Gold g;
     const std::vector<float> src = uniform(2048, 4321);
@@ -439,5 +469,6 @@ int main(int argc, char ** argv) {
     gen_mul_mat2(dir);
     gen_dequant3(dir);
     gen_mul_mat3(dir);
+    gen_quant2(dir);
     return 0;
 }

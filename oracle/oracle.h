@@ -53,6 +53,8 @@ float    orc_fp16_to_fp32(uint16_t h);
 
 /* activation quantizers, bit-exact restatements of the *_ref functions */
 void orc_quantize_row_q8_0(const float *x, void *y, int64_t k); /* ggml-quants.c:188-211 */
+void orc_quantize_row_q4_0(const float *x, void *y, int64_t k); /* ggml-quants.c:25-60 (the KV-cache store format of -ctk q4_0) */
+void orc_fp32_to_bf16_row(const float *x, uint16_t *y, int64_t k); /* ggml-impl.h:453-466, ggml.c ggml_fp32_to_bf16_row_ref */
 void orc_quantize_row_q8_1(const float *x, void *y, int64_t k); /* ggml-quants.c:214-247 */
 void orc_quantize_row_q8_K(const float *x, void *y, int64_t k); /* ggml-quants.c:2471-2508 */
 

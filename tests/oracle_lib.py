@@ -42,9 +42,11 @@ _lib.orc_fp32_to_fp16.restype = C.c_uint16
 _lib.orc_fp32_to_fp16.argtypes = [_f]
 _lib.orc_fp16_to_fp32.restype = _f
 _lib.orc_fp16_to_fp32.argtypes = [C.c_uint16]
-for _n in ("q8_0", "q8_1", "q8_K"):
+for _n in ("q8_0", "q8_1", "q8_K", "q4_0"):
     getattr(_lib, "orc_quantize_row_" + _n).argtypes = [_vp, _vp, _i64]
     getattr(_lib, "orc_quantize_row_" + _n).restype = None
+_lib.orc_fp32_to_bf16_row.argtypes = [_vp, _vp, _i64]
+_lib.orc_fp32_to_bf16_row.restype = None
 _lib.orc_dequantize_row.argtypes = [C.c_int, _vp, _vp, _i64]
 _lib.orc_mul_mat_cpu.argtypes = [C.c_int, _vp, _i64, _vp, _vp, _i64, _i64, _i64]
 _lib.orc_mul_mat_q8_1.argtypes = [C.c_int, _vp, _i64, _vp, _vp, _i64, _i64, _i64]
@@ -78,6 +80,13 @@ def quantize_row(t, x):
     x = np.ascontiguousarray(x, dtype=np.float32)
     out = np.zeros(row_size(t, x.size), dtype=np.uint8)
     getattr(_lib, "orc_quantize_row_" + TYPE_NAMES[t])(_p(x), _p(out), x.size)
+    return out
+
+
+def fp32_to_bf16_row(x):
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    out = np.zeros(x.size, dtype=np.uint16)
+    _lib.orc_fp32_to_bf16_row(_p(x), _p(out), x.size)
     return out
 
 

@@ -20,7 +20,7 @@ OPS = ["MUL_MAT", "MUL_MAT_ID", "FLASH_ATTN_EXT", "ADD", "MUL", "SUB", "DIV", "R
        "ABS", "SGN", "NEG", "STEP", "TANH", "ELU", "RELU", "SIGMOID", "GELU", "GELU_QUICK", "SILU", "HARDSWISH", "HARDSIGMOID", "EXP", "GELU_ERF",
        "SQR", "SQRT", "SIN", "COS", "LOG", "CLAMP", "NORM", "L2_NORM"]
 # lower bounds on the number of cases that must actually RUN on the device (not "not supported")
-MIN_RUN = {"MUL_MAT": 640, "SET_ROWS": 50, "MUL_MAT_ID": 160, "FLASH_ATTN_EXT": 1900, "ROPE": 50, "SOFT_MAX": 100}
+MIN_RUN = {"MUL_MAT": 640, "SET_ROWS": 80, "CPY": 40, "MUL_MAT_ID": 160, "FLASH_ATTN_EXT": 1900, "ROPE": 50, "SOFT_MAX": 100}
 
 
 def _run(op):
@@ -198,6 +198,22 @@ def test_llama_logits_match_ggml_cpu(ftype, ctk, tmp_path):
     assert e_cpu < 5e-2, e_cpu                      # the yardstick itself is sane
     assert e_gpu <= 1.25 * e_cpu + 2e-4, (e_gpu, e_cpu)
     assert d <= 2.0 * e_cpu + 2e-4, (d, e_cpu)        # two roundings of the same exact values
+
+
+@pytest.mark.parametrize("ctk", ["q4_0", "bf16"])
+def test_q4_0_and_bf16_kv_cache_stay_on_the_device(ctk, tmp_path):
+    """`-ctk q4_0 -ctv q4_0` / `bf16`: FLASH_ATTN_EXT reads such a cache, and the stores into it -- CPY (or SET_ROWS) f32 -> q4_0
+    (quantize_row_q4_0_ref) / bf16 -- run on the device too: no CPU compute split, logits as close to the exact twin's as ggml-cpu's
+    with the same cache type."""
+    tool = os.path.join(ROOT, "tools", "run_llama_bench.sh")
+    r = subprocess.run([tool, "tiny", "Q4_K_M", "-ctk", ctk, "-ctv", ctk, "-p", "64", "-n", "8", "-r", "1"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "graph splits = 2" in r.stderr + r.stdout, (r.stderr + r.stdout)[-3000:]
+    e_cpu, e_gpu, d = _logits_vs_exact_twin(tmp_path, "tiny", "Q4_K_M", ctk)
+    # (4-bit K / V rows on a random model: ggml-cpu itself is far from the twin, NMSE ~0.5 -- the plugin has to be no farther)
+    assert e_cpu < (1.0 if ctk == "q4_0" else 8e-2), e_cpu
+    assert e_gpu <= 1.25 * e_cpu + 2e-4, (e_gpu, e_cpu)
+    assert d <= 2.0 * e_cpu + 2e-4, (d, e_cpu)
 
 
 @pytest.mark.parametrize("model,ctk", [("hd80", "f16"), ("hd96", "f16"), ("hd96", "q8_0"), ("hd256", "f16"), ("hd256", "q8_0")])

@@ -25,6 +25,16 @@ def test_quantize_bit_exact(name, t):
     assert np.array_equal(got, want), f"{np.count_nonzero(got != want)} bytes differ"
 
 
+@pytest.mark.parametrize("name", ["cos0", "u1234", "wide", "edge"])
+def test_kv_store_formats_bit_exact(name):
+    """q4_0 blocks (quantize_row_q4_0_ref) and bf16 rows (ggml_fp32_to_bf16_row_ref) -- what CPY / SET_ROWS write into a q4_0 / bf16 KV
+    cache -- of the oracle against the reference's own output (quantize2.gold)"""
+    g = load_gold("quantize2.gold")
+    x = g["x." + name]
+    assert np.array_equal(O.quantize_row(O.Q4_0, x), g["q4_0." + name])
+    assert np.array_equal(O.fp32_to_bf16_row(x), g["bf16." + name])
+
+
 @pytest.mark.parametrize("src", ["rand", "quant"])
 @pytest.mark.parametrize("t", O.WEIGHT_TYPES)
 def test_dequantize_bit_exact(src, t):

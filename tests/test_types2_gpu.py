@@ -141,17 +141,19 @@ def test_mul_mat_f_broadcast_and_strides(ops):
     assert float(((got - ref) ** 2).sum() / (ref ** 2).sum()) <= 1e-11
 
 
-@pytest.mark.parametrize("tdst", [B.F32, B.F16, B.Q8_0])
+@pytest.mark.parametrize("tdst", [B.F32, B.F16, B.Q8_0, B.Q4_0, B.BF16])
 def test_set_rows(ops, tdst):
     """GGML_OP_SET_ROWS (ggml-cpu/ops.cpp:5179-5227): rows scattered by an i64 index that is broadcast over dims 2, 3;
-    q8_0 rows are bit-exact with quantize_row_q8_0_ref"""
+    q8_0 / q4_0 rows are bit-exact with quantize_row_q8_0_ref / quantize_row_q4_0_ref, bf16 rows with ggml_fp32_to_bf16_row_ref"""
     import torch
     rng = np.random.default_rng(11)
     ne3, ne2, n, k, nrows = 3, 4, 5, 64, 11
     src = rng.standard_normal((ne3, ne2, n, k)).astype(np.float32)
     ids = np.stack([rng.permutation(nrows)[:n] for _ in range(2 * 1)]).reshape(1, 2, n).astype(np.int64)   # ids [1][2][n]
-    if tdst == B.Q8_0:
-        dst = torch.zeros((ne3, ne2, nrows, k // 32 * 34), dtype=torch.uint8, device="cuda")
+    if tdst in (B.Q8_0, B.Q4_0):
+        dst = torch.zeros((ne3, ne2, nrows, k // 32 * B.TYPE_SIZE[tdst]), dtype=torch.uint8, device="cuda")
+    elif tdst == B.BF16:
+        dst = torch.full((ne3, ne2, nrows, k), 7, dtype=torch.int16, device="cuda")
     else:
         dst = torch.full((ne3, ne2, nrows, k), -7.0, dtype=torch.float32 if tdst == B.F32 else torch.float16, device="cuda")
     before = dst.clone()
@@ -163,8 +165,37 @@ def test_set_rows(ops, tdst):
             for i in range(n):
                 r = ids[0, i2 % 2, i]
                 touched[i3, i2, r] = True
-                if tdst == B.Q8_0:
-                    assert np.array_equal(got[i3, i2, r], O.quantize_row(O.Q8_0, src[i3, i2, i]))
+                if tdst in (B.Q8_0, B.Q4_0):
+                    assert np.array_equal(got[i3, i2, r], O.quantize_row(tdst, src[i3, i2, i]))
+                elif tdst == B.BF16:
+                    assert np.array_equal(got[i3, i2, r].view(np.uint16), O.fp32_to_bf16_row(src[i3, i2, i]))
                 else:
                     assert np.array_equal(got[i3, i2, r], src[i3, i2, i].astype(got.dtype))
     assert np.array_equal(got[~touched], was[~touched])
+
+
+@pytest.mark.parametrize("name", ["cos0", "u1234", "wide", "edge"])
+def test_cpy_into_q4_0_and_bf16_golden(ops, name):
+    """CPY f32 -> q4_0 / bf16 (the KV-cache stores of -ctk q4_0 / bf16; ggml-cuda/cpy.cu) against the reference's own blocks / rows
+    (tests/golden/quantize2.gold, written by quantize_row_q4_0_ref and ggml_fp32_to_bf16_row_ref): bit-exact, edge blocks included."""
+    import torch
+    import llm_amd.kernels as K
+    g = load_gold("quantize2.gold")
+    x = dev(g["x." + name].reshape(4, -1))          # four rows
+    s = torch.cuda.current_stream().cuda_stream
+    k = x.shape[1]
+    def desc(t, type_id, k_elems, unit):
+        d = K.Tensor()
+        d.data, d.type = t.data_ptr(), type_id
+        d.ne[0], d.ne[1], d.ne[2], d.ne[3] = k_elems, t.shape[0], 1, 1
+        d.nb[0] = unit; d.nb[1] = t.stride(0) * t.element_size(); d.nb[2] = d.nb[3] = d.nb[1] * t.shape[0]
+        return d
+    q = torch.zeros((4, k // 32 * 18), dtype=torch.uint8, device="cuda")
+    K.check(K.lib.mi355_cpy(desc(x, B.F32, k, 4), desc(q, B.Q4_0, k, 18), s), "cpy q4_0")
+    got, want = q.cpu().numpy().reshape(-1, 18), g["q4_0." + name].reshape(-1, 18)
+    bad = [i for i in range(want.shape[0]) if not np.array_equal(got[i], want[i])]
+    assert not bad, (bad[:8], [(got[i].tolist(), want[i].tolist(), g["x." + name][32 * i:32 * i + 4].tolist()) for i in bad[:2]])
+    b = torch.zeros((4, k), dtype=torch.int16, device="cuda")
+    K.check(K.lib.mi355_cpy(desc(x, B.F32, k, 4), desc(b, B.BF16, k, 2), s), "cpy bf16")
+    assert np.array_equal(b.cpu().numpy().view(np.uint16).ravel(), g["bf16." + name])
+

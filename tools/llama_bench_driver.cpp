@@ -24,6 +24,7 @@ static ggml_type kv_type(const std::string & s) {
     if (s == "f16") return GGML_TYPE_F16;
     if (s == "q8_0") return GGML_TYPE_Q8_0;
     if (s == "q4_0") return GGML_TYPE_Q4_0;
+    if (s == "bf16") return GGML_TYPE_BF16;
     if (s == "f32") return GGML_TYPE_F32;
     fprintf(stderr, "unknown kv type %s\n", s.c_str()); exit(2);
 }
