@@ -601,6 +601,9 @@ MI355_API int mi355_set_rows(const mi355_tensor *src, const mi355_tensor *ids, c
  * kv_table[2 * kv_slot + 1] (V) -- the table of mi355_qkv_rope_args, for graph replay -- and k_dst / v_dst are ignored. */
 MI355_API int mi355_kv_store_q8_0(const float *k_src, int64_t n_k, void *k_dst, const float *v_src, int64_t n_v, void *v_dst,
                                   void *const *kv_table, int kv_slot, void *stream);
+/* the same for a cache of `type` Q8_0 or Q4_0 (quantize_row_q4_0_ref, ggml-quants.c:25-60; ggml_cpy_f32_q4_0_cuda) */
+MI355_API int mi355_kv_store_q(int type, const float *k_src, int64_t n_k, void *k_dst, const float *v_src, int64_t n_v, void *v_dst,
+                               void *const *kv_table, int kv_slot, void *stream);
 
 /* dst = x * scale + bias (f32, contiguous).  ggml_cuda_op_scale (ggml-cuda/scale.cu). */
 MI355_API int mi355_scale_f32(const mi355_tensor *x, const mi355_tensor *dst, float scale, float bias, void *stream);

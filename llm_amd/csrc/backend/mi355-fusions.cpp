@@ -777,7 +777,8 @@ static bool mi355_try_fuse_moe_router(mi355_backend_ctx * ctx, ggml_cgraph * cgr
 struct qkv_nodes {
     ggml_tensor * mq, * rq, * mk, * rk, * mv, * ck, * cv;
     int idx[7];
-    bool kv_q8;
+    bool kv_q8;      // a quantized cache (q8_0 or q4_0, kv_qt): K / V leave the fused launch as f32 rows and one more launch quantizes them
+    int kv_qt;
 };
 
 static bool qkv_match(ggml_cgraph * cgraph, int i, const std::vector<char> & done, bool (*mm_ok)(const ggml_tensor *), qkv_nodes & q) {
@@ -831,7 +832,8 @@ static bool qkv_match(ggml_cgraph * cgraph, int i, const std::vector<char> & don
     if (ggml_nelements(rq) != Mq * N || ggml_nelements(rk) != Mk * N) return false;
     const int32_t * rp = (const int32_t *)rq->op_params;
     if (rp[2] != 0 && rp[2] != 2) return false;
-    q.kv_q8 = ck->type == GGML_TYPE_Q8_0 && cv->type == GGML_TYPE_Q8_0;
+    q.kv_q8 = ck->type == cv->type && (ck->type == GGML_TYPE_Q8_0 || ck->type == GGML_TYPE_Q4_0);
+    q.kv_qt = (int)ck->type;
     for (ggml_tensor * c : {ck, cv}) {
         if ((c->type != GGML_TYPE_F16 && c->type != GGML_TYPE_F32 && !q.kv_q8) || !ggml_is_contiguous(c) || !ggml_is_contiguous(c->src[0])) return false;
         if (c->src[0]->type != GGML_TYPE_F32) return false;
@@ -939,7 +941,7 @@ static bool mi355_try_fuse_qkv_gemm(mi355_backend_ctx * ctx, ggml_cgraph * cgrap
     qkv_rope_params(q.rq, &f.n_dims, &f.mode, &f.n_ctx_orig, f6);
     f.freq_base = f6[0]; f.freq_scale = f6[1]; f.ext_factor = f6[2]; f.attn_factor = f6[3]; f.beta_fast = f6[4]; f.beta_slow = f6[5];
     MI_CHECK(mi355_qkv_finish(&f, ctx->stream));
-    if (kv_tmp) MI_CHECK(mi355_kv_store_q8_0(kv_tmp, N * Mk, q.ck->data, kv_tmp + N * Mk, N * Mv, q.cv->data, nullptr, 0, ctx->stream));
+    if (kv_tmp) MI_CHECK(mi355_kv_store_q(q.kv_qt, kv_tmp, N * Mk, q.ck->data, kv_tmp + N * Mk, N * Mv, q.cv->data, nullptr, 0, ctx->stream));
     for (int m = 1; m < 7; m++) done[q.idx[m]] = 1;
     ctx->act_invalidate_if_written(q.rq);
     return true;
@@ -1070,7 +1072,7 @@ static bool mi355_try_fuse_qkv_small(mi355_backend_ctx * ctx, ggml_cgraph * cgra
         mi355_mul_mat(ctx, &t);
     }
     MI_CHECK(mi355_qkv_finish(&f, ctx->stream));
-    if (kv_tmp) MI_CHECK(mi355_kv_store_q8_0(kv_tmp, N * Mk, q.ck->data, kv_tmp + N * Mk, N * Mv, q.cv->data, nullptr, 0, ctx->stream));
+    if (kv_tmp) MI_CHECK(mi355_kv_store_q(q.kv_qt, kv_tmp, N * Mk, q.ck->data, kv_tmp + N * Mk, N * Mv, q.cv->data, nullptr, 0, ctx->stream));
     for (int m = 1; m < 7; m++) done[q.idx[m]] = 1;
     ctx->act_invalidate_if_written(q.rq);
     return true;
@@ -1222,7 +1224,7 @@ static bool mi355_try_fuse_qkv_rope(mi355_backend_ctx * ctx, ggml_cgraph * cgrap
     const int rc = mi355_qkv_rope_matvec(&a, ctx->stream);
     if (rc == MI355_E_UNSUPPORTED || rc == MI355_E_SHAPE || rc == MI355_E_ALIGN) return false;
     MI_CHECK(rc);
-    if (kv_q8) MI_CHECK(mi355_kv_store_q8_0(kv_tmp, Mk, ck->data, kv_tmp + Mk, Mv, cv->data, kv_table, kv_slot, ctx->stream));
+    if (kv_q8) MI_CHECK(mi355_kv_store_q(qn.kv_qt, kv_tmp, Mk, ck->data, kv_tmp + Mk, Mv, cv->data, kv_table, kv_slot, ctx->stream));
     for (int m = 1; m < 7; m++) done[idx[m]] = 1;
     if (kv_table) { ctx->gc.kv_push(idx[5], 0); ctx->gc.kv_push(idx[6], 0); ctx->gc.n_slots++; }
     ctx->act_invalidate_if_written(rq);

@@ -670,13 +670,14 @@ template <int TYPE> struct QBlk { static constexpr int bytes = TYPE == MI355_TYP
 
 // K and V rows of one decode token, f32 -> q8_0 cache rows, in one launch; the destinations come from the arguments or, under graph
 // replay, from the device table the fused Q/K/V launch uses (slot pair 2 s, 2 s + 1)
+template <int TYPE>
 __global__ void __launch_bounds__(64)
-kv_store_q8_0_kernel(const float * k_src, int nbk, uint8_t * k_dst, const float * v_src, int nbv, uint8_t * v_dst, void * const * tab, int slot) {
+kv_store_q_kernel(const float * k_src, int nbk, uint8_t * k_dst, const float * v_src, int nbv, uint8_t * v_dst, void * const * tab, int slot) {
     const int ib = blockIdx.x * 64 + threadIdx.x;
     if (ib >= nbk + nbv) return;
     if (tab) { k_dst = (uint8_t *)tab[2 * slot]; v_dst = (uint8_t *)tab[2 * slot + 1]; }
-    if (ib < nbk) quant_block_q8_0(k_src + 32 * ib, k_dst + 34 * ib);
-    else          quant_block_q8_0(v_src + 32 * (ib - nbk), v_dst + 34 * (ib - nbk));
+    if (ib < nbk) quant_block<TYPE>(k_src + 32 * ib, k_dst + QBlk<TYPE>::bytes * ib);
+    else          quant_block<TYPE>(v_src + 32 * (ib - nbk), v_dst + QBlk<TYPE>::bytes * (ib - nbk));
 }
 
 // f32 -> q8_0 / q4_0: one lane per 32-value block
@@ -1144,14 +1145,24 @@ int mi355_cpy(const mi355_tensor * src, const mi355_tensor * dst, void * stream)
 
 int mi355_kv_store_q8_0(const float * k_src, int64_t n_k, void * k_dst, const float * v_src, int64_t n_v, void * v_dst,
                         void * const * kv_table, int kv_slot, void * stream) {
+    return mi355_kv_store_q(MI355_TYPE_Q8_0, k_src, n_k, k_dst, v_src, n_v, v_dst, kv_table, kv_slot, stream);
+}
+
+int mi355_kv_store_q(int type, const float * k_src, int64_t n_k, void * k_dst, const float * v_src, int64_t n_v, void * v_dst,
+                     void * const * kv_table, int kv_slot, void * stream) {
+    if (type != MI355_TYPE_Q8_0 && type != MI355_TYPE_Q4_0) return MI355_E_TYPE;
     if (!k_src || !v_src || (!kv_table && (!k_dst || !v_dst))) return MI355_E_NULL;
     if (n_k < 0 || n_v < 0 || n_k % 32 || n_v % 32 || n_k + n_v > 0x7fffffff) return MI355_E_SHAPE;
     if ((((uintptr_t)k_src | (uintptr_t)v_src) & 3) || (((uintptr_t)k_dst | (uintptr_t)v_dst) & 1) || ((uintptr_t)kv_table & 7)) return MI355_E_ALIGN;
     if (kv_table && kv_slot < 0) return MI355_E_SHAPE;
     const int nb = (int)((n_k + n_v) / 32);
     if (nb == 0) return MI355_OK;
-    MI355_LAUNCH("kv_store", kv_store_q8_0_kernel, dim3((unsigned)((nb + 63) / 64)), dim3(64), 0, (hipStream_t)stream,
-                 k_src, (int)(n_k / 32), (uint8_t *)k_dst, v_src, (int)(n_v / 32), (uint8_t *)v_dst, kv_table, kv_slot);
+    if (type == MI355_TYPE_Q8_0)
+        MI355_LAUNCH("kv_store", kv_store_q_kernel<MI355_TYPE_Q8_0>, dim3((unsigned)((nb + 63) / 64)), dim3(64), 0, (hipStream_t)stream,
+                     k_src, (int)(n_k / 32), (uint8_t *)k_dst, v_src, (int)(n_v / 32), (uint8_t *)v_dst, kv_table, kv_slot);
+    else
+        MI355_LAUNCH("kv_store", kv_store_q_kernel<MI355_TYPE_Q4_0>, dim3((unsigned)((nb + 63) / 64)), dim3(64), 0, (hipStream_t)stream,
+                     k_src, (int)(n_k / 32), (uint8_t *)k_dst, v_src, (int)(n_v / 32), (uint8_t *)v_dst, kv_table, kv_slot);
     MI355_CHECK_LAUNCH();
     return MI355_OK;
 }

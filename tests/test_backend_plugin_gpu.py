@@ -280,7 +280,7 @@ def test_gate_up_glu_gemm_is_bit_exact(tmp_path, ftype):
     assert np.array_equal(outs["fused"][0], outs["no_glu_gemm"][0])
 
 
-@pytest.mark.parametrize("kv", ["f16", "q8_0"])
+@pytest.mark.parametrize("kv", ["f16", "q8_0", "q4_0"])
 def test_small_batch_forms_are_bit_exact_and_run(tmp_path, kv):
     """The 12-token batch of the parity sequence takes the skinny kernels: the norm and the GLU write the q8_K planes themselves
     (mi355_rms_norm_mul_q8k_f32, mi355_glu_q8k_f32) and Q/K/V + 2 ROPE + 2 CPY run as three products and one mi355_qkv_finish.  Each
@@ -341,7 +341,12 @@ def test_fusions_are_bit_exact_with_a_q8_0_cache(tmp_path):
     test_fusions_are_bit_exact(tmp_path, "tiny", kv="q8_0")
 
 
-@pytest.mark.parametrize("model,kv", [("tiny", "f16"), ("tinymoe", "f16"), ("tiny", "q8_0")])
+def test_fusions_are_bit_exact_with_a_q4_0_cache(tmp_path):
+    """-ctk q4_0 -ctv q4_0: the same path with mi355_kv_store_q(Q4_0) -- the bits of the CPY f32 -> q4_0 nodes launched one by one"""
+    test_fusions_are_bit_exact(tmp_path, "tiny", kv="q4_0")
+
+
+@pytest.mark.parametrize("model,kv", [("tiny", "f16"), ("tinymoe", "f16"), ("tiny", "q8_0"), ("tiny", "q4_0")])
 def test_decode_graph_replay_is_bit_exact(tmp_path, model, kv):
     """the plugin captures a decode token's launches into a hipGraph and replays it while the ggml graph keeps
     its shape (the KV-cache rows of the new token go through a device table).  230 decode steps after a 48-token prompt
