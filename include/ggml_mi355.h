@@ -30,6 +30,8 @@
  *   GGML_MI355_NO_FUSE=1     run every graph node with its own kernel, no activation-quantization cache
  *   GGML_MI355_NO_PINNED=1   do not offer the pinned host buffer type
  *   GGML_MI355_NO_SKINNY=1   MUL_MAT with 4..64 columns: mat-vec / bf16 GEMM kernels instead of the skinny int8-MFMA ones
+ *   GGML_MI355_NO_KQ_ONLY=1  33..64 columns: only matrices of >= 32 M weights (GGML_MI355_SKINNY_WIDE_MIN) take the skinny kernels, whatever
+ *                            the types of the other matrices that read the same activations
  *   GGML_MI355_NO_SKINNY_GROUP=1  steps of 5..32 tokens: one skinny launch per matrix instead of one for wq + wk (+ wv) and one for
  *                            ffn_up + ffn_gate (mi355_mul_mat_skinny_k_group); the results are the same bits either way
  *   GGML_MI355_NO_GLU_MATVEC=1  decode ffn: grouped gate+up mat-vec and a separate GLU kernel instead of mi355_glu_matvec

@@ -298,6 +298,7 @@ bool is_block_weight_type(enum ggml_type t);        // + q4_1, q5_0, q5_1, q2_K,
 bool is_float_weight_type(enum ggml_type t);
 size_t align_up(size_t x, size_t a);
 int  mi355_mul_mat_path(const ggml_tensor * src0, const ggml_tensor * src1, const ggml_tensor * dst = nullptr);
+void mi355_note_graph_activations(ggml_cgraph * cgraph);     // what mi355_mul_mat_path may know about the graph in flight
 mi355_act_layout mi355_act_planes(int path, int64_t K, int64_t rows);
 void mi355_mul_mat(mi355_backend_ctx * ctx, ggml_tensor * dst);
 void mi355_mul_mat_id(mi355_backend_ctx * ctx, ggml_tensor * dst);

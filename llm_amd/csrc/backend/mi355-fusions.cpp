@@ -1391,6 +1391,7 @@ static bool mi355_try_fuse_decode_layer(mi355_backend_ctx * ctx, ggml_cgraph * c
 enum ggml_status mi355_issue_graph(mi355_backend_ctx * ctx, ggml_cgraph * cgraph) {
     ctx->act_cache.valid = false; // tensors may have been rewritten through set_tensor / copies between calls
     ctx->moe_tables.valid = false;
+    mi355_note_graph_activations(cgraph);
     ctx->dl_used = 0;
     const int n = ggml_graph_n_nodes(cgraph);
     const bool fuse = !MI355_ENV_SET("GGML_MI355_NO_FUSE");

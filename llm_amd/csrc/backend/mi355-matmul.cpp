@@ -37,6 +37,31 @@ size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 // batches of more rows than this are "prefill-sized": the K-quant MUL_MATs that read them take the bf16 GEMM, so fused producers (norm,
 // GLU, attention) store the bf16 rows alongside their f32 result.  A consumer that wants another format converts for itself, as always.
 
+// Activations of the graph in flight whose MUL_MAT readers ALL have K-quant weights (a Llama layer's attn_norm: wq / wk / wv; not
+// Mixtral's, whose wk / wv are q8_0): one q8_K quantization serves every reader, so the 4096 x 4096 class takes the skinny kernels
+// up to 64 columns as well (8B Q4_K_M pp33 / 48 / 64 4910 / 6955 / 8783 -> 5117 / 7207 / 9032 t/s; with q8_0 siblings the GEMM stays
+// ahead, 8x7B pp64 4317 against 4160).  Built by mi355_note_graph_activations before a graph's launches are issued -- the same for
+// the fused and the unfused run, a captured and an eager one -- and asked by tensor identity.  GGML_MI355_NO_KQ_ONLY=1: off.
+static thread_local std::vector<std::pair<const ggml_tensor *, bool>> g_act_readers;
+void mi355_note_graph_activations(ggml_cgraph * cgraph) {
+    g_act_readers.clear();
+    if (MI355_ENV_SET("GGML_MI355_NO_KQ_ONLY")) return;
+    const int n = ggml_graph_n_nodes(cgraph);
+    for (int i = 0; i < n; i++) {
+        const ggml_tensor * t = ggml_graph_node(cgraph, i);
+        if (t->op != GGML_OP_MUL_MAT || is_float_weight_type(t->src[0]->type)) continue;
+        const enum ggml_type wt = t->src[0]->type;
+        const bool kq = wt == GGML_TYPE_Q4_K || wt == GGML_TYPE_Q5_K || wt == GGML_TYPE_Q6_K;
+        bool found = false;
+        for (auto & e : g_act_readers) if (e.first == t->src[1]) { e.second = e.second && kq; found = true; break; }
+        if (!found) g_act_readers.emplace_back(t->src[1], kq);
+    }
+}
+static bool act_read_by_kquants_only(const ggml_tensor * src1) {
+    for (const auto & e : g_act_readers) if (e.first == src1) return e.second;
+    return false;
+}
+
 // dst: the MUL_MAT node when the caller has it (its op_params carry the precision request)
 int mi355_mul_mat_path(const ggml_tensor * src0, const ggml_tensor * src1, const ggml_tensor * dst) {
     static const bool int8_mmq = MI355_ENV_SET("GGML_MI355_MMQ_INT8");
@@ -69,7 +94,7 @@ int mi355_mul_mat_path(const ggml_tensor * src0, const ggml_tensor * src1, const
         // Q/K/V finish and add + norm launches with it (8x7B, whose dense matrices are all of that class: pp64 4294 on the GEMM, 4069 here).
         // src0->ne[1] is the whole matrix's row count, so a row-split matrix still takes the unsplit one's path.
         static const int64_t wide_min = [] { const char * e = getenv("GGML_MI355_SKINNY_WIDE_MIN"); return e ? atoll(e) : (int64_t)32 << 20; }();
-        const int64_t n_max = src0->ne[1] * K >= wide_min ? skinny_max : std::min<int64_t>(skinny_max, 32);
+        const int64_t n_max = src0->ne[1] * K >= wide_min || (kq && N > 32 && act_read_by_kquants_only(src1)) ? skinny_max : std::min<int64_t>(skinny_max, 32);
         if (kq  && N >= (src0->type == GGML_TYPE_Q6_K ? 5 : 4) && N <= n_max) return MM_SKINNY_K;
         if (!kq && N > 8  && N <= (K >= 8192 ? 64 : 32))  return MM_SKINNY;
     }
