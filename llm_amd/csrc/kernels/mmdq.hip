@@ -488,12 +488,16 @@ static __device__ __forceinline__ void gemm_dma_piece(const void * gsrc, unsigne
 // BMW x BNW: 128 x 256 (8 multiplying waves of 64 x 64, 4 dequantizing; wide launches) or 64 x 128 (4 multiplying waves of
 // 64 x 32, 2 dequantizing; two workgroups per CU, with split-K for the launches of few tiles: gridDim.z == 2 adds the two
 // halves of K into a zeroed dst, exactly as mmdq_kernel does).
-template <int TYPE, int BMW, int BNW, bool GLU = false, int TYPE2 = -1>
+// IDS (MUL_MAT_ID, prefill-sized batches): the tile's 256 columns are (token, slot) pairs routed to one expert, listed by
+// moe_bucket_kernel with tiles of BNW pairs -- the activation DMA gathers their rows (every lane brings its own address), the weight rows
+// are the expert's, the results scatter to the pairs' rows.
+template <int TYPE, int BMW, int BNW, bool GLU = false, int TYPE2 = -1, bool IDS = false>
 __global__ void __launch_bounds__(BMW * BNW == 128 * 256 ? 768 : 384)
 mmdq_ws_kernel(const DArgs a_in) {
     static_assert(!GLU || (BMW == 128 && BNW == 256), "the gate / up / GLU form exists for the 128 x 256 tile");
     constexpr bool PAIR = TYPE2 >= 0;
     static_assert(!PAIR || !GLU, "pair and GLU forms are separate");
+    static_assert(!IDS || (!PAIR && !GLU && BMW == 128 && BNW == 256), "the MUL_MAT_ID form exists for the plain 128 x 256 tile");
     const bool second = PAIR && (int)blockIdx.y >= a_in.y2;
     DArgs a = a_in;
     if (PAIR && second) { a.W = a_in.W2; a.w_row_stride = a_in.w2_row_stride; a.m = a_in.m2; a.part = a_in.part2; }
@@ -511,13 +515,29 @@ mmdq_ws_kernel(const DArgs a_in) {
     const int n0 = blockIdx.x * BNW, m0 = by * (GLU ? BMW / 2 : BMW);
     const int kspan = a.k / (int)gridDim.z, kbeg = (int)blockIdx.z * kspan;
     const int nstage = kspan / BK;
+    __shared__ int s_pair[IDS ? BNW : 1];
+    int expert = 0;
+    if constexpr (IDS) {
+        // column tile blockIdx.x -> (expert, tile inside the expert), as in mmdq_kernel; the grid is sized for the worst case
+        const int ti = blockIdx.x;
+        const int total_tiles = a.tile_off[a.n_expert];
+        for (int b0 = 0; b0 < a.n_expert; b0 += 64) {
+            const int end = b0 + lane < a.n_expert ? a.tile_off[b0 + lane + 1] : 0x7fffffff;
+            expert += __builtin_popcountll(__ballot(end <= ti));
+        }
+        if (ti >= total_tiles) return;                                // (the whole workgroup, before any barrier)
+        const int base = a.off[expert] + (ti - a.tile_off[expert]) * BNW, cnt = a.off[expert + 1] - base;
+        if (tid < BNW) s_pair[tid] = tid < cnt ? a.sorted[base + tid] : -1;
+        __syncthreads();
+    }
 
     if (wave >= NMW) {                                                // ---- dequantizing waves
         if (a.dbg & 8) return;                                        // lab: the multiplying waves run free (no stage barriers)
         const int pt = tid - 64 * NMW, sr = pt >> 1, hf = pt & 1;     // weight row sr of the tile, 32-value half hf of the stage
         const int srm = GLU ? (sr & 63) : sr;
         const int wr = m0 + srm < a.m ? m0 + srm : a.m - 1;
-        const uint8_t * wrow = GLU && sr >= 64 ? a.W2 + (int64_t)wr * a.w2_row_stride : a.W + (int64_t)wr * a.w_row_stride;
+        const uint8_t * wrow = GLU && sr >= 64 ? a.W2 + (int64_t)wr * a.w2_row_stride
+                                                : a.W + (IDS ? (int64_t)expert * a.w_expert_stride : 0) + (int64_t)wr * a.w_row_stride;
 #ifndef MMDQ_PFD
 #define MMDQ_PFD 2        // stages of raw weight bytes a dequantizing thread holds in flight
 #endif
@@ -567,7 +587,14 @@ mmdq_ws_kernel(const DArgs a_in) {
 #pragma unroll
     for (int i = 0; i < MAXP; i++) {
         const int p = wave + NMW * i, c = 64 * p + lane, r = (c * 7282) >> 16, j = c - 9 * r;
-        const int col = n0 + r < a.n ? n0 + r : a.n - 1;
+        int col;
+        if constexpr (IDS) {       // the pair's activation row; slots past the expert's count re-read the tile's first pair, their products are never stored
+            int pair = r < BNW ? s_pair[r] : -1;
+            if (pair < 0) pair = s_pair[0];
+            col = (pair / a.n_used) * a.act_ne1 + (pair % a.n_used) % a.act_ne1;
+        } else {
+            col = n0 + r < a.n ? n0 + r : a.n - 1;
+        }
         on[i]  = p < NPIECE && j < 8;
         src[i] = a.x + (int64_t)col * a.x_row_stride + kbeg + j * 8;
     }
@@ -666,8 +693,9 @@ mmdq_ws_kernel(const DArgs a_in) {
         for (int tn = 0; tn < TN; tn++)
 #pragma unroll
             for (int r = 0; r < 16; r++) {
-                const int n = n0 + wn_ * 32 * TN + tn * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (m < a.m && n < a.n) {
+                const int nl = wn_ * 32 * TN + tn * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int n = IDS ? s_pair[nl] : n0 + nl;
+                if (m < a.m && (IDS ? n >= 0 : n < a.n)) {
                     float * o = a.dst + (int64_t)n * a.dst_col_stride + m;
                     if (a.part)            a.part[((int64_t)blockIdx.z * a.n + n) * a.m + m] = acc[tm][tn][r];
                     else if (gridDim.z > 1) atomicAdd(o, acc[tm][tn][r]);   // two addends onto 0: the sum does not depend on the order
@@ -811,8 +839,21 @@ static int launch(const DArgs & a_in, int64_t m_total, hipStream_t s, const char
 }
 
 // ---- MUL_MAT_ID for prefill-sized batches: route on the device (moe_bucket.h), then one GEMM launch over all experts.
+// the role-split 128 x 256 tile for MUL_MAT_ID (tiles of 256 pairs; the five weight types a MoE GGUF is made of)
+static bool ids_wide(int type, int64_t m) {
+    static const int on = [] { const char * e = getenv("MI355_MMDQ_ID_WIDE"); return e ? atoi(e) : 1; }();
+    return on && m >= 1024 && (type == MI355_TYPE_Q4_0 || type == MI355_TYPE_Q8_0 || type == MI355_TYPE_Q4_K || type == MI355_TYPE_Q5_K || type == MI355_TYPE_Q6_K);
+}
+
 template <int TYPE>
 static int launch_ids(const DArgs & a, int max_tiles, hipStream_t s, const char * tag) {
+    if constexpr (TYPE == MI355_TYPE_Q4_0 || TYPE == MI355_TYPE_Q8_0 || TYPE == MI355_TYPE_Q4_K || TYPE == MI355_TYPE_Q5_K || TYPE == MI355_TYPE_Q6_K) {
+        if (ids_wide(TYPE, a.m)) {
+            MI355_LAUNCH(tag, (mmdq_ws_kernel<TYPE, 128, 256, false, -1, true>), dim3((unsigned)max_tiles, (unsigned)((a.m + 127) / 128)), dim3(768), 0, s, a);
+            MI355_CHECK_LAUNCH();
+            return MI355_OK;
+        }
+    }
     if (a.m >= 1024) MI355_LAUNCH(tag, (mmdq_kernel<TYPE, 128, true>), dim3((unsigned)max_tiles, (unsigned)((a.m + 127) / 128)), dim3(256), 0, s, a);
     else             MI355_LAUNCH(tag, (mmdq_kernel<TYPE, 64, true>), dim3((unsigned)max_tiles, (unsigned)((a.m + 63) / 64)), dim3(256), 0, s, a);
     MI355_CHECK_LAUNCH();
@@ -1049,7 +1090,8 @@ extern "C" int mi355_mul_mat_id_dq(int type, const void * as, int64_t w_row_stri
     int * off = sorted + n_tokens * n_used, * tile_off = off + n_expert + 1;
     int rc = mi355_act_bf16(b, act, k, b_ne1, n_tokens, 1, b_nb1, b_nb2, 0, stream);
     if (rc != MI355_OK) return rc;
-    MI355_LAUNCH("moe_bucket", moe_bucket_kernel, dim3(1), dim3(1024), 0, s, ids, ids_stride, (int)n_tokens, (int)n_used, (int)n_expert, BN,
+    const int bn = ids_wide(type, m) ? 256 : BN;            // pairs per column tile of the kernel that will run
+    MI355_LAUNCH("moe_bucket", moe_bucket_kernel, dim3(1), dim3(1024), 0, s, ids, ids_stride, (int)n_tokens, (int)n_used, (int)n_expert, bn,
                  sorted, off, tile_off);
     MI355_CHECK_LAUNCH();
     DArgs a;
@@ -1058,7 +1100,7 @@ extern "C" int mi355_mul_mat_id_dq(int type, const void * as, int64_t w_row_stri
     a.sorted = sorted; a.off = off; a.tile_off = tile_off; a.n_expert = (int)n_expert; a.n_used = (int)n_used; a.act_ne1 = (int)b_ne1;
     a.w_expert_stride = w_expert_stride; a.dbg = 0; a.part = nullptr;
     a.W2 = nullptr; a.w2_row_stride = 0; a.hbf = nullptr; a.glu_op = 0; a.y2 = 0; a.m2 = 0; a.part2 = nullptr;
-    const int max_tiles = (int)((n_tokens * n_used + BN - 1) / BN + n_expert);   // sum over experts of ceil(cnt_e / BN) never exceeds this
+    const int max_tiles = (int)((n_tokens * n_used + bn - 1) / bn + n_expert);   // sum over experts of ceil(cnt_e / bn) never exceeds this
     switch (type) {
         case MI355_TYPE_Q4_0: return launch_ids<MI355_TYPE_Q4_0>(a, max_tiles, s, "mmdq_id_q4_0");
         case MI355_TYPE_Q8_0: return launch_ids<MI355_TYPE_Q8_0>(a, max_tiles, s, "mmdq_id_q8_0");

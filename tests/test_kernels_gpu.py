@@ -1206,7 +1206,10 @@ def test_flash_attn_fused_bf16_output(ops, tkv, d, nh, nhkv, nq, nkv):
 
 
 @pytest.mark.parametrize("t", B.WEIGHT_TYPES)
-@pytest.mark.parametrize("m,k,n_exp,n_used,n_tok,b1", [(192, 256, 8, 2, 40, 1), (130, 512, 4, 2, 200, 2), (64, 256, 8, 3, 33, 3), (256, 1024, 8, 2, 512, 1)])
+@pytest.mark.parametrize("m,k,n_exp,n_used,n_tok,b1", [(192, 256, 8, 2, 40, 1), (130, 512, 4, 2, 200, 2), (64, 256, 8, 3, 33, 3), (256, 1024, 8, 2, 512, 1),
+                                                       # >= 1024 rows: the role-split 128 x 256 tile in MUL_MAT_ID mode (tiles of 256 pairs: several per expert,
+                                                       # ragged last tiles, ragged row tile)
+                                                       (1024, 512, 8, 2, 300, 1), (1100, 256, 4, 2, 700, 2), (2048, 1024, 8, 2, 64, 1)])
 def test_mul_mat_id_grouped_gemm(ops, t, m, k, n_exp, n_used, n_tok, b1):
     """prefill-sized MUL_MAT_ID: device-side bucketing by expert + one bf16-MFMA GEMM launch, vs exact
     dequant(as[ids]) . b in f64 (budget of the op: NMSE 5e-4, tests/test-backend-ops.cpp:2357-2359), and vs the
