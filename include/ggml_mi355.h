@@ -37,6 +37,7 @@
  *   GGML_MI355_NO_GLU_MATVEC=1  decode ffn: grouped gate+up mat-vec and a separate GLU kernel instead of mi355_glu_matvec
  *   GGML_MI355_NO_MOE_DOWN=1    MoE decode: MUL_MAT_ID(down_exps), the weight MUL and the expert / residual ADDs as separate nodes
  *   GGML_MI355_NO_NORM_ROUTER=1 MoE decode: the ffn norm as a launch of its own in front of the router's (mi355_moe_router_f32) instead of inside it
+ *   GGML_MI355_NO_MOE_COMBINE=1 MoE batches: MUL(experts, weights) and the ADD of its two slot views as two launches instead of mi355_moe_combine2_f32
  *   GGML_MI355_NO_MOE_READY=1   MoE steps of 2..64 tokens: every MUL_MAT_ID quantizes its own input and buckets its own ids (no q8_K planes from
  *                            the norm / GLU launches, no routing tables kept from the up / gate launch for ffn_down)
  *   GGML_MI355_NO_MATVEC_ADD=1  decode: wo / ffn_down mat-vec and the residual ADD as separate nodes

@@ -661,6 +661,13 @@ MI355_API int mi355_moe_router_norm_f32(const float *x, int64_t x_row_stride, co
                                         float *act_ds, const float *gate_inp, int64_t gate_row_stride, int64_t k, int64_t n_expert,
                                         int64_t n_used, int64_t n_tokens, float *logits, float *probs, int32_t *order, float *w,
                                         float *wsum, float *wn, void *stream);
+/* The experts' results of a batch combined in one pass: weighted[t][s][:] = e[t][s][:] * w[t][s] and sum[t][:] = weighted[t][0][:] +
+ * weighted[t][1][:] -- the MUL and the ADD behind ffn_moe_down for two experts per token (build_moe_ffn, src/llama-graph.cpp:773-790;
+ * ggml-cpu binary ops), each value with the same single f32 multiply / add.  e, weighted: dense [n_tokens][2][m] (weighted may be e
+ * itself); sum: dense [n_tokens][m]; w: one float at w + t * w_token_stride + s * w_slot_stride (bytes).  m % 4 == 0, else
+ * MI355_E_UNSUPPORTED; n_tokens <= 65535. */
+MI355_API int mi355_moe_combine2_f32(const float *e, const float *w, int64_t w_token_stride, int64_t w_slot_stride, float *weighted,
+                                     float *sum, int64_t m, int64_t n_tokens, void *stream);
 
 
 /* row softmax with optional f16/f32 mask and ALiBi slope: dst = softmax(x*scale + slope*mask).

@@ -627,6 +627,39 @@ static bool mi355_try_fuse_moe_down(mi355_backend_ctx * ctx, ggml_cgraph * cgrap
     return true;
 }
 
+// The same tail for a batch of tokens, when ffn_moe_down itself ran as a grouped GEMM: MUL(experts, weights) and the ADD of its two
+// slot views as one pass (mi355_moe_combine2_f32); both tensors are written, so no use analysis is needed.
+static bool mi355_try_fuse_moe_combine(mi355_backend_ctx * ctx, ggml_cgraph * cgraph, int i, std::vector<char> & done) {
+    if (MI355_ENV_SET("GGML_MI355_NO_MOE_COMBINE")) return false;
+    const ggml_tensor * mul = ggml_graph_node(cgraph, i);
+    const ggml_tensor * e = mul->src[0], * w = mul->src[1];
+    if (!e || !w || mul->type != GGML_TYPE_F32 || e->type != GGML_TYPE_F32 || w->type != GGML_TYPE_F32) return false;
+    const int64_t M = e->ne[0], T = e->ne[2];
+    if (e->ne[1] != 2 || e->ne[3] != 1 || T < 1 || T > 65535 || M % 4 != 0 || !ggml_are_same_shape(mul, e) || !ggml_is_contiguous(e) || !ggml_is_contiguous(mul)) return false;
+    if (w->ne[0] != 1 || w->ne[1] != 2 || w->ne[2] != T || w->ne[3] != 1) return false;
+    const int ja = next_active_node(cgraph, i, done);
+    if (ja < 0) return false;
+    const ggml_tensor * add = ggml_graph_node(cgraph, ja);
+    if (add->op != GGML_OP_ADD || add->type != GGML_TYPE_F32 || add->ne[0] != M || add->ne[1] != T || ggml_nrows(add) != T || !ggml_is_contiguous(add)) return false;
+    for (int s2 = 0; s2 < 2; s2++) {
+        const ggml_tensor * v = add->src[s2];
+        if (!v || view_root(v) != mul || v->type != GGML_TYPE_F32 || v->ne[0] != M || v->ne[1] != T || ggml_nrows(v) != T || v->nb[0] != sizeof(float) ||
+            v->nb[1] != mul->nb[2]) return false;
+        if (v->data != (const char *)mul->data + s2 * mul->nb[1]) return false;
+    }
+    if (!same_or_apart(mul, e)) return false;
+    if (ranges_overlap(add->data, ggml_nbytes(add), e->data, ggml_nbytes(e)) || ranges_overlap(add->data, ggml_nbytes(add), mul->data, ggml_nbytes(mul))) return false;
+    if (ranges_overlap(w->data, ggml_nbytes(w), mul->data, ggml_nbytes(mul)) || ranges_overlap(w->data, ggml_nbytes(w), add->data, ggml_nbytes(add))) return false;
+    const int rc = mi355_moe_combine2_f32((const float *)e->data, (const float *)w->data, (int64_t)w->nb[2], (int64_t)w->nb[1], (float *)mul->data,
+                                          (float *)add->data, M, T, ctx->stream);
+    if (rc == MI355_E_UNSUPPORTED || rc == MI355_E_ALIGN) return false;
+    MI_CHECK(rc);
+    done[ja] = 1;
+    ctx->act_invalidate_if_written(mul);
+    ctx->act_invalidate_if_written(add);
+    return true;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Fused attention input of a decode step.  llm_build_llama (src/llama-model.cpp:4898-5052) spells it as
 //     Qcur = MUL_MAT(wq, x)  RESHAPE  ROPE      Kcur = MUL_MAT(wk, x)  RESHAPE  ROPE      Vcur = MUL_MAT(wv, x)  RESHAPE
@@ -1446,6 +1479,7 @@ enum ggml_status mi355_issue_graph(mi355_backend_ctx * ctx, ggml_cgraph * cgraph
             done[i + 1] = 1;
             continue;
         }
+        if (fuse && node->op == GGML_OP_MUL && node->ne[1] == 2 && mi355_try_fuse_moe_combine(ctx, cgraph, i, done)) continue;
         // fusion: decode mat-vecs that share their activation run as one grouped launch
         if (fuse && matvec_groupable(node)) {
             int members[MI355_MMVQ_MAX_GROUP];

@@ -1599,3 +1599,33 @@ extern "C" int mi355_moe_router_norm_f32(const float * x, int64_t x_row_stride, 
     MI355_CHECK_LAUNCH();
     return MI355_OK;
 }
+
+// The experts' results of a batch combined: weighted[t][s][:] = e[t][s][:] * w[t][s], sum[t][:] = weighted[t][0][:] + weighted[t][1][:]
+// -- the MUL and the ADD behind ffn_moe_down (build_moe_ffn, src/llama-graph.cpp:773-790) as one pass over the rows, each value
+// with the one f32 multiply / add the two launches would have done.
+__global__ __launch_bounds__(256) void moe_combine2_kernel(const float4 * __restrict__ e, const char * __restrict__ w, int64_t w_token_stride,
+                                                           int64_t w_slot_stride, float4 * weighted, float4 * __restrict__ sum, int m4) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= m4) return;
+    const int64_t t = blockIdx.y;
+    const float w0 = *(const float *)(w + t * w_token_stride), w1 = *(const float *)(w + t * w_token_stride + w_slot_stride);
+    const float4 a = e[(2 * t) * m4 + c], b = e[(2 * t + 1) * m4 + c];
+    const float4 p0 = make_float4(a.x * w0, a.y * w0, a.z * w0, a.w * w0), p1 = make_float4(b.x * w1, b.y * w1, b.z * w1, b.w * w1);
+    weighted[(2 * t) * m4 + c] = p0;
+    weighted[(2 * t + 1) * m4 + c] = p1;
+    sum[t * m4 + c] = make_float4(p0.x + p1.x, p0.y + p1.y, p0.z + p1.z, p0.w + p1.w);
+}
+
+extern "C" int mi355_moe_combine2_f32(const float * e, const float * w, int64_t w_token_stride, int64_t w_slot_stride, float * weighted,
+                                      float * sum, int64_t m, int64_t n_tokens, void * stream) {
+    if (!e || !w || !weighted || !sum) return MI355_E_NULL;
+    if (m <= 0 || m > 0x7fffffff || n_tokens < 0 || n_tokens > 65535) return MI355_E_SHAPE;
+    if (m % 4 != 0) return MI355_E_UNSUPPORTED;
+    if ((((uintptr_t)e | (uintptr_t)weighted | (uintptr_t)sum) & 15) || ((w_token_stride | w_slot_stride | (int64_t)(uintptr_t)w) & 3)) return MI355_E_ALIGN;
+    if (n_tokens == 0) return MI355_OK;
+    const int m4 = (int)(m / 4);
+    MI355_LAUNCH("moe_combine2", moe_combine2_kernel, dim3((unsigned)((m4 + 255) / 256), (unsigned)n_tokens), dim3(256), 0, (hipStream_t)stream,
+                 (const float4 *)e, (const char *)w, w_token_stride, w_slot_stride, (float4 *)weighted, (float4 *)sum, m4);
+    MI355_CHECK_LAUNCH();
+    return MI355_OK;
+}

@@ -27,7 +27,7 @@ EXPORTS = [
     "mi355_scale_f32", "mi355_soft_max_f32", "mi355_flash_attn_ext_workspace_bytes", "mi355_flash_attn_ext", "mi355_flash_attn_ext_quant", "mi355_flash_attn_ext_bf16", "mi355_flash_attn_ext_noalloc_max_bytes", "mi355_flash_attn_ext_noalloc",
     "mi355_dequantize_row", "mi355_mul_mat_vec_q", "mi355_mul_mat_q", "mi355_mul_mat_skinny", "mi355_mul_mat_skinny_slice", "mi355_quantize_act_q8k", "mi355_mul_mat_skinny_k", "mi355_mul_mat_skinny_k_slice", "mi355_mul_mat_skinny_k_group", "mi355_mul_mat_qk", "mi355_mul_mat_id_skinny_workspace_bytes", "mi355_mul_mat_id_skinny", "mi355_mul_mat_id_skinny_pair", "mi355_argsort_f32", "mi355_moe_router_f32", "mi355_sum_rows_f32", "mi355_mul_mat_f32", "mi355_mul_mat_dq", "mi355_mul_mat_dq_slice", "mi355_kv_store_q8_0", "mi355_mul_mat_dq_slice_ws", "mi355_glu_mul_mat_dq", "mi355_mul_mat_dq_parts_bytes", "mi355_mul_mat_dq_parts", "mi355_mul_mat_dq_parts_pair", "mi355_qkv_finish", "mi355_mul_mat_dq_workspace_bytes", "mi355_act_bf16", "mi355_mul_mat_id_dq_workspace_bytes", "mi355_mul_mat_id_dq", "mi355_mul_mat_workspace_bytes", "mi355_mul_mat",
     "mi355_decode_layer_sync_bytes", "mi355_decode_layer", "mi355_stream_read", "mi355_map_f32", "mi355_norm_f32",
-    "mi355_mul_mat_id_tables_bytes", "mi355_mul_mat_id_skinny_ex", "mi355_moe_router_norm_f32", "mi355_kv_store_q",
+    "mi355_mul_mat_id_tables_bytes", "mi355_mul_mat_id_skinny_ex", "mi355_moe_router_norm_f32", "mi355_kv_store_q", "mi355_moe_combine2_f32",
 ]
 
 
@@ -174,6 +174,7 @@ lib.mi355_mul_mat_id_skinny_pair.argtypes = [C.c_int, _vp, _vp, _i64, _i64, _vp,
 lib.mi355_mul_mat_id_skinny_ex.argtypes = [C.c_int, _vp, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _vp, _vp] + [_i64] * 6 + [_vp, _i64, _vp, C.c_int, _vp]
 lib.mi355_mul_mat_id_tables_bytes.restype = _i64
 lib.mi355_moe_router_f32.argtypes = [_vp, _i64, _vp, _i64, _i64, _i64, _i64, _i64] + [_vp] * 7
+lib.mi355_moe_combine2_f32.argtypes = [_vp, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _vp]
 lib.mi355_moe_router_norm_f32.argtypes = [_vp, _i64, _vp, C.c_float, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64] + [_vp] * 7
 lib.mi355_mul_mat_id_tables_bytes.argtypes = [_i64] * 3
 lib.mi355_mul_mat_id_dq_workspace_bytes.restype = _i64

@@ -92,6 +92,9 @@ def test_moe_router_is_one_launch_for_small_batches_too():
     # ggml-alloc puts its gathered weights on the bytes of the layer's dead input there, which the experts still read when the fused
     # launch would write them
     assert count("moe_router") == 9 and count("argsort") == 3 and count("soft_max") == 3, r.stderr[-2000:]
+    # and the tail of every layer, MUL(experts, weights) + ADD of its two slot views, is mi355_moe_combine2_f32's one pass (the last layer
+    # of a step has one token and takes the decode form, the MoE-down mat-vec with the sum in its epilogue)
+    assert count("moe_combine2") == 9, r.stderr[-2000:]
     # decode: the ffn norm runs in the router's launch too (mi355_moe_router_norm_f32) -- in the layers whose router is fused (not the last)
     r = subprocess.run([tool, "tinymoe", "Q4_K_M", "-p", "0", "-n", "4", "-r", "1"], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stderr[-3000:]

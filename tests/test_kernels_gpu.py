@@ -1455,3 +1455,24 @@ def test_moe_router_and_its_norm_form(ops, k, n_exp, n_used, n_tok):
     assert K.lib.mi355_moe_router_norm_f32(x.data_ptr(), 8192 * 4, nw.data_ptr(), 1e-5, xn2.data_ptr(), None, None, gate.data_ptr(), 8192 * 4,
                                            8192, n_exp, n_used, 1, *[t.data_ptr() for t in b], s) == -6
 
+
+
+@pytest.mark.parametrize("m,n_tok,in_place", [(4096, 1, True), (1024, 12, True), (4100, 7, False), (14336, 512, True)])
+def test_moe_combine_vs_numpy(ops, m, n_tok, in_place):
+    """mi355_moe_combine2_f32: weighted = e * w and sum = weighted[:, 0] + weighted[:, 1], each value one f32 multiply / add as ggml-cpu's
+    MUL and ADD do them -> bit-exact against numpy; the weights are read through strides (llama.cpp hands a [1, 2, T] view)."""
+    import llm_amd.kernels as K
+    rng = np.random.default_rng(m + n_tok)
+    e = rng.standard_normal((n_tok, 2, m)).astype(np.float32)
+    w = rng.uniform(0.1, 0.9, (n_tok, 3)).astype(np.float32)        # row stride 3 floats: slot s at [t, s]
+    e_d, w_d = dev(e), dev(w)
+    weighted = e_d if in_place else torch.full((n_tok, 2, m), float("nan"), device="cuda")
+    total = torch.full((n_tok, m), float("nan"), device="cuda")
+    rc = K.lib.mi355_moe_combine2_f32(e_d.data_ptr(), w_d.data_ptr(), 12, 4, weighted.data_ptr(), total.data_ptr(), m, n_tok,
+                                      torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    torch.cuda.synchronize()
+    want = e * w[:, :2, None]
+    assert np.array_equal(weighted.cpu().numpy(), want)
+    assert np.array_equal(total.cpu().numpy(), want[:, 0] + want[:, 1])
+    assert K.lib.mi355_moe_combine2_f32(e_d.data_ptr(), w_d.data_ptr(), 12, 4, weighted.data_ptr(), total.data_ptr(), 4098, 1, 0) == -6      # MI355_E_UNSUPPORTED
