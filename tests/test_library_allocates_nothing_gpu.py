@@ -69,6 +69,12 @@ def _battery(scale):
         y = torch.empty_like(x)
         K.check(K.lib.mi355_norm_f32(K.Tensor.of(x), K.Tensor.of(y), 1e-5, l2, torch.cuda.current_stream().cuda_stream), "norm")
         outs.append(y)
+    e = torch.randn((5 * scale, 2, 512 * scale), device="cuda", generator=g)       # the experts' rows of a batch, combined
+    wts = torch.rand((5 * scale, 2), device="cuda", generator=g)
+    tot = torch.empty((5 * scale, 512 * scale), device="cuda")
+    K.check(K.lib.mi355_moe_combine2_f32(e.data_ptr(), wts.data_ptr(), 8, 4, e.data_ptr(), tot.data_ptr(), 512 * scale, 5 * scale,
+                                         torch.cuda.current_stream().cuda_stream), "moe_combine2")
+    outs.append(tot)
     torch.cuda.synchronize()
     assert all(torch.isfinite(o).all() for o in outs)
 
