@@ -846,9 +846,12 @@ static bool ids_wide(int type, int64_t m) {
 }
 
 template <int TYPE>
-static int launch_ids(const DArgs & a, int max_tiles, hipStream_t s, const char * tag) {
+static int launch_ids(const DArgs & a_in, int max_tiles, hipStream_t s, const char * tag) {
+    const DArgs & a = a_in;
     if constexpr (TYPE == MI355_TYPE_Q4_0 || TYPE == MI355_TYPE_Q8_0 || TYPE == MI355_TYPE_Q4_K || TYPE == MI355_TYPE_Q5_K || TYPE == MI355_TYPE_Q6_K) {
         if (ids_wide(TYPE, a.m)) {
+            DArgs a = a_in;       // (the lab switch of the role-split kernel, as in launch())
+            { static const int dbg = [] { const char * e = getenv("MI355_MMDQ_DBG"); return e ? atoi(e) : 0; }(); a.dbg = dbg; }
             MI355_LAUNCH(tag, (mmdq_ws_kernel<TYPE, 128, 256, false, -1, true>), dim3((unsigned)max_tiles, (unsigned)((a.m + 127) / 128)), dim3(768), 0, s, a);
             MI355_CHECK_LAUNCH();
             return MI355_OK;
