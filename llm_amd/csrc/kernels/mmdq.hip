@@ -501,7 +501,11 @@ mmdq_ws_kernel(const DArgs a_in) {
     const bool second = PAIR && (int)blockIdx.y >= a_in.y2;
     DArgs a = a_in;
     if (PAIR && second) { a.W = a_in.W2; a.w_row_stride = a_in.w2_row_stride; a.m = a_in.m2; a.part = a_in.part2; }
-    const int by = PAIR && second ? (int)blockIdx.y - a_in.y2 : (int)blockIdx.y;
+    // MUL_MAT_ID: the grid is (row tiles, column tiles) -- row tiles fastest, so that the column tiles no expert fills (the grid is sized for the
+    // worst routing) are the END of the dispatch order.  With them interleaved (column tiles fastest) the 32 x 8 live workgroups of an 8x7B
+    // ffn_down at 512 tokens did not land one per CU: 2.4 us per stage against 1.4 with 896 live workgroups (tools/moe_gemm_routing_lab.py shapes)
+    const int by = IDS ? (int)blockIdx.x : PAIR && second ? (int)blockIdx.y - a_in.y2 : (int)blockIdx.y;
+    const int bx = IDS ? (int)blockIdx.y : (int)blockIdx.x;
     constexpr int TN = BMW == 128 ? 2 : 1;                                    // 32-column MFMA tiles per multiplying wave
     constexpr int WAVES_M = BMW / 64, NMW = WAVES_M * (BNW / (32 * TN));      // multiplying waves
     constexpr int NPIECE = BNW * PITCH / 1024;                                // 1 KiB pieces per activation stage: 36 / 18
@@ -512,14 +516,14 @@ mmdq_ws_kernel(const DArgs a_in) {
     __shared__ __attribute__((aligned(16))) uint8_t Lw[2][BMW * PITCH];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // GLU: the tile's 128 weight rows are 64 rows of W (tile rows 0..63) and the SAME 64 rows of W2 (tile rows 64..127)
-    const int n0 = blockIdx.x * BNW, m0 = by * (GLU ? BMW / 2 : BMW);
+    const int n0 = bx * BNW, m0 = by * (GLU ? BMW / 2 : BMW);
     const int kspan = a.k / (int)gridDim.z, kbeg = (int)blockIdx.z * kspan;
     const int nstage = kspan / BK;
     __shared__ int s_pair[IDS ? BNW : 1];
     int expert = 0;
     if constexpr (IDS) {
-        // column tile blockIdx.x -> (expert, tile inside the expert), as in mmdq_kernel; the grid is sized for the worst case
-        const int ti = blockIdx.x;
+        // column tile bx -> (expert, tile inside the expert), as in mmdq_kernel; the grid is sized for the worst case
+        const int ti = bx;
         const int total_tiles = a.tile_off[a.n_expert];
         for (int b0 = 0; b0 < a.n_expert; b0 += 64) {
             const int end = b0 + lane < a.n_expert ? a.tile_off[b0 + lane + 1] : 0x7fffffff;
@@ -852,7 +856,7 @@ static int launch_ids(const DArgs & a_in, int max_tiles, hipStream_t s, const ch
         if (ids_wide(TYPE, a.m)) {
             DArgs a = a_in;       // (the lab switch of the role-split kernel, as in launch())
             { static const int dbg = [] { const char * e = getenv("MI355_MMDQ_DBG"); return e ? atoi(e) : 0; }(); a.dbg = dbg; }
-            MI355_LAUNCH(tag, (mmdq_ws_kernel<TYPE, 128, 256, false, -1, true>), dim3((unsigned)max_tiles, (unsigned)((a.m + 127) / 128)), dim3(768), 0, s, a);
+            MI355_LAUNCH(tag, (mmdq_ws_kernel<TYPE, 128, 256, false, -1, true>), dim3((unsigned)((a.m + 127) / 128), (unsigned)max_tiles), dim3(768), 0, s, a);
             MI355_CHECK_LAUNCH();
             return MI355_OK;
         }

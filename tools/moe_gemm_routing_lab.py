@@ -16,10 +16,14 @@ def routing(kind, n_tok, n_exp):
     if kind >= 2: ids[200 : 400, 0] = 1; ids[200 : 400, 1] = 2 + t[200:400] % (n_exp - 2)   # expert 1 as well
     return ids.astype(np.int32)
 
-for name, m, k, b1 in (("down", 4096, 14336, 2), ("gate/up", 14336, 4096, 1)):
+SHAPES = [("down", 4096, 14336, 2), ("gate/up", 14336, 4096, 1)]
+if len(sys.argv) > 1 and sys.argv[1] == "shapes":      # which of the two differences matters: the depth of K or the number of row tiles
+    SHAPES = [("m4096 k4096", 4096, 4096, 2), ("m4096 k8192", 4096, 8192, 2), ("m4096 k14336", 4096, 14336, 2), ("m8192 k14336", 8192, 14336, 2),
+              ("m14336 k14336", 14336, 14336, 2), ("m14336 k4096", 14336, 4096, 2)]
+for name, m, k, b1 in SHAPES:
     w = torch.from_numpy(B.random_blocks(B.Q4_K, 8 * m, k, seed=1)).cuda()
     b = torch.randn((512, b1, k), device="cuda")
-    for kind in (0, 1, 2):
+    for kind in ((0,) if len(SHAPES) > 2 else (0, 1, 2)):
         ids = torch.from_numpy(routing(kind, 512, 8)).cuda()
         counts = np.bincount(ids.cpu().numpy().ravel(), minlength=8)
         for _ in range(3): ops.mul_mat_id_dq(B.Q4_K, w, b, ids, m, 8)
@@ -28,4 +32,5 @@ for name, m, k, b1 in (("down", 4096, 14336, 2), ("gate/up", 14336, 4096, 1)):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(); ops.mul_mat_id_dq(B.Q4_K, w, b, ids, m, 8); e1.record(); torch.cuda.synchronize()
             ts.append(e0.elapsed_time(e1) * 1000)
-        print(f"{name:8s} pairs per expert {counts.tolist()} tiles {int(sum((c + 255) // 256 for c in counts))}: {np.median(ts):7.1f} us", flush=True)
+        stages = (m // 128) * int(sum((c + 255) // 256 for c in counts)) * (k // 64)
+        print(f"{name:14s} {np.median(ts) * 256 / stages:6.2f} us per stage at 256 workgroups in flight; pairs per expert {counts.tolist()} tiles {int(sum((c + 255) // 256 for c in counts))}: {np.median(ts):7.1f} us", flush=True)
