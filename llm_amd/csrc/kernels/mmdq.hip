@@ -338,7 +338,8 @@ mmdq_kernel(const DArgs a) {
     __shared__ __attribute__((aligned(16))) uint8_t La[2][BN * PITCH];
     __shared__ int s_pair[IDS ? BN : 1];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
+    // (MUL_MAT_ID: grid (row tiles, column tiles), so that the column tiles no expert fills come last in dispatch order -- see mmdq_ws_kernel)
+    const int n0 = (IDS ? blockIdx.y : blockIdx.x) * BN, m0 = (IDS ? blockIdx.x : blockIdx.y) * BM;
     const int wm_ = wave % WAVES_M, wn_ = wave / WAVES_M;
     const int lr = lane & 31, lh = lane >> 5;
 
@@ -349,10 +350,10 @@ mmdq_kernel(const DArgs a) {
     bool col_ok;
     const uint16_t * xcol;
     if (IDS) {
-        // column tile blockIdx.x -> (expert, tile inside the expert); the grid is sized for the worst case
+        // column tile blockIdx.y -> (expert, tile inside the expert); the grid is sized for the worst case
         // (the expert = the number of experts whose tiles end at or before ti: table entries requested together and counted with a
         // ballot, not walked one dependent load at a time)
-        const int ti = blockIdx.x;
+        const int ti = blockIdx.y;
         const int total_tiles = a.tile_off[a.n_expert];
         int e = 0;
         for (int b0 = 0; b0 < a.n_expert; b0 += 64) {
@@ -861,8 +862,8 @@ static int launch_ids(const DArgs & a_in, int max_tiles, hipStream_t s, const ch
             return MI355_OK;
         }
     }
-    if (a.m >= 1024) MI355_LAUNCH(tag, (mmdq_kernel<TYPE, 128, true>), dim3((unsigned)max_tiles, (unsigned)((a.m + 127) / 128)), dim3(256), 0, s, a);
-    else             MI355_LAUNCH(tag, (mmdq_kernel<TYPE, 64, true>), dim3((unsigned)max_tiles, (unsigned)((a.m + 63) / 64)), dim3(256), 0, s, a);
+    if (a.m >= 1024) MI355_LAUNCH(tag, (mmdq_kernel<TYPE, 128, true>), dim3((unsigned)((a.m + 127) / 128), (unsigned)max_tiles), dim3(256), 0, s, a);
+    else             MI355_LAUNCH(tag, (mmdq_kernel<TYPE, 64, true>), dim3((unsigned)((a.m + 63) / 64), (unsigned)max_tiles), dim3(256), 0, s, a);
     MI355_CHECK_LAUNCH();
     return MI355_OK;
 }
