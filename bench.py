@@ -159,7 +159,7 @@ def other_configs(budget_s):
         return {"error": "oracle/_ref/llama-bench, make-random-gguf or the plugin is not built"}
     # (name, model, ftype, llama-bench arguments, extra environment, keep the GGUF for the next leg)
     legs = [("config3_8b_q8_0_q8kv", "8b", "Q8_0", ["-p", "2048", "-n", "0", "-ctk", "q8_0", "-ctv", "q8_0"], {}, False),
-            ("config5_8x7b_q4km", "8x7b", "Q4_K_M", ["-p", "8,16,32,64", "-n", "64"], {}, False),
+            ("config5_8x7b_q4km", "8x7b", "Q4_K_M", ["-p", "8,16,32,64,512", "-n", "64"], {}, False),
             ("config4_70b_q4km_1gpu", "70b", "Q4_K_M", ["-p", "512", "-n", "64"], {}, True),
             # the row-split code path of config 4 (-sm row: fused launches on row slices, the token replayed as a graph) rehearsed on
             # this one GPU as two ggml devices: what the split costs, not what it gains -- the 2 / 4 / 8-GPU rows need a node
